@@ -1,0 +1,289 @@
+"""ctypes front-end of the CPU oracle (oracle/apref.c).   *** TEST INFRASTRUCTURE ONLY ***
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module; the product package ``astrophotography_amd`` never does.  Every function cites the reference
+lines it restates in ``apref.c``.  Results are pinned against golden vectors generated from the
+imported reference by ``tests/golden/make_golden.py`` (see ``tests/test_oracle_golden.py``).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libapref.so')
+_lib = None
+
+OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
+
+
+def build(force=False):
+    """Compile oracle/libapref.so with gcc (a few seconds)."""
+    src = os.path.join(_HERE, 'apref.c')
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libapref.so'], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.apref_pairwise_sum_f32.restype = C.c_float
+        _lib.apref_pairwise_sum_f64.restype = C.c_double
+        _lib.apref_threshold_mask_f32.restype = C.c_long
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def num_threads():
+    return int(lib().apref_num_threads())
+
+
+def set_num_threads(n):
+    lib().apref_set_num_threads(C.c_int(int(n)))
+
+
+def pairwise_sum_f32(a):
+    a = _c(a, np.float32).ravel()
+    return np.float32(lib().apref_pairwise_sum_f32(_p(a), C.c_long(a.size)))
+
+
+def flat_normalize(flat):
+    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190) -> (nflat f32, norm f32)."""
+    flat = _c(flat, np.float32)
+    nflat = np.empty_like(flat)
+    norm = C.c_float()
+    rc = lib().apref_flat_normalize_f32(_p(flat), C.c_long(flat.size), _p(nflat), C.byref(norm))
+    assert rc == 0
+    return nflat, np.float32(norm.value)
+
+
+def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biased=False):
+    """A2 ApCalibrate.calibrate arithmetic (ApCalibrate.py:439-464) on a slab raw[N,H,W] (u16|f32).
+
+    exp_ratio: scalar or [N] python floats (cast to float32 like numpy does); pedestal: None or [N].
+    """
+    raw = np.asarray(raw)
+    single = raw.ndim == 2
+    if single:
+        raw = raw[None]
+    N = raw.shape[0]
+    P = raw[0].size
+    if raw.dtype == np.uint16:
+        dt = 1
+    elif raw.dtype == np.float32:
+        dt = 0
+    else:
+        raise TypeError(raw.dtype)
+    raw = np.ascontiguousarray(raw)
+    bias = _c(bias, np.float32)
+    dark = _c(dark, np.float32)
+    nflat = _c(nflat, np.float32)
+    e = np.ascontiguousarray(np.broadcast_to(np.asarray(exp_ratio, np.float64), (N,)).astype(np.float32))
+    ped = None if pedestal is None else np.ascontiguousarray(
+        np.broadcast_to(np.asarray(pedestal, np.float64), (N,)).astype(np.float32))
+    out = np.empty(raw.shape, np.float32)
+    rc = lib().apref_calibrate(_p(raw), C.c_int(dt), _p(bias), _p(dark), _p(nflat), _p(e), _p(ped),
+                               C.c_int(int(bool(dark_still_biased))), _p(out), C.c_long(N), C.c_long(P))
+    assert rc == 0
+    return out[0] if single else out
+
+
+def stack_sigclip(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
+                  stdfunc='std', pixmask=None, want=('mean', 'median', 'std', 'lo', 'hi', 'count', 'keep')):
+    """A7 astropy.stats.sigma_clipped_stats(cube, axis=0) C fast path (sigma_clipping.py:298-383,
+    924-937).  Returns a dict of float64 planes (+ int32 count, bool keep[N,...])."""
+    cube = np.asarray(cube)
+    if cube.dtype == np.float32:
+        dt = 0
+        cube = np.ascontiguousarray(cube)
+    else:
+        dt = 2
+        cube = np.ascontiguousarray(cube, dtype=np.float64)
+    N = cube.shape[0]
+    shp = cube.shape[1:]
+    P = int(np.prod(shp)) if shp else 1
+    sl = sigma if sigma_lower is None else sigma_lower
+    su = sigma if sigma_upper is None else sigma_upper
+    outs = {}
+    for k in ('mean', 'median', 'std', 'lo', 'hi'):
+        outs[k] = np.empty(shp, np.float64) if k in want else None
+    outs['count'] = np.empty(shp, np.int32) if 'count' in want else None
+    outs['keep'] = np.empty(cube.shape, np.uint8) if 'keep' in want else None
+    pm = _c(pixmask, np.uint8)
+    rc = lib().apref_stack_sigclip(_p(cube), C.c_int(dt), C.c_long(N), C.c_long(P), _p(pm),
+                                   C.c_double(sl), C.c_double(su),
+                                   C.c_int(-1 if maxiters is None else int(maxiters)),
+                                   C.c_int(int(cenfunc == 'median')), C.c_int(int(stdfunc == 'mad_std')),
+                                   _p(outs['mean']), _p(outs['median']), _p(outs['std']),
+                                   _p(outs['lo']), _p(outs['hi']), _p(outs['count']), _p(outs['keep']))
+    assert rc == 0, rc
+    if outs['keep'] is not None:
+        outs['keep'] = outs['keep'].astype(bool)
+    return {k: v for k, v in outs.items() if v is not None}
+
+
+def combine_ccdproc(cube, low=5.0, high=5.0):
+    """A6 ccdproc.combine settings of ap_combine_darks.py:394-420 (PARITY UNPINNED)."""
+    cube = np.asarray(cube)
+    dt = 0 if cube.dtype == np.float32 else 2
+    cube = np.ascontiguousarray(cube) if dt == 0 else np.ascontiguousarray(cube, dtype=np.float64)
+    N = cube.shape[0]
+    shp = cube.shape[1:]
+    P = int(np.prod(shp))
+    mean = np.empty(shp, np.float64)
+    cnt = np.empty(shp, np.int32)
+    std = np.empty(shp, np.float64)
+    rc = lib().apref_combine_ccdproc(_p(cube), C.c_int(dt), C.c_long(N), C.c_long(P), C.c_double(low),
+                                     C.c_double(high), _p(mean), _p(cnt), _p(std))
+    assert rc == 0
+    return dict(mean=mean, count=cnt, std=std)
+
+
+def stack_median(cube):
+    """np.nanmedian(cube, axis=0) in float64 (config 4 median stack)."""
+    cube = np.asarray(cube)
+    dt = 0 if cube.dtype == np.float32 else 2
+    cube = np.ascontiguousarray(cube) if dt == 0 else np.ascontiguousarray(cube, dtype=np.float64)
+    N = cube.shape[0]
+    shp = cube.shape[1:]
+    out = np.empty(shp, np.float64)
+    rc = lib().apref_stack_median(_p(cube), C.c_int(dt), C.c_long(N), C.c_long(int(np.prod(shp))), _p(out))
+    assert rc == 0
+    return out
+
+
+def sigclip_global(data, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5):
+    """A3 sigma_clipped_stats(data, sigma) with axis=None as called at ApFindBadPixels.py:191.
+
+    Returns dict(mean, median, std, lo, hi, niter, nkeep); statistics are numpy float32 scalars for
+    float32 input and float64 for integer input (numpy dtype rules)."""
+    data = np.asarray(data)
+    sl = sigma if sigma_lower is None else sigma_lower
+    su = sigma if sigma_upper is None else sigma_upper
+    out = np.empty(7, np.float64)
+    mi = C.c_int(-1 if maxiters is None else int(maxiters))
+    if data.dtype == np.float32:
+        d = np.ascontiguousarray(data).ravel()
+        rc = lib().apref_sigclip_global_f32(_p(d), C.c_long(d.size), C.c_double(sl), C.c_double(su), mi, _p(out))
+        cast = np.float32
+    else:
+        d = np.ascontiguousarray(data, dtype=np.float64).ravel()
+        rc = lib().apref_sigclip_global_f64(_p(d), C.c_long(d.size), C.c_double(sl), C.c_double(su), mi, _p(out))
+        cast = np.float64
+    assert rc == 0
+    return dict(mean=cast(out[0]), median=cast(out[1]), std=cast(out[2]), lo=out[3], hi=out[4],
+                niter=int(out[5]), nkeep=int(out[6]))
+
+
+def badpix_thresholds(median, std, sigma):
+    """ApFindBadPixels.py:194-195 with numpy-1.26 scalar promotion (np.float32 * float -> float64)."""
+    return float(median) - sigma * float(std), float(median) + sigma * float(std)
+
+
+def threshold_mask(data, lothresh, hithresh):
+    """A4 ApFindBadPixels._generate_sigmaclip_mask (ApFindBadPixels.py:199-216) -> (mask u8, nbad)."""
+    data = np.asarray(data)
+    if data.dtype != np.float32:
+        # integer data: numpy compares in float32 after value-based promotion; u16 -> f32 is exact
+        data = data.astype(np.float32)
+    d = np.ascontiguousarray(data)
+    mask = np.empty(d.shape, np.uint8)
+    nbad = lib().apref_threshold_mask_f32(_p(d), C.c_long(d.size), C.c_double(lothresh), C.c_double(hithresh), _p(mask))
+    return mask, int(nbad)
+
+
+def mask_add_rects(mask, rects, value=2):
+    """A4 overlays (ApFindBadPixels.py:90,128,154): mask[r0:r1,c0:c1] += value, rects 0-based half-open."""
+    mask = np.ascontiguousarray(mask, dtype=np.uint8).copy()
+    r = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(-1, 4))
+    lib().apref_mask_add_rects(_p(mask), C.c_long(mask.shape[0]), C.c_long(mask.shape[1]), _p(r),
+                               C.c_long(r.shape[0]), C.c_int(value))
+    return mask
+
+
+def fix_badpix(data, mask, deltapix=1, min_valid=4):
+    """A5 ApFixBadPixels.fix_bad_pixels (ApFixBadPixels.py:292-445) -> (out f32, dict(nbad,nfix,nrem))."""
+    d = _c(data, np.float32)
+    m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+    out = np.empty_like(d)
+    st = np.zeros(3, np.int64)
+    rc = lib().apref_fix_badpix_f32(_p(d), _p(m), C.c_long(d.shape[0]), C.c_long(d.shape[1]),
+                                    C.c_int(int(deltapix)), C.c_int(int(min_valid)), _p(out), _p(st))
+    assert rc == 0
+    return out, dict(nbad=int(st[0]), nfix=int(st[1]), nrem=int(st[2]))
+
+
+def imarith(a, op, b):
+    """A8 ApImArith.process_files op block (ApImArith.py:320-333)."""
+    a = np.asarray(a)
+    opi = OPS[op]
+    if a.dtype == np.float32:
+        a = np.ascontiguousarray(a)
+        out = np.empty_like(a)
+        if np.isscalar(b):
+            rc = lib().apref_imarith_f32(_p(a), None, C.c_double(float(b)), C.c_int(1), C.c_int(opi), _p(out), C.c_long(a.size))
+        else:
+            bb = _c(b, np.float32)
+            rc = lib().apref_imarith_f32(_p(a), _p(bb), C.c_double(0.0), C.c_int(0), C.c_int(opi), _p(out), C.c_long(a.size))
+    elif a.dtype == np.uint16:
+        if np.isscalar(b) or opi == 3:
+            raise TypeError('numpy raises UFuncTypeError for u16 (+) scalar and u16 DIV (same_kind cast)')
+        a = np.ascontiguousarray(a)
+        bb = _c(b, np.uint16)
+        out = np.empty_like(a)
+        rc = lib().apref_imarith_u16(_p(a), _p(bb), C.c_int(opi), _p(out), C.c_long(a.size))
+    else:
+        raise TypeError(a.dtype)
+    assert rc == 0
+    return out
+
+
+def bayer_split(raw, pattern=(0, 1, 3, 2), black=None):
+    """A9 RawConv split geometry (RawConv.py:111-128).  pattern = colour index (R0 G1 B2 G2 3) of the
+    2x2 cell positions (0,0),(0,1),(1,0),(1,1); default RGGB with G1 on the red row."""
+    raw = _c(raw, np.uint16)
+    H, W = raw.shape
+    planes = np.empty((4, H, W), np.uint16)
+    pat = np.asarray(pattern, np.int32)
+    blk = None if black is None else np.asarray(black, np.int32)
+    rc = lib().apref_bayer_split_u16(_p(raw), C.c_long(H), C.c_long(W), _p(pat), _p(blk), _p(planes))
+    assert rc == 0
+    return planes
+
+
+def calibrate_stack(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biased=False,
+                    sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std'):
+    """Fused A2 + A7 (the benchmarked path) -> (mean f32 [H,W], count i32 [H,W])."""
+    raw = np.ascontiguousarray(raw)
+    N = raw.shape[0]
+    shp = raw.shape[1:]
+    P = int(np.prod(shp))
+    dt = 1 if raw.dtype == np.uint16 else 0
+    assert raw.dtype in (np.uint16, np.float32)
+    bias = _c(bias, np.float32)
+    dark = _c(dark, np.float32)
+    nflat = _c(nflat, np.float32)
+    e = np.ascontiguousarray(np.broadcast_to(np.asarray(exp_ratio, np.float64), (N,)).astype(np.float32))
+    ped = None if pedestal is None else np.ascontiguousarray(
+        np.broadcast_to(np.asarray(pedestal, np.float64), (N,)).astype(np.float32))
+    mean = np.empty(shp, np.float32)
+    cnt = np.empty(shp, np.int32)
+    rc = lib().apref_calibrate_stack(_p(raw), C.c_int(dt), _p(bias), _p(dark), _p(nflat), _p(e), _p(ped),
+                                     C.c_int(int(bool(dark_still_biased))), C.c_long(N), C.c_long(P),
+                                     C.c_double(sigma), C.c_double(sigma),
+                                     C.c_int(-1 if maxiters is None else int(maxiters)),
+                                     C.c_int(int(cenfunc == 'median')), C.c_int(int(stdfunc == 'mad_std')),
+                                     _p(mean), _p(cnt))
+    assert rc == 0
+    return mean, cnt
