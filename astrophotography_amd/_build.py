@@ -1,0 +1,73 @@
+"""Builds libapgpu.so (the HIP kernels + C ABI, include/apgpu.h) for gfx950 with hipcc.
+
+``python -m astrophotography_amd._build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without
+a GPU; the .so is written next to this file so that it travels with the source tree.
+"""
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(PKG, 'libapgpu.so')
+
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'stack.hip',
+           'stack_inst_f32_calib.hip', 'stack_inst_f32_plain.hip',
+           'stack_inst_u16_calib.hip', 'stack_inst_u16_plain.hip']
+HEADERS = ['common.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h')]
+
+# -ffp-contract=off: the reference's NumPy expressions round after every operation, so no FMA
+# contraction anywhere; fused operations are written explicitly (fma()) where wanted.
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+               '-fno-fast-math', '-Wall', '-Wno-unused-function', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return 'hipcc'
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p if os.path.isabs(p) else os.path.join(CSRC, p)) for p in paths)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    srcp = os.path.join(CSRC, src)
+    dep_time = max(os.path.getmtime(srcp), _newest(HEADERS))
+    if os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
+        return obj, False
+    cmd = [_hipcc()] + HIPCC_FLAGS + ['-c', srcp, '-o', obj]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout[-4000:]))
+    return obj, True
+
+
+def build_library(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    jobs = jobs or min(len(SOURCES), os.cpu_count() or 4)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        results = list(ex.map(_compile, SOURCES))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s' % r.stdout[-4000:])
+    if verbose:
+        print('libapgpu.so %s' % ('rebuilt' if rebuilt else 'up to date'), LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv, verbose=True)

@@ -1,0 +1,83 @@
+"""ctypes binding of libapgpu.so (C ABI: include/apgpu.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  The CPU oracle under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libapgpu.so')
+
+APGPU_F32, APGPU_U16 = 0, 1
+OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
+CENTER = {'median': 0, 'mean': 1}
+DEV = {'std': 0, 'mad_std': 1}
+MAX_STACK = 128
+
+E_INVAL, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4
+
+
+class ApGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libapgpu error %d: %s' % (code, msg))
+        self.code = code
+
+
+class StackArgs(C.Structure):
+    """struct apgpu_stack_args (include/apgpu.h)."""
+    _fields_ = [
+        ('frames', C.c_void_p), ('dtype', C.c_int32), ('n_frames', C.c_int32), ('n_pixels', C.c_int64),
+        ('bias', C.c_void_p), ('dark', C.c_void_p), ('nflat', C.c_void_p), ('exp_ratio', C.c_void_p),
+        ('pedestal', C.c_void_p), ('dark_still_biased', C.c_int32), ('center', C.c_int32),
+        ('dev', C.c_int32), ('maxiters', C.c_int32), ('sigma_lower', C.c_double), ('sigma_upper', C.c_double),
+        ('pixmask', C.c_void_p), ('mean', C.c_void_p), ('median', C.c_void_p), ('std', C.c_void_p),
+        ('count', C.c_void_p), ('moments', C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/apgpu.h declares
+SIGNATURES = {
+    'apgpu_last_error': (C.c_char_p, []),
+    'apgpu_version': (C.c_int, []),
+    'apgpu_flat_normalize_ws_bytes': (C.c_size_t, [C.c_int64]),
+    'apgpu_flat_normalize_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_calibrate': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'apgpu_stack_sigclip': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
+    'apgpu_stack_median': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
+    'apgpu_moments_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
+    'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_threshold_mask_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p]),
+    'apgpu_mask_add_rects_u8': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    'apgpu_fix_badpix_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    'apgpu_imarith': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_bayer_split_u16': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libapgpu.so; raises ImportError (no CPU fallback) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('%s is missing: build it with `python -m astrophotography_amd._build` '
+                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise ApGpuError(rc, load().apgpu_last_error().decode('utf-8', 'replace'))

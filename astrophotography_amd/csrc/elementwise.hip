@@ -1,0 +1,487 @@
+// elementwise.hip - the streaming (one pass, HBM-bound) kernels of the calibrate path on gfx950:
+//   A1 flat normalisation     ApCalibrate._generate_flat            core/ApCalibrate.py:166-190
+//   A2 calibrate              ApCalibrate.calibrate                 core/ApCalibrate.py:439-464
+//   A4 threshold mask         ApFindBadPixels._generate_sigmaclip_mask  core/ApFindBadPixels.py:194-216
+//   A4 user overlays          ApFindBadPixels._add_bad_*            core/ApFindBadPixels.py:70-158
+//   A8 image arithmetic       ApImArith.process_files               core/ApImArith.py:320-333
+//   A9 Bayer split            RawConv._build_raw_channel_images     core/RawConv.py:111-128
+// All float arithmetic is separately rounded IEEE float32 (built with -ffp-contract=off, __fdiv_rn)
+// because the reference's NumPy expressions round after every ufunc.
+//
+// Access pattern: 16 bytes per lane per load (float4 / 8 x u16), grid-stride over 2048 workgroups so
+// every CU holds several waves with independent 1 KiB wave-loads in flight.
+#include "common.h"
+
+namespace {
+using namespace apgpu;
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = kNumCU * 8;
+
+inline unsigned grid_for(int64_t work_items)
+{
+    int64_t g = (work_items + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2 calibrate.  One (frame, 4-pixel group) per lane-iteration; masters are re-read per frame from
+// L2/Infinity Cache (3 x 64 MB at 4096^2 stay resident in the 256 MB Infinity Cache).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float calib_one(float x, float ped, bool has_ped, float b, float D, float e,
+                                           bool has_flat, float nf)
+{
+    if (has_ped) x = x + ped;                 // ApCalibrate.py:318-326 (PEDESTAL is added at read time)
+    x = x - b;                                // :439
+    const float ds = e * D;                   // :450  float32(exp_ratio) * dark
+    x = x - ds;                               // :451
+    if (has_flat && nf != 0.f) x = __fdiv_rn(x, nf);   // :462-464 (NaN != 0 -> divide -> NaN)
+    return x;
+}
+
+template <typename RawT>
+__global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restrict__ raw, const float *__restrict__ bias,
+                                                          const float *__restrict__ dark,
+                                                          const float *__restrict__ nflat,
+                                                          const float *__restrict__ exp_ratio,
+                                                          const float *__restrict__ pedestal, int still_biased,
+                                                          float *__restrict__ out, int64_t N, int64_t P, int vec)
+{
+    // vec = 0 when P % 4 != 0: frame starts are then not 16-byte aligned and every pixel takes the
+    // scalar tail path.
+    const int64_t groups = vec ? P / 4 : 0;   // 4-pixel groups per frame (vector body)
+    const int64_t total = N * groups;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool has_flat = nflat != nullptr;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t f = t / groups;
+        const int64_t g = t - f * groups;
+        const float e = exp_ratio[f];
+        const float ped = pedestal ? pedestal[f] : 0.f;
+        const bool has_ped = ped != 0.f;
+        const float4 b4 = reinterpret_cast<const float4 *>(bias)[g];
+        const float4 d4 = reinterpret_cast<const float4 *>(dark)[g];
+        float4 n4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (has_flat) n4 = reinterpret_cast<const float4 *>(nflat)[g];
+        float x[4];
+        const RawT *rp = raw + f * P + g * 4;
+        if constexpr (sizeof(RawT) == 4) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(rp);
+            x[0] = r4.x; x[1] = r4.y; x[2] = r4.z; x[3] = r4.w;
+        } else {
+            const ushort4 r4 = *reinterpret_cast<const ushort4 *>(rp);
+            x[0] = (float)r4.x; x[1] = (float)r4.y; x[2] = (float)r4.z; x[3] = (float)r4.w;
+        }
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
+        float y[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float D = still_biased ? dd[k] - bb[k] : dd[k];      // :440-445
+            y[k] = calib_one(x[k], ped, has_ped, bb[k], D, e, has_flat, nn[k]);
+        }
+        *reinterpret_cast<float4 *>(out + f * P + g * 4) = make_float4(y[0], y[1], y[2], y[3]);
+    }
+    // tail pixels (P % 4) of every frame
+    const int64_t tail0 = groups * 4;
+    const int64_t ntail = P - tail0;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * ntail; t += stride) {
+        const int64_t f = t / ntail;
+        const int64_t p = tail0 + (t - f * ntail);
+        const float e = exp_ratio[f];
+        const float ped = pedestal ? pedestal[f] : 0.f;
+        const float b = bias[p], d = dark[p];
+        const float D = still_biased ? d - b : d;
+        const float nf = has_flat ? nflat[p] : 1.f;
+        out[f * P + p] = calib_one((float)raw[f * P + p], ped, ped != 0.f, b, D, e, has_flat, nf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1 flat normalisation.  np.nanmean(float32) = numpy's pairwise float32 sum taken over 8192-element
+// buffer pieces that are accumulated sequentially (verified against numpy 1.26.4 / 2.2.6, golden G7):
+//   piece sum  : binary tree over 64 leaves of 128 elements; a leaf keeps 8 strided accumulators
+//                r[k] += a[8j+k] and reduces ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+//   total      : ((0 + piece0) + piece1) + ...   in float32;  norm = f32(f64(total) / count)
+// Kernel 1: one wavefront per full piece, one lane per leaf, in-wave tree with the same pairing as
+//           numpy's recursion (halves of equal size).  NaNs count as 0 (np.nanmean) and are counted.
+// Kernel 2: one thread folds the piece sums in order, handles the ragged last piece with the
+//           general recursion, and writes norm.   Kernel 3: nflat = flat / norm.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPiece = 8192;
+constexpr int kLeaf = 128;
+
+__device__ __forceinline__ float nan0(float x, int &nans)
+{
+    if (x != x) { nans++; return 0.f; }
+    return x;
+}
+
+__device__ float leaf_sum(const float *a, int n, int &nans)
+{
+    // numpy pairwise_sum for 8 <= n <= 128
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = nan0(a[k], nans);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = r[k] + nan0(a[i + k], nans);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + nan0(a[i], nans);
+    return res;
+}
+
+__device__ float pairwise_generic(const float *a, int n, int &nans)
+{
+    // iterative form of numpy's recursion for the ragged last piece (n < 8192): explicit stack
+    struct Item { int off, len; };
+    Item stack[32];
+    float vals[32];
+    int state[32];
+    int sp = 0, vp = 0;
+    stack[sp] = {0, n}; state[sp] = 0; sp++;
+    // post-order evaluation
+    while (sp > 0) {
+        Item it = stack[sp - 1];
+        int stt = state[sp - 1];
+        if (it.len < 8) {
+            float res = 0.f;
+            for (int i = 0; i < it.len; i++) res = res + nan0(a[it.off + i], nans);
+            vals[vp++] = res; sp--;
+        } else if (it.len <= kLeaf) {
+            vals[vp++] = leaf_sum(a + it.off, it.len, nans); sp--;
+        } else if (stt == 0) {
+            int n2 = it.len / 2; n2 -= n2 % 8;
+            state[sp - 1] = 1;
+            // evaluate left first, then right
+            stack[sp] = {it.off + n2, it.len - n2}; state[sp] = 0; sp++;
+            stack[sp] = {it.off, n2}; state[sp] = 0; sp++;
+        } else {
+            // both children evaluated: left was pushed last so it was evaluated first
+            float right = vals[--vp];
+            float left = vals[--vp];
+            vals[vp++] = left + right;
+            sp--;
+        }
+    }
+    return vals[0];
+}
+
+__global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const float *__restrict__ flat, int64_t n,
+                                                                float *__restrict__ piece_sums,
+                                                                unsigned long long *__restrict__ nan_count)
+{
+    const int64_t npieces_full = n / kPiece;
+    const int wave = threadIdx.x / kWave;
+    const int lane = threadIdx.x % kWave;
+    const int waves_per_block = kBlock / kWave;
+    for (int64_t piece = (int64_t)blockIdx.x * waves_per_block + wave; piece < npieces_full;
+         piece += (int64_t)gridDim.x * waves_per_block) {
+        int nans = 0;
+        float s = leaf_sum(flat + piece * kPiece + lane * kLeaf, kLeaf, nans);
+        // numpy's recursion on 8192 = 64 leaves halves evenly: pair neighbours, then pairs of pairs ...
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const float other = __shfl_xor(s, d);
+            // the lower lane of each pair holds the left operand
+            s = (lane & d) ? other + s : s + other;
+        }
+        int tot_nans = nans;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) tot_nans += __shfl_xor(tot_nans, d);
+        if (lane == 0) {
+            piece_sums[piece] = s;
+            if (tot_nans) atomicAdd(nan_count, (unsigned long long)tot_nans);
+        }
+    }
+}
+
+__global__ void flat_norm_kernel(const float *__restrict__ flat, int64_t n, const float *__restrict__ piece_sums,
+                                 const unsigned long long *__restrict__ nan_count, float *__restrict__ norm_out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int64_t npieces_full = n / kPiece;
+    float res = 0.f;
+    for (int64_t i = 0; i < npieces_full; i++) res = res + piece_sums[i];
+    int nans = 0;
+    const int rem = (int)(n - npieces_full * kPiece);
+    if (rem > 0) res = res + pairwise_generic(flat + npieces_full * kPiece, rem, nans);
+    const unsigned long long bad = *nan_count + (unsigned long long)nans;
+    const double cnt = (double)(n - (int64_t)bad);
+    norm_out[0] = (float)((double)res / cnt);          // numpy 1.26: float32 / int -> float64 -> float32
+}
+
+__global__ __launch_bounds__(kBlock) void divide_by_scalar_kernel(const float *__restrict__ in,
+                                                                 const float *__restrict__ scalar,
+                                                                 float *__restrict__ out, int64_t n)
+{
+    const float s = scalar[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(in)[i];
+        reinterpret_cast<float4 *>(out)[i] =
+            make_float4(__fdiv_rn(a.x, s), __fdiv_rn(a.y, s), __fdiv_rn(a.z, s), __fdiv_rn(a.w, s));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = __fdiv_rn(in[i], s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4 threshold mask + count
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void threshold_mask_kernel(const float *__restrict__ data, int64_t n, double lo_d,
+                                                               double hi_d, const double *__restrict__ thr_dev,
+                                                               uint8_t *__restrict__ mask,
+                                                               unsigned long long *__restrict__ nbad)
+{
+    if (thr_dev) { lo_d = thr_dev[0]; hi_d = thr_dev[1]; }
+    const float lo = (float)lo_d, hi = (float)hi_d;     // numpy 1.26 demotes the float64 scalar to float32
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n / 4;
+    unsigned cnt = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = reinterpret_cast<const float4 *>(data)[i];
+        uchar4 m;
+        m.x = (a.x < lo) || (a.x > hi);
+        m.y = (a.y < lo) || (a.y > hi);
+        m.z = (a.z < lo) || (a.z > hi);
+        m.w = (a.w < lo) || (a.w > hi);
+        cnt += m.x + m.y + m.z + m.w;
+        reinterpret_cast<uchar4 *>(mask)[i] = m;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint8_t b = (data[i] < lo) || (data[i] > hi);
+        mask[i] = b;
+        cnt += b;
+    }
+    // wave reduction, one atomic per wave
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
+    if ((threadIdx.x % kWave) == 0 && cnt) atomicAdd(nbad, (unsigned long long)cnt);
+}
+
+__global__ __launch_bounds__(kBlock) void mask_add_rects_kernel(uint8_t *mask, int64_t W, const int32_t *__restrict__ rects,
+                                                               int value)
+{
+    // blockIdx.y = rectangle; rectangles are applied one launch-row each, overlapping rectangles
+    // are serialised by launching them in separate kernel calls from the host side (see C entry).
+    const int r0 = rects[0], r1 = rects[1], c0 = rects[2], c1 = rects[3];
+    const int64_t w = c1 - c0, h = r1 - r0;
+    const int64_t total = w * h;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = r0 + t / w, c = c0 + t % w;
+        mask[r * W + c] = (uint8_t)(mask[r * W + c] + value);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A8 image arithmetic
+// ------------------------------------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ float arith(float a, float b)
+{
+    if constexpr (OP == APGPU_OP_ADD) return a + b;
+    if constexpr (OP == APGPU_OP_SUB) return a - b;
+    if constexpr (OP == APGPU_OP_MUL) return a * b;
+    return __fdiv_rn(a, b);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void imarith_f32_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                            float scalar, float *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        float4 y = make_float4(scalar, scalar, scalar, scalar);
+        if (b) y = reinterpret_cast<const float4 *>(b)[i];
+        reinterpret_cast<float4 *>(out)[i] =
+            make_float4(arith<OP>(x.x, y.x), arith<OP>(x.y, y.y), arith<OP>(x.z, y.z), arith<OP>(x.w, y.w));
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = arith<OP>(a[i], b ? b[i] : scalar);
+}
+
+template <int OP>
+__global__ __launch_bounds__(kBlock) void imarith_u16_kernel(const uint16_t *__restrict__ a, const uint16_t *__restrict__ b,
+                                                            uint16_t *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned x = a[i], y = b[i];
+        unsigned r;
+        if constexpr (OP == APGPU_OP_ADD) r = x + y;
+        else if constexpr (OP == APGPU_OP_SUB) r = x - y;
+        else r = x * y;
+        out[i] = (uint16_t)r;                          // numpy integer ufuncs wrap modulo 2^16
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9 Bayer split
+// ------------------------------------------------------------------------------------------------
+struct BayerParams {
+    int pattern[4];
+    int black[4];
+};
+
+__global__ __launch_bounds__(kBlock) void bayer_split_kernel(const uint16_t *__restrict__ raw, int64_t H, int64_t W,
+                                                            BayerParams bp, uint16_t *__restrict__ planes)
+{
+    const int64_t P = H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += stride) {
+        const int64_t r = i / W, c = i - r * W;
+        const int k = bp.pattern[(int)(r & 1) * 2 + (int)(c & 1)];
+        int v = (int)raw[i] - bp.black[k];
+        v = v < 0 ? 0 : v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) planes[q * P + i] = (q == k) ? (uint16_t)v : (uint16_t)0;
+    }
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias, const float *dark, const float *nflat,
+                               const float *exp_ratio, const float *pedestal, int dark_still_biased, float *out,
+                               int64_t n_frames, int64_t n_pixels, void *stream)
+{
+    if (!raw || !bias || !dark || !exp_ratio || !out) return fail(APGPU_EINVAL, "calibrate: NULL pointer argument");
+    if (n_frames <= 0 || n_pixels <= 0) return fail(APGPU_EINVAL, "calibrate: empty slab (%lld x %lld)", (long long)n_frames, (long long)n_pixels);
+    if (raw_dtype != APGPU_F32 && raw_dtype != APGPU_U16) return fail(APGPU_EINVAL, "calibrate: bad raw dtype %d", raw_dtype);
+    if (!aligned16(raw) || !aligned16(bias) || !aligned16(dark) || !aligned16(out) || (nflat && !aligned16(nflat)))
+        return fail(APGPU_EINVAL, "calibrate: buffers must be 16-byte aligned");
+    const int vec = (n_pixels % 4) == 0 || n_frames == 1;
+    const unsigned grid = grid_for(n_frames * ((n_pixels + 3) / 4));
+    hipStream_t st = as_stream(stream);
+    if (raw_dtype == APGPU_F32)
+        hipLaunchKernelGGL(calibrate_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (const float *)raw, bias, dark, nflat,
+                           exp_ratio, pedestal, dark_still_biased, out, n_frames, n_pixels, vec);
+    else
+        hipLaunchKernelGGL(calibrate_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, st, (const uint16_t *)raw, bias, dark,
+                           nflat, exp_ratio, pedestal, dark_still_biased, out, n_frames, n_pixels, vec);
+    return check_launch("calibrate");
+}
+
+extern "C" size_t apgpu_flat_normalize_ws_bytes(int64_t n_pixels)
+{
+    if (n_pixels < 0) return 0;
+    return 16 + sizeof(float) * (size_t)(n_pixels / kPiece + 1);
+}
+
+extern "C" int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *norm_out, int64_t n_pixels, void *ws,
+                                        size_t ws_bytes, void *stream)
+{
+    if (!flat || !norm_out || !ws) return fail(APGPU_EINVAL, "flat_normalize: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "flat_normalize: n_pixels = %lld", (long long)n_pixels);
+    if (ws_bytes < apgpu_flat_normalize_ws_bytes(n_pixels))
+        return fail(APGPU_EWORKSPACE, "flat_normalize: workspace %zu < %zu bytes", ws_bytes, apgpu_flat_normalize_ws_bytes(n_pixels));
+    if (!aligned16(flat) || (nflat && !aligned16(nflat)) || !aligned16(ws)) return fail(APGPU_EINVAL, "flat_normalize: buffers must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    unsigned long long *nan_count = static_cast<unsigned long long *>(ws);
+    float *piece_sums = reinterpret_cast<float *>(static_cast<char *>(ws) + 16);
+    if (hipMemsetAsync(nan_count, 0, 16, st) != hipSuccess) return fail(APGPU_ELAUNCH, "flat_normalize: memset failed");
+    const int64_t npieces = n_pixels / kPiece;
+    if (npieces > 0) {
+        const unsigned grid = grid_for(npieces * kWave);
+        hipLaunchKernelGGL(flat_piece_sums_kernel, dim3(grid), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count);
+        if (int rc = check_launch("flat_piece_sums")) return rc;
+    }
+    hipLaunchKernelGGL(flat_norm_kernel, dim3(1), dim3(64), 0, st, flat, n_pixels, piece_sums, nan_count, norm_out);
+    if (int rc = check_launch("flat_norm")) return rc;
+    if (nflat) {
+        hipLaunchKernelGGL(divide_by_scalar_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, flat, norm_out, nflat,
+                           n_pixels);
+        if (int rc = check_launch("flat_divide")) return rc;
+    }
+    return APGPU_OK;
+}
+
+extern "C" int apgpu_threshold_mask_f32(const float *data, int64_t n_pixels, double lothresh, double hithresh,
+                                        const double *thresholds_dev, uint8_t *mask, int64_t *nbad_out, void *stream)
+{
+    if (!data || !mask || !nbad_out) return fail(APGPU_EINVAL, "threshold_mask: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "threshold_mask: n_pixels = %lld", (long long)n_pixels);
+    if (!aligned16(data) || (reinterpret_cast<uintptr_t>(mask) & 3)) return fail(APGPU_EINVAL, "threshold_mask: misaligned buffers");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(nbad_out, 0, sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "threshold_mask: memset failed");
+    hipLaunchKernelGGL(threshold_mask_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, data, n_pixels, lothresh,
+                       hithresh, thresholds_dev, mask, reinterpret_cast<unsigned long long *>(nbad_out));
+    return check_launch("threshold_mask");
+}
+
+extern "C" int apgpu_mask_add_rects_u8(uint8_t *mask, int64_t height, int64_t width, const int32_t *rects, int32_t n_rects,
+                                       int32_t value, void *stream)
+{
+    if (!mask || (n_rects > 0 && !rects)) return fail(APGPU_EINVAL, "mask_add_rects: NULL pointer argument");
+    if (height <= 0 || width <= 0 || n_rects < 0) return fail(APGPU_EINVAL, "mask_add_rects: bad shape");
+    hipStream_t st = as_stream(stream);
+    // one launch per rectangle: overlapping rectangles must accumulate (the reference sums flags),
+    // stream order serialises the read-modify-write of shared pixels.
+    for (int k = 0; k < n_rects; k++) {
+        hipLaunchKernelGGL(mask_add_rects_kernel, dim3(256), dim3(kBlock), 0, st, mask, width, rects + 4 * k, value);
+        if (int rc = check_launch("mask_add_rects")) return rc;
+    }
+    return APGPU_OK;
+}
+
+extern "C" int apgpu_imarith(const void *a, const void *b, double scalar, int op, int dtype, void *out, int64_t n_pixels,
+                             void *stream)
+{
+    if (!a || !out) return fail(APGPU_EINVAL, "imarith: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "imarith: n_pixels = %lld", (long long)n_pixels);
+    if (op < APGPU_OP_ADD || op > APGPU_OP_DIV) return fail(APGPU_EINVAL, "imarith: bad operation %d", op);
+    hipStream_t st = as_stream(stream);
+    const unsigned grid = grid_for(n_pixels / 4 + 1);
+    if (dtype == APGPU_F32) {
+        if (!aligned16(a) || !aligned16(out) || (b && !aligned16(b))) return fail(APGPU_EINVAL, "imarith: buffers must be 16-byte aligned");
+        const float *fa = (const float *)a, *fb = (const float *)b;
+        float *fo = (float *)out;
+        const float s = (float)scalar;
+        switch (op) {
+        case APGPU_OP_ADD: hipLaunchKernelGGL(imarith_f32_kernel<APGPU_OP_ADD>, dim3(grid), dim3(kBlock), 0, st, fa, fb, s, fo, n_pixels); break;
+        case APGPU_OP_SUB: hipLaunchKernelGGL(imarith_f32_kernel<APGPU_OP_SUB>, dim3(grid), dim3(kBlock), 0, st, fa, fb, s, fo, n_pixels); break;
+        case APGPU_OP_MUL: hipLaunchKernelGGL(imarith_f32_kernel<APGPU_OP_MUL>, dim3(grid), dim3(kBlock), 0, st, fa, fb, s, fo, n_pixels); break;
+        default: hipLaunchKernelGGL(imarith_f32_kernel<APGPU_OP_DIV>, dim3(grid), dim3(kBlock), 0, st, fa, fb, s, fo, n_pixels); break;
+        }
+    } else if (dtype == APGPU_U16) {
+        if (!b) return fail(APGPU_EUNSUPPORTED, "imarith: uint16 image (op) scalar is rejected (numpy raises UFuncTypeError)");
+        if (op == APGPU_OP_DIV) return fail(APGPU_EUNSUPPORTED, "imarith: uint16 DIV is rejected (numpy raises UFuncTypeError)");
+        const uint16_t *ua = (const uint16_t *)a, *ub = (const uint16_t *)b;
+        uint16_t *uo = (uint16_t *)out;
+        switch (op) {
+        case APGPU_OP_ADD: hipLaunchKernelGGL(imarith_u16_kernel<APGPU_OP_ADD>, dim3(grid), dim3(kBlock), 0, st, ua, ub, uo, n_pixels); break;
+        case APGPU_OP_SUB: hipLaunchKernelGGL(imarith_u16_kernel<APGPU_OP_SUB>, dim3(grid), dim3(kBlock), 0, st, ua, ub, uo, n_pixels); break;
+        default: hipLaunchKernelGGL(imarith_u16_kernel<APGPU_OP_MUL>, dim3(grid), dim3(kBlock), 0, st, ua, ub, uo, n_pixels); break;
+        }
+    } else {
+        return fail(APGPU_EINVAL, "imarith: bad dtype %d", dtype);
+    }
+    return check_launch("imarith");
+}
+
+extern "C" int apgpu_bayer_split_u16(const uint16_t *raw, int64_t height, int64_t width, const int32_t *pattern_host,
+                                     const int32_t *black_host, uint16_t *planes, void *stream)
+{
+    if (!raw || !planes || !pattern_host) return fail(APGPU_EINVAL, "bayer_split: NULL pointer argument");
+    if (height <= 0 || width <= 0) return fail(APGPU_EINVAL, "bayer_split: bad shape");
+    BayerParams bp;
+    for (int k = 0; k < 4; k++) {
+        if (pattern_host[k] < 0 || pattern_host[k] > 3) return fail(APGPU_EINVAL, "bayer_split: pattern entries must be 0..3");
+        bp.pattern[k] = pattern_host[k];
+        bp.black[k] = black_host ? black_host[k] : 0;
+    }
+    hipLaunchKernelGGL(bayer_split_kernel, dim3(grid_for(height * width)), dim3(kBlock), 0, as_stream(stream), raw, height, width,
+                       bp, planes);
+    return check_launch("bayer_split");
+}

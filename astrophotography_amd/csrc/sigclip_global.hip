@@ -1,0 +1,497 @@
+// sigclip_global.hip - A3: astropy.stats.sigma_clipped_stats(data, sigma) with axis=None, the call
+// ApFindBadPixels makes on a master dark (core/ApFindBadPixels.py:191), on gfx950.
+//
+// Reference algorithm (astropy/stats/sigma_clipping.py:385-433 _sigmaclip_noaxis with numpy
+// nan-functions - the reference environment has no bottleneck):
+//     x = finite values of data (order kept)
+//     repeat <= maxiters:  c = np.nanmedian(x); s = np.nanstd(x)
+//                          x = x[(x >= c - s*sigma_lower) & (x <= c + s*sigma_upper)]
+//                          stop when nothing was removed
+//     return np.nanmean(x), np.nanmedian(x), np.nanstd(x)
+// For float32 input numpy does all of this in float32 and the result depends on numpy's summation
+// tree, so the tree is reproduced exactly (bit-exact statistics -> bit-exact bad-pixel mask):
+//     np.sum      = sequential float32 fold of 8192-element pieces, each piece a pairwise tree over
+//                   128-element leaves with 8 strided accumulators  (numpy loops_utils.h.src)
+//     np.median   = exact order statistic (radix select on order-preserving keys, 4 x 8-bit passes);
+//                   even count -> float32(a + b) / 2
+//     np.var      = mean = sum / float32(n); float32 sum of (x - mean)^2; float32(float64(sum) / n)
+//     bounds      = float64 (np.float32 * python float promotes to float64 under numpy 1.26), demoted
+//                   to float32 when compared with the float32 array
+// The surviving values are kept compacted IN ORDER in a ping-pong pair of workspace buffers because
+// the summation tree depends on element positions.
+//
+// Everything runs on the stream without host synchronisation: the iteration count is a launch-time
+// constant and a device-side `done` flag turns the remaining iterations into no-ops.
+// Traffic: ~9 reads + 1 write of the surviving values per iteration (67 MB at 4096^2 - resident in the
+// 256 MB Infinity Cache after the first pass).
+#include "common.h"
+
+namespace {
+using namespace apgpu;
+
+constexpr int kBlock = 256;
+constexpr int kTile = 2048;            // elements per compaction tile (8 per thread)
+constexpr int kPiece = 8192;           // numpy reduction buffer
+constexpr int kLeaf = 128;             // numpy PW_BLOCKSIZE
+constexpr int kMaxItersCap = 32;
+
+struct GState {
+    long long m;                // survivors in the current buffer
+    long long m_next;
+    long long k;                // rank searched by the radix select
+    unsigned long long cnt_less;
+    unsigned prefix;            // key prefix found so far
+    unsigned max_less_key;      // order-preserving key of max{x < v_hi}
+    int done;                   // set when an iteration removed nothing
+    int iter;                   // iterations executed
+    int cur;                    // index (0/1) of the buffer holding the survivors
+    int pad;
+    float tot;                  // np.sum of the survivors
+    float s2;                   // np.sum((x - mean)^2)
+    float med, sd;
+    double lo, hi;
+    unsigned hist[256];
+};
+
+__device__ __forceinline__ unsigned f2key(float x)
+{
+    const unsigned b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(b);
+}
+
+// ---- order-preserving compaction: tile counts -> scan -> scatter -------------------------------
+// mode 0: keep finite values of `data` (length n, host-known); mode 1: keep lo <= x <= hi of the
+// current survivors (length st->m).
+template <int MODE>
+__device__ __forceinline__ bool keep_pred(float x, float lof, float hif)
+{
+    if constexpr (MODE == 0) return fabsf(x) < __builtin_inff();
+    else return (x >= lof) && (x <= hif);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restrict__ src0, const float *__restrict__ src1,
+                                                           long long n_static, const GState *__restrict__ st,
+                                                           unsigned *__restrict__ tile_counts)
+{
+    if (MODE == 1 && st->done) return;
+    const float *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
+    const long long m = (MODE == 0) ? n_static : st->m;
+    const float lof = (float)st->lo, hif = (float)st->hi;
+    const long long ntiles = (m + kTile - 1) / kTile;
+    __shared__ unsigned wsum[kBlock / kWave];
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + (long long)threadIdx.x * 8;
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const long long i = base + j;
+            if (i < m) c += keep_pred<MODE>(src[i], lof, hif) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) c += __shfl_down(c, d);
+        if ((threadIdx.x % kWave) == 0) wsum[threadIdx.x / kWave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GState *__restrict__ st,
+                                                        const unsigned *__restrict__ tile_counts,
+                                                        unsigned long long *__restrict__ tile_offsets)
+{
+    if (MODE == 1 && st->done) return;
+    const long long m = (MODE == 0) ? n_static : st->m;
+    const long long ntiles = (m + kTile - 1) / kTile;
+    const long long per = (ntiles + 1023) / 1024;
+    const long long t0 = (long long)threadIdx.x * per;
+    const long long t1 = t0 + per < ntiles ? t0 + per : ntiles;
+    unsigned long long local = 0;
+    for (long long t = t0; t < t1; t++) local += tile_counts[t];
+    __shared__ unsigned long long sums[1024];
+    sums[threadIdx.x] = local;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int d = 1; d < 1024; d <<= 1) {
+        unsigned long long v = threadIdx.x >= d ? sums[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = sums[threadIdx.x] - local;
+    for (long long t = t0; t < t1; t++) {
+        tile_offsets[t] = run;
+        run += tile_counts[t];
+    }
+    if (threadIdx.x == 1023) st->m_next = (long long)sums[1023];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void tile_scatter_kernel(const float *__restrict__ src0, const float *__restrict__ src1,
+                                                             float *__restrict__ dst0, float *__restrict__ dst1,
+                                                             long long n_static, const GState *__restrict__ st,
+                                                             const unsigned long long *__restrict__ tile_offsets)
+{
+    if (MODE == 1 && st->done) return;
+    const float *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
+    float *dst = (MODE == 0) ? dst0 : (st->cur ? dst0 : dst1);
+    const long long m = (MODE == 0) ? n_static : st->m;
+    const float lof = (float)st->lo, hif = (float)st->hi;
+    const long long ntiles = (m + kTile - 1) / kTile;
+    __shared__ unsigned wsum[kBlock / kWave];
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + (long long)threadIdx.x * 8;
+        float x[8];
+        bool kp[8];
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const long long i = base + j;
+            x[j] = i < m ? src[i] : 0.f;
+            kp[j] = (i < m) && keep_pred<MODE>(x[j], lof, hif);
+            c += kp[j] ? 1u : 0u;
+        }
+        // exclusive scan of c over the block: wave inclusive scan + wave totals
+        unsigned inc = c;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        unsigned long long pos = tile_offsets[tile] + woff + (inc - c);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (kp[j]) dst[pos++] = x[j];
+        __syncthreads();
+    }
+}
+
+// commit a compaction: MODE 0 initialises the state, MODE 1 closes a clipping iteration
+template <int MODE>
+__global__ void commit_kernel(GState *st)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (MODE == 0) {
+        st->m = st->m_next;
+        st->cur = 0;
+        st->done = 0;
+        st->iter = 0;
+        st->lo = __builtin_nan("");
+        st->hi = __builtin_nan("");
+        for (int i = 0; i < 256; i++) st->hist[i] = 0;
+    } else {
+        if (st->done) return;
+        st->iter += 1;
+        if (st->m_next == st->m) st->done = 1;      // nothing removed: survivors stay in buffer `cur`
+        else { st->m = st->m_next; st->cur ^= 1; }
+    }
+}
+
+// ---- exact median: radix select ------------------------------------------------------------------
+__global__ void select_begin_kernel(GState *st, int final_pass)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!final_pass && st->done) return;
+    st->k = st->m / 2;              // upper median rank (0-based); odd m: the median itself
+    st->prefix = 0;
+    st->cnt_less = 0;
+    st->max_less_key = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void hist_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+                                                     GState *__restrict__ st, int pass, int final_pass)
+{
+    if (!final_pass && st->done) return;
+    const float *src = st->cur ? b1 : b0;
+    const long long m = st->m;
+    const int shift = 24 - 8 * pass;
+    const unsigned prefix = st->prefix;
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned key = f2key(src[i]);
+        const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
+        if (match) atomicAdd(&h[(key >> shift) & 0xffu], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void select_digit_kernel(GState *st, int final_pass)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!final_pass && st->done) return;
+    long long k = st->k;
+    unsigned d = 0;
+    long long cum = 0;
+    for (d = 0; d < 256; d++) {
+        const long long c = st->hist[d];
+        if (k < cum + c) break;
+        cum += c;
+    }
+    if (d > 255) d = 255;
+    st->k = k - cum;
+    st->prefix = (st->prefix << 8) | d;
+    for (int i = 0; i < 256; i++) st->hist[i] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void less_stats_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+                                                           GState *__restrict__ st, int final_pass)
+{
+    if (!final_pass && st->done) return;
+    const float *src = st->cur ? b1 : b0;
+    const long long m = st->m;
+    const unsigned vkey = st->prefix;
+    unsigned cnt = 0, mx = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned key = f2key(src[i]);
+        if (key < vkey) { cnt++; mx = key > mx ? key : mx; }
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        cnt += __shfl_down(cnt, d);
+        const unsigned o = __shfl_down(mx, d);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x % kWave) == 0 && cnt) {
+        atomicAdd(&st->cnt_less, (unsigned long long)cnt);
+        atomicMax(&st->max_less_key, mx);
+    }
+}
+
+__global__ void median_finish_kernel(GState *st, int final_pass)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!final_pass && st->done) return;
+    const long long m = st->m;
+    if (m <= 0) { st->med = __builtin_nanf(""); return; }
+    const float vhi = key2f(st->prefix);
+    if (m & 1) { st->med = vhi; return; }
+    const long long k2 = m / 2;
+    // rank k2-1 holds vhi again if fewer than k2 values are strictly below vhi
+    const float vlo = ((long long)st->cnt_less <= k2 - 1) ? vhi : key2f(st->max_less_key);
+    const float t = vlo + vhi;                              // np.mean of the two middle float32 values
+    st->med = (float)((double)t / 2.0);
+}
+
+// ---- numpy float32 pairwise sums --------------------------------------------------------------------
+template <int SQ>
+__device__ __forceinline__ float tr(float x, float mean)
+{
+    if constexpr (SQ) { const float d = x - mean; return d * d; }
+    else return x;
+}
+
+template <int SQ>
+__device__ float leaf_sum(const float *a, int n, float mean)
+{
+    float r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = tr<SQ>(a[k], mean);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ>(a[i + k], mean);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + tr<SQ>(a[i], mean);
+    return res;
+}
+
+template <int SQ>
+__device__ float pairwise_rec(const float *a, int n, float mean)
+{
+    // numpy's recursion for a ragged piece (n < 8192); depth <= 7
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res = res + tr<SQ>(a[i], mean);
+        return res;
+    }
+    if (n <= kLeaf) return leaf_sum<SQ>(a, n, mean);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const float l = pairwise_rec<SQ>(a, n2, mean);
+    const float r = pairwise_rec<SQ>(a + n2, n - n2, mean);
+    return l + r;
+}
+
+__device__ __forceinline__ float var_mean(const GState *st)
+{
+    return st->tot / (float)st->m;          // np.var: arrmean = true_divide(sum, n) in float32
+}
+
+template <int SQ>
+__global__ __launch_bounds__(kBlock) void piece_sums_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+                                                           const GState *__restrict__ st, float *__restrict__ piece_sums,
+                                                           int final_pass)
+{
+    if (!final_pass && st->done) return;
+    const float *src = st->cur ? b1 : b0;
+    const long long m = st->m;
+    const float mean = SQ ? var_mean(st) : 0.f;
+    const long long npieces_full = m / kPiece;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    const int wpb = kBlock / kWave;
+    for (long long piece = (long long)blockIdx.x * wpb + wave; piece < npieces_full; piece += (long long)gridDim.x * wpb) {
+        float s = leaf_sum<SQ>(src + piece * kPiece + lane * kLeaf, kLeaf, mean);
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const float other = __shfl_xor(s, d);
+            s = (lane & d) ? other + s : s + other;
+        }
+        if (lane == 0) piece_sums[piece] = s;
+    }
+}
+
+template <int SQ>
+__global__ void fold_kernel(const float *__restrict__ b0, const float *__restrict__ b1, GState *__restrict__ st,
+                            const float *__restrict__ piece_sums, int final_pass)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!final_pass && st->done) return;
+    const float *src = st->cur ? b1 : b0;
+    const long long m = st->m;
+    const float mean = SQ ? var_mean(st) : 0.f;
+    const long long npieces_full = m / kPiece;
+    float res = 0.f;
+    for (long long i = 0; i < npieces_full; i++) res = res + piece_sums[i];
+    const int rem = (int)(m - npieces_full * kPiece);
+    if (rem > 0) res = res + pairwise_rec<SQ>(src + npieces_full * kPiece, rem, mean);
+    if (SQ) {
+        st->s2 = res;
+        const float var = (float)((double)res / (double)m);
+        st->sd = sqrtf(var);
+    } else {
+        st->tot = res;
+    }
+}
+
+__global__ void bounds_kernel(GState *st, double sigma_lower, double sigma_upper)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st->done) return;
+    if (st->m <= 0) { st->lo = st->hi = __builtin_nan(""); return; }
+    // SigmaClip._compute_bounds: float32 scalars * python float -> float64 (numpy 1.26)
+    st->lo = (double)st->med - (double)st->sd * sigma_lower;
+    st->hi = (double)st->med + (double)st->sd * sigma_upper;
+}
+
+__global__ void publish_kernel(const GState *st, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long m = st->m;
+    const double nan = __builtin_nan("");
+    out[0] = m > 0 ? (double)(float)((double)st->tot / (double)m) : nan;    // np.mean: f32(f64(sum)/n)
+    out[1] = m > 0 ? (double)st->med : nan;
+    out[2] = m > 0 ? (double)st->sd : nan;
+    out[3] = st->lo;
+    out[4] = st->hi;
+    out[5] = (double)st->iter;
+    out[6] = (double)m;
+    out[7] = 0.0;
+}
+
+struct WsLayout {
+    size_t state, buf0, buf1, pieces, tcounts, toffsets, total;
+};
+
+WsLayout layout(int64_t n)
+{
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    WsLayout L;
+    size_t off = 0;
+    L.state = off; off = up(off + sizeof(GState));
+    L.buf0 = off; off = up(off + sizeof(float) * (size_t)n);
+    L.buf1 = off; off = up(off + sizeof(float) * (size_t)n);
+    L.pieces = off; off = up(off + sizeof(float) * (size_t)(n / kPiece + 1));
+    const size_t ntiles = (size_t)((n + kTile - 1) / kTile);
+    L.tcounts = off; off = up(off + sizeof(unsigned) * (ntiles + 1));
+    L.toffsets = off; off = up(off + sizeof(unsigned long long) * (ntiles + 1));
+    L.total = off;
+    return L;
+}
+
+}  // namespace
+
+extern "C" size_t apgpu_sigclip_global_ws_bytes(int64_t n_pixels)
+{
+    if (n_pixels <= 0) return 0;
+    return layout(n_pixels).total;
+}
+
+extern "C" int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters,
+                                        double *stats_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!data || !stats_out || !ws) return fail(APGPU_EINVAL, "sigclip_global: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "sigclip_global: n_pixels = %lld", (long long)n_pixels);
+    if (maxiters == 0) return fail(APGPU_EINVAL, "sigclip_global: maxiters must be >= 1 or < 0");
+    const WsLayout L = layout(n_pixels);
+    if (ws_bytes < L.total) return fail(APGPU_EWORKSPACE, "sigclip_global: workspace %zu < %zu bytes", ws_bytes, L.total);
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(APGPU_EINVAL, "sigclip_global: workspace must be 16-byte aligned");
+    // maxiters < 0 (until convergence): the device loop is a launch-time constant; 32 passes always
+    // converge in practice (every pass but the last removes at least one value).
+    const int iters = (maxiters < 0 || maxiters > kMaxItersCap) ? kMaxItersCap : maxiters;
+    char *w = static_cast<char *>(ws);
+    GState *st = reinterpret_cast<GState *>(w + L.state);
+    float *b0 = reinterpret_cast<float *>(w + L.buf0);
+    float *b1 = reinterpret_cast<float *>(w + L.buf1);
+    float *pieces = reinterpret_cast<float *>(w + L.pieces);
+    unsigned *tcounts = reinterpret_cast<unsigned *>(w + L.tcounts);
+    unsigned long long *toffs = reinterpret_cast<unsigned long long *>(w + L.toffsets);
+    hipStream_t s = as_stream(stream);
+    const long long n = n_pixels;
+    const long long ntiles = (n + kTile - 1) / kTile;
+    const unsigned gtile = (unsigned)(ntiles < kNumCU * 8 ? ntiles : kNumCU * 8);
+    const unsigned gflat = (unsigned)((n + kBlock - 1) / kBlock < kNumCU * 8 ? (n + kBlock - 1) / kBlock : kNumCU * 8);
+    const unsigned gpiece = (unsigned)((n / kPiece) / (kBlock / kWave) + 1 < kNumCU * 8 ? (n / kPiece) / (kBlock / kWave) + 1 : kNumCU * 8);
+
+    if (hipMemsetAsync(st, 0, sizeof(GState), s) != hipSuccess) return fail(APGPU_ELAUNCH, "sigclip_global: memset failed");
+    // finite values of data -> buffer 0
+    hipLaunchKernelGGL(tile_count_kernel<0>, dim3(gtile), dim3(kBlock), 0, s, data, data, n, st, tcounts);
+    hipLaunchKernelGGL(tile_scan_kernel<0>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
+    hipLaunchKernelGGL(tile_scatter_kernel<0>, dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, toffs);
+    hipLaunchKernelGGL(commit_kernel<0>, dim3(1), dim3(64), 0, s, st);
+    if (int rc = check_launch("sigclip_global: compact finite")) return rc;
+
+    auto stats_pass = [&](int final_pass) {
+        hipLaunchKernelGGL(select_begin_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
+        for (int pass = 0; pass < 4; pass++) {
+            hipLaunchKernelGGL(hist_kernel, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
+            hipLaunchKernelGGL(select_digit_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
+        }
+        hipLaunchKernelGGL(less_stats_kernel, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, final_pass);
+        hipLaunchKernelGGL(median_finish_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
+        hipLaunchKernelGGL(piece_sums_kernel<0>, dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL(fold_kernel<0>, dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL(piece_sums_kernel<1>, dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL(fold_kernel<1>, dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+    };
+
+    for (int it = 0; it < iters; it++) {
+        stats_pass(0);
+        hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, s, st, sigma_lower, sigma_upper);
+        hipLaunchKernelGGL(tile_count_kernel<1>, dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, tcounts);
+        hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
+        hipLaunchKernelGGL(tile_scatter_kernel<1>, dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, toffs);
+        hipLaunchKernelGGL(commit_kernel<1>, dim3(1), dim3(64), 0, s, st);
+        if (int rc = check_launch("sigclip_global: iteration")) return rc;
+    }
+    // statistics of the survivors (the last iteration's statistics belong to the pre-clip set unless
+    // it removed nothing)
+    stats_pass(1);
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, st, stats_out);
+    return check_launch("sigclip_global: publish");
+}

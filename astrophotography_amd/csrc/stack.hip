@@ -1,0 +1,105 @@
+// stack.hip - argument checking and dispatch for the stack reductions (kernels: stack_kernels.h,
+// instantiated per raw dtype / fused-calibration flag in stack_inst_*.hip so they build in parallel).
+#include "stack_kernels.h"
+
+namespace apgpu_stack {
+extern template int launch_np<float, true>(const StackParams &, bool, hipStream_t);
+extern template int launch_np<float, false>(const StackParams &, bool, hipStream_t);
+extern template int launch_np<uint16_t, true>(const StackParams &, bool, hipStream_t);
+extern template int launch_np<uint16_t, false>(const StackParams &, bool, hipStream_t);
+}  // namespace apgpu_stack
+
+namespace {
+using namespace apgpu;
+using namespace apgpu_stack;
+
+__global__ __launch_bounds__(256) void moments_finalize_kernel(const float *__restrict__ mom, float *mean,
+                                                              float *std, int64_t P)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const float s = mom[p], q = mom[P + p], n = mom[2 * P + p];
+    const float m = s / n;                                    // n == 0 -> NaN
+    if (mean) mean[p] = n > 0.f ? m : __builtin_nanf("");
+    if (std) {
+        float var = q / n - m * m;
+        var = var > 0.f ? var : 0.f;
+        std[p] = n > 0.f ? sqrtf(var) : __builtin_nanf("");
+    }
+}
+
+int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
+{
+    if (!args) return fail(APGPU_EINVAL, "stack: args is NULL");
+    if (!args->frames) return fail(APGPU_EINVAL, "stack: frames is NULL");
+    if (args->n_pixels <= 0) return fail(APGPU_EINVAL, "stack: n_pixels = %lld", (long long)args->n_pixels);
+    if (args->n_frames < 1) return fail(APGPU_EINVAL, "stack: n_frames = %d", args->n_frames);
+    if (args->n_frames > APGPU_MAX_STACK)
+        return fail(APGPU_EUNSUPPORTED, "stack: n_frames = %d exceeds APGPU_MAX_STACK = %d (shard the frames or "
+                    "combine partial moments)", args->n_frames, APGPU_MAX_STACK);
+    if (args->dtype != APGPU_F32 && args->dtype != APGPU_U16) return fail(APGPU_EINVAL, "stack: bad dtype %d", args->dtype);
+    const bool calib = args->bias != nullptr;
+    if (calib && (!args->dark || !args->exp_ratio))
+        return fail(APGPU_EINVAL, "stack: fused calibration needs bias, dark and exp_ratio");
+    if (!median_only) {
+        if (args->center != APGPU_CENTER_MEDIAN && args->center != APGPU_CENTER_MEAN)
+            return fail(APGPU_EINVAL, "stack: bad center %d", args->center);
+        if (args->dev != APGPU_DEV_STD && args->dev != APGPU_DEV_MAD_STD)
+            return fail(APGPU_EINVAL, "stack: bad dev %d", args->dev);
+        if (args->dev == APGPU_DEV_MAD_STD)
+            return fail(APGPU_EUNSUPPORTED, "stack: dev = mad_std is not built yet");
+        if (args->maxiters == 0) return fail(APGPU_EINVAL, "stack: maxiters must be >= 1 or < 0");
+        if (!(args->sigma_lower >= 0.0) || !(args->sigma_upper >= 0.0))
+            return fail(APGPU_EINVAL, "stack: sigma must be >= 0");
+        if (!args->mean && !args->median && !args->std && !args->count && !args->moments)
+            return fail(APGPU_EINVAL, "stack: no output requested");
+    } else if (!args->median) {
+        return fail(APGPU_EINVAL, "stack_median: median output is NULL");
+    }
+    StackParams prm{};
+    prm.frames = args->frames;
+    prm.bias = args->bias;
+    prm.dark = args->dark;
+    prm.nflat = args->nflat;
+    prm.exp_ratio = args->exp_ratio;
+    prm.pedestal = args->pedestal;
+    prm.pixmask = args->pixmask;
+    prm.mean = args->mean;
+    prm.median = args->median;
+    prm.std = args->std;
+    prm.moments = args->moments;
+    prm.count = args->count;
+    prm.P = args->n_pixels;
+    prm.sl2 = args->sigma_lower * args->sigma_lower;
+    prm.su2 = args->sigma_upper * args->sigma_upper;
+    prm.N = args->n_frames;
+    prm.still_biased = args->dark_still_biased;
+    prm.center = args->center;
+    prm.maxiters = args->maxiters;
+    hipStream_t st = as_stream(stream);
+    if (args->dtype == APGPU_F32)
+        return calib ? launch_np<float, true>(prm, median_only, st) : launch_np<float, false>(prm, median_only, st);
+    return calib ? launch_np<uint16_t, true>(prm, median_only, st) : launch_np<uint16_t, false>(prm, median_only, st);
+}
+
+}  // namespace
+
+extern "C" int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream)
+{
+    return stack_dispatch(args, false, stream);
+}
+
+extern "C" int apgpu_stack_median(const apgpu_stack_args *args, void *stream)
+{
+    return stack_dispatch(args, true, stream);
+}
+
+extern "C" int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_t n_pixels, void *stream)
+{
+    if (!moments || n_pixels <= 0) return fail(APGPU_EINVAL, "moments_finalize: bad arguments");
+    const int block = 256;
+    const int64_t grid = (n_pixels + block - 1) / block;
+    hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)grid), dim3(block), 0, as_stream(stream), moments, mean,
+                       std, n_pixels);
+    return check_launch("moments_finalize");
+}

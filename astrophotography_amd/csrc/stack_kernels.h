@@ -1,0 +1,452 @@
+// stack_kernels.h - per-pixel reduction of a frame slab [N][P] along N on gfx950 (MI355X).
+//
+// Replaces, for the N-frame stack, the arithmetic of
+//   astropy.stats.sigma_clipped_stats(cube, axis=0)        (astropy/stats/sigma_clipping.py:298-383,
+//                                                           924-937; C loop src/compute_bounds.c)
+//   ccdproc.combine(sigma_clip=True, median/mad_std)       (reference call site
+//                                                           scripts/ap_combine_darks.py:394-420)
+// optionally fused with ApCalibrate.calibrate's per-value arithmetic (core/ApCalibrate.py:439-464)
+// so that a raw slab is read from HBM exactly once.
+//
+// Data layout: frames[f][p], p fastest.  One lane owns one pixel: for every frame f a wavefront
+// reads 64 consecutive pixels (a fully coalesced 256-byte segment for f32), so the N loads of a
+// lane are N independent row streams.  The lane's column of N values stays in VGPRs for the whole
+// kernel (N <= 128): it is sorted once with a Batcher odd-even merge network (static register
+// indices only), after which every clipping iteration only trims the two ends of the sorted column:
+//   survivors are always a contiguous range [a, b) of the sorted column,
+//   S = sum(x - c), Q = sum((x - c)^2) over the range are kept in float64 relative to a pivot c
+//   (the first median) and updated for the few trimmed elements only,
+//   keep-tests are done without division or square root:
+//        x >= cen - s_lo*std   <=>   not( w < 0 and w^2 > s_lo^2 * (n*Q - S^2) ),  w = n*(x - cen)
+// The bound is algebraically the one astropy computes (cen +/- sigma*sqrt(sum((mean-x)^2)/n));
+// it differs from astropy's float64 evaluation by a few ulp(float64), far below the float32 spacing of
+// the data, so keep/reject decisions - and therefore the survivors - are identical.
+//
+// HBM traffic per output pixel (algorithmic): N*sizeof(raw) + 12 (bias, dark, nflat) read,
+// 4 per requested output plane written.  No LDS, no cross-lane traffic: the kernel is a pure
+// stream-in / reduce-in-registers / stream-out design, bounded by HBM when the VALU work hides.
+#pragma once
+#include "common.h"
+
+#include <utility>
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+// -------------------------------------------------------------------------------------------------
+// Batcher odd-even merge sorting network for NP = 2^k inputs, generated at compile time.
+// -------------------------------------------------------------------------------------------------
+struct CE {
+    unsigned char a, b;
+};
+
+template <int NP>
+struct Net {
+    CE ce[NP * 12];     // NP=128 needs 1471 < 1536
+    int n;
+};
+
+template <int NP>
+constexpr Net<NP> make_net()
+{
+    Net<NP> net{};
+    int c = 0;
+    for (int p = 1; p < NP; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= NP - 1 - k; j += 2 * k) {
+                int lim = (k - 1 < NP - j - k - 1) ? k - 1 : NP - j - k - 1;
+                for (int i = 0; i <= lim; i++)
+                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2)) {
+                        net.ce[c].a = (unsigned char)(i + j);
+                        net.ce[c].b = (unsigned char)(i + j + k);
+                        c++;
+                    }
+            }
+    net.n = c;
+    return net;
+}
+
+__device__ __forceinline__ void cmpx(float &x, float &y)
+{
+    float lo = fminf(x, y);
+    float hi = fmaxf(x, y);
+    x = lo;
+    y = hi;
+}
+
+template <int NP, int BASE, int... I>
+__device__ __forceinline__ void net_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_net<NP>();
+    (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int NP, int BASE>
+__device__ __forceinline__ void net_from(float (&v)[NP])
+{
+    constexpr int total = make_net<NP>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        net_chunk<NP, BASE>(v, std::make_integer_sequence<int, len>{});
+        net_from<NP, BASE + len>(v);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void sort_column(float (&v)[NP])
+{
+    if constexpr (NP > 1) net_from<NP, 0>(v);
+}
+
+// v[idx] for a per-lane index: binary multiplexer tree (NP-1 v_cndmask), static register indices.
+template <int LO, int LEN, int NP>
+__device__ __forceinline__ float pick(const float (&v)[NP], int idx)
+{
+    if constexpr (LEN == 1) {
+        return v[LO];
+    } else {
+        constexpr int H = LEN / 2;
+        float lo = pick<LO, H, NP>(v, idx);
+        float hi = pick<LO + H, H, NP>(v, idx);
+        return (idx & H) ? hi : lo;
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ float pick_at(const float (&v)[NP], int idx)
+{
+    idx = idx < 0 ? 0 : (idx > NP - 1 ? NP - 1 : idx);
+    return pick<0, NP, NP>(v, idx);
+}
+
+// Per-lane state of the clipping loop.  Survivors are v[a .. b) of the sorted column.
+struct ClipState {
+    double S, Q;            // sum(x - c), sum((x - c)^2) over the survivors
+    double c;               // pivot
+    double cen, nn;         // centre and count the last bounds were computed with
+    double Tlo, Thi;        // sigma^2 * (n*Q - S^2): squared, n^2-scaled half-widths of the bounds
+    int a, b;
+};
+
+__device__ __forceinline__ bool below(const ClipState &st, double xd)
+{
+    const double w = st.nn * (xd - st.cen);
+    return (w < 0.0) && (w * w > st.Tlo);
+}
+
+__device__ __forceinline__ bool above(const ClipState &st, double xd)
+{
+    const double w = st.nn * (xd - st.cen);
+    return (w > 0.0) && (w * w > st.Thi);
+}
+
+// float -> double of a column element, opaque to the optimiser: without the barrier LLVM hoists and
+// CSEs the 64 conversions out of the clipping loop and keeps 64 doubles (128 VGPRs) live.
+__device__ __forceinline__ double widen(float x)
+{
+    asm volatile("" : "+v"(x));
+    return (double)x;
+}
+
+// Trim rejected values from the low end: element I, then (only if some lane still has its cut
+// above I) element I+1, ...  Static recursion keeps every register index a compile-time constant.
+template <int I, int NP>
+__device__ __forceinline__ void trim_low(const float (&v)[NP], ClipState &st, bool active)
+{
+    if constexpr (I < NP) {
+        const double xd = widen(v[I]);
+        const bool rej = active && (I >= st.a) && (I < st.b) && below(st, xd);
+        if (rej) {
+            const double d = xd - st.c;
+            st.S -= d;
+            st.Q = fma(-d, d, st.Q);
+            st.a = I + 1;
+        }
+        if (__any(active && (st.a > I))) trim_low<I + 1, NP>(v, st, active);
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
+{
+    if constexpr (I >= 0) {
+        const double xd = widen(v[I]);
+        const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
+        if (rej) {
+            const double d = xd - st.c;
+            st.S -= d;
+            st.Q = fma(-d, d, st.Q);
+            st.b = I;
+        }
+        if (__any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void readmit_low(const float (&v)[NP], ClipState &st, int &a_new)
+{
+    if constexpr (I < NP) {
+        if (__any(I < st.a)) {
+            const double xd = widen(v[I]);
+            const bool keep = (I < st.a) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                a_new = a_new < I ? a_new : I;
+            }
+            readmit_low<I + 1, NP>(v, st, a_new);
+        }
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new)
+{
+    if constexpr (I >= 0) {
+        if (__any(I >= st.b)) {
+            const double xd = widen(v[I]);
+            const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                b_new = b_new > I + 1 ? b_new : I + 1;
+            }
+            readmit_high<I - 1, NP>(v, st, n, b_new);
+        }
+    }
+}
+
+struct StackParams {
+    const void *frames;
+    const float *bias, *dark, *nflat, *exp_ratio, *pedestal;
+    const uint8_t *pixmask;
+    float *mean, *median, *std, *moments;
+    int32_t *count;
+    int64_t P;
+    double sl2, su2;        // sigma_lower^2, sigma_upper^2
+    int N;
+    int still_biased;
+    int center;             // 0 median, 1 mean
+    int maxiters;           // < 0: until convergence
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
+
+// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
+// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY>
+__device__ __forceinline__ int load_column(const StackParams &prm, int64_t base, int lane, float (&v)[NP])
+{
+    // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
+    const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
+    const int N = prm.N;
+    const int64_t P = prm.P;
+    const int64_t p = base + lane;
+    RawT raw[NP];
+#pragma unroll
+    for (int f = 0; f < NP; f++) {
+        raw[f] = fb[lane];
+        if (f + 1 < N) fb += P;                 // padded slots re-read the last frame (cache hit)
+    }
+    float b = 0.f, D = 0.f, nf = 1.f;
+    bool dodiv = false;
+    if constexpr (CALIB) {
+        b = prm.bias[p];
+        const float d = prm.dark[p];
+        D = prm.still_biased ? d - b : d;                    // ApCalibrate.py:440-445
+        if (prm.nflat) {
+            nf = prm.nflat[p];
+            dodiv = (nf != 0.f);                             // ApCalibrate.py:462 (NaN != 0 is True)
+        }
+    }
+    const bool skip = prm.pixmask && prm.pixmask[p];
+    int n = 0;
+#pragma unroll
+    for (int f = 0; f < NP; f++) {
+        float x = to_f32(raw[f]);
+        if constexpr (CALIB) {
+            const int ff = f < N ? f : N - 1;
+            const float e = prm.exp_ratio[ff];
+            const float ped = prm.pedestal ? prm.pedestal[ff] : 0.f;
+            if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
+            x = x - b;                                       // :439
+            const float ds = e * D;                          // :450
+            x = x - ds;                                      // :451
+            if (dodiv) x = __fdiv_rn(x, nf);                 // :463
+        }
+        bool ok;
+        if constexpr (FINITE_ONLY) ok = fabsf(x) < __builtin_inff();
+        else ok = (x == x);
+        ok = ok && (f < N) && !skip;
+        n += ok ? 1 : 0;
+        v[f] = ok ? x : __builtin_inff();
+    }
+    return n;
+}
+
+template <int NP, typename RawT, bool CALIB>
+__global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams prm)
+{
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int lane = threadIdx.x;
+    const int64_t p = base + lane;
+    if (p >= prm.P) return;
+
+    float v[NP];
+    const int n = load_column<NP, RawT, CALIB, true>(prm, base, lane, v);
+    sort_column<NP>(v);
+
+    // pivot: the lower median of the finite values
+    const float cf = n > 0 ? pick_at<NP>(v, (n - 1) >> 1) : 0.f;
+    const double c = (double)cf;
+    double S0 = 0.0, Q0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const float x = (i < n) ? v[i] : cf;
+        const double d = (double)x - c;
+        S0 += d;
+        Q0 = fma(d, d, Q0);
+    }
+
+    ClipState st;
+    st.S = S0;
+    st.Q = Q0;
+    st.c = c;
+    st.a = 0;
+    st.b = n;
+    // parameters of the last bounds computed for this lane
+    st.cen = c;
+    st.nn = (double)n;
+    st.Tlo = 0.0;
+    st.Thi = 0.0;
+    bool active = n > 0;
+    int it = 0;
+    const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
+
+    while (__any(active)) {
+        const int a0 = st.a, b0 = st.b;
+        if (active) {
+            st.nn = (double)(st.b - st.a);
+            if (use_median) {
+                const float m1 = pick_at<NP>(v, (st.a + st.b - 1) >> 1);
+                const float m2 = pick_at<NP>(v, (st.a + st.b) >> 1);
+                st.cen = 0.5 * ((double)m1 + (double)m2);    // wirth_median (even: mean of the two)
+            } else {
+                st.cen = c + st.S / st.nn;
+            }
+            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
+            V = V > 0.0 ? V : 0.0;
+            st.Tlo = prm.sl2 * V;
+            st.Thi = prm.su2 * V;
+        }
+        trim_low<0, NP>(v, st, active);
+        trim_high<NP - 1, NP>(v, st, active);
+        it++;
+        const bool changed = (st.a != a0) || (st.b != b0);
+        active = active && changed && (prm.maxiters < 0 || it < prm.maxiters);
+    }
+
+    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by
+    // an earlier, tighter pass that lie inside the final bounds are re-admitted.
+    if (__any(st.a > 0)) {
+        int a_new = st.a;
+        readmit_low<0, NP>(v, st, a_new);
+        st.a = a_new;
+    }
+    if (__any(st.b < n)) {
+        int b_new = st.b;
+        readmit_high<NP - 1, NP>(v, st, n, b_new);
+        st.b = b_new;
+    }
+    const int a = st.a, b = st.b;
+    const double S = st.S, Q = st.Q;
+
+    const int cnt = b - a;
+    const double nf = (double)cnt;
+    const double nan = __builtin_nan("");
+    const double ms = S / nf;                                 // mean - c
+    if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (prm.count) prm.count[p] = cnt;
+    if (prm.std) {
+        // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
+        // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
+        double s1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double dd = (double)v[i] - c;
+            s1 += (i >= a && i < b) ? dd : 0.0;
+        }
+        const double m1 = s1 / nf;
+        double q1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double dd = ((double)v[i] - c) - m1;
+            const double d = (i >= a && i < b) ? dd : 0.0;
+            q1 = fma(d, d, q1);
+        }
+        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
+    }
+    if (prm.median) {
+        const float m1 = pick_at<NP>(v, (a + b - 1) >> 1);
+        const float m2 = pick_at<NP>(v, (a + b) >> 1);
+        prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
+    }
+    if (prm.moments) {
+        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
+        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
+        prm.moments[p] = (float)sum;
+        prm.moments[prm.P + p] = (float)sq;
+        prm.moments[2 * prm.P + p] = (float)cnt;
+    }
+}
+
+// np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
+template <int NP, typename RawT, bool CALIB>
+__global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm)
+{
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int lane = threadIdx.x;
+    const int64_t p = base + lane;
+    if (p >= prm.P) return;
+    float v[NP];
+    const int n = load_column<NP, RawT, CALIB, false>(prm, base, lane, v);
+    sort_column<NP>(v);
+    const float m1 = pick_at<NP>(v, (n - 1) >> 1);
+    const float m2 = pick_at<NP>(v, n >> 1);
+    const double med = ((double)m1 + (double)m2) / 2.0;
+    if (prm.median) prm.median[p] = n > 0 ? (float)med : __builtin_nanf("");
+    if (prm.count) prm.count[p] = n;
+}
+
+template <int NP, typename RawT, bool CALIB>
+int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
+{
+    const int block = 256;
+    const int64_t grid = (prm.P + block - 1) / block;
+    if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    if (median_only)
+        hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    else
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    return check_launch("stack kernel");
+}
+
+template <typename RawT, bool CALIB>
+int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
+{
+    const int N = prm.N;
+    if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st);
+    if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st);
+    if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st);
+    if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st);
+    if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st);
+    return launch_one<128, RawT, CALIB>(prm, median_only, st);
+}
+
+
+}  // namespace apgpu_stack

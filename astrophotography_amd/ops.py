@@ -1,0 +1,301 @@
+"""Array-level entry points: torch tensors in HBM -> libapgpu.so kernels (include/apgpu.h).
+
+These are the slab/array forms underneath the file-based Ap* classes (the reference has no in-memory
+API for this path: "TODO: Allow calibration of images in memory", core/ApCalibrate.py:3).  PyTorch
+only owns device memory and streams here; every computation is a hand-written HIP kernel.  All calls are
+asynchronous on the current torch stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import APGPU_F32, APGPU_U16, StackArgs, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError('libapgpu operates on device tensors (got a %s tensor); there is no CPU path' % t.device)
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    return t.contiguous()
+
+
+def _raw_dtype(t):
+    if t.dtype == torch.float32:
+        return APGPU_F32
+    if t.dtype in (torch.uint16, torch.int16):          # int16 storage is reinterpreted as uint16
+        return APGPU_U16
+    raise TypeError('frame data must be float32 or uint16, got %s' % t.dtype)
+
+
+def to_device_u16(a, device='cuda'):
+    """numpy uint16 array -> device tensor with dtype torch.uint16."""
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    return torch.from_numpy(a.view(np.int16)).to(device).view(torch.uint16)
+
+
+def _per_frame(x, n, device):
+    """python float / sequence / tensor -> float32 device tensor [n] (float32 cast like numpy's weak scalar)."""
+    if x is None:
+        return None
+    if torch.is_tensor(x):
+        t = x.to(device=device, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1 and n > 1:
+            t = t.expand(n)
+        return t.contiguous()
+    a = np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+# ---------------------------------------------------------------------------------------------------
+def flat_normalize(flat):
+    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190): returns (nflat, norm[1] device tensor)."""
+    _need_cuda(flat)
+    flat = _f32c(flat, 'flat')
+    lib = _lib.load()
+    n = flat.numel()
+    ws_bytes = lib.apgpu_flat_normalize_ws_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=flat.device)
+    nflat = torch.empty_like(flat)
+    norm = torch.empty(1, dtype=torch.float32, device=flat.device)
+    check(lib.apgpu_flat_normalize_f32(_ptr(flat), _ptr(nflat), _ptr(norm), n, _ptr(ws), ws_bytes, _stream()))
+    return nflat, norm
+
+
+def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biased=False, out=None):
+    """A2 ApCalibrate.calibrate arithmetic (ApCalibrate.py:439-464) on raw[H,W] or a slab raw[N,H,W]."""
+    _need_cuda(raw, bias, dark, nflat)
+    lib = _lib.load()
+    raw = raw.contiguous()
+    dt = _raw_dtype(raw)
+    single = raw.dim() == 2
+    N = 1 if single else raw.shape[0]
+    P = raw[0].numel() if not single else raw.numel()
+    bias, dark, nflat = _f32c(bias, 'bias'), _f32c(dark, 'dark'), _f32c(nflat, 'nflat')
+    for nm, t in (('bias', bias), ('dark', dark), ('nflat', nflat)):
+        if t is not None and t.numel() != P:
+            raise RuntimeError('%s has %d pixels, frames have %d' % (nm, t.numel(), P))
+    e = _per_frame(exp_ratio, N, raw.device)
+    ped = _per_frame(pedestal, N, raw.device)
+    if out is None:
+        out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
+    check(lib.apgpu_calibrate(_ptr(raw), dt, _ptr(bias), _ptr(dark), _ptr(nflat), _ptr(e), _ptr(ped),
+                              int(bool(dark_still_biased)), _ptr(out), N, P, _stream()))
+    return out
+
+
+def _stack_args(frames, calib, pixmask, keep):
+    frames = frames.contiguous()
+    if frames.dim() < 2:
+        raise ValueError('frames must be [N, ...]')
+    N = frames.shape[0]
+    shp = tuple(frames.shape[1:])
+    P = frames[0].numel()
+    a = StackArgs()
+    a.frames = frames.data_ptr()
+    a.dtype = _raw_dtype(frames)
+    a.n_frames = N
+    a.n_pixels = P
+    keep.append(frames)
+    if calib is not None:
+        bias, dark = _f32c(calib['bias'], 'bias'), _f32c(calib['dark'], 'dark')
+        nflat = _f32c(calib.get('nflat'), 'nflat')
+        e = _per_frame(calib['exp_ratio'], N, frames.device)
+        ped = _per_frame(calib.get('pedestal'), N, frames.device)
+        for nm, t in (('bias', bias), ('dark', dark), ('nflat', nflat)):
+            if t is not None and t.numel() != P:
+                raise RuntimeError('%s has %d pixels, frames have %d' % (nm, t.numel(), P))
+        keep += [bias, dark, nflat, e, ped]
+        a.bias, a.dark = bias.data_ptr(), dark.data_ptr()
+        a.nflat = nflat.data_ptr() if nflat is not None else None
+        a.exp_ratio = e.data_ptr()
+        a.pedestal = ped.data_ptr() if ped is not None else None
+        a.dark_still_biased = int(bool(calib.get('dark_still_biased', False)))
+    if pixmask is not None:
+        if pixmask.dtype != torch.uint8 or pixmask.numel() != P:
+            raise TypeError('pixmask must be uint8 with one entry per pixel')
+        pixmask = pixmask.contiguous()
+        keep.append(pixmask)
+        a.pixmask = pixmask.data_ptr()
+    return a, N, P, shp, frames.device
+
+
+def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
+                  stdfunc='std', calib=None, pixmask=None, outputs=('mean',)):
+    """Per-pixel sigma-clipped reduction along N = astropy sigma_clipped_stats(cube, axis=0)
+    (sigma_clipping.py:298-383, 924-937), optionally fused with the calibration of each value.
+
+    calib: None or dict(bias, dark, nflat=None, exp_ratio, pedestal=None, dark_still_biased=False).
+    outputs: any of 'mean', 'median', 'std', 'count', 'moments' -> dict of device tensors.
+    """
+    _need_cuda(frames)
+    lib = _lib.load()
+    keep = []
+    a, N, P, shp, dev = _stack_args(frames, calib, pixmask, keep)
+    a.center = _lib.CENTER[cenfunc]
+    a.dev = _lib.DEV[stdfunc]
+    a.maxiters = -1 if maxiters is None else int(maxiters)
+    a.sigma_lower = float(sigma if sigma_lower is None else sigma_lower)
+    a.sigma_upper = float(sigma if sigma_upper is None else sigma_upper)
+    res = {}
+    for k in outputs:
+        if k in ('mean', 'median', 'std'):
+            res[k] = torch.empty(shp, dtype=torch.float32, device=dev)
+        elif k == 'count':
+            res[k] = torch.empty(shp, dtype=torch.int32, device=dev)
+        elif k == 'moments':
+            res[k] = torch.empty((3,) + shp, dtype=torch.float32, device=dev)
+        else:
+            raise ValueError('unknown output %r' % (k,))
+        setattr(a, k, res[k].data_ptr())
+    check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
+    return res
+
+
+def stack_median(frames, calib=None, pixmask=None, want_count=False):
+    """np.nanmedian(cube, axis=0) (config 4), optionally fused with calibration."""
+    _need_cuda(frames)
+    lib = _lib.load()
+    keep = []
+    a, N, P, shp, dev = _stack_args(frames, calib, pixmask, keep)
+    med = torch.empty(shp, dtype=torch.float32, device=dev)
+    a.median = med.data_ptr()
+    cnt = None
+    if want_count:
+        cnt = torch.empty(shp, dtype=torch.int32, device=dev)
+        a.count = cnt.data_ptr()
+    check(lib.apgpu_stack_median(C.byref(a), _stream()))
+    return (med, cnt) if want_count else med
+
+
+def moments_finalize(moments, want_std=True):
+    """mean = sum/cnt, std = sqrt(sumsq/cnt - mean^2) from (all-reduced) moments[3, ...]."""
+    _need_cuda(moments)
+    lib = _lib.load()
+    moments = _f32c(moments, 'moments')
+    shp = tuple(moments.shape[1:])
+    P = moments[0].numel()
+    mean = torch.empty(shp, dtype=torch.float32, device=moments.device)
+    std = torch.empty(shp, dtype=torch.float32, device=moments.device) if want_std else None
+    check(lib.apgpu_moments_finalize(_ptr(moments), _ptr(mean), _ptr(std), P, _stream()))
+    return (mean, std) if want_std else mean
+
+
+def sigclip_global(data, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5):
+    """A3 sigma_clipped_stats(data, sigma) with axis=None (ApFindBadPixels.py:191).
+
+    Returns a float64 device tensor [8] = mean, median, std, lo, hi, iterations, survivors, 0."""
+    _need_cuda(data)
+    lib = _lib.load()
+    data = _f32c(data, 'data')
+    n = data.numel()
+    ws_bytes = lib.apgpu_sigclip_global_ws_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=data.device)
+    stats = torch.empty(8, dtype=torch.float64, device=data.device)
+    sl = float(sigma if sigma_lower is None else sigma_lower)
+    su = float(sigma if sigma_upper is None else sigma_upper)
+    check(lib.apgpu_sigclip_global_f32(_ptr(data), n, sl, su, -1 if maxiters is None else int(maxiters),
+                                       _ptr(stats), _ptr(ws), ws_bytes, _stream()))
+    return stats
+
+
+def threshold_mask(data, lothresh=0.0, hithresh=0.0, thresholds=None):
+    """A4 ApFindBadPixels._generate_sigmaclip_mask (ApFindBadPixels.py:199-216).
+
+    thresholds: optional float64 device tensor [2] read on the device instead of the two floats.
+    Returns (mask uint8, nbad int64[1] device tensor)."""
+    _need_cuda(data, thresholds)
+    lib = _lib.load()
+    data = _f32c(data, 'data')
+    mask = torch.empty(data.shape, dtype=torch.uint8, device=data.device)
+    nbad = torch.empty(1, dtype=torch.int64, device=data.device)
+    if thresholds is not None and (thresholds.dtype != torch.float64 or thresholds.numel() < 2):
+        raise TypeError('thresholds must be a float64 tensor with 2 entries')
+    check(lib.apgpu_threshold_mask_f32(_ptr(data), data.numel(), float(lothresh), float(hithresh), _ptr(thresholds),
+                                       _ptr(mask), _ptr(nbad), _stream()))
+    return mask, nbad
+
+
+def mask_add_rects(mask, rects, value=2):
+    """A4 overlays (ApFindBadPixels.py:90,128,154): mask[r0:r1, c0:c1] += value in place."""
+    _need_cuda(mask)
+    if mask.dtype != torch.uint8 or mask.dim() != 2 or not mask.is_contiguous():
+        raise TypeError('mask must be a contiguous 2-D uint8 tensor')
+    r = np.ascontiguousarray(np.asarray(rects, dtype=np.int32).reshape(-1, 4))
+    if r.shape[0] == 0:
+        return mask
+    H, W = mask.shape
+    if (r[:, 0] < 0).any() or (r[:, 1] > H).any() or (r[:, 2] < 0).any() or (r[:, 3] > W).any():
+        raise ValueError('rectangle outside the image')
+    rd = torch.from_numpy(r).to(mask.device)
+    check(_lib.load().apgpu_mask_add_rects_u8(_ptr(mask), H, W, _ptr(rd), r.shape[0], int(value), _stream()))
+    return mask
+
+
+def fix_badpix(data, mask, deltapix=1, min_valid=4):
+    """A5 ApFixBadPixels.fix_bad_pixels (ApFixBadPixels.py:292-445).
+
+    Returns (out float32, stats int64[3] device tensor = nbad, nfixed, nremaining)."""
+    _need_cuda(data, mask)
+    data = _f32c(data, 'data')
+    if data.dim() != 2:
+        raise ValueError('data must be 2-D')
+    if tuple(mask.shape) != tuple(data.shape):
+        raise RuntimeError('Error, the shape of the input data array (%s) does not match that of the bad pixel '
+                           'mask array (%s).' % (tuple(data.shape), tuple(mask.shape)))
+    m8 = (mask != 0).to(torch.uint8).contiguous() if mask.dtype != torch.uint8 else mask.contiguous()
+    out = torch.empty_like(data)
+    stats = torch.empty(3, dtype=torch.int64, device=data.device)
+    check(_lib.load().apgpu_fix_badpix_f32(_ptr(data), _ptr(m8), data.shape[0], data.shape[1], int(deltapix),
+                                           int(min_valid), _ptr(out), _ptr(stats), _stream()))
+    return out, stats
+
+
+def imarith(a, op, b):
+    """A8 ApImArith op block (ApImArith.py:320-333): a (op) b, b a tensor or a python float."""
+    _need_cuda(a)
+    a = a.contiguous()
+    dt = _raw_dtype(a)
+    out = torch.empty_like(a)
+    opi = _lib.OPS[op]
+    if torch.is_tensor(b):
+        _need_cuda(b)
+        if b.shape != a.shape:
+            raise RuntimeError('Error, the dimension of the second data array does not match the first.')
+        if _raw_dtype(b) != dt:
+            raise TypeError('operands must have the same dtype')
+        b = b.contiguous()
+        check(_lib.load().apgpu_imarith(_ptr(a), _ptr(b), 0.0, opi, dt, _ptr(out), a.numel(), _stream()))
+    else:
+        check(_lib.load().apgpu_imarith(_ptr(a), None, float(b), opi, dt, _ptr(out), a.numel(), _stream()))
+    return out
+
+
+def bayer_split(raw, pattern=(0, 1, 3, 2), black=None):
+    """A9 RawConv split geometry (RawConv.py:111-128): four full-size planes [4,H,W] (R, G1, B, G2)."""
+    _need_cuda(raw)
+    if _raw_dtype(raw) != APGPU_U16 or raw.dim() != 2:
+        raise TypeError('raw must be a 2-D uint16 tensor')
+    raw = raw.contiguous()
+    H, W = raw.shape
+    planes = torch.empty((4, H, W), dtype=raw.dtype, device=raw.device)
+    pat = (C.c_int32 * 4)(*[int(x) for x in pattern])
+    blk = (C.c_int32 * 4)(*[int(x) for x in black]) if black is not None else None
+    check(_lib.load().apgpu_bayer_split_u16(_ptr(raw), H, W, pat, blk, _ptr(planes), _stream()))
+    return planes

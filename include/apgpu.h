@@ -1,0 +1,188 @@
+/*
+ * apgpu.h - C ABI of libapgpu.so: the MI355X (gfx950) implementation of AstroPhotography's per-pixel
+ * calibrate -> mask -> arithmetic -> stack-reduce hot path.
+ *
+ * The reference (DaveStrickland/AstroPhotography v0.5.1) is pure Python and has no FFI of its own;
+ * its boundary for this path is the Ap* class API.  Each entry point below replaces
+ * the NumPy/astropy/ccdproc arithmetic of one reference method (cited as file:line relative to
+ * AstroPhotography/ in the reference tree); the Python Ap* shells in astrophotography_amd/ bind them
+ * with ctypes (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
+ *  - the caller owns every buffer; the library allocates nothing and keeps no state;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is asynchronous
+ *    with respect to the host, no call synchronises;
+ *  - functions return 0 on success or a negative APGPU_E* code; apgpu_last_error() returns a
+ *    thread-local message for the last failing call;
+ *  - images are row-major [H][W]; frame stacks are contiguous slabs [N][H][W] (P = H*W pixels);
+ *  - workspace sizes are returned by the matching *_ws_bytes function; workspaces need 16-byte
+ *    alignment (any hipMalloc / torch allocation has it).
+ */
+#ifndef APGPU_H
+#define APGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APGPU_VERSION 100           /* 0.1.0 */
+
+/* error codes */
+#define APGPU_OK            0
+#define APGPU_EINVAL       -1       /* bad argument (NULL pointer, bad enum, size <= 0 ...) */
+#define APGPU_EUNSUPPORTED -2       /* valid request this build cannot serve (e.g. N > APGPU_MAX_STACK) */
+#define APGPU_ELAUNCH      -3       /* HIP runtime error at launch */
+#define APGPU_EWORKSPACE   -4       /* workspace too small */
+
+/* element types of pixel data */
+#define APGPU_F32 0
+#define APGPU_U16 1
+
+/* ApImArith._allowed_ops (core/ApImArith.py:34) */
+#define APGPU_OP_ADD 0
+#define APGPU_OP_SUB 1
+#define APGPU_OP_MUL 2
+#define APGPU_OP_DIV 3
+
+/* clip centre / deviation estimators (astropy SigmaClip cenfunc / stdfunc) */
+#define APGPU_CENTER_MEDIAN 0
+#define APGPU_CENTER_MEAN   1
+#define APGPU_DEV_STD       0
+#define APGPU_DEV_MAD_STD   1
+
+/* largest N one stack call reduces (the per-pixel column lives in registers) */
+#define APGPU_MAX_STACK 128
+
+const char *apgpu_last_error(void);
+int apgpu_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1  ApCalibrate._generate_flat (core/ApCalibrate.py:166-190)
+ *     norm = np.nanmean(flat) [float32 pairwise sum in 8192-element pieces, / count of non-NaN],
+ *     nflat = flat / norm.  Bit-exact with numpy.  norm is written to norm_out[0] (device).
+ * ------------------------------------------------------------------------------------------- */
+size_t apgpu_flat_normalize_ws_bytes(int64_t n_pixels);
+int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *norm_out, int64_t n_pixels,
+                             void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A2  ApCalibrate.calibrate arithmetic block (core/ApCalibrate.py:439-464) incl. the read-time
+ *     conversions of _read_fits (core/ApCalibrate.py:304-326), over a slab of N frames:
+ *       x = (f32(raw) [+ pedestal[f]]) - bias;  D = dark_still_biased ? dark - bias : dark;
+ *       x = x - exp_ratio[f] * D;  out = nflat ? (nflat != 0 ? x / nflat : x) : x
+ *     every operation separately rounded to float32 (no FMA contraction, IEEE division).
+ *     exp_ratio[N] (float32(EXPTIME_img / EXPTIME_dark)) and pedestal[N] are device arrays;
+ *     pedestal may be NULL; a zero pedestal entry adds nothing.  nflat may be NULL (no flat).
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias, const float *dark,
+                    const float *nflat, const float *exp_ratio, const float *pedestal,
+                    int dark_still_biased, float *out, int64_t n_frames, int64_t n_pixels, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A6/A7 + the fused north-star kernel: per-pixel sigma-clipped reduction along N of a slab
+ *     [N][P], optionally calibrating each value on the fly (A2) so the raw slab is read once.
+ *     Semantics = astropy.stats.sigma_clipped_stats(cube, axis=0, sigma_lower, sigma_upper,
+ *     maxiters, cenfunc, stdfunc) (astropy/stats/sigma_clipping.py:298-383, 924-937): non-finite
+ *     values dropped; <= maxiters passes of { centre, dev, keep lo <= x <= hi }; final bounds
+ *     applied to all values; outputs are the float64 statistics rounded once to float32.
+ *     maxiters < 0 iterates to convergence.  With maxiters = 1, centre = median, dev = mad_std and
+ *     sigma_lower = sigma_upper = 5 this is the ccdproc.combine configuration of
+ *     scripts/ap_combine_darks.py:394-420.
+ *     Outputs (each may be NULL): mean/median/std [P] float32, count [P] int32 survivors,
+ *     and the N-shard partial moments sum/sumsq/cnt packed as moments[3][P] float32
+ *     (all-reduced over ranks, then apgpu_moments_finalize).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct apgpu_stack_args {
+    const void *frames;          /* [N][P] APGPU_F32 or APGPU_U16 */
+    int32_t dtype;
+    int32_t n_frames;            /* 1 .. APGPU_MAX_STACK */
+    int64_t n_pixels;
+    /* fused calibration: bias == NULL -> frames are reduced as they are */
+    const float *bias;           /* [P] */
+    const float *dark;           /* [P] */
+    const float *nflat;          /* [P] or NULL */
+    const float *exp_ratio;      /* [N] */
+    const float *pedestal;       /* [N] or NULL */
+    int32_t dark_still_biased;
+    int32_t center;              /* APGPU_CENTER_* */
+    int32_t dev;                 /* APGPU_DEV_* */
+    int32_t maxiters;            /* >= 1, or < 0 = until convergence */
+    double sigma_lower;
+    double sigma_upper;
+    const uint8_t *pixmask;      /* [P] or NULL; non-zero = pixel excluded (outputs NaN / 0) */
+    float *mean;                 /* [P] or NULL */
+    float *median;               /* [P] or NULL */
+    float *std;                  /* [P] or NULL */
+    int32_t *count;              /* [P] or NULL */
+    float *moments;              /* [3][P] or NULL: sum, sum of squares, count of survivors */
+} apgpu_stack_args;
+
+int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
+
+/* Plain median along N (np.nanmedian(axis=0)); config 4.  Optional fused calibration as above. */
+int apgpu_stack_median(const apgpu_stack_args *args, void *stream);
+
+/* mean = sum / cnt, std = sqrt(max(sumsq / cnt - mean^2, 0)) from all-reduced moments[3][P];
+ * cnt == 0 -> NaN.  mean/std may be NULL. */
+int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_t n_pixels, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A3  astropy.stats.sigma_clipped_stats(data, sigma) with axis=None as called at
+ *     core/ApFindBadPixels.py:191 (astropy/stats/sigma_clipping.py:385-433, numpy nan-functions):
+ *     global iterative clip of a float32 image with numpy's float32 arithmetic (exact median by
+ *     radix select, float32 pairwise sums).  result_host? no - results stay on the device:
+ *     stats_out[8] float64 = { mean, median, std, lo, hi, iterations, survivors, reserved }.
+ * ------------------------------------------------------------------------------------------- */
+size_t apgpu_sigclip_global_ws_bytes(int64_t n_pixels);
+int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, double sigma_lower, double sigma_upper,
+                             int maxiters, double *stats_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4  ApFindBadPixels._generate_sigmaclip_mask (core/ApFindBadPixels.py:194-216):
+ *     mask = (data < f32(lo)) | (data > f32(hi)) as uint8; nbad_out[0] (device int64) = sum(mask).
+ *     If thresholds_dev != NULL the two float64 thresholds are read from the device
+ *     (thresholds_dev[0], [1]) instead of the by-value arguments, so A3 -> A4 chains without a sync.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_threshold_mask_f32(const float *data, int64_t n_pixels, double lothresh, double hithresh,
+                             const double *thresholds_dev, uint8_t *mask, int64_t *nbad_out, void *stream);
+
+/* A4 user overlays (core/ApFindBadPixels.py:70-158): mask[r0:r1, c0:c1] += value for n_rects
+ * 0-based half-open rectangles rects[n][4] = {r0, r1, c0, c1} (device int32). uint8 wrap-around. */
+int apgpu_mask_add_rects_u8(uint8_t *mask, int64_t height, int64_t width, const int32_t *rects,
+                            int32_t n_rects, int32_t value, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A5  ApFixBadPixels.fix_bad_pixels (core/ApFixBadPixels.py:292-445): every pixel with mask != 0
+ *     becomes the median of the good pixels of the ORIGINAL image inside the (2*deltapix+1)^2 window
+ *     clipped to the image, if at least min_valid of them exist; otherwise it is left unchanged.
+ *     out may not alias data.  stats_out[3] (device int64) = { nbad, nfixed, nremaining }.
+ *     deltapix <= 3.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_fix_badpix_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width,
+                         int32_t deltapix, int32_t min_valid, float *out, int64_t *stats_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A8  ApImArith.process_files op block (core/ApImArith.py:320-333): out = a (op) b, with b an image
+ *     (b != NULL) or the scalar float32(scalar).  APGPU_F32: IEEE float32.  APGPU_U16: image (op)
+ *     image only, ADD/SUB/MUL wrap modulo 2^16 (numpy); DIV and scalar operands are rejected with
+ *     APGPU_EUNSUPPORTED just as numpy raises UFuncTypeError.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_imarith(const void *a, const void *b, double scalar, int op, int dtype, void *out,
+                  int64_t n_pixels, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A9  RawConv split geometry (core/RawConv.py:111-128, 163-190): planes[k] = where(colour == k,
+ *     max(raw - black[k], 0), 0) for k = R0 G1 B2 G2 3, full-size planes [4][H][W].
+ *     pattern_host[4] = colour of cell positions (0,0),(0,1),(1,0),(1,1); black_host may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_bayer_split_u16(const uint16_t *raw, int64_t height, int64_t width, const int32_t *pattern_host,
+                          const int32_t *black_host, uint16_t *planes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APGPU_H */

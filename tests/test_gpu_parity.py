@@ -1,0 +1,334 @@
+"""GPU parity tests: the HIP kernels (through the C ABI, libapgpu.so) against the CPU oracle and the
+golden vectors captured from the reference.  Run with `pytest -m gpu` on an MI355X."""
+import json
+
+import numpy as np
+import pytest
+
+from tests.util import (assert_biteq, assert_ulp, load_golden, meta, synth_cube, synth_masters)
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from astrophotography_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope='module')
+def apref():
+    from oracle import apref as _a
+    return _a
+
+
+def dev(a, ops):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.uint16:
+        return ops.to_device_u16(a)
+    return torch.from_numpy(a).cuda()
+
+
+def host(t):
+    if t.dtype == torch.uint16:
+        return t.view(torch.int16).cpu().numpy().view(np.uint16)
+    return t.cpu().numpy()
+
+
+# ---- A1 -----------------------------------------------------------------------------------------------
+def test_flat_normalize_golden(ops):
+    g = load_golden('g7_nanmean.npz')
+    for ci in range(int(g['ncases'])):
+        a = g[f'a{ci}']
+        nflat, norm = ops.flat_normalize(dev(a.reshape(-1), ops))
+        assert_biteq(host(norm)[0:1], np.array([g[f'nanmean{ci}']], np.float32), f'norm case {ci}')
+        assert_biteq(host(nflat), (a.reshape(-1) / g[f'nanmean{ci}']).astype(np.float32), f'nflat case {ci}')
+        b = a.copy().reshape(-1)
+        b[::17] = np.nan
+        _, normb = ops.flat_normalize(dev(b, ops))
+        assert_biteq(host(normb)[0:1], np.array([g[f'nanmean_withnan{ci}']], np.float32), f'norm-with-nan case {ci}')
+
+
+def test_flat_normalize_large(ops, apref):
+    rng = np.random.default_rng(1)
+    for n in (8192 * 3, 8192 * 5 + 4097, 1024 * 1024 + 13):
+        a = rng.normal(30000, 300, n).astype(np.float32)
+        a[rng.integers(0, n, 5)] = np.nan
+        nflat, norm = ops.flat_normalize(dev(a, ops))
+        rn, rnorm = apref.flat_normalize(a)
+        assert_biteq(host(norm)[0:1], np.array([rnorm], np.float32), f'n={n}')
+        assert_biteq(host(nflat), rn, f'n={n}')
+
+
+# ---- A2 (+A5) golden ------------------------------------------------------------------------------------
+def test_calibrate_golden(ops):
+    g = load_golden('g1_calibrate.npz')
+    n = int(g['ncases'])
+    for ci in range(n):
+        m = meta(g, f'c{ci}_meta')
+        H, W = m['shape']
+        shp = f'_{H}x{W}'
+        raw = dev(g['raw_' + m['raw'] + shp], ops)
+        bias, dark = dev(g['bias' + shp], ops), dev(g['dark' + shp], ops)
+        nflat = None
+        if m['flatmode'] != 'noflat':
+            nflat, _ = ops.flat_normalize(dev(g[m['flatmode'] + shp], ops))
+            assert_biteq(host(nflat), g['n' + m['flatmode'] + shp], f'nflat case {ci}')
+        out = ops.calibrate(raw, bias, dark, nflat, m['img_exp'] / m['dark_exp'], pedestal=m['pedestal'],
+                            dark_still_biased=m['dark_still_biased'])
+        if m['use_mask']:
+            out, st = ops.fix_badpix(out, dev(g['mask' + shp], ops), m['deltapix'])
+            hdr = {k: v for k, v, _ in json.loads(str(g[f'c{ci}_hdr']))}
+            assert [int(x) for x in host(st)] == [int(hdr['BPIXNBAD']), int(hdr['BPIXNFIX']), int(hdr['BPIXNREM'])]
+        assert_biteq(host(out), g[f'c{ci}_out'].astype(np.float32), f'calibrate case {ci} {m}')
+
+
+def test_calibrate_slab_vs_oracle(ops, apref):
+    rng = np.random.default_rng(2)
+    for (N, shape, dt) in [(5, (33, 64), np.float32), (4, (16, 37), np.uint16), (3, (7, 9), np.float32), (1, (5, 3), np.uint16)]:
+        bias, dark, flat = synth_masters(rng, shape)
+        flat[1, 2] = 0.0
+        flat[3, 1] = np.nan
+        raw = synth_cube(rng, N, shape, dtype=dt)
+        e = rng.uniform(0.2, 2.0, N)
+        ped = np.where(rng.random(N) < 0.5, 0.0, -100.0)
+        nflat_ref, _ = apref.flat_normalize(flat)
+        for sb in (False, True):
+            for use_flat in (True, False):
+                ref = apref.calibrate(raw, bias, dark, nflat_ref if use_flat else None, e, ped, sb)
+                out = ops.calibrate(dev(raw, ops), dev(bias, ops), dev(dark, ops), dev(nflat_ref, ops) if use_flat else None,
+                                    e, ped, sb)
+                assert_biteq(host(out), ref, f'N={N} {shape} {dt} sb={sb} flat={use_flat}')
+
+
+# ---- A7 golden ------------------------------------------------------------------------------------------
+def test_stack_sigclip_golden(ops):
+    g = load_golden('g5_stack.npz')
+    exact = []
+    for ci in range(int(g['ncfg'])):
+        cfg = meta(g, f's{ci}_cfg')
+        if cfg['stdfunc'] != 'std':
+            continue
+        cube = g[f'cube_N{cfg["N"]}']
+        r = ops.stack_sigclip(dev(cube, ops), sigma=cfg['sigma'], maxiters=cfg['maxiters'], cenfunc=cfg['cenfunc'],
+                              stdfunc=cfg['stdfunc'], outputs=('mean', 'median', 'std', 'count'))
+        refmask = np.unpackbits(g[f's{ci}_mask'])[:cube.size].reshape(cube.shape).astype(bool)
+        assert np.array_equal(host(r['count']), (~refmask).sum(0)), cfg
+        exact.append(assert_ulp(host(r['mean']), g[f's{ci}_mean'].astype(np.float32), 1, f'mean {cfg}'))
+        assert_ulp(host(r['median']), g[f's{ci}_median'].astype(np.float32), 1, f'median {cfg}')
+        # std: sqrt of a float64 variance computed from shifted moments; 2 ulp(f32) bound
+        assert_ulp(host(r['std']), g[f's{ci}_std'].astype(np.float32), 2, f'std {cfg}')
+    assert len(exact) >= 48 and min(exact) > 0.99
+    cfg = meta(g, 'asym_cfg')
+    r = ops.stack_sigclip(dev(g['cube_N16'], ops), sigma_lower=cfg['sigma_lower'], sigma_upper=cfg['sigma_upper'],
+                          maxiters=cfg['maxiters'])
+    assert_ulp(host(r['mean']), g['asym_mean'].astype(np.float32), 1, 'asym')
+    r = ops.stack_sigclip(dev(g['u16_cube'], ops), sigma=3.0, maxiters=5, outputs=('mean', 'median', 'std'))
+    assert_ulp(host(r['mean']), g['u16_mean'].astype(np.float32), 1, 'u16 mean')
+    assert_ulp(host(r['median']), g['u16_median'].astype(np.float32), 1, 'u16 median')
+
+
+@pytest.mark.parametrize('N', [1, 2, 3, 5, 8, 13, 16, 20, 32, 33, 64, 65, 100, 128])
+def test_stack_sigclip_vs_oracle(ops, apref, N):
+    rng = np.random.default_rng(100 + N)
+    shape = (37, 53)
+    cube = synth_cube(rng, N, shape, nan_frac=0.01)
+    cube[:, 0, 0] = 7.0
+    cube[:, 0, 1] = np.nan
+    cube[:, 0, 2] = np.arange(N)
+    d = dev(cube, ops)
+    for (sigma, maxiters, cen) in [(3.0, 5, 'median'), (2.0, None, 'median'), (3.0, 1, 'mean'), (1.5, 5, 'mean'), (0.5, 3, 'mean')]:
+        ref = apref.stack_sigclip(cube, sigma=sigma, maxiters=maxiters, cenfunc=cen)
+        r = ops.stack_sigclip(d, sigma=sigma, maxiters=maxiters, cenfunc=cen, outputs=('mean', 'median', 'std', 'count', 'moments'))
+        what = f'N={N} sigma={sigma} maxiters={maxiters} cen={cen}'
+        assert np.array_equal(host(r['count']), ref['count']), what
+        assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, 'mean ' + what)
+        assert_ulp(host(r['median']), ref['median'].astype(np.float32), 1, 'median ' + what)
+        assert_ulp(host(r['std']), ref['std'].astype(np.float32), 2, 'std ' + what)
+        mom = host(r['moments'])
+        assert np.array_equal(mom[2], ref['count'].astype(np.float32)), what
+        kept = np.where(ref['keep'], cube.astype(np.float64), 0.0)
+        np.testing.assert_allclose(mom[0], kept.sum(0), rtol=3e-7, atol=1e-30)
+        np.testing.assert_allclose(mom[1], (kept * kept).sum(0), rtol=3e-7, atol=1e-30)
+
+
+def test_stack_u16_and_pixmask(ops, apref):
+    rng = np.random.default_rng(7)
+    cube = synth_cube(rng, 16, (19, 40), dtype=np.uint16)
+    pm = (rng.random((19, 40)) < 0.1).astype(np.uint8)
+    ref = apref.stack_sigclip(cube, sigma=3.0, maxiters=5, pixmask=pm)
+    r = ops.stack_sigclip(dev(cube, ops), sigma=3.0, maxiters=5, pixmask=dev(pm, ops), outputs=('mean', 'count'))
+    assert np.array_equal(host(r['count']), ref['count'])
+    assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, 'u16 pixmask')
+    assert np.isnan(host(r['mean'])[pm != 0]).all()
+
+
+@pytest.mark.parametrize('dt', [np.float32, np.uint16])
+def test_fused_calibrate_stack_vs_oracle(ops, apref, dt):
+    rng = np.random.default_rng(11)
+    for N, shape in [(8, (24, 64)), (64, (16, 48)), (20, (9, 21))]:
+        bias, dark, flat = synth_masters(rng, shape)
+        flat[0, 0] = 0.0
+        flat[0, 1] = np.nan
+        raw = synth_cube(rng, N, shape, dtype=dt)
+        raw = (raw.astype(np.float64) + 1000).astype(dt) if dt == np.float32 else (raw + 1000).astype(dt)
+        e = np.full(N, 120.0 / 300.0)
+        e[::3] = 0.5
+        nflat, _ = apref.flat_normalize(flat)
+        for sb in (False, True):
+            ref_mean, ref_cnt = apref.calibrate_stack(raw, bias, dark, nflat, e, None, sb, sigma=3.0, maxiters=5)
+            calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=e, dark_still_biased=sb)
+            r = ops.stack_sigclip(dev(raw, ops), sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
+            assert np.array_equal(host(r['count']), ref_cnt), (N, shape, sb)
+            assert_ulp(host(r['mean']), ref_mean, 1, f'fused N={N} {shape} sb={sb}')
+            # fused == unfused on the GPU, bit for bit
+            cal = ops.calibrate(dev(raw, ops), calib['bias'], calib['dark'], calib['nflat'], e, None, sb)
+            r2 = ops.stack_sigclip(cal, sigma=3.0, maxiters=5, outputs=('mean', 'count'))
+            assert_biteq(host(r2['mean']), host(r['mean']), 'fused vs unfused')
+
+
+def test_stack_median_vs_oracle(ops, apref):
+    rng = np.random.default_rng(13)
+    for N in (1, 2, 5, 8, 16, 31, 64, 100):
+        cube = synth_cube(rng, N, (11, 70), nan_frac=0.02)
+        cube[~np.isfinite(cube) & (rng.random(cube.shape) < 0.5)] = np.nan
+        ref = apref.stack_median(cube)
+        med = ops.stack_median(dev(cube, ops))
+        assert_ulp(host(med), ref.astype(np.float32), 0 if N % 2 else 1, f'median N={N}')
+    g = load_golden('g6_madstd.npz')
+    for N in (5, 8, 16):
+        med = ops.stack_median(dev(g[f'cube_N{N}'], ops))
+        assert_ulp(host(med), g[f'median_N{N}'].astype(np.float32), 1, f'golden median N={N}')
+
+
+def test_stack_properties_large(ops):
+    """Size-independent properties at a larger size: permutation invariance (bit-exact: the kernel sums
+    in sorted order), constant frames, and rejection of a planted outlier."""
+    g = torch.Generator(device='cuda').manual_seed(5)
+    N, H, W = 64, 512, 1024
+    cube = torch.randn((N, H, W), generator=g, device='cuda') * 20 + 500
+    cube[7, ::5, ::7] += 4000
+    r1 = ops.stack_sigclip(cube, outputs=('mean', 'count'))
+    perm = torch.randperm(N, device='cuda')
+    r2 = ops.stack_sigclip(cube[perm].contiguous(), outputs=('mean', 'count'))
+    assert torch.equal(r1['mean'], r2['mean']) and torch.equal(r1['count'], r2['count'])
+    assert int(r1['count'][::5, ::7].max()) <= N - 1
+    plain = cube.double().mean(0)
+    assert float((r1['mean'].double() - plain).abs().max()) < 100
+    const = torch.full((N, 64, 64), 123.25, device='cuda')
+    rc = ops.stack_sigclip(const, outputs=('mean', 'std', 'count'))
+    assert torch.all(rc['mean'] == 123.25) and torch.all(rc['std'] == 0) and torch.all(rc['count'] == N)
+    mean, std = ops.moments_finalize(ops.stack_sigclip(cube, outputs=('moments',))['moments'])
+    assert float((mean - r1['mean']).abs().max()) < 1e-3
+
+
+# ---- A3 / A4 ---------------------------------------------------------------------------------------------
+def test_sigclip_global_and_mask_golden(ops):
+    g = load_golden('g2_findbadpix.npz')
+    for ci in range(int(g['ncases'])):
+        dark = g[f'd{ci}_dark']
+        if dark.dtype != np.float32:
+            continue
+        d = dev(dark, ops)
+        st = ops.sigclip_global(d, sigma=4.0, maxiters=5)
+        s = host(st)
+        ref = g[f'd{ci}_stats']
+        assert_biteq(s[:3].astype(np.float32), ref.astype(np.float32), f'stats case {ci}')
+        lo = float(np.float32(s[1])) - 4.0 * float(np.float32(s[2]))
+        hi = float(np.float32(s[1])) + 4.0 * float(np.float32(s[2]))
+        assert [lo, hi] == list(g[f'd{ci}_thresh'])
+        mask, nbad = ops.threshold_mask(d, lo, hi)
+        assert np.array_equal(host(mask), g[f'd{ci}_mask_auto'])
+        assert int(host(nbad)[0]) == int(g[f'd{ci}_nbad_auto'])
+        thr = torch.tensor([lo, hi], dtype=torch.float64, device='cuda')
+        mask2, _ = ops.threshold_mask(d, thresholds=thr)
+        assert torch.equal(mask, mask2)
+        if f'd{ci}_mask_user' in g:
+            H, W = dark.shape
+            rects = [[0, H, c - 1, c] for c in (12, 13, 17)] + [[0, 1, 0, 1], [4, 6, 6, 12], [199, 300, 399, 420]]
+            ops.mask_add_rects(mask, rects, 2)
+            assert np.array_equal(host(mask), g[f'd{ci}_mask_user'])
+
+
+def test_sigclip_global_vs_oracle(ops, apref):
+    rng = np.random.default_rng(17)
+    for n in (1, 7, 100, 8191, 8192, 8193, 70001, 1 << 20):
+        x = rng.normal(20, 3, n).astype(np.float32)
+        hot = rng.random(n) < 0.001
+        x[hot] = rng.uniform(2000, 6000, hot.sum())
+        if n > 50:
+            x[rng.integers(0, n, 3)] = np.nan
+            x[rng.integers(0, n, 2)] = np.inf
+        for sigma, maxiters in [(4.0, 5), (3.0, 2), (2.5, None)]:
+            ref = apref.sigclip_global(x, sigma=sigma, maxiters=maxiters)
+            s = host(ops.sigclip_global(dev(x, ops), sigma=sigma, maxiters=maxiters))
+            what = f'n={n} sigma={sigma} maxiters={maxiters}'
+            assert_biteq(s[:3].astype(np.float32), np.array([ref['mean'], ref['median'], ref['std']], np.float32), what)
+            assert int(s[6]) == ref['nkeep'] and int(s[5]) == ref['niter'], what
+            assert (s[3] == ref['lo'] and s[4] == ref['hi']) or (np.isnan(s[3]) and np.isnan(ref['lo'])), what
+
+
+# ---- A5 --------------------------------------------------------------------------------------------------
+def test_fix_badpix_golden(ops):
+    g = load_golden('g3_fixbadpix.npz')
+    data, mask = dev(g['data'], ops), dev(g['mask'], ops)
+    for dp in (1, 2, 3):
+        out, st = ops.fix_badpix(data, mask, dp)
+        assert_biteq(host(out), g[f'out_dp{dp}'], f'dp={dp}')
+        ref = json.loads(str(g[f'stats_dp{dp}']))
+        assert [int(x) for x in host(st)] == [ref['BPIXNBAD'][0], ref['BPIXNFIX'][0], ref['BPIXNREM'][0]]
+    out, st = ops.fix_badpix(data, torch.zeros_like(mask), 1)
+    assert_biteq(host(out), g['out_emptymask'])
+    assert [int(x) for x in host(st)] == [0, 0, 0]
+    with pytest.raises(RuntimeError):
+        ops.fix_badpix(data, mask[:10], 1)
+
+
+def test_fix_badpix_vs_oracle(ops, apref):
+    rng = np.random.default_rng(19)
+    data = rng.normal(500, 20, (301, 257)).astype(np.float32)
+    data[5, 5] = np.nan
+    mask = (rng.random(data.shape) < 0.03).astype(np.uint8) * 3
+    mask[100:110, 50:60] = 1
+    for dp in (1, 2):
+        ref, st = apref.fix_badpix(data, mask, dp)
+        out, s = ops.fix_badpix(dev(data, ops), dev(mask, ops), dp)
+        assert_biteq(host(out), ref)
+        assert [int(x) for x in host(s)] == [st['nbad'], st['nfix'], st['nrem']]
+
+
+# ---- A8 / A9 ----------------------------------------------------------------------------------------------
+def test_imarith_golden(ops):
+    g = load_golden('g4_imarith.npz')
+    a, b, au, bu = (dev(g[k], ops) for k in ('a', 'b', 'au', 'bu'))
+    for op in ('ADD', 'SUB', 'MUL', 'DIV'):
+        assert_biteq(host(ops.imarith(a, op, b)), g[f'f32_arr_{op}'].astype(np.float32), op)
+        assert_biteq(host(ops.imarith(a, op, 3.25)), g[f'f32_scl_{op}'].astype(np.float32), op)
+    for op in ('ADD', 'SUB', 'MUL'):
+        assert np.array_equal(host(ops.imarith(au, op, bu)), g[f'u16_arr_{op}'])
+    from astrophotography_amd._lib import ApGpuError
+    with pytest.raises(ApGpuError):
+        ops.imarith(au, 'DIV', bu)
+    with pytest.raises(ApGpuError):
+        ops.imarith(au, 'ADD', 2.0)
+
+
+def test_bayer_split_vs_oracle(ops, apref):
+    rng = np.random.default_rng(23)
+    raw = rng.integers(0, 16384, (46, 62)).astype(np.uint16)
+    for pattern, black in [((0, 1, 3, 2), None), ((0, 1, 3, 2), (256, 256, 256, 256)), ((2, 3, 1, 0), (100, 0, 50, 7))]:
+        ref = apref.bayer_split(raw, pattern, black)
+        out = ops.bayer_split(dev(raw, ops), pattern, black)
+        assert np.array_equal(host(out), ref)
+
+
+def test_errors_are_loud(ops):
+    from astrophotography_amd._lib import ApGpuError
+    with pytest.raises(ApGpuError):
+        ops.stack_sigclip(torch.zeros((129, 4, 4), device='cuda'))
+    with pytest.raises(ValueError):
+        ops.stack_sigclip(torch.zeros((4, 4, 4)))
