@@ -32,7 +32,7 @@ class StackArgs(C.Structure):
         ('pedestal', C.c_void_p), ('dark_still_biased', C.c_int32), ('center', C.c_int32),
         ('dev', C.c_int32), ('maxiters', C.c_int32), ('sigma_lower', C.c_double), ('sigma_upper', C.c_double),
         ('pixmask', C.c_void_p), ('mean', C.c_void_p), ('median', C.c_void_p), ('std', C.c_void_p),
-        ('count', C.c_void_p), ('moments', C.c_void_p),
+        ('count', C.c_void_p), ('moments', C.c_void_p), ('frame_stride', C.c_int64),
     ]
 
 
@@ -69,6 +69,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise ImportError('%s is missing: build it with `python -m astrophotography_amd._build` '
                               '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64.so; it must be in the process BEFORE libapgpu.so so
+        # that both resolve to ONE HIP runtime (stream handles are only valid inside the runtime that
+        # created them).
+        try:
+            import torch  # noqa: F401
+        except ImportError:      # symbol-only use without torch (no device work possible then)
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -38,6 +38,8 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
         return fail(APGPU_EUNSUPPORTED, "stack: n_frames = %d exceeds APGPU_MAX_STACK = %d (shard the frames or "
                     "combine partial moments)", args->n_frames, APGPU_MAX_STACK);
     if (args->dtype != APGPU_F32 && args->dtype != APGPU_U16) return fail(APGPU_EINVAL, "stack: bad dtype %d", args->dtype);
+    if (args->frame_stride != 0 && args->frame_stride < args->n_pixels)
+        return fail(APGPU_EINVAL, "stack: frame_stride %lld < n_pixels %lld", (long long)args->frame_stride, (long long)args->n_pixels);
     const bool calib = args->bias != nullptr;
     if (calib && (!args->dark || !args->exp_ratio))
         return fail(APGPU_EINVAL, "stack: fused calibration needs bias, dark and exp_ratio");
@@ -70,6 +72,7 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
     prm.moments = args->moments;
     prm.count = args->count;
     prm.P = args->n_pixels;
+    prm.stride = args->frame_stride > 0 ? args->frame_stride : args->n_pixels;
     prm.sl2 = args->sigma_lower * args->sigma_lower;
     prm.su2 = args->sigma_upper * args->sigma_upper;
     prm.N = args->n_frames;

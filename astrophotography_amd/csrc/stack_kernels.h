@@ -100,17 +100,18 @@ __device__ __forceinline__ void sort_column(float (&v)[NP])
     if constexpr (NP > 1) net_from<NP, 0>(v);
 }
 
-// v[idx] for a per-lane index: binary multiplexer tree (NP-1 v_cndmask), static register indices.
+// v[LO + rel] for a per-lane rel in [0, LEN): binary multiplexer tree (LEN-1 v_cndmask), static
+// register indices only (a runtime-indexed register array would be demoted to scratch memory).
 template <int LO, int LEN, int NP>
-__device__ __forceinline__ float pick(const float (&v)[NP], int idx)
+__device__ __forceinline__ float pick_rel(const float (&v)[NP], int rel)
 {
     if constexpr (LEN == 1) {
         return v[LO];
     } else {
         constexpr int H = LEN / 2;
-        float lo = pick<LO, H, NP>(v, idx);
-        float hi = pick<LO + H, H, NP>(v, idx);
-        return (idx & H) ? hi : lo;
+        float lo = pick_rel<LO, H, NP>(v, rel);
+        float hi = pick_rel<LO + H, H, NP>(v, rel);
+        return (rel & H) ? hi : lo;
     }
 }
 
@@ -118,7 +119,30 @@ template <int NP>
 __device__ __forceinline__ float pick_at(const float (&v)[NP], int idx)
 {
     idx = idx < 0 ? 0 : (idx > NP - 1 ? NP - 1 : idx);
-    return pick<0, NP, NP>(v, idx);
+    return pick_rel<0, NP, NP>(v, idx);
+}
+
+// The two middle elements v[i1], v[i2] (i2 = i1 or i1 + 1) of the survivor range.  The clip trims a
+// few values off either end, so the middle stays within a few slots of NP/2: if every lane of the
+// wave is inside the 8-slot window around NP/2 the multiplexer needs 2 x 7 selects instead of
+// 2 x (NP-1); otherwise the whole wave takes the full tree.
+template <int NP>
+__device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2, float &m1, float &m2)
+{
+    if constexpr (NP <= 8) {
+        m1 = pick_at<NP>(v, i1);
+        m2 = pick_at<NP>(v, i2);
+    } else {
+        constexpr int WLO = NP / 2 - 4;
+        const bool inside = (i1 >= WLO) && (i2 < WLO + 8);
+        if (__all(inside)) {
+            m1 = pick_rel<WLO, 8, NP>(v, i1 - WLO);
+            m2 = pick_rel<WLO, 8, NP>(v, i2 - WLO);
+        } else {
+            m1 = pick_at<NP>(v, i1);
+            m2 = pick_at<NP>(v, i2);
+        }
+    }
 }
 
 // Per-lane state of the clipping loop.  Survivors are v[a .. b) of the sorted column.
@@ -227,6 +251,7 @@ struct StackParams {
     float *mean, *median, *std, *moments;
     int32_t *count;
     int64_t P;
+    int64_t stride;         // elements between frames
     double sl2, su2;        // sigma_lower^2, sigma_upper^2
     int N;
     int still_biased;
@@ -251,7 +276,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, int64_t base,
 #pragma unroll
     for (int f = 0; f < NP; f++) {
         raw[f] = fb[lane];
-        if (f + 1 < N) fb += P;                 // padded slots re-read the last frame (cache hit)
+        if (f + 1 < N) fb += prm.stride;        // padded slots re-read the last frame (cache hit)
     }
     float b = 0.f, D = 0.f, nf = 1.f;
     bool dodiv = false;
@@ -289,7 +314,10 @@ __device__ __forceinline__ int load_column(const StackParams &prm, int64_t base,
     return n;
 }
 
-template <int NP, typename RawT, bool CALIB>
+// EXTRA = the optional median / std planes are compiled in.  They cost ~100 extra VGPRs (a two-pass
+// std over the column and two more multiplexer trees), so the mean/count/moments-only kernel - the
+// benchmarked path - is a separate, leaner instantiation.
+template <int NP, typename RawT, bool CALIB, bool EXTRA>
 __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -302,16 +330,21 @@ __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams pr
     sort_column<NP>(v);
 
     // pivot: the lower median of the finite values
-    const float cf = n > 0 ? pick_at<NP>(v, (n - 1) >> 1) : 0.f;
+    float cf, cf2;
+    pick_middle<NP>(v, (n - 1) >> 1, (n - 1) >> 1, cf, cf2);
+    cf = n > 0 ? cf : 0.f;
     const double c = (double)cf;
-    double S0 = 0.0, Q0 = 0.0;
+    // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
+    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const float x = (i < n) ? v[i] : cf;
         const double d = (double)x - c;
-        S0 += d;
-        Q0 = fma(d, d, Q0);
+        Sa[i & 3] += d;
+        Qa[i & 3] = fma(d, d, Qa[i & 3]);
     }
+    const double S0 = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+    const double Q0 = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
 
     ClipState st;
     st.S = S0;
@@ -330,11 +363,11 @@ __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams pr
 
     while (__any(active)) {
         const int a0 = st.a, b0 = st.b;
+        float m1 = 0.f, m2 = 0.f;
+        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
         if (active) {
             st.nn = (double)(st.b - st.a);
             if (use_median) {
-                const float m1 = pick_at<NP>(v, (st.a + st.b - 1) >> 1);
-                const float m2 = pick_at<NP>(v, (st.a + st.b) >> 1);
                 st.cen = 0.5 * ((double)m1 + (double)m2);    // wirth_median (even: mean of the two)
             } else {
                 st.cen = c + st.S / st.nn;
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams pr
     const double ms = S / nf;                                 // mean - c
     if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
     if (prm.count) prm.count[p] = cnt;
-    if (prm.std) {
+    if (EXTRA && prm.std) {
         // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
         // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
         double s1 = 0.0;
@@ -391,7 +424,7 @@ __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams pr
         }
         prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
     }
-    if (prm.median) {
+    if (EXTRA && prm.median) {
         const float m1 = pick_at<NP>(v, (a + b - 1) >> 1);
         const float m2 = pick_at<NP>(v, (a + b) >> 1);
         prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
@@ -431,8 +464,10 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (median_only)
         hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    else if (prm.median || prm.std)
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     else
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     return check_launch("stack kernel");
 }
 

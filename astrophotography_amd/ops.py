@@ -101,17 +101,20 @@ def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biase
 
 
 def _stack_args(frames, calib, pixmask, keep):
-    frames = frames.contiguous()
     if frames.dim() < 2:
         raise ValueError('frames must be [N, ...]')
     N = frames.shape[0]
     shp = tuple(frames.shape[1:])
     P = frames[0].numel()
+    # a row stripe frames_full[:, r0:r1] of a contiguous slab is reduced in place (frame_stride > P)
+    if not (frames[0].is_contiguous() and (N == 1 or frames.stride(0) >= P)):
+        frames = frames.contiguous()
     a = StackArgs()
     a.frames = frames.data_ptr()
     a.dtype = _raw_dtype(frames)
     a.n_frames = N
     a.n_pixels = P
+    a.frame_stride = frames.stride(0) if N > 1 else P
     keep.append(frames)
     if calib is not None:
         bias, dark = _f32c(calib['bias'], 'bias'), _f32c(calib['dark'], 'dark')
@@ -184,14 +187,19 @@ def stack_median(frames, calib=None, pixmask=None, want_count=False):
     return (med, cnt) if want_count else med
 
 
-def moments_finalize(moments, want_std=True):
+def moments_finalize(moments, want_std=True, out_mean=None):
     """mean = sum/cnt, std = sqrt(sumsq/cnt - mean^2) from (all-reduced) moments[3, ...]."""
     _need_cuda(moments)
     lib = _lib.load()
     moments = _f32c(moments, 'moments')
     shp = tuple(moments.shape[1:])
     P = moments[0].numel()
-    mean = torch.empty(shp, dtype=torch.float32, device=moments.device)
+    if out_mean is None:
+        mean = torch.empty(shp, dtype=torch.float32, device=moments.device)
+    else:
+        mean = out_mean
+        if mean.dtype != torch.float32 or mean.numel() != P or not mean.is_contiguous():
+            raise TypeError('out_mean must be a contiguous float32 tensor with one entry per pixel')
     std = torch.empty(shp, dtype=torch.float32, device=moments.device) if want_std else None
     check(lib.apgpu_moments_finalize(_ptr(moments), _ptr(mean), _ptr(std), P, _stream()))
     return (mean, std) if want_std else mean

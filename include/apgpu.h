@@ -119,6 +119,8 @@ typedef struct apgpu_stack_args {
     float *std;                  /* [P] or NULL */
     int32_t *count;              /* [P] or NULL */
     float *moments;              /* [3][P] or NULL: sum, sum of squares, count of survivors */
+    int64_t frame_stride;        /* elements between the starts of consecutive frames; 0 = n_pixels.
+                                    > n_pixels lets a call reduce a row stripe of a larger slab */
 } apgpu_stack_args;
 
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
