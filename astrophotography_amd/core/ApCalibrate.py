@@ -1,0 +1,249 @@
+"""ApCalibrate - host shell over the HIP calibration kernels (reference: core/ApCalibrate.py).
+
+Keeps the reference's file-based API - ``ApCalibrate(master_bias_file, master_dark_file, master_flat_file,
+master_badpix_file, loglevel, dark_still_biased=None)`` (:48-113) and ``calibrate(raw_image, cal_image,
+delta_pix, norm_flat, fixcosmic)`` (:406-509) - and adds what the reference lists as a TODO ("Allow
+calibration of images in memory", :3): slab entry points that keep the masters resident in HBM and
+calibrate (and optionally stack) N frames per kernel launch.
+
+Arithmetic (ApCalibrate.py:439-464), all float32, each operation rounded separately:
+    x = raw - bias;  D = dark - bias if dark_still_biased else dark;  x = x - float32(exp_ratio) * D
+    y = where(nflat != 0, x / nflat, x)   with nflat = flat / nanmean(flat)   (:166-190)
+"""
+import time
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+
+from .. import __version__, fitsio
+from . import _common
+from .ApFixBadPixels import ApFixBadPixels
+
+
+class ApCalibrate:
+    MEAN_FULL = 0       #: Mean value of entire flat field.
+    MEDIAN_FULL = 1     #: Median value of entire flat field (not implemented in the reference either).
+
+    def __init__(self, master_bias_file, master_dark_file, master_flat_file, master_badpix_file, loglevel,
+                 dark_still_biased=None):
+        self._name = 'ApCalibrate'
+        self._version = __version__
+        self._master_bias_file = master_bias_file
+        self._master_dark_file = master_dark_file
+        self._master_flat_file = master_flat_file
+        self._master_badpix_file = master_badpix_file
+        self._loglevel = loglevel
+        self._logger = _common.make_logger(self._name, loglevel)
+        self._master_bias = Path(master_bias_file)
+        self._master_dark = Path(master_dark_file)
+        self._dark_still_biased = bool(dark_still_biased) if dark_still_biased is not None else False
+        self._bpix = None
+        self._bias_data, self._bias_hdr = self._read_master(self._master_bias)
+        self._dark_data, self._dark_hdr = self._read_master(self._master_dark)
+        if self._bias_data.shape != self._dark_data.shape:
+            raise RuntimeError(f'Master bias {tuple(self._bias_data.shape)} and master dark '
+                               f'{tuple(self._dark_data.shape)} have different shapes.')
+        self._norm_flat = None
+        if master_flat_file is not None:
+            self._master_flat = Path(master_flat_file)
+            self._flat_method = ApCalibrate.MEAN_FULL
+            self._logger.info(f'Reading master flat field {self._master_flat.name}')
+            flat_data, _ = self._read_master(self._master_flat)
+            self._norm_flat = self._generate_flat(flat_data, self._flat_method)
+        if master_badpix_file is not None:
+            self._bpix = ApFixBadPixels(loglevel)
+            self._master_bpix = Path(master_badpix_file)
+            msk, self._mskhdr, _ = _common.read_fits(self._logger, self._master_bpix)
+            import torch
+            self._mskdata = torch.from_numpy(np.ascontiguousarray(msk != 0).view(np.uint8)).cuda()
+
+    # -------------------------------------------------------------------------------------------
+    def _read_master(self, path):
+        """Master frame -> float32 device tensor (+ header).  PEDESTAL handling as _read_fits."""
+        import torch
+        data, hdr, _ = _common.read_fits(self._logger, path, to_float32=True)
+        if data.dtype != np.float32:
+            # ccdproc writes float64 masters; the reference would then calibrate in float64
+            self._logger.warning(f'{Path(path).name} is {data.dtype}; the device path calibrates in float32.')
+            data = data.astype(np.float32)
+        return torch.from_numpy(np.ascontiguousarray(data)).cuda(), hdr
+
+    def _find_exptime_ratio(self, img_hdr, dark_hdr):
+        """EXPOSURE, then EXPTIME (ApCalibrate.py:128-164)."""
+        img_exp = dark_exp = None
+        for kw in ['EXPOSURE', 'EXPTIME']:
+            if img_exp is None and kw in img_hdr:
+                img_exp = float(img_hdr[kw])
+            if dark_exp is None and kw in dark_hdr:
+                dark_exp = float(dark_hdr[kw])
+        msg = None
+        if img_exp is None and dark_exp is None:
+            msg = 'Could not determine exposure time for both image and dark.'
+        elif img_exp is None:
+            msg = 'Could not determine exposure time for image (dark exposure found).'
+        elif dark_exp is None:
+            msg = 'Could not determine exposure time for dark (img exposure found).'
+        if msg is not None:
+            self._logger.error(msg)
+            raise RuntimeError(msg)
+        exp_ratio = img_exp / dark_exp
+        self._logger.info(f'Image to dark exposure time ratio: {exp_ratio:.3f}')
+        return exp_ratio
+
+    def _generate_flat(self, flat_data, flat_method):
+        from .. import ops
+        if flat_method != ApCalibrate.MEAN_FULL:
+            msg = f'Error, flat field normalization method {flat_method} has not been implemented yet.'
+            self._logger.error(msg)
+            raise RuntimeError(msg)
+        out_flat, norm = ops.flat_normalize(flat_data)
+        self._norm_factor = float(norm.item())
+        self._logger.info(f'Flat field normalization factor: {self._norm_factor:.2f}')
+        return out_flat
+
+    def _read_raw(self, raw_image):
+        """Raw light frame -> (device tensor uint16|float32, header, pedestal to add on the device)."""
+        import torch
+        from .. import ops
+        raw_image = _common.check_file_exists(self._logger, raw_image)
+        data, hdr = fitsio.read(str(raw_image))
+        if hdr['NAXIS'] == 3:
+            self._logger.error('Error, 3-D handling has not been implemented yet.')
+            raise SystemExit(1)
+        pedestal = float(hdr['PEDESTAL']) if 'PEDESTAL' in hdr else 0.0
+        if data.dtype == np.uint16:
+            t = ops.to_device_u16(data)
+        else:
+            if data.dtype != np.float32:
+                if np.issubdtype(data.dtype, np.floating):
+                    self._logger.warning(f'{raw_image.name} is {data.dtype}; the device path calibrates in float32.')
+                data = data.astype(np.float32)               # ApCalibrate.py:304-307 for integers
+            t = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        if tuple(t.shape) != tuple(self._bias_data.shape):
+            raise RuntimeError(f'{raw_image.name} has shape {tuple(t.shape)}, the masters have {tuple(self._bias_data.shape)}.')
+        return t, hdr, pedestal
+
+    def _write_corrected_image(self, inpdata_file, outdata_file, odata, odict):
+        """Copy of the raw header minus PEDESTAL/BSCALE/BZERO, + keywords, + HISTORY (ApCalibrate.py:348-404)."""
+        self._logger.debug(f'FITS header keywords added to output: {odict}')
+        _common.check_file_exists(self._logger, inpdata_file)
+        _, hdr = fitsio.read(str(inpdata_file), want_data=False)
+        _common.remove_pedestal_kw(self._logger, hdr)
+        for kw in ['BSCALE', 'BZERO']:
+            if kw in hdr:
+                del hdr[kw]
+        for kw, val in odict.items():
+            hdr[kw] = val
+        tnow = datetime.now().isoformat(timespec='milliseconds')
+        hdr['HISTORY'] = f'Processed by {self._name} {self._version} at {tnow}'
+        fitsio.write(str(outdata_file), odata, hdr, overwrite=True)
+        self._logger.info(f'Wrote bias/dark/flat corrected file to {outdata_file}')
+
+    def _base_keywords(self):
+        odict = {'BIASCORR': (True, 'True if bias subtracted.'),
+                 'BIASFILE': (self._master_bias.name, 'Master bias file used.'),
+                 'DARKCORR': (True, 'True if scaled dark subtracted.'),
+                 'DARKFILE': (self._master_dark.name, 'Master dark file used.'),
+                 'BUNIT': ('adu', 'Pixel value units.')}
+        if self._norm_flat is not None:
+            odict['FLATCORR'] = (True, 'True if flat field applied.')
+            odict['FLATFILE'] = (self._master_flat.name, 'Master flat file used.')
+        return odict
+
+    # -- reference API ------------------------------------------------------------------------------
+    def calibrate(self, raw_image, cal_image, delta_pix, norm_flat, fixcosmic):
+        from .. import ops
+        perf_time_start = time.perf_counter()
+        if fixcosmic:
+            msg = ('Cosmic ray removal (ApFixCosmicRays -> ccdproc.cosmicray_lacosmic) is outside the scope of the '
+                   'MI355X calibrate/stack path; run with fixcosmic=False.')
+            self._logger.error(msg)
+            raise RuntimeError(msg)
+        raw_image = Path(raw_image)
+        raw, raw_hdr, pedestal = self._read_raw(raw_image)
+        if self._dark_still_biased:
+            self._logger.info('Subtracting bias from dark')
+        else:
+            self._logger.debug('Dark assumed to already be bias-subtracted.')
+        exp_ratio = self._find_exptime_ratio(raw_hdr, self._dark_hdr)
+        img_bdf = ops.calibrate(raw, self._bias_data, self._dark_data, self._norm_flat, exp_ratio,
+                                pedestal=pedestal if pedestal != 0 else None,
+                                dark_still_biased=self._dark_still_biased)
+        odict = self._base_keywords()
+        if self._norm_flat is not None:
+            if norm_flat is not None:
+                self._logger.debug(f'Writing normalized flat field to {norm_flat}')
+                self._write_corrected_image(raw_image, norm_flat, self._norm_flat.cpu().numpy(), {})
+        else:
+            self._logger.info('No flat field correction applied.')
+        if self._bpix is not None:
+            fixed, st = ops.fix_badpix(img_bdf, self._mskdata, int(delta_pix), self._bpix._min_valid)
+            nbad, nfixed, nnotfix = (int(x) for x in st.cpu().numpy())
+            img_bdf = fixed
+            odict['BPIXFILE'] = (self._master_bpix.name, 'Name of master bad pixel file used')
+            odict['BPIXNBAD'] = (nbad, 'Total number of bad pixels in bad pixel file')
+            odict['BPIX_MIN'] = (self._bpix._min_valid, 'Minimum number of good neighors needed')
+            odict['BPIXDPIX'] = (int(delta_pix), 'Half height/width of collection region (pixels)')
+            odict['BPIXNREM'] = (nnotfix, 'Number of bad pixels not corrected')
+            odict['BPIXCORR'] = (nfixed > 0, 'True if any bad pixels were corrected')
+            odict['BPIXNFIX'] = (nfixed, 'Number of bad pixels corrected')
+        else:
+            self._logger.info('No bad pixel correction applied.')
+        out = img_bdf.cpu().numpy()
+        run_time_secs = time.perf_counter() - perf_time_start
+        self._logger.info(f'Writing calibrated image to {cal_image}')
+        self._write_corrected_image(raw_image, cal_image, out, odict)
+        self._logger.info(f'Calibrated {raw_image.name} in {run_time_secs:.3f} seconds.')
+
+    # -- slab API (new) -----------------------------------------------------------------------------
+    def masters(self):
+        """The resident masters: dict(bias, dark, nflat, dark_still_biased) of device tensors."""
+        return dict(bias=self._bias_data, dark=self._dark_data, nflat=self._norm_flat,
+                    dark_still_biased=self._dark_still_biased)
+
+    def load_slab(self, raw_images):
+        """Reads N raw frames into one contiguous [N,H,W] device slab.
+
+        Returns (slab, headers, exp_ratio[N], pedestal[N] or None)."""
+        import torch
+        tensors, hdrs, ratios, peds = [], [], [], []
+        for f in raw_images:
+            t, hdr, ped = self._read_raw(f)
+            tensors.append(t)
+            hdrs.append(hdr)
+            ratios.append(self._find_exptime_ratio(hdr, self._dark_hdr))
+            peds.append(ped)
+        if len({t.dtype for t in tensors}) != 1:            # mixed uint16 / float32 inputs: widen exactly
+            tensors = [t if t.dtype == torch.float32
+                       else (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32) for t in tensors]
+        slab = torch.stack(tensors, 0)
+        return slab, hdrs, ratios, (peds if any(p != 0 for p in peds) else None)
+
+    def calibrate_slab(self, slab, exp_ratio, pedestal=None):
+        """raw[N,H,W] (uint16|float32 device tensor) -> calibrated float32 [N,H,W] in one launch."""
+        from .. import ops
+        return ops.calibrate(slab, self._bias_data, self._dark_data, self._norm_flat, exp_ratio, pedestal=pedestal,
+                             dark_still_biased=self._dark_still_biased)
+
+    def calibrate_files(self, raw_images, cal_images, delta_pix=2):
+        """Batch form of calibrate(): one slab read, one calibrate launch, N outputs."""
+        from .. import ops
+        if len(raw_images) != len(cal_images):
+            raise ValueError('raw_images and cal_images differ in length')
+        slab, hdrs, ratios, peds = self.load_slab(raw_images)
+        cal = self.calibrate_slab(slab, ratios, peds)
+        for i, (src, dst) in enumerate(zip(raw_images, cal_images)):
+            odict = self._base_keywords()
+            img = cal[i]
+            if self._bpix is not None:
+                img, st = ops.fix_badpix(img, self._mskdata, int(delta_pix), self._bpix._min_valid)
+                nbad, nfixed, nnotfix = (int(x) for x in st.cpu().numpy())
+                odict.update({'BPIXFILE': (self._master_bpix.name, 'Name of master bad pixel file used'),
+                              'BPIXNBAD': (nbad, 'Total number of bad pixels in bad pixel file'),
+                              'BPIX_MIN': (self._bpix._min_valid, 'Minimum number of good neighors needed'),
+                              'BPIXDPIX': (int(delta_pix), 'Half height/width of collection region (pixels)'),
+                              'BPIXNREM': (nnotfix, 'Number of bad pixels not corrected'),
+                              'BPIXCORR': (nfixed > 0, 'True if any bad pixels were corrected'),
+                              'BPIXNFIX': (nfixed, 'Number of bad pixels corrected')})
+            self._write_corrected_image(src, dst, img.cpu().numpy(), odict)

@@ -2,6 +2,8 @@
 // instantiated per raw dtype / fused-calibration flag in stack_inst_*.hip so they build in parallel).
 #include "stack_kernels.h"
 
+#include <cstdlib>
+
 namespace apgpu_stack {
 extern template int launch_np<float, true>(const StackParams &, bool, hipStream_t);
 extern template int launch_np<float, false>(const StackParams &, bool, hipStream_t);
@@ -48,8 +50,6 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
             return fail(APGPU_EINVAL, "stack: bad center %d", args->center);
         if (args->dev != APGPU_DEV_STD && args->dev != APGPU_DEV_MAD_STD)
             return fail(APGPU_EINVAL, "stack: bad dev %d", args->dev);
-        if (args->dev == APGPU_DEV_MAD_STD)
-            return fail(APGPU_EUNSUPPORTED, "stack: dev = mad_std is not built yet");
         if (args->maxiters == 0) return fail(APGPU_EINVAL, "stack: maxiters must be >= 1 or < 0");
         if (!(args->sigma_lower >= 0.0) || !(args->sigma_upper >= 0.0))
             return fail(APGPU_EINVAL, "stack: sigma must be >= 0");
@@ -78,7 +78,9 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
     prm.N = args->n_frames;
     prm.still_biased = args->dark_still_biased;
     prm.center = args->center;
+    prm.dev = median_only ? 0 : args->dev;
     prm.maxiters = args->maxiters;
+    if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;   // development: all frames alias frame 0 (compute-only timing)
     hipStream_t st = as_stream(stream);
     if (args->dtype == APGPU_F32)
         return calib ? launch_np<float, true>(prm, median_only, st) : launch_np<float, false>(prm, median_only, st);

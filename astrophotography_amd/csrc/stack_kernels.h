@@ -43,7 +43,7 @@ struct CE {
 
 template <int NP>
 struct Net {
-    CE ce[NP * 12];     // NP=128 needs 1471 < 1536
+    CE ce[NP * 12 + 1]; // NP=128 needs 1471 < 1536
     int n;
 };
 
@@ -150,19 +150,20 @@ struct ClipState {
     double S, Q;            // sum(x - c), sum((x - c)^2) over the survivors
     double c;               // pivot
     double cen, nn;         // centre and count the last bounds were computed with
+    double wscale;          // scale of the bound test: n (std mode, T = sigma^2 n^2 var) or 1 (mad_std mode)
     double Tlo, Thi;        // sigma^2 * (n*Q - S^2): squared, n^2-scaled half-widths of the bounds
     int a, b;
 };
 
 __device__ __forceinline__ bool below(const ClipState &st, double xd)
 {
-    const double w = st.nn * (xd - st.cen);
+    const double w = st.wscale * (xd - st.cen);
     return (w < 0.0) && (w * w > st.Tlo);
 }
 
 __device__ __forceinline__ bool above(const ClipState &st, double xd)
 {
-    const double w = st.nn * (xd - st.cen);
+    const double w = st.wscale * (xd - st.cen);
     return (w > 0.0) && (w * w > st.Thi);
 }
 
@@ -244,6 +245,49 @@ __device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st
     }
 }
 
+// astropy.stats.mad_std of the survivors v[a .. b): 1.482602218505602 * median(|x - med|)
+// (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  The deviations are sorted as
+// float32 keys with a second network - rounding is monotone, so the k-th smallest ROUNDED deviation is
+// the rounding of the k-th smallest exact one - and the exact float64 value is then recovered from
+// the (almost always single) element whose key equals it.
+template <int NP>
+__device__ __forceinline__ double mad_std_range(const float (&v)[NP], int a, int b, double med)
+{
+    float dv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const double d = fabs((double)v[i] - med);
+        dv[i] = (i >= a && i < b) ? (float)d : __builtin_inff();
+    }
+    sort_column<NP>(dv);
+    const int n = b - a;
+    const int k1 = (n - 1) >> 1, k2 = n >> 1;
+    const float D1 = pick_at<NP>(dv, k1), D2 = pick_at<NP>(dv, k2);
+    int less1 = 0, eq1 = 0, less2 = 0, eq2 = 0;
+    double mn1 = __builtin_inf(), mx1 = 0.0, mn2 = __builtin_inf(), mx2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const bool in = (i >= a && i < b);
+        const double d = fabs((double)v[i] - med);
+        const float r = (float)d;
+        const bool e1 = in && (r == D1), e2 = in && (r == D2);
+        less1 += (in && r < D1) ? 1 : 0;
+        less2 += (in && r < D2) ? 1 : 0;
+        eq1 += e1 ? 1 : 0;
+        eq2 += e2 ? 1 : 0;
+        mn1 = (e1 && d < mn1) ? d : mn1;
+        mx1 = (e1 && d > mx1) ? d : mx1;
+        mn2 = (e2 && d < mn2) ? d : mn2;
+        mx2 = (e2 && d > mx2) ? d : mx2;
+    }
+    // rank inside the group of equal keys: first -> smallest exact value, last -> largest; an interior
+    // rank of a >= 3-way tie (exact values within one float32 ulp of each other) takes the midpoint
+    const int j1 = k1 - less1, j2 = k2 - less2;
+    const double x1 = (j1 <= 0) ? mn1 : ((j1 >= eq1 - 1) ? mx1 : 0.5 * (mn1 + mx1));
+    const double x2 = (j2 <= 0) ? mn2 : ((j2 >= eq2 - 1) ? mx2 : 0.5 * (mn2 + mx2));
+    return (0.5 * (x1 + x2)) * 1.482602218505602;
+}
+
 struct StackParams {
     const void *frames;
     const float *bias, *dark, *nflat, *exp_ratio, *pedestal;
@@ -256,28 +300,104 @@ struct StackParams {
     int N;
     int still_biased;
     int center;             // 0 median, 1 mean
+    int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
     int maxiters;           // < 0: until convergence
 };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
 
-// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
-// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY>
-__device__ __forceinline__ int load_column(const StackParams &prm, int64_t base, int lane, float (&v)[NP])
+// x / nf for a per-pixel divisor with y = RN(1 / nf) precomputed: two Newton steps on the quotient with
+// exact FMA residuals (Markstein): q0 = RN(x*y) is within 1.5 ulp, q1 is faithful, q2 = RN(x / nf)
+// provided nothing over/underflows - the caller guards the ranges and falls back to IEEE division.
+// 5 instructions instead of the 12 of the IEEE sequence (v_div_scale x2, v_rcp, 6 FMA, v_div_fmas,
+// v_div_fixup), 64 times per pixel.
+__device__ __forceinline__ float div_by_recip(float x, float nf, float y)
+{
+    const float q0 = x * y;
+    const float r0 = __builtin_fmaf(-nf, q0, x);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-nf, q1, x);
+    return __builtin_fmaf(r1, y, q1);
+}
+
+// Per-frame scalars (exposure ratio, pedestal) staged in LDS once per workgroup: as SGPR values the
+// 2*NP scalars exceed the 102-SGPR budget and get spilled to VGPR lanes; from LDS they arrive as
+// broadcast ds_read_b128 (4 frames per instruction) just before use.
+template <int NP>
+struct FrameScalars {
+    float e[NP];
+    float ped[NP];
+};
+
+template <int NP>
+__device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, FrameScalars<NP> &fs)
+{
+    for (int t = threadIdx.x; t < NP; t += blockDim.x) {
+        const int ff = t < prm.N ? t : prm.N - 1;
+        fs.e[t] = prm.exp_ratio[ff];
+        fs.ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
+    }
+    __syncthreads();
+}
+
+template <int NP, typename RawT, bool FULL>
+__device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[NP])
 {
     // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
     const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
-    const int N = prm.N;
-    const int64_t P = prm.P;
-    const int64_t p = base + lane;
-    RawT raw[NP];
 #pragma unroll
     for (int f = 0; f < NP; f++) {
         raw[f] = fb[lane];
-        if (f + 1 < N) fb += prm.stride;        // padded slots re-read the last frame (cache hit)
+        if (FULL || f + 1 < prm.N) fb += prm.stride;    // padded slots re-read the last frame (cache hit)
+        // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
+        if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// Fast calibration of a full column (N == NP): reciprocal division, no per-value fix-ups.  Returns
+// true if the lane's results are exact AND all finite; otherwise the wave redoes the column exactly.
+template <int NP, typename RawT, bool HAS_PED>
+__device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[NP], float b, float D, float nf,
+                                               bool dodiv, float (&v)[NP])
+{
+    const float y = __fdiv_rn(1.0f, dodiv ? nf : 1.0f);
+    const float anf = fabsf(nf);
+    const bool nf_ok = !dodiv || (anf >= 0x1p-40f && anf <= 0x1p40f);
+    float acc = 0.f, mx = 0.f, mn = __builtin_inff();
+#pragma unroll
+    for (int f = 0; f < NP; f++) {
+        float x = to_f32(raw[f]);
+        if constexpr (HAS_PED) {
+            const float ped = fs.ped[f];
+            if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
+        }
+        x = x - b;                                           // :439
+        const float ds = fs.e[f] * D;                        // :450
+        x = x - ds;                                          // :451
+        const float q = div_by_recip(x, nf, y);
+        x = dodiv ? q : x;                                   // :462-464
+        v[f] = x;
+        acc = __builtin_fmaf(x, 0.0f, acc);                  // NaN iff some value is not finite
+        mx = fmaxf(mx, fabsf(x));
+        mn = fminf(mn, fabsf(x));
+    }
+    const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
+    return nf_ok && range_ok && (acc == 0.f);
+}
+
+// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
+// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
+// FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
+// wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes).
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+__device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
+                                           float (&v)[NP])
+{
+    const int N = prm.N;
+    const int64_t p = base + lane;
+    RawT raw[NP];
+    load_raw<NP, RawT, FULL>(prm, base, lane, raw);
     float b = 0.f, D = 0.f, nf = 1.f;
     bool dodiv = false;
     if constexpr (CALIB) {
@@ -290,14 +410,21 @@ __device__ __forceinline__ int load_column(const StackParams &prm, int64_t base,
         }
     }
     const bool skip = prm.pixmask && prm.pixmask[p];
+    if constexpr (CALIB && FULL && FINITE_ONLY) {
+        bool good;
+        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
+        else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
+        if (__all(good && !skip)) return NP;
+        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave
+        load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+    }
     int n = 0;
 #pragma unroll
     for (int f = 0; f < NP; f++) {
         float x = to_f32(raw[f]);
         if constexpr (CALIB) {
-            const int ff = f < N ? f : N - 1;
-            const float e = prm.exp_ratio[ff];
-            const float ped = prm.pedestal ? prm.pedestal[ff] : 0.f;
+            const float e = fs.e[f];
+            const float ped = fs.ped[f];
             if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
             x = x - b;                                       // :439
             const float ds = e * D;                          // :450
@@ -307,7 +434,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, int64_t base,
         bool ok;
         if constexpr (FINITE_ONLY) ok = fabsf(x) < __builtin_inff();
         else ok = (x == x);
-        ok = ok && (f < N) && !skip;
+        ok = ok && (FULL || f < N) && !skip;
         n += ok ? 1 : 0;
         v[f] = ok ? x : __builtin_inff();
     }
@@ -317,16 +444,18 @@ __device__ __forceinline__ int load_column(const StackParams &prm, int64_t base,
 // EXTRA = the optional median / std planes are compiled in.  They cost ~100 extra VGPRs (a two-pass
 // std over the column and two more multiplexer trees), so the mean/count/moments-only kernel - the
 // benchmarked path - is a separate, leaner instantiation.
-template <int NP, typename RawT, bool CALIB, bool EXTRA>
-__global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams prm)
+template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
+__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 4 : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
+    __shared__ FrameScalars<NP> fs;
+    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
 
     float v[NP];
-    const int n = load_column<NP, RawT, CALIB, true>(prm, base, lane, v);
+    const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
     sort_column<NP>(v);
 
     // pivot: the lower median of the finite values
@@ -355,27 +484,37 @@ __global__ __launch_bounds__(256) void stack_sigclip_kernel(const StackParams pr
     // parameters of the last bounds computed for this lane
     st.cen = c;
     st.nn = (double)n;
+    st.wscale = (double)n;
     st.Tlo = 0.0;
     st.Thi = 0.0;
     bool active = n > 0;
     int it = 0;
     const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
+    const bool use_mad = EXTRA && prm.dev == APGPU_DEV_MAD_STD;
 
     while (__any(active)) {
         const int a0 = st.a, b0 = st.b;
         float m1 = 0.f, m2 = 0.f;
-        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
+        if (use_median || use_mad) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
+        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
+        double mad = 0.0;
+        if constexpr (EXTRA) {
+            if (use_mad) mad = mad_std_range<NP>(v, st.a, st.b, med);
+        }
         if (active) {
             st.nn = (double)(st.b - st.a);
-            if (use_median) {
-                st.cen = 0.5 * ((double)m1 + (double)m2);    // wirth_median (even: mean of the two)
+            st.cen = use_median ? med : c + st.S / st.nn;
+            if (use_mad) {
+                st.wscale = 1.0;
+                st.Tlo = prm.sl2 * (mad * mad);
+                st.Thi = prm.su2 * (mad * mad);
             } else {
-                st.cen = c + st.S / st.nn;
+                st.wscale = st.nn;
+                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
+                V = V > 0.0 ? V : 0.0;
+                st.Tlo = prm.sl2 * V;
+                st.Thi = prm.su2 * V;
             }
-            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
-            V = V > 0.0 ? V : 0.0;
-            st.Tlo = prm.sl2 * V;
-            st.Thi = prm.su2 * V;
         }
         trim_low<0, NP>(v, st, active);
         trim_high<NP - 1, NP>(v, st, active);
@@ -445,9 +584,11 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
+    __shared__ FrameScalars<NP> fs;
+    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
-    const int n = load_column<NP, RawT, CALIB, false>(prm, base, lane, v);
+    const int n = load_column<NP, RawT, CALIB, false, false>(prm, fs, base, lane, v);
     sort_column<NP>(v);
     const float m1 = pick_at<NP>(v, (n - 1) >> 1);
     const float m2 = pick_at<NP>(v, n >> 1);
@@ -464,10 +605,12 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (median_only)
         hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
-    else if (prm.median || prm.std)
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    else if (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD)
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    else if (prm.N == NP)
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     else
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     return check_launch("stack kernel");
 }
 
@@ -475,6 +618,7 @@ template <typename RawT, bool CALIB>
 int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
 {
     const int N = prm.N;
+    if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st);
     if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st);
     if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st);
     if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st);

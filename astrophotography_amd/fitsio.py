@@ -1,0 +1,328 @@
+"""Minimal FITS primary-HDU reader/writer (numpy only).
+
+The reference does all I/O through ``astropy.io.fits`` (``fits.open(uint=True,
+do_not_scale_image_data=False)`` / ``writeto``; e.g. core/ApCalibrate.py:260-328, 348-404).  astropy is
+not available next to the GPU, and the hot path only ever touches the primary image HDU, so this
+module implements exactly that subset:
+
+* header: ordered 80-column cards with update/append/delete and HISTORY/COMMENT, value types
+  bool / int / float / str, pass-through of unparsed cards;
+* data: BITPIX 8, 16, 32, 64, -32, -64, big-endian on disk; the unsigned-integer convention
+  (BITPIX=16, BSCALE=1, BZERO=32768 -> uint16; likewise uint32/uint64) as astropy's ``uint=True``;
+  any other BSCALE/BZERO is applied like astropy does (float32 for <=16-bit integers, float64 above);
+* extensions after the primary HDU are preserved verbatim on rewrite.
+"""
+import os
+
+import numpy as np
+
+BLOCK = 2880
+_BITPIX_DTYPE = {8: '>u1', 16: '>i2', 32: '>i4', 64: '>i8', -32: '>f4', -64: '>f8'}
+_COMMENTARY = ('HISTORY', 'COMMENT', '')
+
+
+class Card:
+    __slots__ = ('key', 'value', 'comment', 'raw')
+
+    def __init__(self, key, value=None, comment='', raw=None):
+        self.key = key
+        self.value = value
+        self.comment = comment
+        self.raw = raw              # original 80-char image if the card was read and not modified
+
+    def __repr__(self):
+        return 'Card(%r, %r, %r)' % (self.key, self.value, self.comment)
+
+
+def _parse_value(s):
+    """Value/comment field (columns 11-80) of a FITS card -> (value, comment)."""
+    s = s.rstrip()
+    t = s.lstrip()
+    if t.startswith("'"):
+        # quoted string; '' is an escaped quote
+        i = 1
+        out = []
+        while i < len(t):
+            if t[i] == "'":
+                if i + 1 < len(t) and t[i + 1] == "'":
+                    out.append("'")
+                    i += 2
+                    continue
+                break
+            out.append(t[i])
+            i += 1
+        val = ''.join(out).rstrip()
+        rest = t[i + 1:]
+        comment = rest.split('/', 1)[1].strip() if '/' in rest else ''
+        return val, comment
+    if '/' in t:
+        v, comment = t.split('/', 1)
+        comment = comment.strip()
+    else:
+        v, comment = t, ''
+    v = v.strip()
+    if v == '':
+        return None, comment
+    if v == 'T':
+        return True, comment
+    if v == 'F':
+        return False, comment
+    try:
+        return int(v), comment
+    except ValueError:
+        pass
+    try:
+        return float(v.replace('D', 'E').replace('d', 'e')), comment
+    except ValueError:
+        return v, comment
+
+
+def _format_value(value):
+    if isinstance(value, (bool, np.bool_)):
+        return '%20s' % ('T' if value else 'F')
+    if isinstance(value, (int, np.integer)):
+        return '%20d' % int(value)
+    if isinstance(value, (float, np.floating)):
+        v = float(value)
+        if v != v or v in (float('inf'), float('-inf')):
+            raise ValueError('FITS cannot store %r' % v)
+        s = repr(v).upper()
+        if 'E' not in s and '.' not in s:
+            s += '.0'
+        return '%20s' % s
+    if value is None:
+        return ''
+    s = str(value).replace("'", "''")
+    return ("'%-8s'" % s).ljust(20)
+
+
+def _format_card(card):
+    if card.raw is not None:
+        return card.raw
+    key = card.key.upper()
+    if key in _COMMENTARY:
+        text = '' if card.value is None else str(card.value)
+        return ('%-8s%s' % (key, text))[:80].ljust(80)
+    if len(key) > 8:
+        head = 'HIERARCH %s = ' % key
+    else:
+        head = '%-8s= ' % key
+    body = _format_value(card.value)
+    img = head + body
+    if card.comment:
+        img += ' / ' + card.comment
+    if len(img) > 80:
+        # keep the value intact, truncate the comment (strings longer than the card are cut)
+        img = img[:80]
+    return img.ljust(80)
+
+
+class Header:
+    """Ordered FITS header with a small dict-like API (subset of astropy.io.fits.Header)."""
+
+    def __init__(self, cards=None):
+        self.cards = list(cards) if cards else []
+
+    # -- dict-like -------------------------------------------------------------------------------
+    def _find(self, key):
+        key = key.upper()
+        for i, c in enumerate(self.cards):
+            if c.key == key and key not in _COMMENTARY:
+                return i
+        return -1
+
+    def __contains__(self, key):
+        return self._find(key) >= 0
+
+    def __getitem__(self, key):
+        i = self._find(key)
+        if i < 0:
+            raise KeyError("Keyword '%s' not found." % key)
+        return self.cards[i].value
+
+    def get(self, key, default=None):
+        i = self._find(key)
+        return self.cards[i].value if i >= 0 else default
+
+    def comment(self, key):
+        i = self._find(key)
+        return self.cards[i].comment if i >= 0 else ''
+
+    def __setitem__(self, key, value):
+        """hdr[key] = value or (value, comment); HISTORY/COMMENT always append (astropy semantics)."""
+        key = key.upper()
+        comment = None
+        if isinstance(value, tuple):
+            value, comment = (value + ('',))[:2]
+        if key in _COMMENTARY:
+            self.cards.append(Card(key, value, ''))
+            return
+        i = self._find(key)
+        if i >= 0:
+            c = self.cards[i]
+            c.value = value
+            if comment is not None:
+                c.comment = comment
+            c.raw = None
+        else:
+            self.cards.append(Card(key, value, comment or ''))
+
+    def __delitem__(self, key):
+        i = self._find(key)
+        if i < 0:
+            raise KeyError("Keyword '%s' not found." % key)
+        del self.cards[i]
+
+    def keys(self):
+        return [c.key for c in self.cards]
+
+    def items(self):
+        return [(c.key, c.value) for c in self.cards]
+
+    def history(self):
+        return [c.value for c in self.cards if c.key == 'HISTORY']
+
+    def copy(self):
+        return Header([Card(c.key, c.value, c.comment, c.raw) for c in self.cards])
+
+    # -- (de)serialisation -----------------------------------------------------------------------
+    @classmethod
+    def fromstring(cls, text):
+        cards = []
+        for i in range(0, len(text), 80):
+            img = text[i:i + 80]
+            key = img[:8].rstrip().upper()
+            if key == 'END':
+                break
+            if key in _COMMENTARY:
+                if img.strip() == '':
+                    continue
+                cards.append(Card(key, img[8:].rstrip(), '', img))
+            elif img[8:10] == '= ':
+                val, com = _parse_value(img[10:])
+                cards.append(Card(key, val, com, img))
+            elif img.startswith('HIERARCH') and '=' in img:
+                k, rest = img[8:].split('=', 1)
+                val, com = _parse_value(rest)
+                cards.append(Card(k.strip().upper(), val, com, img))
+            else:
+                cards.append(Card(key, img[8:].rstrip(), '', img))
+        return cls(cards)
+
+    def tostring(self):
+        out = ''.join(_format_card(c) for c in self.cards) + 'END'.ljust(80)
+        pad = (-len(out)) % BLOCK
+        return out + ' ' * pad
+
+
+def _structural(hdr, data):
+    """Header with the mandatory structural keywords rewritten for `data` (astropy does the same)."""
+    dt = data.dtype
+    drop = {'SIMPLE', 'BITPIX', 'NAXIS', 'EXTEND'} | {'NAXIS%d' % i for i in range(1, 10)}
+    rest = [c for c in hdr.cards if c.key not in drop]
+    bzero = None
+    if dt == np.uint8:
+        bitpix = 8
+    elif dt == np.int16:
+        bitpix = 16
+    elif dt == np.uint16:
+        bitpix, bzero = 16, 32768
+    elif dt == np.int32:
+        bitpix = 32
+    elif dt == np.uint32:
+        bitpix, bzero = 32, 2147483648
+    elif dt == np.int64:
+        bitpix = 64
+    elif dt == np.float32:
+        bitpix = -32
+    elif dt == np.float64:
+        bitpix = -64
+    else:
+        raise TypeError('cannot write dtype %s to FITS' % dt)
+    head = [Card('SIMPLE', True, 'conforms to FITS standard'), Card('BITPIX', bitpix, 'array data type'),
+            Card('NAXIS', data.ndim, 'number of array dimensions')]
+    for i, n in enumerate(reversed(data.shape)):
+        head.append(Card('NAXIS%d' % (i + 1), int(n), ''))
+    had_extend = any(c.key == 'EXTEND' for c in hdr.cards)
+    if had_extend:
+        head.append(Card('EXTEND', True, ''))
+    rest = [c for c in rest if c.key not in ('BSCALE', 'BZERO')] if bzero is not None or dt.kind == 'f' else rest
+    if bzero is not None:
+        head += [Card('BSCALE', 1, ''), Card('BZERO', bzero, '')]
+    return Header(head + rest)
+
+
+def read(path, want_data=True):
+    """Primary HDU -> (data, Header).  Mirrors fits.open(path, uint=True, do_not_scale_image_data=False)."""
+    with open(path, 'rb') as f:
+        raw = f.read()
+    if raw[:6] != b'SIMPLE':
+        raise OSError('%s is not a FITS file (no SIMPLE card).' % path)
+    # header: whole 2880-byte blocks up to the END card
+    pos = 0
+    text = ''
+    while True:
+        block = raw[pos:pos + BLOCK]
+        if len(block) < BLOCK:
+            raise OSError('%s: header is truncated.' % path)
+        pos += BLOCK
+        s = block.decode('ascii', 'replace')
+        text += s
+        if any(s[i:i + 8] == 'END     ' for i in range(0, BLOCK, 80)):
+            break
+    hdr = Header.fromstring(text)
+    naxis = int(hdr.get('NAXIS', 0))
+    shape = tuple(int(hdr['NAXIS%d' % i]) for i in range(naxis, 0, -1))
+    bitpix = int(hdr['BITPIX'])
+    if bitpix not in _BITPIX_DTYPE:
+        raise OSError('%s: unsupported BITPIX %d' % (path, bitpix))
+    count = int(np.prod(shape)) if naxis > 0 else 0
+    nbytes = count * abs(bitpix) // 8
+    data = None
+    if want_data and count > 0:
+        if len(raw) < pos + nbytes:
+            raise OSError('%s: data unit is truncated.' % path)
+        arr = np.frombuffer(raw, dtype=_BITPIX_DTYPE[bitpix], count=count, offset=pos).reshape(shape)
+        bscale = hdr.get('BSCALE', 1)
+        bzero = hdr.get('BZERO', 0)
+        if bitpix > 0 and bscale == 1 and bzero == 2 ** (bitpix - 1) and bitpix in (16, 32, 64):
+            udt = {16: np.uint16, 32: np.uint32, 64: np.uint64}[bitpix]
+            sdt = {16: np.int16, 32: np.int32, 64: np.int64}[bitpix]
+            data = (arr.astype(sdt).view(udt) ^ udt(1 << (bitpix - 1))).astype(udt)
+        elif bscale != 1 or bzero != 0:
+            ft = np.float32 if (bitpix > 0 and bitpix <= 16) else np.float64
+            data = (arr.astype(ft) * ft(bscale) + ft(bzero)).astype(ft)
+        else:
+            data = arr.astype(arr.dtype.newbyteorder('='))
+    hdr._tail = raw[pos + ((nbytes + BLOCK - 1) // BLOCK) * BLOCK:]        # extensions, kept verbatim
+    return data, hdr
+
+
+def getheader(path):
+    return read(path, want_data=False)[1]
+
+
+def write(path, data, header=None, overwrite=True):
+    """Writes a primary HDU (+ the extensions `header` was read with, if any)."""
+    if os.path.exists(path) and not overwrite:
+        raise OSError("File '%s' already exists." % path)
+    data = np.asarray(data)
+    hdr = _structural(header if header is not None else Header(), data)
+    dt = data.dtype
+    if dt == np.uint16:
+        disk = (data ^ np.uint16(0x8000)).view(np.int16).astype('>i2')
+    elif dt == np.uint32:
+        disk = (data ^ np.uint32(0x80000000)).view(np.int32).astype('>i4')
+    else:
+        disk = data.astype(dt.newbyteorder('>'))
+    payload = disk.tobytes()
+    pad = (-len(payload)) % BLOCK
+    tail = getattr(header, '_tail', b'') if header is not None else b''
+    tmp = str(path) + '.tmp%d' % os.getpid()
+    with open(tmp, 'wb') as f:
+        f.write(hdr.tostring().encode('ascii'))
+        f.write(payload)
+        f.write(b'\0' * pad)
+        f.write(tail)
+    os.replace(tmp, path)
+    return hdr

@@ -1,0 +1,242 @@
+"""End-to-end GPU tests of the Ap* shells and ap_* scripts against golden vectors from the reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, assert_biteq, assert_ulp, load_golden, meta, synth_cube
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+
+
+def _wf(path, data, **kw):
+    from astrophotography_amd import fitsio
+    h = fitsio.Header()
+    for k, v in kw.items():
+        h[k.replace('_', '-')] = v
+    fitsio.write(str(path), data, h)
+
+
+def test_apcalibrate_files_golden(tmp_path):
+    """Same FITS files astropy wrote for the reference -> same calibrated pixels and header keywords."""
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    g = load_golden('g1_calibrate.npz')
+    import shutil
+    for n in ('raw', 'bias', 'dark', 'flat', 'cal'):                    # the names the reference run used
+        shutil.copy(os.path.join(GOLDEN, f'g1_c0_{n}.fits'), tmp_path / f'{n}.fits')
+    src = lambda n: str(tmp_path / f'{n}.fits')
+    cal = ap.ApCalibrate(src('bias'), src('dark'), src('flat'), None, 'CRITICAL', dark_still_biased=False)
+    out = tmp_path / 'cal_out.fits'
+    nf = tmp_path / 'nflat.fits'
+    cal.calibrate(src('raw'), str(out), 2, str(nf), False)
+    data, hdr = fitsio.read(str(out))
+    ref, rhdr = fitsio.read(src('cal'))
+    assert data.dtype == np.float32 and hdr['BITPIX'] == -32
+    assert_biteq(data, ref, 'calibrated image')
+    for k in ('BIASCORR', 'BIASFILE', 'DARKCORR', 'DARKFILE', 'BUNIT', 'FLATCORR', 'FLATFILE', 'EXPTIME'):
+        assert hdr[k] == rhdr[k] and hdr.comment(k) == rhdr.comment(k), k
+    assert 'BZERO' not in hdr and 'BSCALE' not in hdr
+    assert hdr.history()[-1].startswith('Processed by ApCalibrate ')
+    assert_biteq(fitsio.read(str(nf))[0], g['nflat_64x64'], 'normalised flat file')
+    with pytest.raises(RuntimeError):
+        cal.calibrate(src('raw'), str(out), 2, None, True)           # cosmic rays: out of scope, loud
+    with pytest.raises(RuntimeError):
+        ap.ApCalibrate(src('bias'), str(tmp_path / 'missing.fits'), None, None, 'CRITICAL')
+
+
+def test_apcalibrate_all_golden_cases(tmp_path):
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    g = load_golden('g1_calibrate.npz')
+    for ci in range(int(g['ncases'])):
+        m = meta(g, f'c{ci}_meta')
+        H, W = m['shape']
+        shp = f'_{H}x{W}'
+        d = tmp_path / f'c{ci}'
+        d.mkdir()
+        _wf(d / 'bias.fits', g['bias' + shp])
+        _wf(d / 'dark.fits', g['dark' + shp], EXPTIME=m['dark_exp'])
+        flat = None
+        if m['flatmode'] != 'noflat':
+            flat = str(d / 'flat.fits')
+            _wf(flat, g[m['flatmode'] + shp])
+        kw = {m['expkw']: m['img_exp']}
+        if m['expkw'] == 'EXPOSURE':
+            kw['EXPTIME'] = 999.0
+        if m['pedestal'] is not None:
+            kw['PEDESTAL'] = m['pedestal']
+        _wf(d / 'raw.fits', g['raw_' + m['raw'] + shp], **kw)
+        bp = None
+        if m['use_mask']:
+            bp = str(d / 'bpix.fits')
+            _wf(bp, g['mask' + shp])
+        cal = ap.ApCalibrate(str(d / 'bias.fits'), str(d / 'dark.fits'), flat, bp, 'CRITICAL', dark_still_biased=m['dark_still_biased'])
+        cal.calibrate(str(d / 'raw.fits'), str(d / 'cal.fits'), m['deltapix'], None, False)
+        out, hdr = fitsio.read(str(d / 'cal.fits'))
+        assert_biteq(out, g[f'c{ci}_out'].astype(np.float32), f'case {ci} {m}')
+        ref = {k: v for k, v, _ in json.loads(str(g[f'c{ci}_hdr']))}
+        for k in ref:
+            if k.startswith('BPIX') or k in ('FLATCORR', 'DARKCORR', 'BIASCORR'):
+                assert repr(hdr[k]) == ref[k], (ci, k, hdr[k], ref[k])
+        assert 'PEDESTAL' not in hdr
+        if ci == 0:      # batch / slab form gives the same file
+            cal.calibrate_files([str(d / 'raw.fits')] * 3, [str(d / f'b{i}.fits') for i in range(3)], m['deltapix'])
+            assert_biteq(fitsio.read(str(d / 'b2.fits'))[0], out)
+
+
+def test_apfindbadpixels_golden(tmp_path):
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    g = load_golden('g2_findbadpix.npz')
+    for ci in range(int(g['ncases'])):
+        dark = g[f'd{ci}_dark']
+        p = tmp_path / f'dark{ci}.fits'
+        _wf(p, dark, TELESCOP='synth', INSTRUME='cam', XBINNING=1)
+        fb = ap.ApFindBadPixels(str(p), 4.0, 'CRITICAL')
+        assert fb.get_mask().dtype == np.uint8
+        if dark.dtype == np.float32:
+            assert np.array_equal(fb.get_mask(), g[f'd{ci}_mask_auto'])
+            assert fb._nbad_auto == int(g[f'd{ci}_nbad_auto'])
+            st = fb.get_stats()
+            assert [st['lothresh'], st['hithresh']] == list(g[f'd{ci}_thresh'])
+        else:
+            # integer dark: numpy uses float64 statistics, the device float32 ones; the mask still agrees
+            assert (fb.get_mask() != g[f'd{ci}_mask_auto']).sum() == 0
+        if f'd{ci}_mask_user' in g:
+            fb.add_user_badpix(os.path.join(GOLDEN, 'user_badpixels.yml'))
+            assert np.array_equal(fb.get_mask(), g[f'd{ci}_mask_user'])
+            assert fb._nbad_user == int(g[f'd{ci}_nbad_user'])
+            mp = tmp_path / 'mask.fits'
+            fb.write_mask(str(mp))
+            m, hdr = fitsio.read(str(mp))
+            assert m.dtype == np.uint8 and np.array_equal(m, g[f'd{ci}_mask_user'])
+            ref = {k: v for k, v, _ in json.loads(str(g[f'd{ci}_maskfile_hdr']))}
+            for k in ('IMAGETYP', 'CREATOR', 'NBADAUTO', 'NBADUSER', 'USERFILE', 'TELESCOP', 'INSTRUME', 'XBINNING'):
+                assert repr(hdr[k]) == ref[k], k
+
+
+def test_apfixbadpixels_and_imarith_golden(tmp_path):
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    g = load_golden('g3_fixbadpix.npz')
+    fx = ap.ApFixBadPixels('CRITICAL')
+    for dp in (1, 2, 3):
+        nd, st = fx.fix_bad_pixels(g['data'], g['mask'], dp)
+        assert_biteq(nd, g[f'out_dp{dp}'])
+        ref = json.loads(str(g[f'stats_dp{dp}']))
+        for k in ref:
+            assert st[k][0] == ref[k][0] and st[k][1] == ref[k][1], k
+    nd, st = fx.fix_bad_pixels(g['data_u16'], g['mask'], 1)
+    assert nd.dtype == np.uint16 and np.array_equal(nd, g['out_u16_dp1'])
+    _wf(tmp_path / 'd.fits', g['data'], PEDESTAL=0)
+    _wf(tmp_path / 'm.fits', g['mask'])
+    fx.fix_files(str(tmp_path / 'd.fits'), str(tmp_path / 'm.fits'), str(tmp_path / 'o.fits'), 2)
+    o, h = fitsio.read(str(tmp_path / 'o.fits'))
+    assert_biteq(o, g['out_dp2'])
+    assert h['BPIXFILE'] == 'm.fits' and h['BPIXDPIX'] == 2 and 'PEDESTAL' not in h
+
+    g = load_golden('g4_imarith.npz')
+    ia = ap.ApImArith('CRITICAL')
+    _wf(tmp_path / 'a.fits', g['a'], BUNIT='adu')
+    _wf(tmp_path / 'b.fits', g['b'])
+    _wf(tmp_path / 'au.fits', g['au'])
+    _wf(tmp_path / 'bu.fits', g['bu'])
+    for op in ('ADD', 'SUB', 'MUL', 'DIV'):
+        ia.process_files(str(tmp_path / 'a.fits'), op, str(tmp_path / 'b.fits'), str(tmp_path / 'o.fits'), None)
+        assert_biteq(fitsio.read(str(tmp_path / 'o.fits'))[0], g[f'f32_arr_{op}'].astype(np.float32), op)
+        ia.process_files(str(tmp_path / 'a.fits'), ' ' + op.lower() + ' ', '3.25', str(tmp_path / 'o.fits'), 'electrons')
+        o, h = fitsio.read(str(tmp_path / 'o.fits'))
+        assert_biteq(o, g[f'f32_scl_{op}'].astype(np.float32), op)
+        assert h['BUNIT'] == 'electrons' and h.history()[-1].endswith(f'a.fits {op} 3.25')
+    for op in ('ADD', 'SUB', 'MUL'):
+        ia.process_files(str(tmp_path / 'au.fits'), op, str(tmp_path / 'bu.fits'), str(tmp_path / 'o.fits'), None)
+        o, _ = fitsio.read(str(tmp_path / 'o.fits'))
+        assert o.dtype == np.uint16 and np.array_equal(o, g[f'u16_arr_{op}'])
+    # error behaviour recorded from the reference
+    for tag, args in (('u16_arr_DIV', ('au.fits', 'DIV', str(tmp_path / 'bu.fits'))), ('u16_scl_ADD', ('au.fits', 'ADD', '2.0')),
+                      ('f32_badop', ('a.fits', 'POW', '2.0')), ('f32_badfile', ('a.fits', 'ADD', str(tmp_path / 'none.fits')))):
+        exc = {'ValueError': ValueError, 'UFuncTypeError': TypeError, 'TypeError': TypeError}[str(g[tag + '_exc'])]
+        with pytest.raises(exc):
+            ia.process_files(str(tmp_path / args[0]), args[1], args[2], str(tmp_path / 'o.fits'), None)
+
+
+def test_apmastercal_and_apstack(tmp_path):
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    from oracle import apref
+    rng = np.random.default_rng(3)
+    N, shape = 12, (40, 64)
+    cube = synth_cube(rng, N, shape, dtype=np.uint16)
+    d = tmp_path / 'darks'
+    d.mkdir()
+    for i in range(N):
+        _wf(d / f'dark{i:02d}.fits', cube[i], TELESCOP='T05', IMAGETYP='Dark Frame', EXPTIME=300.0, SET_TEMP=-20.0,
+            CCD_TEMP=-20.0 + 0.01 * i, DATE_OBS='2020-01-01', FILTER='none')
+    mc = ap.ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')
+    mc.make_master(str(d / 'master_dark.fits'))
+    m, h = fitsio.read(str(d / 'master_dark.fits'))
+    ref = apref.combine_ccdproc(cube.astype(np.float64), 5.0, 5.0)
+    assert_ulp(m, ref['mean'].astype(np.float32), 1, 'master dark vs ccdproc-style oracle')
+    assert h['IMAGETYP'] == 'MASTER DARK' and h['NCOMBINE'] == N and h['IFILE011'] == 'dark11.fits' and h['BUNIT'] == 'adu'
+    # second construction ignores the master it just wrote
+    assert len(ap.ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')._values('file')) == N
+    # the script front-end
+    from astrophotography_amd.scripts import ap_combine_darks, ap_stack
+    assert ap_combine_darks.main([str(d), str(d / 'master2.fits'), '-l', 'CRITICAL']) == 0
+    assert np.array_equal(fitsio.read(str(d / 'master2.fits'))[0], m)
+    assert ap_combine_darks.main([str(tmp_path / 'nodir'), str(d / 'x.fits'), '-l', 'CRITICAL']) == 1
+
+    # ApStack on files, fused with calibration, vs the oracle
+    bias = rng.normal(100, 2, shape).astype(np.float32)
+    dark = rng.normal(10, 1, shape).astype(np.float32)
+    flat = rng.normal(30000, 300, shape).astype(np.float32)
+    _wf(tmp_path / 'bias.fits', bias)
+    _wf(tmp_path / 'dark.fits', dark, EXPTIME=300.0)
+    _wf(tmp_path / 'flat.fits', flat)
+    files = []
+    for i in range(N):
+        p = tmp_path / f'raw{i:02d}.fits'
+        _wf(p, cube[i], EXPTIME=120.0)
+        files.append(str(p))
+    assert ap_stack.main([str(tmp_path / 'stack.fits')] + files + ['--master_bias', str(tmp_path / 'bias.fits'), '--master_dark',
+                         str(tmp_path / 'dark.fits'), '--master_flat', str(tmp_path / 'flat.fits'), '-l', 'CRITICAL']) == 0
+    s, hs = fitsio.read(str(tmp_path / 'stack.fits'))
+    nflat, _ = apref.flat_normalize(flat)
+    ref_mean, _ = apref.calibrate_stack(cube, bias, dark, nflat, 120.0 / 300.0, sigma=3.0, maxiters=5)
+    assert_ulp(s, ref_mean, 1, 'ap_stack fused')
+    assert hs['NCOMBINE'] == N and hs['STACKMET'] == 'sigclip'
+    st = ap.ApStack('CRITICAL')
+    r = st.stack(torch.from_numpy(cube.astype(np.float32)).cuda(), method='median')
+    assert_ulp(r['median'].cpu().numpy(), apref.stack_median(cube.astype(np.float32)).astype(np.float32), 1, 'median')
+    r = st.stack(torch.from_numpy(cube.astype(np.float32)).cuda(), method='mean')
+    np.testing.assert_allclose(r['mean'].cpu().numpy(), cube.astype(np.float64).mean(0), rtol=2e-7)
+    with pytest.raises(ValueError):
+        st.stack(torch.zeros((2, 4, 4), device='cuda'), method='mode')
+
+
+def test_stack_mad_std_vs_oracle():
+    from astrophotography_amd import ops
+    from oracle import apref
+    rng = np.random.default_rng(29)
+    for N in (3, 8, 16, 33, 64):
+        cube = synth_cube(rng, N, (23, 31), nan_frac=0.01)
+        cube[:, 0, 0] = 5.0
+        d = torch.from_numpy(cube).cuda()
+        for sigma, maxiters, cen in ((5.0, 1, 'median'), (3.0, 5, 'median'), (3.0, None, 'mean')):
+            ref = apref.stack_sigclip(cube, sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc='mad_std')
+            r = ops.stack_sigclip(d, sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc='mad_std', outputs=('mean', 'count'))
+            what = f'N={N} sigma={sigma} maxiters={maxiters} cen={cen}'
+            assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
+            assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
+        c = apref.combine_ccdproc(cube, 5.0, 5.0)
+        r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count'))
+        assert np.array_equal(r['count'].cpu().numpy(), c['count'])

@@ -1,0 +1,197 @@
+"""CPU-only tests: the C ABI exports what include/apgpu.h declares, the FITS module reads/writes what
+astropy wrote, host-side logic of the Ap* shells, the scripts' flags and the sharding helpers."""
+import os
+import re
+import shutil
+
+import numpy as np
+import pytest
+
+from tests.util import GOLDEN, load_golden
+
+ROOT = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
+
+
+def test_capi_exports_every_declared_symbol():
+    from astrophotography_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'apgpu.h')).read()
+    declared = set(re.findall(r'\b(apgpu_[a-z0-9_]+)\s*\(', hdr))
+    declared.discard('apgpu_stack_args')
+    assert len(declared) >= 15
+    lib = _lib.load()                          # loads without a GPU; no compute call is made
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, 'binding missing for ' + name
+    assert set(_lib.SIGNATURES) == declared
+    assert lib.apgpu_version() == 100
+    assert lib.apgpu_last_error() is not None
+    # argument validation happens before any device work
+    assert lib.apgpu_calibrate(None, 0, None, None, None, None, None, 0, None, 1, 1, None) == _lib.E_INVAL
+    assert b'NULL' in lib.apgpu_last_error()
+    assert lib.apgpu_stack_sigclip(None, None) == _lib.E_INVAL
+    assert lib.apgpu_flat_normalize_ws_bytes(4096 * 4096) >= 4 * 2048 + 16
+    assert lib.apgpu_sigclip_global_ws_bytes(1000) >= 8000
+
+
+def test_stack_args_struct_matches_header():
+    import ctypes as C
+    from astrophotography_amd._lib import StackArgs
+    hdr = open(os.path.join(ROOT, 'include', 'apgpu.h')).read()
+    body = hdr[hdr.index('typedef struct apgpu_stack_args {'):hdr.index('} apgpu_stack_args;')]
+    fields = re.findall(r'^\s+(?:const\s+)?[a-z0-9_]+\s*\*?\s*\*?([a-z_]+);', body, re.M)
+    assert fields == [f[0] for f in StackArgs._fields_]
+    assert C.sizeof(StackArgs) == 152
+
+
+def test_fitsio_reads_and_rewrites_astropy_files(tmp_path):
+    from astrophotography_amd import fitsio
+    g = load_golden('g1_calibrate.npz')
+    raw, h = fitsio.read(os.path.join(GOLDEN, 'g1_c0_raw.fits'))
+    assert raw.dtype == np.uint16 and np.array_equal(raw, g['raw_u16_64x64'])
+    assert h['BZERO'] == 32768 and h['EXPTIME'] == 120.0 and h['NAXIS1'] == 64
+    for name, key in (('bias', 'bias_64x64'), ('dark', 'dark_64x64'), ('flat', 'flat_64x64')):
+        d, _ = fitsio.read(os.path.join(GOLDEN, f'g1_c0_{name}.fits'))
+        assert d.dtype == np.float32 and np.array_equal(d, g[key])
+    cal, hc = fitsio.read(os.path.join(GOLDEN, 'g1_c0_cal.fits'))
+    assert np.array_equal(cal, g['c0_out'].astype(np.float32))
+    assert hc['BIASCORR'] is True and hc['BIASFILE'] == 'bias.fits' and hc['BUNIT'] == 'adu'
+    assert hc.comment('DARKCORR') == 'True if scaled dark subtracted.'
+    assert hc.history()[0].startswith('Processed by ApCalibrate 0.5.1')
+    # byte-identical rewrite of both files
+    for fn, data, hh in (('g1_c0_raw.fits', raw, h), ('g1_c0_cal.fits', cal, hc)):
+        out = tmp_path / fn
+        fitsio.write(str(out), data, hh)
+        assert out.read_bytes() == open(os.path.join(GOLDEN, fn), 'rb').read()
+    # header edits: update, append, delete, history, long strings, numbers
+    hh = hc.copy()
+    hh['BUNIT'] = ('electrons', 'Pixel value units')
+    hh['NEWKEY'] = (3, 'an int')
+    hh['FLT'] = 0.5
+    del hh['FLATFILE']
+    hh['HISTORY'] = 'second history line'
+    out = tmp_path / 'edit.fits'
+    fitsio.write(str(out), cal.astype(np.float64), hh)
+    d2, h2 = fitsio.read(str(out))
+    assert d2.dtype == np.float64 and h2['BITPIX'] == -64
+    assert h2['BUNIT'] == 'electrons' and h2['NEWKEY'] == 3 and h2['FLT'] == 0.5 and 'FLATFILE' not in h2
+    assert len(h2.history()) == 2
+    assert len(out.read_bytes()) % 2880 == 0
+    # uint8 mask round trip, no BZERO
+    m = (np.arange(35).reshape(5, 7) % 4).astype(np.uint8)
+    fitsio.write(str(tmp_path / 'm.fits'), m, None)
+    m2, hm = fitsio.read(str(tmp_path / 'm.fits'))
+    assert m2.dtype == np.uint8 and np.array_equal(m, m2) and 'BZERO' not in hm
+    with pytest.raises(OSError):
+        (tmp_path / 'bad.fits').write_bytes(b'not a fits file' * 300)
+        fitsio.read(str(tmp_path / 'bad.fits'))
+
+
+def test_fitsio_scaled_integers(tmp_path):
+    from astrophotography_amd import fitsio
+    h = fitsio.Header()
+    h['BSCALE'] = 2.0
+    h['BZERO'] = 10.0
+    # write raw int16 then patch scaling keywords in by hand (writer drops them for floats only)
+    data = np.array([[1, -2], [300, 4]], np.int16)
+    fitsio.write(str(tmp_path / 's.fits'), data, h)
+    d, hh = fitsio.read(str(tmp_path / 's.fits'))
+    assert hh['BSCALE'] == 2.0
+    assert d.dtype == np.float32 and np.array_equal(d, data.astype(np.float32) * 2 + 10)
+
+
+def test_user_badpix_yaml_semantics(tmp_path):
+    """1-based inclusive -> 0-based half-open, out-of-range entries skipped, slots counted
+    (ApFindBadPixels.py:70-158) - host logic only, no device."""
+    from astrophotography_amd.core import _common
+    from astrophotography_amd.core.ApFindBadPixels import ApFindBadPixels
+    obj = ApFindBadPixels.__new__(ApFindBadPixels)
+    obj._logger = _common.make_logger('ApFindBadPixels', 'CRITICAL')
+    obj._imdata = np.zeros((300, 500), np.float32)
+    y = tmp_path / 'u.yml'
+    shutil.copy(os.path.join(GOLDEN, 'user_badpixels.yml'), y)
+    cols, rows, rects = obj._read_user_badpix(y)
+    assert cols == [12, 13, 17] and rows is None and len(rects) == 3
+    r, n = obj._rects_from_user(cols, rows, rects)
+    assert r == [[0, 300, 11, 12], [0, 300, 12, 13], [0, 300, 16, 17], [0, 1, 0, 1], [4, 6, 6, 12], [199, 300, 399, 420]]
+    g = load_golden('g2_findbadpix.npz')
+    assert n == int(g['d1_nbad_user'])
+    r, n = obj._rects_from_user([0, 501, 500], [301, 1], [[1, 301, 1, 2], [1, 2, 0, 3], [1, 2, 3]])
+    assert r == [[0, 300, 499, 500], [0, 1, 0, 500]] and n == 300 + 500
+    (tmp_path / 'partial.yml').write_text('bad_rows:\n- 3\n')
+    assert obj._read_user_badpix(tmp_path / 'partial.yml') == [None, [3], None]
+
+
+def test_error_conventions_without_device(tmp_path):
+    import astrophotography_amd as ap
+    with pytest.raises(ValueError):
+        ap.ApImArith('NOT_A_LEVEL')
+    ia = ap.ApImArith('CRITICAL')
+    with pytest.raises(ValueError):
+        ia._sanitize_operation('POW')
+    assert ia._sanitize_operation(' sub ') == 'SUB'
+    with pytest.raises(RuntimeError):
+        ap.ApFixBadPixels('CRITICAL').fix_files(str(tmp_path / 'nope.fits'), str(tmp_path / 'm.fits'), str(tmp_path / 'o.fits'))
+    with pytest.raises(RuntimeError):
+        ap.ApMasterCal(str(tmp_path / 'missing_dir'), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')
+    with pytest.raises(AttributeError):
+        ap.NoSuchClass
+
+
+def test_mastercal_file_checks(tmp_path):
+    """Consistency checks and CCD-TEMP filter of ApMasterCal (ap_combine_darks.py:150-287) - headers only."""
+    from astrophotography_amd import fitsio
+    from astrophotography_amd.core.ApMasterCal import ApMasterCal
+    d = tmp_path / 'darks'
+    d.mkdir()
+
+    def mk(name, temp=-20.0, exptime=300.0, imagetyp='Dark Frame', shape=(4, 6)):
+        h = fitsio.Header()
+        for k, v in (('TELESCOP', 'T05'), ('IMAGETYP', imagetyp), ('EXPTIME', exptime), ('SET-TEMP', -20.0),
+                     ('CCD-TEMP', temp), ('DATE-OBS', '2020-01-01T00:00:00'), ('FILTER', 'none')):
+            h[k] = v
+        fitsio.write(str(d / name), np.zeros(shape, np.uint16), h)
+    mk('d1.fits'), mk('d2.fit', temp=-19.8), mk('d3.fits', temp=-18.0), mk('master_dark.fits')
+    mc = ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')
+    assert mc._values('file') == ['d1.fits', 'd2.fit']                 # master* excluded, warm frame dropped
+    kw = mc._generate_final_keywords()
+    assert kw['IMAGETYP'][0] == 'MASTER DARK' and kw['TELESCOP'][0] == 'T05' and kw['IFILE001'] == 'd2.fit'
+    assert kw['SET-TEMP'][0] == -20.0
+    mk('d4.fits', exptime=60.0)
+    with pytest.raises(RuntimeError):
+        ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')
+
+
+def test_scripts_keep_the_reference_flags():
+    from astrophotography_amd.scripts import ap_calibrate, ap_combine_darks, ap_find_badpix, ap_fix_badpix, ap_imarith, ap_stack
+    a = ap_calibrate.command_line_opts(['raw.fits', 'b.fits', 'd.fits', 'out.fits', '--master_flat', 'f.fits',
+                                        '--master_badpix', 'm.fits', '--normflat', 'n.fits', '--deltapix', '3',
+                                        '--fixcosmic', '--dark_still_biased', '-l', 'DEBUG'])
+    assert (a.raw_image, a.master_bias, a.master_dark, a.calibrated_image) == ('raw.fits', 'b.fits', 'd.fits', 'out.fits')
+    assert a.deltapix == 3 and a.fixcosmic and a.dark_still_biased and a.loglevel == 'DEBUG' and a.normflat == 'n.fits'
+    assert ap_calibrate.command_line_opts(['r', 'b', 'd', 'o']).deltapix == 2
+    f = ap_find_badpix.command_line_opts(['dark.fits', 'bp.fits'])
+    assert f.sigma == 4.0 and f.user_badpix is None
+    assert ap_find_badpix.command_line_opts(['dark.fits', 'bp.fits', '--sigma', '5']).sigma == 5.0
+    i = ap_imarith.command_line_opts(['a.fits', 'SUB', '3.5', 'o.fits', '--units', 'adu'])
+    assert (i.operation, i.value, i.units) == ('SUB', '3.5', 'adu')
+    assert ap_fix_badpix.command_line_opts(['a.fits', 'm.fits', 'o.fits']).deltapix == 2
+    c = ap_combine_darks.command_line_opts(['dir', 'master.fits'])
+    assert (c.exclude_pattern, c.telescop, c.temptol) == ('master*', 'UNKNOWN', 0.5)
+    s = ap_stack.command_line_opts(['o.fits', 'a.fits', 'b.fits', '--method', 'median'])
+    assert s.input_images == ['a.fits', 'b.fits'] and s.method == 'median' and s.sigma == 3.0
+    for mod in (ap_calibrate, ap_find_badpix, ap_imarith, ap_fix_badpix, ap_combine_darks):
+        with pytest.raises(SystemExit) as e:
+            mod.command_line_opts(['--help'])
+        assert e.value.code == 0
+
+
+def test_sharding_helpers():
+    from astrophotography_amd import parallel
+    assert parallel.stripe_rows(4096, 8) == [(i * 512, (i + 1) * 512) for i in range(8)]
+    s = parallel.stripe_rows(10, 3)
+    assert s == [(0, 4), (4, 7), (7, 10)]
+    assert parallel.stripe_rows(2, 8) == [(0, 1), (1, 2)]
+    got = [parallel.shard_frames(256, 8, r) for r in range(8)]
+    assert got == [(r * 32, (r + 1) * 32) for r in range(8)]
+    got = [parallel.shard_frames(10, 4, r) for r in range(4)]
+    assert got == [(0, 3), (3, 6), (6, 8), (8, 10)]
