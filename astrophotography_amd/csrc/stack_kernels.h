@@ -357,33 +357,62 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
 
 // Fast calibration of a full column (N == NP): reciprocal division, no per-value fix-ups.  Returns
 // true if the lane's results are exact AND all finite; otherwise the wave redoes the column exactly.
+// Frames are processed in pairs with 2-wide vector arithmetic so that the backend emits the packed
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 forms: the kernel is bound by VALU issue slots (one
+// wave64 instruction per 4 cycles per SIMD) and a packed instruction retires two values per slot.
+// Each lane of a packed operation is an ordinary IEEE float32 operation, so results do not change.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int NP, typename RawT, bool HAS_PED>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[NP], float b, float D, float nf,
                                                bool dodiv, float (&v)[NP])
 {
-    const float y = __fdiv_rn(1.0f, dodiv ? nf : 1.0f);
-    const float anf = fabsf(nf);
-    const bool nf_ok = !dodiv || (anf >= 0x1p-40f && anf <= 0x1p40f);
-    float acc = 0.f, mx = 0.f, mn = __builtin_inff();
+    // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
+    // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
+    const float nfe = dodiv ? nf : 1.0f;
+    const float y = __fdiv_rn(1.0f, nfe);
+    const float anf = fabsf(nfe);
+    const bool nf_ok = (anf >= 0x1p-40f && anf <= 0x1p40f);
+    float mx = 0.f, mn = __builtin_inff();
+    if constexpr (NP >= 2) {
+        v2f acc = {0.f, 0.f};
+        const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
 #pragma unroll
-    for (int f = 0; f < NP; f++) {
-        float x = to_f32(raw[f]);
-        if constexpr (HAS_PED) {
-            const float ped = fs.ped[f];
-            if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
+        for (int f = 0; f < NP; f += 2) {
+            v2f x = {to_f32(raw[f]), to_f32(raw[f + 1])};
+            if constexpr (HAS_PED) {
+                const v2f ped = {fs.ped[f], fs.ped[f + 1]};
+                x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
+            }                                                // which changes nothing but the sign of a -0.0 input
+            const v2f e2 = {fs.e[f], fs.e[f + 1]};
+            x = x - b2;                                      // :439
+            const v2f ds = e2 * D2;                          // :450
+            x = x - ds;                                      // :451
+            const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
+            const v2f r0 = __builtin_elementwise_fma(nf2, q0, x);
+            const v2f q1 = __builtin_elementwise_fma(r0, y2, q0);
+            const v2f r1 = __builtin_elementwise_fma(nf2, q1, x);
+            const v2f q = __builtin_elementwise_fma(r1, y2, q1);
+            v[f] = q.x;
+            v[f + 1] = q.y;
+            acc = __builtin_elementwise_fma(q, zero2, acc);  // NaN iff some value is not finite
+            mx = fmaxf(fmaxf(mx, fabsf(q.x)), fabsf(q.y));
+            mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
         }
-        x = x - b;                                           // :439
-        const float ds = fs.e[f] * D;                        // :450
-        x = x - ds;                                          // :451
-        const float q = div_by_recip(x, nf, y);
-        x = dodiv ? q : x;                                   // :462-464
-        v[f] = x;
-        acc = __builtin_fmaf(x, 0.0f, acc);                  // NaN iff some value is not finite
-        mx = fmaxf(mx, fabsf(x));
-        mn = fminf(mn, fabsf(x));
+        const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
+        return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
+    } else {
+        float x = to_f32(raw[0]);
+        if constexpr (HAS_PED) x = x + fs.ped[0];
+        x = x - b;
+        const float ds = fs.e[0] * D;
+        x = x - ds;
+        const float q = div_by_recip(x, nfe, y);
+        v[0] = q;
+        const float acc = __builtin_fmaf(q, 0.0f, 0.0f);
+        const bool range_ok = !dodiv || (fabsf(q) < 0x1p50f && fabsf(q) > 0x1p-50f);
+        return nf_ok && range_ok && (acc == 0.f);
     }
-    const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
-    return nf_ok && range_ok && (acc == 0.f);
 }
 
 // Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
@@ -445,7 +474,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 // std over the column and two more multiplexer trees), so the mean/count/moments-only kernel - the
 // benchmarked path - is a separate, leaner instantiation.
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
-__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 4 : 1) void stack_sigclip_kernel(const StackParams prm)
+__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
@@ -465,12 +494,21 @@ __global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 4 : 1) void stack_sigcl
     const double c = (double)cf;
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
+    if (__all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const float x = (i < n) ? v[i] : cf;
-        const double d = (double)x - c;
-        Sa[i & 3] += d;
-        Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        for (int i = 0; i < NP; i++) {
+            const double d = (double)v[i] - c;
+            Sa[i & 3] += d;
+            Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float x = (i < n) ? v[i] : cf;
+            const double d = widen(x) - c;      // opaque: keeps this rare path from sharing (and hoisting)
+            Sa[i & 3] += d;                     // the 64 conversions of the common path above
+            Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        }
     }
     const double S0 = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
     const double Q0 = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
