@@ -34,6 +34,9 @@ namespace apgpu_stack {
 
 using namespace apgpu;
 
+// zero-cost section markers in the generated assembly (tools/isa_sections.py counts instructions per section)
+#define APGPU_MARK(name) asm volatile("; APGPU_SECTION " name)
+
 // -------------------------------------------------------------------------------------------------
 // Batcher odd-even merge sorting network for NP = 2^k inputs, generated at compile time.
 // -------------------------------------------------------------------------------------------------
@@ -484,8 +487,11 @@ __global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigcl
     if (p >= prm.P) return;
 
     float v[NP];
+    APGPU_MARK("load_calibrate");
     const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
+    APGPU_MARK("sort");
     sort_column<NP>(v);
+    APGPU_MARK("moments");
 
     // pivot: the lower median of the finite values
     float cf, cf2;
@@ -513,6 +519,7 @@ __global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigcl
     const double S0 = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
     const double Q0 = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
 
+    APGPU_MARK("clip_loop");
     ClipState st;
     st.S = S0;
     st.Q = Q0;
@@ -561,6 +568,7 @@ __global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigcl
         active = active && changed && (prm.maxiters < 0 || it < prm.maxiters);
     }
 
+    APGPU_MARK("readmit_output");
     // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by
     // an earlier, tighter pass that lie inside the final bounds are re-admitted.
     if (__any(st.a > 0)) {
