@@ -81,6 +81,8 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
     prm.dev = median_only ? 0 : args->dev;
     prm.maxiters = args->maxiters;
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;   // development: all frames alias frame 0 (compute-only timing)
+    prm.persistent = getenv("APGPU_PERSISTENT") ? 1 : 0;     // development: load/compute-overlapped variant
+    if (const char *e = getenv("APGPU_DEBUG_MAXITERS")) prm.maxiters = atoi(e);
     hipStream_t st = as_stream(stream);
     if (args->dtype == APGPU_F32)
         return calib ? launch_np<float, true>(prm, median_only, st) : launch_np<float, false>(prm, median_only, st);

@@ -305,6 +305,7 @@ struct StackParams {
     int center;             // 0 median, 1 mean
     int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
     int maxiters;           // < 0: until convergence
+    int persistent;         // use the persistent, load/compute-overlapped kernel where available
 };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -476,19 +477,10 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 // EXTRA = the optional median / std planes are compiled in.  They cost ~100 extra VGPRs (a two-pass
 // std over the column and two more multiplexer trees), so the mean/count/moments-only kernel - the
 // benchmarked path - is a separate, leaner instantiation.
-template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
-__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
+// Everything after the column is in registers: sort, moments, clipping iterations, outputs.
+template <int NP, bool EXTRA>
+__device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
-    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
-    const int lane = threadIdx.x;
-    const int64_t p = base + lane;
-    __shared__ FrameScalars<NP> fs;
-    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
-    if (p >= prm.P) return;
-
-    float v[NP];
-    APGPU_MARK("load_calibrate");
-    const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
     APGPU_MARK("sort");
     sort_column<NP>(v);
     APGPU_MARK("moments");
@@ -623,6 +615,99 @@ __global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigcl
     }
 }
 
+template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
+__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
+{
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int lane = threadIdx.x;
+    const int64_t p = base + lane;
+    __shared__ FrameScalars<NP> fs;
+    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
+    if (p >= prm.P) return;
+
+    float v[NP];
+    APGPU_MARK("load_calibrate");
+    const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
+    reduce_and_store<NP, EXTRA>(prm, v, n, p);
+}
+
+// Persistent form of the lean kernel for full stacks (N == NP) with fused calibration: every
+// workgroup walks over tiles of 256 pixels; as soon as the calibrated column of tile t is in v[] the
+// loads of tile t + gridDim.x are issued into the (now dead) raw registers, so the HBM-bound load
+// phase of the next tile runs underneath the VALU-bound sort / clip of the current one.  Without this
+// the two phases of co-resident workgroups stay in lockstep (identical work) and add up.
+// Register budget: raw[NP] (in flight) + v[NP] + ~50 temporaries -> 2 waves per SIMD, which is enough
+// for a kernel bound by VALU issue (one wave64 instruction per 4 cycles per SIMD).
+template <int NP, typename RawT>
+__global__ __launch_bounds__(256, 2) void stack_sigclip_persistent_kernel(const StackParams prm)
+{
+    __shared__ FrameScalars<NP> fs;
+    stage_frame_scalars<NP>(prm, fs);
+    const int lane = threadIdx.x;
+    const int64_t ntiles = (prm.P + 255) / 256;
+    int64_t tile = blockIdx.x;
+    RawT raw[NP];
+    float b = 0.f, d = 0.f, nf = 1.f;
+    const bool has_flat = prm.nflat != nullptr;
+    auto issue = [&](int64_t t) {
+        const int64_t base = t * 256;
+        int64_t pc = base + lane;
+        pc = pc < prm.P ? pc : prm.P - 1;                   // lanes past the end re-read the last pixel
+        b = prm.bias[pc];
+        d = prm.dark[pc];
+        if (has_flat) nf = prm.nflat[pc];
+        const RawT *fp = static_cast<const RawT *>(prm.frames) + pc;
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            raw[f] = *fp;
+            fp += prm.stride;
+            if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (tile < ntiles) issue(tile);
+    while (tile < ntiles) {
+        const int64_t base = tile * 256;
+        const int64_t p = base + lane;
+        const bool valid = p < prm.P;
+        const int64_t pc = valid ? p : prm.P - 1;
+        float v[NP];
+        APGPU_MARK("p_calibrate");
+        const float D = prm.still_biased ? d - b : d;       // ApCalibrate.py:440-445
+        const bool dodiv = has_flat && (nf != 0.f);         // ApCalibrate.py:462 (NaN != 0 is True)
+        const bool skip = prm.pixmask && prm.pixmask[pc];
+        const float cb = b, cnf = nf;
+        bool good;
+        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, cb, D, cnf, dodiv, v);
+        else good = calibrate_fast<NP, RawT, false>(fs, raw, cb, D, cnf, dodiv, v);
+        // raw[] is dead now: start the next tile's loads, they complete under the reduction below
+        const int64_t next = tile + gridDim.x;
+        if (next < ntiles) issue(next);
+        int n = NP;
+        if (!__all(good && !skip)) {
+            // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
+            // redo the column exactly (IEEE division), one frame at a time
+            n = 0;
+            const RawT *fp = static_cast<const RawT *>(prm.frames) + pc;
+#pragma unroll
+            for (int f = 0; f < NP; f++) {
+                float x = to_f32(*fp);
+                fp += prm.stride;
+                const float ped = fs.ped[f];
+                if (ped != 0.f) x = x + ped;
+                x = x - cb;
+                const float ds = fs.e[f] * D;
+                x = x - ds;
+                if (dodiv) x = __fdiv_rn(x, cnf);
+                const bool ok = (fabsf(x) < __builtin_inff()) && !skip;
+                n += ok ? 1 : 0;
+                v[f] = ok ? x : __builtin_inff();
+            }
+        }
+        if (valid) reduce_and_store<NP, false>(prm, v, n, p);
+        tile = next;
+    }
+}
+
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
 template <int NP, typename RawT, bool CALIB>
 __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm)
@@ -653,8 +738,17 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
         hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     else if (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD)
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
-    else if (prm.N == NP)
+    else if (prm.N == NP) {
+        if constexpr (CALIB) {
+            if (prm.persistent && NP >= 2) {
+                const int64_t ntiles = (prm.P + 255) / 256;
+                const int64_t g = ntiles < 2 * kNumCU ? ntiles : 2 * kNumCU;
+                hipLaunchKernelGGL((stack_sigclip_persistent_kernel<NP, RawT>), dim3((unsigned)g), dim3(block), 0, st, prm);
+                return check_launch("stack kernel (persistent)");
+            }
+        }
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+    }
     else
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     return check_launch("stack kernel");

@@ -65,7 +65,7 @@ def _default_finalize(moments, out_mean):
 
 
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
-                 n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False):
+                 n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank.
 
     One all-reduce per stripe on a side stream, overlapped with the reduction of the next stripe.
@@ -76,9 +76,10 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     n_local, H, W = frames_local.shape
     clip = dict(sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc)
     on_gpu = frames_local.is_cuda
-    stripes = stripe_rows(H, n_stripes if world > 1 else 1)
+    collective = (world > 1) or (force_collective and dist.is_available() and dist.is_initialized())
+    stripes = stripe_rows(H, n_stripes if collective else 1)
     parts = []
-    if world > 1 and on_gpu:
+    if collective and on_gpu:
         comm = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         works = []
@@ -95,7 +96,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     else:
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip)
-            if world > 1:
+            if collective:
                 dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
             parts.append(m)
     mean = torch.empty((H, W), dtype=torch.float32, device=frames_local.device)

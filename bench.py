@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--dtype', default='f32', choices=['f32', 'u16'])
     ap.add_argument('--stripes', type=int, default=8, help='row stripes for collective/compute overlap (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-collective', action='store_true', help='run the striped all-reduce path even with one rank (testing)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
     return ap.parse_args()
 
@@ -78,11 +79,19 @@ def cpu_baseline(frames, masters, nflat, e, seconds):
 
 def main():
     args = parse()
+    # Only the JSON line may appear on stdout: RCCL prints a version banner to the C-level stdout at
+    # exit, so everything else (C and Python) is routed to stderr until the final print.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
@@ -103,10 +112,10 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        if world == 1:
+        if world == 1 and not args.force_collective:
             return ops.stack_sigclip(frames, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', calib=calib,
                                      outputs=('mean',))['mean']
-        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=args.stripes)
+        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=args.stripes, force_collective=args.force_collective)
 
     for _ in range(args.warmup):
         out = step()
@@ -169,10 +178,20 @@ def main():
                 line['cpu_baseline'] = cpu_baseline(frames, masters, nflat, e, args.cpu_seconds)
             else:
                 line['cpu_baseline'] = None
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(saved_stdout, 1)
+    if line is not None:
+        os.write(1, (json.dumps(line) + '\n').encode())
+    # keep late C-level chatter (library destructors) off stdout
+    os.dup2(2, 1)
 
 
 if __name__ == '__main__':

@@ -25,7 +25,7 @@ durs = []
 regs = None
 for f in find('trace/**/*kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        if 'stack_sigclip_kernel' in r.get('Kernel_Name', ''):
+        if 'stack_sigclip' in r.get('Kernel_Name', ''):
             durs.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
             regs = {k: r.get(k) for k in ('VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'Scratch_Size', 'LDS_Block_Size',
                                           'Workgroup_Size', 'Grid_Size')}
@@ -36,7 +36,7 @@ for name, pat in (('FETCH_SIZE', 'pmc_fetch/**/*counter_collection.csv'), ('WRIT
     vals = []
     for f in find(pat):
         for r in csv.DictReader(open(f)):
-            if 'stack_sigclip_kernel' in r.get('Kernel_Name', '') and r.get('Counter_Name') == name:
+            if 'stack_sigclip' in r.get('Kernel_Name', '') and r.get('Counter_Name') == name:
                 vals.append(float(r['Counter_Value']))
     if vals:
         res[name] = {'dispatches': len(vals), 'avg_raw': sum(vals) / len(vals)}

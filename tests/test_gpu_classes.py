@@ -240,3 +240,34 @@ def test_stack_mad_std_vs_oracle():
         c = apref.combine_ccdproc(cube, 5.0, 5.0)
         r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count'))
         assert np.array_equal(r['count'].cpu().numpy(), c['count'])
+
+
+def test_nshard_collective_path_on_one_gpu():
+    """The striped all-reduce path of parallel.stack_nshard, exercised with an RCCL group of one rank:
+    the result must equal the direct single-kernel result (world_size 1 => identical semantics)."""
+    import socket
+    import torch.distributed as dist
+    from astrophotography_amd import ops, parallel, synth
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        N, H, W = 16, 96, 256
+        masters = synth.make_masters(H, W, config_id=3, device='cuda')
+        nflat, _ = ops.flat_normalize(masters['flat'])
+        frames = synth.make_frames(N, masters, nflat, config_id=3)
+        calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
+        direct = ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'moments'))
+        mean, mom = parallel.stack_nshard(frames, calib, n_stripes=5, force_collective=True, return_moments=True)
+        torch.cuda.synchronize()
+        assert torch.equal(mom, direct['moments'])
+        # mean from float32 moments (sum / count) vs the kernel's float64 mean: within 1 ulp
+        assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'moments-finalised mean')
+        # row-sharded exact path: two half images reduce to the same pixels
+        top = parallel.stack_rowshard(frames[:, :48], dict(calib, bias=calib['bias'][:48], dark=calib['dark'][:48], nflat=nflat[:48]))
+        assert torch.equal(top['mean'], direct['mean'][:48])
+    finally:
+        dist.destroy_process_group()

@@ -13,7 +13,7 @@ for d in ('p1','p2'):
     acc=collections.defaultdict(list)
     for f in glob.glob('$OUT/%s/**/*counter_collection.csv'%d, recursive=True):
         for r in csv.DictReader(open(f)):
-            if 'stack_sigclip_kernel' in r['Kernel_Name']:
+            if 'stack_sigclip' in r['Kernel_Name']:
                 acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in acc.items(): print(d,k,sum(v)/len(v))
     import os
