@@ -35,7 +35,11 @@ namespace apgpu_stack {
 using namespace apgpu;
 
 // zero-cost section markers in the generated assembly (tools/isa_sections.py counts instructions per section)
+#ifdef APGPU_PROFILE_SECTIONS
+#define APGPU_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; APGPU_SECTION " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define APGPU_MARK(name) asm volatile("; APGPU_SECTION " name)
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // Batcher odd-even merge sorting network for NP = 2^k inputs, generated at compile time.

@@ -366,3 +366,28 @@ def test_fast_division_is_ieee_exact(ops):
     exact = ops.calibrate(raw, z, z, nflat, 1.0)
     fused = ops.stack_sigclip(raw[None], calib=dict(bias=z, dark=z, nflat=nflat, exp_ratio=1.0), outputs=('mean',))
     assert torch.equal(exact.view(torch.int32), fused['mean'].view(torch.int32))
+
+
+def test_full_size_c2_matches_oracle(ops, apref):
+    """BASELINE.json configs[1] at full size (64 x 4096 x 4096 f32, fused calibrate + 3-sigma clip): every
+    one of the 16.7 M output pixels against the CPU oracle - identical survivor counts, mean within 1 ulp."""
+    from astrophotography_amd import synth
+    N, H, W = 64, 4096, 4096
+    masters = synth.make_masters(H, W, config_id=2, device='cuda')
+    nflat, _ = ops.flat_normalize(masters['flat'])
+    frames = synth.make_frames(N, masters, nflat, config_id=2)
+    calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
+    r = ops.stack_sigclip(frames, sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
+    torch.cuda.synchronize()
+    mean, cnt = host(r['mean']), host(r['count'])
+    ref_mean = np.empty((H, W), np.float32)
+    ref_cnt = np.empty((H, W), np.int32)
+    b, d, nf = host(masters['bias']), host(masters['dark']), host(nflat)
+    for r0 in range(0, H, 1024):                         # 1 GiB of frames at a time through host memory
+        sl = slice(r0, r0 + 1024)
+        m, c = apref.calibrate_stack(host(frames[:, sl]), b[sl], d[sl], nf[sl], synth.EXP_RATIO, sigma=3.0, maxiters=5)
+        ref_mean[sl], ref_cnt[sl] = m, c
+    assert np.array_equal(cnt, ref_cnt)
+    exact = assert_ulp(mean, ref_mean, 1, 'C2 full size')
+    assert exact > 0.999
+    assert 40 <= cnt.min() and cnt.max() == 64 and (cnt < 64).mean() > 0.05      # the clip did real work
