@@ -74,10 +74,14 @@ constexpr Net<NP> make_net()
     return net;
 }
 
+// Compare-exchange.  Written as the two machine instructions: through fminf/fmaxf the compiler has to
+// quiet possible signalling NaNs first (IEEE mode) and adds a v_max_f32 x, x, x canonicalisation per
+// network input (~120 instructions per column); the columns are NaN-free by construction here.
 __device__ __forceinline__ void cmpx(float &x, float &y)
 {
-    float lo = fminf(x, y);
-    float hi = fmaxf(x, y);
+    float lo, hi;
+    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
     x = lo;
     y = hi;
 }
@@ -172,6 +176,16 @@ __device__ __forceinline__ bool above(const ClipState &st, double xd)
 {
     const double w = st.wscale * (xd - st.cen);
     return (w > 0.0) && (w * w > st.Thi);
+}
+
+// Moves a wave-uniform value into VGPRs.  The kernel arguments arrive in 40 SGPRs; whatever stays live
+// across the clipping loop is spilled to VGPR lanes and re-read (v_readlane) on every iteration, so the
+// handful of values needed inside / after the loop are parked in VGPRs once instead.
+template <typename T>
+__device__ __forceinline__ T park_in_vgpr(T x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 // float -> double of a column element, opaque to the optimiser: without the barrier LLVM hoists and
@@ -485,6 +499,14 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 template <int NP, bool EXTRA>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
+    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
+    float *const out_mean = park_in_vgpr(prm.mean);
+    int32_t *const out_count = park_in_vgpr(prm.count);
+    float *const out_moments = park_in_vgpr(prm.moments);
+    const int64_t Pn = park_in_vgpr(prm.P);
+    const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
+    const int maxiters = park_in_vgpr(prm.maxiters);
+    const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
     APGPU_MARK("sort");
     sort_column<NP>(v);
     APGPU_MARK("moments");
@@ -530,7 +552,6 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     st.Thi = 0.0;
     bool active = n > 0;
     int it = 0;
-    const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
     const bool use_mad = EXTRA && prm.dev == APGPU_DEV_MAD_STD;
 
     while (__any(active)) {
@@ -547,21 +568,21 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
             st.cen = use_median ? med : c + st.S / st.nn;
             if (use_mad) {
                 st.wscale = 1.0;
-                st.Tlo = prm.sl2 * (mad * mad);
-                st.Thi = prm.su2 * (mad * mad);
+                st.Tlo = sl2 * (mad * mad);
+                st.Thi = su2 * (mad * mad);
             } else {
                 st.wscale = st.nn;
                 double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
                 V = V > 0.0 ? V : 0.0;
-                st.Tlo = prm.sl2 * V;
-                st.Thi = prm.su2 * V;
+                st.Tlo = sl2 * V;
+                st.Thi = su2 * V;
             }
         }
         trim_low<0, NP>(v, st, active);
         trim_high<NP - 1, NP>(v, st, active);
         it++;
         const bool changed = (st.a != a0) || (st.b != b0);
-        active = active && changed && (prm.maxiters < 0 || it < prm.maxiters);
+        active = active && changed && (maxiters < 0 || it < maxiters);
     }
 
     APGPU_MARK("readmit_output");
@@ -584,8 +605,8 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const double nf = (double)cnt;
     const double nan = __builtin_nan("");
     const double ms = S / nf;                                 // mean - c
-    if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
-    if (prm.count) prm.count[p] = cnt;
+    if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (out_count) out_count[p] = cnt;
     if (EXTRA && prm.std) {
         // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
         // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
@@ -610,12 +631,12 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         const float m2 = pick_at<NP>(v, (a + b) >> 1);
         prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
     }
-    if (prm.moments) {
+    if (out_moments) {
         const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
         const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        prm.moments[p] = (float)sum;
-        prm.moments[prm.P + p] = (float)sq;
-        prm.moments[2 * prm.P + p] = (float)cnt;
+        out_moments[p] = (float)sum;
+        out_moments[Pn + p] = (float)sq;
+        out_moments[2 * Pn + p] = (float)cnt;
     }
 }
 
