@@ -21,7 +21,7 @@ HEADERS = ['common.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h
 
 # -ffp-contract=off: the reference's NumPy expressions round after every operation, so no FMA
 # contraction anywhere; fused operations are written explicitly (fma()) where wanted.
-HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+HIPCC_FLAGS = (['-DAPGPU_DEVELOPMENT'] if os.environ.get('APGPU_DEVELOPMENT') else []) + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
                '-fno-fast-math', '-Wall', '-Wno-unused-function', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
 

@@ -307,3 +307,23 @@ def bayer_split(raw, pattern=(0, 1, 3, 2), black=None):
     blk = (C.c_int32 * 4)(*[int(x) for x in black]) if black is not None else None
     check(_lib.load().apgpu_bayer_split_u16(_ptr(raw), H, W, pat, blk, _ptr(planes), _stream()))
     return planes
+
+
+def bayer_flat_normalize(flat):
+    """Per-channel flat normalisation for a Bayer mosaic (config 4): every 2x2 cell position (R, G1, G2, B)
+    is normalised by the nanmean of its own quarter-plane with the A1 kernel, i.e. four applications of
+    ApCalibrate._generate_flat (ApCalibrate.py:166-190) on the planes RawConv.split separates
+    (RawConv.py:111-128).  Returns (nflat[H,W], norms[2,2] device tensor)."""
+    _need_cuda(flat)
+    flat = _f32c(flat, 'flat')
+    if flat.dim() != 2 or flat.shape[0] % 2 or flat.shape[1] % 2:
+        raise ValueError('a Bayer mosaic needs an even number of rows and columns')
+    nflat = torch.empty_like(flat)
+    norms = torch.empty((2, 2), dtype=torch.float32, device=flat.device)
+    for r0 in (0, 1):
+        for c0 in (0, 1):
+            plane = flat[r0::2, c0::2].contiguous()
+            npl, norm = flat_normalize(plane)
+            nflat[r0::2, c0::2] = npl
+            norms[r0, c0] = norm[0]
+    return nflat, norms

@@ -391,3 +391,35 @@ def test_full_size_c2_matches_oracle(ops, apref):
     exact = assert_ulp(mean, ref_mean, 1, 'C2 full size')
     assert exact > 0.999
     assert 40 <= cnt.min() and cnt.max() == 64 and (cnt < 64).mean() > 0.05      # the clip did real work
+
+
+def test_config4_bayer_u16_median_pipeline(ops, apref):
+    """BASELINE configs[3] at reduced size: uint16 Bayer mosaic frames, per-channel flat normalisation,
+    fused calibration + median stack, then the R/G1/B/G2 split geometry on the stacked result."""
+    rng = np.random.default_rng(41)
+    N, H, W = 64, 40, 96
+    gains = np.array([[0.55, 1.0], [1.0, 0.7]], np.float32)              # R G1 / G2 B
+    gain_map = np.tile(gains, (H // 2, W // 2))
+    bias = rng.normal(1000, 5, (H, W)).astype(np.float32)
+    dark = rng.normal(20, 3, (H, W)).astype(np.float32)
+    flat = (rng.normal(30000, 300, (H, W)) * gain_map).astype(np.float32)
+    sky = 2000 * gain_map
+    raw = np.clip(np.rint(bias + 0.4 * dark + sky + rng.normal(0, 30, (N, H, W))), 0, 65535).astype(np.uint16)
+    raw[rng.random(raw.shape) < 0.002] = 60000
+    nflat, norms = ops.bayer_flat_normalize(dev(flat, ops))
+    ref_nflat = np.empty_like(flat)
+    for r0 in (0, 1):
+        for c0 in (0, 1):
+            pl, nm = apref.flat_normalize(np.ascontiguousarray(flat[r0::2, c0::2]))
+            ref_nflat[r0::2, c0::2] = pl
+            assert host(norms)[r0, c0] == nm
+    assert_biteq(host(nflat), ref_nflat, 'per-channel nflat')
+    calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=nflat, exp_ratio=0.4)
+    med = ops.stack_median(dev(raw, ops), calib=calib)
+    ref = apref.stack_median(apref.calibrate(raw, bias, dark, ref_nflat, 0.4))
+    assert_ulp(host(med), ref.astype(np.float32), 1, 'C4 median stack')
+    # channel geometry (RawConv.split): RGGB, G1 on the red row
+    planes = ops.bayer_split(dev(raw[0], ops), (0, 1, 3, 2), (256, 256, 256, 256))
+    assert np.array_equal(host(planes), apref.bayer_split(raw[0], (0, 1, 3, 2), (256, 256, 256, 256)))
+    p = host(planes)
+    assert (p[0][1::2] == 0).all() and (p[0][:, 1::2] == 0).all() and (p[2][::2] == 0).all()
