@@ -59,15 +59,36 @@ class ApCalibrate:
             self._mskdata = torch.from_numpy(np.ascontiguousarray(msk != 0).view(np.uint8)).cuda()
 
     # -------------------------------------------------------------------------------------------
-    def _read_master(self, path):
-        """Master frame -> float32 device tensor (+ header).  PEDESTAL handling as _read_fits."""
+    @staticmethod
+    def _to_f32(t):
         import torch
-        data, hdr, _ = _common.read_fits(self._logger, path, to_float32=True)
-        if data.dtype != np.float32:
+        if t.dtype == torch.float32:
+            return t
+        if t.dtype == torch.uint16:                       # exact widening
+            return (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32)
+        return t.to(torch.float32)
+
+    def _read_master(self, path):
+        """Master frame -> float32 device tensor (+ header); payload decoded on the device (fitsio.read_device).
+        PEDESTAL handling as _read_fits (core/ApCalibrate.py:318-326): a non-zero pedestal is added."""
+        import torch
+        from .. import ops
+        path = _common.check_file_exists(self._logger, path)
+        self._logger.info('Loading extension {} of FITS file {}'.format(0, path))
+        data, hdr = fitsio.read_device(str(path))
+        if hdr['NAXIS'] == 3:
+            self._logger.error('Error, 3-D handling has not been implemented yet.')
+            raise SystemExit(1)
+        if data is None or data.dim() != 2:
+            raise RuntimeError(f'{path}: expected a 2-D primary image, found NAXIS={hdr["NAXIS"]}.')
+        if data.dtype == torch.float64:
             # ccdproc writes float64 masters; the reference would then calibrate in float64
-            self._logger.warning(f'{Path(path).name} is {data.dtype}; the device path calibrates in float32.')
-            data = data.astype(np.float32)
-        return torch.from_numpy(np.ascontiguousarray(data)).cuda(), hdr
+            self._logger.warning(f'{Path(path).name} is float64; the device path calibrates in float32.')
+        data = self._to_f32(data).contiguous()
+        if 'PEDESTAL' in hdr and float(hdr['PEDESTAL']) != 0:
+            self._logger.debug(f'Removing a PEDESTAL value of {float(hdr["PEDESTAL"])} ADU.')
+            data = ops.imarith(data, 'ADD', float(hdr['PEDESTAL']))
+        return data, hdr
 
     def _find_exptime_ratio(self, img_hdr, dark_hdr):
         """EXPOSURE, then EXPTIME (ApCalibrate.py:128-164)."""
@@ -105,21 +126,18 @@ class ApCalibrate:
     def _read_raw(self, raw_image):
         """Raw light frame -> (device tensor uint16|float32, header, pedestal to add on the device)."""
         import torch
-        from .. import ops
         raw_image = _common.check_file_exists(self._logger, raw_image)
-        data, hdr = fitsio.read(str(raw_image))
+        t, hdr = fitsio.read_device(str(raw_image))
         if hdr['NAXIS'] == 3:
             self._logger.error('Error, 3-D handling has not been implemented yet.')
             raise SystemExit(1)
+        if t is None or t.dim() != 2:
+            raise RuntimeError(f'{raw_image}: expected a 2-D primary image, found NAXIS={hdr["NAXIS"]}.')
         pedestal = float(hdr['PEDESTAL']) if 'PEDESTAL' in hdr else 0.0
-        if data.dtype == np.uint16:
-            t = ops.to_device_u16(data)
-        else:
-            if data.dtype != np.float32:
-                if np.issubdtype(data.dtype, np.floating):
-                    self._logger.warning(f'{raw_image.name} is {data.dtype}; the device path calibrates in float32.')
-                data = data.astype(np.float32)               # ApCalibrate.py:304-307 for integers
-            t = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        if t.dtype not in (torch.uint16, torch.float32):
+            if t.dtype == torch.float64:
+                self._logger.warning(f'{raw_image.name} is float64; the device path calibrates in float32.')
+            t = t.to(torch.float32)                          # ApCalibrate.py:304-307 for integers
         if tuple(t.shape) != tuple(self._bias_data.shape):
             raise RuntimeError(f'{raw_image.name} has shape {tuple(t.shape)}, the masters have {tuple(self._bias_data.shape)}.')
         return t, hdr, pedestal
@@ -137,7 +155,10 @@ class ApCalibrate:
             hdr[kw] = val
         tnow = datetime.now().isoformat(timespec='milliseconds')
         hdr['HISTORY'] = f'Processed by {self._name} {self._version} at {tnow}'
-        fitsio.write(str(outdata_file), odata, hdr, overwrite=True)
+        if isinstance(odata, np.ndarray):
+            fitsio.write(str(outdata_file), odata, hdr, overwrite=True)
+        else:
+            fitsio.write_device(str(outdata_file), odata, hdr, overwrite=True)     # big-endian encode on the device
         self._logger.info(f'Wrote bias/dark/flat corrected file to {outdata_file}')
 
     def _base_keywords(self):
@@ -174,7 +195,7 @@ class ApCalibrate:
         if self._norm_flat is not None:
             if norm_flat is not None:
                 self._logger.debug(f'Writing normalized flat field to {norm_flat}')
-                self._write_corrected_image(raw_image, norm_flat, self._norm_flat.cpu().numpy(), {})
+                self._write_corrected_image(raw_image, norm_flat, self._norm_flat, {})
         else:
             self._logger.info('No flat field correction applied.')
         if self._bpix is not None:
@@ -190,10 +211,9 @@ class ApCalibrate:
             odict['BPIXNFIX'] = (nfixed, 'Number of bad pixels corrected')
         else:
             self._logger.info('No bad pixel correction applied.')
-        out = img_bdf.cpu().numpy()
         run_time_secs = time.perf_counter() - perf_time_start
         self._logger.info(f'Writing calibrated image to {cal_image}')
-        self._write_corrected_image(raw_image, cal_image, out, odict)
+        self._write_corrected_image(raw_image, cal_image, img_bdf, odict)
         self._logger.info(f'Calibrated {raw_image.name} in {run_time_secs:.3f} seconds.')
 
     # -- slab API (new) -----------------------------------------------------------------------------
@@ -246,4 +266,4 @@ class ApCalibrate:
                               'BPIXNREM': (nnotfix, 'Number of bad pixels not corrected'),
                               'BPIXCORR': (nfixed > 0, 'True if any bad pixels were corrected'),
                               'BPIXNFIX': (nfixed, 'Number of bad pixels corrected')})
-            self._write_corrected_image(src, dst, img.cpu().numpy(), odict)
+            self._write_corrected_image(src, dst, img, odict)

@@ -347,6 +347,50 @@ __global__ __launch_bounds__(kBlock) void bayer_split_kernel(const uint16_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// F1  FITS payload decode / encode on the device (the step either side of the path: astropy's read of
+//     big-endian BITPIX 16 / -32 data with the BZERO = 32768 unsigned convention, core/ApCalibrate.py:
+//     270-277, and the float32 write of :392-399).  The host only moves raw bytes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned bswap32(unsigned x) { return __builtin_bswap32(x); }
+__device__ __forceinline__ unsigned bswap16x2(unsigned x) { return ((x & 0x00ff00ffu) << 8) | ((x & 0xff00ff00u) >> 8); }
+
+// BITPIX 16: big-endian int16 + 32768 -> uint16 (flip the sign bit after the byte swap)
+__global__ __launch_bounds__(kBlock) void fits_decode_u16_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out,
+                                                                int64_t nwords, const uint8_t *__restrict__ tail_in,
+                                                                uint16_t *__restrict__ tail_out, int has_tail)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride)
+        out[i] = bswap16x2(in[i]) ^ 0x80008000u;
+    if (has_tail && blockIdx.x == 0 && threadIdx.x == 0)
+        tail_out[0] = (uint16_t)((((unsigned)tail_in[0] << 8) | tail_in[1]) ^ 0x8000u);
+}
+
+// BITPIX 16 without the unsigned convention: big-endian int16 -> float32 (ApCalibrate.py:304-307)
+__global__ __launch_bounds__(kBlock) void fits_decode_i16_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+                                                                    int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const short v = (short)(((unsigned)in[2 * i] << 8) | in[2 * i + 1]);
+        out[i] = (float)v;
+    }
+}
+
+// BITPIX -32 / 32: 4-byte swap (decode and encode are the same operation)
+__global__ __launch_bounds__(kBlock) void fits_swap32_kernel(const unsigned *__restrict__ in, unsigned *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        uint4 v = reinterpret_cast<const uint4 *>(in)[i];
+        v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
+        reinterpret_cast<uint4 *>(out)[i] = v;
+    }
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = bswap32(in[i]);
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -484,4 +528,37 @@ extern "C" int apgpu_bayer_split_u16(const uint16_t *raw, int64_t height, int64_
     hipLaunchKernelGGL(bayer_split_kernel, dim3(grid_for(height * width)), dim3(kBlock), 0, as_stream(stream), raw, height, width,
                        bp, planes);
     return check_launch("bayer_split");
+}
+
+extern "C" int apgpu_fits_decode(const void *payload, int bitpix, int unsigned16, void *out, int64_t n_pixels, void *stream)
+{
+    if (!payload || !out) return fail(APGPU_EINVAL, "fits_decode: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "fits_decode: n_pixels = %lld", (long long)n_pixels);
+    if (!aligned16(payload) || !aligned16(out)) return fail(APGPU_EINVAL, "fits_decode: buffers must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (bitpix == 16 && unsigned16) {
+        const int64_t nwords = n_pixels / 2;
+        const int has_tail = (int)(n_pixels & 1);
+        hipLaunchKernelGGL(fits_decode_u16_kernel, dim3(grid_for(nwords + 1)), dim3(kBlock), 0, st, (const unsigned *)payload,
+                           (unsigned *)out, nwords, (const uint8_t *)payload + 4 * nwords, (uint16_t *)out + 2 * nwords, has_tail);
+    } else if (bitpix == 16) {
+        hipLaunchKernelGGL(fits_decode_i16_f32_kernel, dim3(grid_for(n_pixels)), dim3(kBlock), 0, st, (const uint8_t *)payload,
+                           (float *)out, n_pixels);
+    } else if (bitpix == -32 || bitpix == 32) {
+        hipLaunchKernelGGL(fits_swap32_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, (const unsigned *)payload,
+                           (unsigned *)out, n_pixels);
+    } else {
+        return fail(APGPU_EUNSUPPORTED, "fits_decode: BITPIX %d is decoded on the host", bitpix);
+    }
+    return check_launch("fits_decode");
+}
+
+extern "C" int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, void *stream)
+{
+    if (!data || !payload) return fail(APGPU_EINVAL, "fits_encode: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "fits_encode: n_pixels = %lld", (long long)n_pixels);
+    if (!aligned16(data) || !aligned16(payload)) return fail(APGPU_EINVAL, "fits_encode: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(fits_swap32_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, as_stream(stream),
+                       (const unsigned *)data, (unsigned *)payload, n_pixels);
+    return check_launch("fits_encode");
 }

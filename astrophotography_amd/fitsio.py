@@ -326,3 +326,99 @@ def write(path, data, header=None, overwrite=True):
         f.write(tail)
     os.replace(tmp, path)
     return hdr
+
+
+# ---------------------------------------------------------------------------------------------------
+# Device-side payload decode / encode (C ABI: apgpu_fits_decode / apgpu_fits_encode_f32).  The host
+# only parses the header and moves raw bytes; the big-endian -> native conversion, the BZERO = 32768
+# unsigned convention and the int16 -> float32 widening run as HIP kernels.
+# ---------------------------------------------------------------------------------------------------
+def _split_file(path):
+    raw = np.fromfile(str(path), dtype=np.uint8)
+    if raw.size < BLOCK or bytes(raw[:6]) != b'SIMPLE':
+        raise OSError('%s is not a FITS file (no SIMPLE card).' % path)
+    pos = 0
+    text = ''
+    while True:
+        block = raw[pos:pos + BLOCK]
+        if block.size < BLOCK:
+            raise OSError('%s: header is truncated.' % path)
+        pos += BLOCK
+        t = block.tobytes().decode('ascii', 'replace')
+        text += t
+        if any(t[i:i + 8] == 'END     ' for i in range(0, BLOCK, 80)):
+            break
+    return raw, pos, Header.fromstring(text)
+
+
+def read_device(path, device='cuda'):
+    """Primary HDU -> (device tensor, Header).  uint16 for the BZERO = 32768 convention, float32 for plain
+    int16 (widened like ApCalibrate._read_fits does) and for BITPIX -32; other layouts are decoded on the
+    host by read() and uploaded."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    raw, pos, hdr = _split_file(path)
+    naxis = int(hdr.get('NAXIS', 0))
+    shape = tuple(int(hdr['NAXIS%d' % i]) for i in range(naxis, 0, -1))
+    bitpix = int(hdr['BITPIX'])
+    count = int(np.prod(shape)) if naxis > 0 else 0
+    nbytes = count * abs(bitpix) // 8
+    bscale, bzero = hdr.get('BSCALE', 1), hdr.get('BZERO', 0)
+    unsigned16 = bitpix == 16 and bscale == 1 and bzero == 32768
+    plain = bscale == 1 and bzero == 0
+    hdr._tail = raw[pos + ((nbytes + BLOCK - 1) // BLOCK) * BLOCK:].tobytes()
+    if count == 0 or naxis != 2 or not (unsigned16 or (plain and bitpix in (16, -32))):
+        data, hdr2 = read(path)
+        if data is None:
+            return None, hdr2
+        if data.dtype == np.uint16:
+            t = torch.from_numpy(data.view(np.int16)).to(device).view(torch.uint16)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(data)).to(device)
+        return t, hdr2
+    if raw.size < pos + nbytes:
+        raise OSError('%s: data unit is truncated.' % path)
+    payload = torch.from_numpy(raw[pos:pos + nbytes].copy()).to(device)
+    out = torch.empty(shape, dtype=torch.uint16 if unsigned16 else torch.float32, device=device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().apgpu_fits_decode(C.c_void_p(payload.data_ptr()), bitpix, int(unsigned16),
+                                            C.c_void_p(out.data_ptr()), count, stream))
+    out._fits_payload = payload          # keep the source alive until the stream has consumed it
+    return out, hdr
+
+
+def write_device(path, tensor, header=None, overwrite=True):
+    """float32 device tensor -> BITPIX -32 primary HDU (big-endian conversion on the device)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if os.path.exists(path) and not overwrite:
+        raise OSError("File '%s' already exists." % path)
+    if tensor.dtype != torch.float32 or not tensor.is_cuda:
+        return write(path, tensor.cpu().numpy() if tensor.dtype != torch.uint16
+                     else tensor.view(torch.int16).cpu().numpy().view(np.uint16), header, overwrite)
+    tensor = tensor.contiguous()
+    payload = torch.empty(tensor.numel() * 4, dtype=torch.uint8, device=tensor.device)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().apgpu_fits_encode_f32(C.c_void_p(tensor.data_ptr()), C.c_void_p(payload.data_ptr()),
+                                                tensor.numel(), stream))
+    data_bytes = payload.cpu().numpy().tobytes()
+    hdr = _structural(header if header is not None else Header(), _ShapeOnly(tuple(tensor.shape), np.dtype(np.float32)))
+    pad = (-len(data_bytes)) % BLOCK
+    tail = getattr(header, '_tail', b'') if header is not None else b''
+    tmp = str(path) + '.tmp%d' % os.getpid()
+    with open(tmp, 'wb') as f:
+        f.write(hdr.tostring().encode('ascii'))
+        f.write(data_bytes)
+        f.write(b'\0' * pad)
+        f.write(tail)
+    os.replace(tmp, path)
+    return hdr
+
+
+class _ShapeOnly:
+    """What _structural() needs from an array (dtype, ndim, shape) without materialising one."""
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype, self.ndim = shape, dtype, len(shape)

@@ -184,6 +184,18 @@ int apgpu_imarith(const void *a, const void *b, double scalar, int op, int dtype
 int apgpu_bayer_split_u16(const uint16_t *raw, int64_t height, int64_t width, const int32_t *pattern_host,
                           const int32_t *black_host, uint16_t *planes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * F1  FITS payload <-> device arrays: what astropy.io.fits does at core/ApCalibrate.py:270-277 (read,
+ *     uint=True) and :392-399 (write).  `payload` is the big-endian data unit exactly as in the file
+ *     (device copy of the raw bytes).
+ *     decode: BITPIX 16 with unsigned16 != 0 (BSCALE 1, BZERO 32768) -> uint16[n];
+ *             BITPIX 16 with unsigned16 == 0 -> float32[n] (integers are converted to float32 at read
+ *             time, core/ApCalibrate.py:304-307); BITPIX -32 -> float32[n]; BITPIX 32 -> int32[n].
+ *     encode: float32[n] -> big-endian BITPIX -32 payload.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_fits_decode(const void *payload, int bitpix, int unsigned16, void *out, int64_t n_pixels, void *stream);
+int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
