@@ -15,6 +15,8 @@ _LAZY = {
     'ApMasterCal': ('.core.ApMasterCal', 'ApMasterCal'),
     'ApStack': ('.core.ApStack', 'ApStack'),
     'ApCombine': ('.core.ApStack', 'ApCombine'),
+    'ApImageDifference': ('.core.ApCalcReadNoise', 'ApImageDifference'),
+    'ApCalcReadNoise': ('.core.ApCalcReadNoise', 'ApCalcReadNoise'),
 }
 
 __all__ = sorted(_LAZY) + ['__version__']

@@ -50,6 +50,11 @@ SIGNATURES = {
     'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
     'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_sigclip_global_f64_ws_bytes': (C.c_size_t, [C.c_int64]),
+    'apgpu_sigclip_global_f64': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_image_difference_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_void_p]),
     'apgpu_threshold_mask_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     'apgpu_mask_add_rects_u8': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -44,13 +44,23 @@ class ApFindBadPixels:
         from .. import ops
         npix = data.size
         self._logger.debug(f'Generating a bad pixel mask using sigma={sigma} clipping on the input image data values.')
-        if data.dtype != np.float32:
-            # numpy evaluates integer / float64 darks in float64; the device path is float32 (u16 -> f32 is exact)
-            self._logger.debug(f'Converting {data.dtype} dark to float32 for the device statistics.')
-        d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).cuda()
-        stats = ops.sigclip_global(d, sigma=sigma, maxiters=5)
+        # float32 darks: numpy's float32 statistics; integer / float64 darks: float64 statistics (numpy's
+        # dtype rules), both reproduced exactly on the device
+        if data.dtype == np.float32:
+            d = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+            stats = ops.sigclip_global(d, sigma=sigma, maxiters=5)
+            cast = np.float32
+        else:
+            if data.dtype == np.uint16:
+                dsrc = ops.to_device_u16(data)
+            else:
+                dsrc = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+            stats = ops.sigclip_global(dsrc, sigma=sigma, maxiters=5)
+            cast = np.float64
+            # the threshold comparison runs in float32 (numpy promotes uint16 vs a float scalar to float32)
+            d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).cuda()
         s = stats.cpu().numpy()
-        mean, med, std = np.float32(s[0]), np.float32(s[1]), np.float32(s[2])
+        mean, med, std = cast(s[0]), cast(s[1]), cast(s[2])
         self._logger.debug(f'Sigma-clipped mean={mean:.2f}, median={med:.2f}, and madstddev={std:.2f} values (ADU).')
         # ApFindBadPixels.py:194-195: np.float32 scalar -/+ python float * np.float32 -> float64 (numpy 1.x)
         lothresh = float(med) - (sigma * float(std))

@@ -35,54 +35,81 @@ constexpr int kPiece = 8192;           // numpy reduction buffer
 constexpr int kLeaf = 128;             // numpy PW_BLOCKSIZE
 constexpr int kMaxItersCap = 32;
 
+// T = float : float32 data, numpy float32 statistics (float32 darks / flats)
+// T = double: float64 data and statistics - what numpy computes for INTEGER images (np.median/np.var of
+//             a uint16 array run in float64; the host widens integer images exactly) and for float64 data.
 struct GState {
     long long m;                // survivors in the current buffer
     long long m_next;
     long long k;                // rank searched by the radix select
     unsigned long long cnt_less;
-    unsigned prefix;            // key prefix found so far
-    unsigned max_less_key;      // order-preserving key of max{x < v_hi}
+    unsigned long long prefix;          // key prefix found so far
+    unsigned long long max_less_key;    // order-preserving key of max{x < v_hi}
+    unsigned long long min_key, max_key;    // extremes of the survivors (final pass)
     int done;                   // set when an iteration removed nothing
     int iter;                   // iterations executed
     int cur;                    // index (0/1) of the buffer holding the survivors
     int pad;
-    float tot;                  // np.sum of the survivors
-    float s2;                   // np.sum((x - mean)^2)
-    float med, sd;
+    double tot;                 // np.sum of the survivors          (holds a float32 value when T = float)
+    double s2;                  // np.sum((x - mean)^2)
+    double med, sd;
     double lo, hi;
     unsigned hist[256];
 };
 
-__device__ __forceinline__ unsigned f2key(float x)
-{
-    const unsigned b = __float_as_uint(x);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(unsigned k)
-{
-    const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(b);
-}
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> {
+    using type = unsigned;
+    static constexpr int passes = 4;
+    __device__ static unsigned to(float x)
+    {
+        const unsigned b = __float_as_uint(x);
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
+    __device__ static float from(unsigned long long k64)
+    {
+        const unsigned k = (unsigned)k64;
+        const unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+        return __uint_as_float(b);
+    }
+};
+template <> struct KeyOf<double> {
+    using type = unsigned long long;
+    static constexpr int passes = 8;
+    __device__ static unsigned long long to(double x)
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    }
+    __device__ static double from(unsigned long long k)
+    {
+        const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        return __longlong_as_double((long long)b);
+    }
+};
+
+template <typename T> __device__ __forceinline__ bool is_finite(T x) { return fabs((double)x) < __builtin_inf(); }
 
 // ---- order-preserving compaction: tile counts -> scan -> scatter -------------------------------
 // mode 0: keep finite values of `data` (length n, host-known); mode 1: keep lo <= x <= hi of the
 // current survivors (length st->m).
-template <int MODE>
-__device__ __forceinline__ bool keep_pred(float x, float lof, float hif)
+template <int MODE, typename T>
+__device__ __forceinline__ bool keep_pred(T x, T lof, T hif)
 {
-    if constexpr (MODE == 0) return fabsf(x) < __builtin_inff();
+    if constexpr (MODE == 0) return is_finite<T>(x);
     else return (x >= lof) && (x <= hif);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restrict__ src0, const float *__restrict__ src1,
+template <int MODE, typename T>
+__global__ __launch_bounds__(kBlock) void tile_count_kernel(const T *__restrict__ src0, const T *__restrict__ src1,
                                                            long long n_static, const GState *__restrict__ st,
                                                            unsigned *__restrict__ tile_counts)
 {
     if (MODE == 1 && st->done) return;
-    const float *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
+    const T *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
     const long long m = (MODE == 0) ? n_static : st->m;
-    const float lof = (float)st->lo, hif = (float)st->hi;
+    // float32: the float64 bounds are demoted to float32 for the comparison, as numpy 1.26 does
+    const T lof = (T)st->lo, hif = (T)st->hi;
     const long long ntiles = (m + kTile - 1) / kTile;
     __shared__ unsigned wsum[kBlock / kWave];
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -91,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const float *__restr
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const long long i = base + j;
-            if (i < m) c += keep_pred<MODE>(src[i], lof, hif) ? 1u : 0u;
+            if (i < m) c += keep_pred<MODE, T>(src[i], lof, hif) ? 1u : 0u;
         }
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) c += __shfl_down(c, d);
@@ -133,30 +160,30 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
     if (threadIdx.x == 1023) st->m_next = (long long)sums[1023];
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void tile_scatter_kernel(const float *__restrict__ src0, const float *__restrict__ src1,
-                                                             float *__restrict__ dst0, float *__restrict__ dst1,
+template <int MODE, typename T>
+__global__ __launch_bounds__(kBlock) void tile_scatter_kernel(const T *__restrict__ src0, const T *__restrict__ src1,
+                                                             T *__restrict__ dst0, T *__restrict__ dst1,
                                                              long long n_static, const GState *__restrict__ st,
                                                              const unsigned long long *__restrict__ tile_offsets)
 {
     if (MODE == 1 && st->done) return;
-    const float *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
-    float *dst = (MODE == 0) ? dst0 : (st->cur ? dst0 : dst1);
+    const T *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
+    T *dst = (MODE == 0) ? dst0 : (st->cur ? dst0 : dst1);
     const long long m = (MODE == 0) ? n_static : st->m;
-    const float lof = (float)st->lo, hif = (float)st->hi;
+    const T lof = (T)st->lo, hif = (T)st->hi;
     const long long ntiles = (m + kTile - 1) / kTile;
     __shared__ unsigned wsum[kBlock / kWave];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = tile * kTile + (long long)threadIdx.x * 8;
-        float x[8];
+        T x[8];
         bool kp[8];
         unsigned c = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const long long i = base + j;
-            x[j] = i < m ? src[i] : 0.f;
-            kp[j] = (i < m) && keep_pred<MODE>(x[j], lof, hif);
+            x[j] = i < m ? src[i] : (T)0;
+            kp[j] = (i < m) && keep_pred<MODE, T>(x[j], lof, hif);
             c += kp[j] ? 1u : 0u;
         }
         // exclusive scan of c over the block: wave inclusive scan + wave totals
@@ -208,23 +235,27 @@ __global__ void select_begin_kernel(GState *st, int final_pass)
     st->prefix = 0;
     st->cnt_less = 0;
     st->max_less_key = 0;
+    st->min_key = ~0ull;
+    st->max_key = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void hist_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void hist_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
                                                      GState *__restrict__ st, int pass, int final_pass)
 {
+    using K = KeyOf<T>;
     if (!final_pass && st->done) return;
-    const float *src = st->cur ? b1 : b0;
+    const T *src = st->cur ? b1 : b0;
     const long long m = st->m;
-    const int shift = 24 - 8 * pass;
-    const unsigned prefix = st->prefix;
+    const int shift = 8 * (K::passes - 1 - pass);
+    const typename K::type prefix = (typename K::type)st->prefix;
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned key = f2key(src[i]);
+        const typename K::type key = K::to(src[i]);
         const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
-        if (match) atomicAdd(&h[(key >> shift) & 0xffu], 1u);
+        if (match) atomicAdd(&h[(unsigned)(key >> shift) & 0xffu], 1u);
     }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
@@ -248,134 +279,151 @@ __global__ void select_digit_kernel(GState *st, int final_pass)
     for (int i = 0; i < 256; i++) st->hist[i] = 0;
 }
 
-__global__ __launch_bounds__(kBlock) void less_stats_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void less_stats_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
                                                            GState *__restrict__ st, int final_pass)
 {
+    using K = KeyOf<T>;
     if (!final_pass && st->done) return;
-    const float *src = st->cur ? b1 : b0;
+    const T *src = st->cur ? b1 : b0;
     const long long m = st->m;
-    const unsigned vkey = st->prefix;
-    unsigned cnt = 0, mx = 0;
+    const unsigned long long vkey = st->prefix;
+    unsigned cnt = 0;
+    unsigned long long mx = 0, lo = ~0ull, hi = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned key = f2key(src[i]);
+        const unsigned long long key = K::to(src[i]);
         if (key < vkey) { cnt++; mx = key > mx ? key : mx; }
+        lo = key < lo ? key : lo;
+        hi = key > hi ? key : hi;
     }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
         cnt += __shfl_down(cnt, d);
-        const unsigned o = __shfl_down(mx, d);
+        const unsigned long long o = __shfl_down(mx, d);
         mx = o > mx ? o : mx;
+        const unsigned long long l2 = __shfl_down(lo, d), h2 = __shfl_down(hi, d);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x % kWave) == 0 && cnt) {
-        atomicAdd(&st->cnt_less, (unsigned long long)cnt);
-        atomicMax(&st->max_less_key, mx);
+    if ((threadIdx.x % kWave) == 0) {
+        if (cnt) {
+            atomicAdd(&st->cnt_less, (unsigned long long)cnt);
+            atomicMax(&st->max_less_key, mx);
+        }
+        if (final_pass && hi >= lo) {
+            atomicMin(&st->min_key, lo);
+            atomicMax(&st->max_key, hi);
+        }
     }
 }
 
+template <typename T>
 __global__ void median_finish_kernel(GState *st, int final_pass)
 {
+    using K = KeyOf<T>;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!final_pass && st->done) return;
     const long long m = st->m;
-    if (m <= 0) { st->med = __builtin_nanf(""); return; }
-    const float vhi = key2f(st->prefix);
-    if (m & 1) { st->med = vhi; return; }
+    if (m <= 0) { st->med = __builtin_nan(""); return; }
+    const T vhi = K::from(st->prefix);
+    if (m & 1) { st->med = (double)vhi; return; }
     const long long k2 = m / 2;
     // rank k2-1 holds vhi again if fewer than k2 values are strictly below vhi
-    const float vlo = ((long long)st->cnt_less <= k2 - 1) ? vhi : key2f(st->max_less_key);
-    const float t = vlo + vhi;                              // np.mean of the two middle float32 values
-    st->med = (float)((double)t / 2.0);
+    const T vlo = ((long long)st->cnt_less <= k2 - 1) ? vhi : K::from(st->max_less_key);
+    const T t = vlo + vhi;                                  // np.mean of the two middle values, in T
+    st->med = (double)(T)((double)t / 2.0);
 }
 
 // ---- numpy float32 pairwise sums --------------------------------------------------------------------
-template <int SQ>
-__device__ __forceinline__ float tr(float x, float mean)
+template <int SQ, typename T>
+__device__ __forceinline__ T tr(T x, T mean)
 {
-    if constexpr (SQ) { const float d = x - mean; return d * d; }
+    if constexpr (SQ) { const T d = x - mean; return d * d; }
     else return x;
 }
 
-template <int SQ>
-__device__ float leaf_sum(const float *a, int n, float mean)
+template <int SQ, typename T>
+__device__ T leaf_sum(const T *a, int n, T mean)
 {
-    float r[8];
+    T r[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = tr<SQ>(a[k], mean);
+    for (int k = 0; k < 8; k++) r[k] = tr<SQ, T>(a[k], mean);
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ>(a[i + k], mean);
+        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ, T>(a[i + k], mean);
     }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + tr<SQ>(a[i], mean);
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + tr<SQ, T>(a[i], mean);
     return res;
 }
 
-template <int SQ>
-__device__ float pairwise_rec(const float *a, int n, float mean)
+template <int SQ, typename T>
+__device__ T pairwise_rec(const T *a, int n, T mean)
 {
     // numpy's recursion for a ragged piece (n < 8192); depth <= 7
     if (n < 8) {
-        float res = 0.f;
-        for (int i = 0; i < n; i++) res = res + tr<SQ>(a[i], mean);
+        T res = 0;
+        for (int i = 0; i < n; i++) res = res + tr<SQ, T>(a[i], mean);
         return res;
     }
-    if (n <= kLeaf) return leaf_sum<SQ>(a, n, mean);
+    if (n <= kLeaf) return leaf_sum<SQ, T>(a, n, mean);
     int n2 = n / 2;
     n2 -= n2 % 8;
-    const float l = pairwise_rec<SQ>(a, n2, mean);
-    const float r = pairwise_rec<SQ>(a + n2, n - n2, mean);
+    const T l = pairwise_rec<SQ, T>(a, n2, mean);
+    const T r = pairwise_rec<SQ, T>(a + n2, n - n2, mean);
     return l + r;
 }
 
-__device__ __forceinline__ float var_mean(const GState *st)
+template <typename T>
+__device__ __forceinline__ T var_mean(const GState *st)
 {
-    return st->tot / (float)st->m;          // np.var: arrmean = true_divide(sum, n) in float32
+    return (T)st->tot / (T)st->m;           // np.var: arrmean = true_divide(sum, n) in the array's dtype
 }
 
-template <int SQ>
-__global__ __launch_bounds__(kBlock) void piece_sums_kernel(const float *__restrict__ b0, const float *__restrict__ b1,
-                                                           const GState *__restrict__ st, float *__restrict__ piece_sums,
+template <int SQ, typename T>
+__global__ __launch_bounds__(kBlock) void piece_sums_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
+                                                           const GState *__restrict__ st, T *__restrict__ piece_sums,
                                                            int final_pass)
 {
     if (!final_pass && st->done) return;
-    const float *src = st->cur ? b1 : b0;
+    const T *src = st->cur ? b1 : b0;
     const long long m = st->m;
-    const float mean = SQ ? var_mean(st) : 0.f;
+    const T mean = SQ ? var_mean<T>(st) : (T)0;
     const long long npieces_full = m / kPiece;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     const int wpb = kBlock / kWave;
     for (long long piece = (long long)blockIdx.x * wpb + wave; piece < npieces_full; piece += (long long)gridDim.x * wpb) {
-        float s = leaf_sum<SQ>(src + piece * kPiece + lane * kLeaf, kLeaf, mean);
+        T s = leaf_sum<SQ, T>(src + piece * kPiece + lane * kLeaf, kLeaf, mean);
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
-            const float other = __shfl_xor(s, d);
+            const T other = __shfl_xor(s, d);
             s = (lane & d) ? other + s : s + other;
         }
         if (lane == 0) piece_sums[piece] = s;
     }
 }
 
-template <int SQ>
-__global__ void fold_kernel(const float *__restrict__ b0, const float *__restrict__ b1, GState *__restrict__ st,
-                            const float *__restrict__ piece_sums, int final_pass)
+template <int SQ, typename T>
+__global__ void fold_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
+                            const T *__restrict__ piece_sums, int final_pass)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (!final_pass && st->done) return;
-    const float *src = st->cur ? b1 : b0;
+    const T *src = st->cur ? b1 : b0;
     const long long m = st->m;
-    const float mean = SQ ? var_mean(st) : 0.f;
+    const T mean = SQ ? var_mean<T>(st) : (T)0;
     const long long npieces_full = m / kPiece;
-    float res = 0.f;
+    T res = 0;
     for (long long i = 0; i < npieces_full; i++) res = res + piece_sums[i];
     const int rem = (int)(m - npieces_full * kPiece);
-    if (rem > 0) res = res + pairwise_rec<SQ>(src + npieces_full * kPiece, rem, mean);
+    if (rem > 0) res = res + pairwise_rec<SQ, T>(src + npieces_full * kPiece, rem, mean);
     if (SQ) {
-        st->s2 = res;
-        const float var = (float)((double)res / (double)m);
-        st->sd = sqrtf(var);
+        st->s2 = (double)res;
+        const T var = (T)((double)res / (double)m);         // ret.dtype.type(ret / rcount)
+        st->sd = (double)(T)sqrt((double)var);              // sqrt of a T value rounded to T (exact for float32 via float64)
     } else {
-        st->tot = res;
+        st->tot = (double)res;
     }
 }
 
@@ -385,38 +433,42 @@ __global__ void bounds_kernel(GState *st, double sigma_lower, double sigma_upper
     if (st->done) return;
     if (st->m <= 0) { st->lo = st->hi = __builtin_nan(""); return; }
     // SigmaClip._compute_bounds: float32 scalars * python float -> float64 (numpy 1.26)
-    st->lo = (double)st->med - (double)st->sd * sigma_lower;
-    st->hi = (double)st->med + (double)st->sd * sigma_upper;
+    st->lo = st->med - st->sd * sigma_lower;
+    st->hi = st->med + st->sd * sigma_upper;
 }
 
+template <typename T>
 __global__ void publish_kernel(const GState *st, double *out)
 {
+    using K = KeyOf<T>;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long m = st->m;
     const double nan = __builtin_nan("");
-    out[0] = m > 0 ? (double)(float)((double)st->tot / (double)m) : nan;    // np.mean: f32(f64(sum)/n)
-    out[1] = m > 0 ? (double)st->med : nan;
-    out[2] = m > 0 ? (double)st->sd : nan;
+    out[0] = m > 0 ? (double)(T)(st->tot / (double)m) : nan;        // np.mean: T(float64(sum) / n)
+    out[1] = m > 0 ? st->med : nan;
+    out[2] = m > 0 ? st->sd : nan;
     out[3] = st->lo;
     out[4] = st->hi;
     out[5] = (double)st->iter;
     out[6] = (double)m;
-    out[7] = 0.0;
+    out[7] = m > 0 ? (double)K::from(st->min_key) : nan;
+    out[8] = m > 0 ? (double)K::from(st->max_key) : nan;
+    out[9] = 0.0;
 }
 
 struct WsLayout {
     size_t state, buf0, buf1, pieces, tcounts, toffsets, total;
 };
 
-WsLayout layout(int64_t n)
+WsLayout layout(int64_t n, size_t elem)
 {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     WsLayout L;
     size_t off = 0;
     L.state = off; off = up(off + sizeof(GState));
-    L.buf0 = off; off = up(off + sizeof(float) * (size_t)n);
-    L.buf1 = off; off = up(off + sizeof(float) * (size_t)n);
-    L.pieces = off; off = up(off + sizeof(float) * (size_t)(n / kPiece + 1));
+    L.buf0 = off; off = up(off + elem * (size_t)n);
+    L.buf1 = off; off = up(off + elem * (size_t)n);
+    L.pieces = off; off = up(off + elem * (size_t)(n / kPiece + 1));
     const size_t ntiles = (size_t)((n + kTile - 1) / kTile);
     L.tcounts = off; off = up(off + sizeof(unsigned) * (ntiles + 1));
     L.toffsets = off; off = up(off + sizeof(unsigned long long) * (ntiles + 1));
@@ -424,21 +476,15 @@ WsLayout layout(int64_t n)
     return L;
 }
 
-}  // namespace
-
-extern "C" size_t apgpu_sigclip_global_ws_bytes(int64_t n_pixels)
+template <typename T>
+int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters, double *stats_out,
+                       void *ws, size_t ws_bytes, void *stream)
 {
-    if (n_pixels <= 0) return 0;
-    return layout(n_pixels).total;
-}
-
-extern "C" int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters,
-                                        double *stats_out, void *ws, size_t ws_bytes, void *stream)
-{
+    using K = KeyOf<T>;
     if (!data || !stats_out || !ws) return fail(APGPU_EINVAL, "sigclip_global: NULL pointer argument");
     if (n_pixels <= 0) return fail(APGPU_EINVAL, "sigclip_global: n_pixels = %lld", (long long)n_pixels);
     if (maxiters == 0) return fail(APGPU_EINVAL, "sigclip_global: maxiters must be >= 1 or < 0");
-    const WsLayout L = layout(n_pixels);
+    const WsLayout L = layout(n_pixels, sizeof(T));
     if (ws_bytes < L.total) return fail(APGPU_EWORKSPACE, "sigclip_global: workspace %zu < %zu bytes", ws_bytes, L.total);
     if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(APGPU_EINVAL, "sigclip_global: workspace must be 16-byte aligned");
     // maxiters < 0 (until convergence): the device loop is a launch-time constant; 32 passes always
@@ -446,9 +492,9 @@ extern "C" int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, dou
     const int iters = (maxiters < 0 || maxiters > kMaxItersCap) ? kMaxItersCap : maxiters;
     char *w = static_cast<char *>(ws);
     GState *st = reinterpret_cast<GState *>(w + L.state);
-    float *b0 = reinterpret_cast<float *>(w + L.buf0);
-    float *b1 = reinterpret_cast<float *>(w + L.buf1);
-    float *pieces = reinterpret_cast<float *>(w + L.pieces);
+    T *b0 = reinterpret_cast<T *>(w + L.buf0);
+    T *b1 = reinterpret_cast<T *>(w + L.buf1);
+    T *pieces = reinterpret_cast<T *>(w + L.pieces);
     unsigned *tcounts = reinterpret_cast<unsigned *>(w + L.tcounts);
     unsigned long long *toffs = reinterpret_cast<unsigned long long *>(w + L.toffsets);
     hipStream_t s = as_stream(stream);
@@ -460,38 +506,97 @@ extern "C" int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, dou
 
     if (hipMemsetAsync(st, 0, sizeof(GState), s) != hipSuccess) return fail(APGPU_ELAUNCH, "sigclip_global: memset failed");
     // finite values of data -> buffer 0
-    hipLaunchKernelGGL(tile_count_kernel<0>, dim3(gtile), dim3(kBlock), 0, s, data, data, n, st, tcounts);
+    hipLaunchKernelGGL((tile_count_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, n, st, tcounts);
     hipLaunchKernelGGL(tile_scan_kernel<0>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
-    hipLaunchKernelGGL(tile_scatter_kernel<0>, dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, toffs);
+    hipLaunchKernelGGL((tile_scatter_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, toffs);
     hipLaunchKernelGGL(commit_kernel<0>, dim3(1), dim3(64), 0, s, st);
     if (int rc = check_launch("sigclip_global: compact finite")) return rc;
 
     auto stats_pass = [&](int final_pass) {
         hipLaunchKernelGGL(select_begin_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
-        for (int pass = 0; pass < 4; pass++) {
-            hipLaunchKernelGGL(hist_kernel, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
+        for (int pass = 0; pass < K::passes; pass++) {
+            hipLaunchKernelGGL(hist_kernel<T>, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
             hipLaunchKernelGGL(select_digit_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
         }
-        hipLaunchKernelGGL(less_stats_kernel, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, final_pass);
-        hipLaunchKernelGGL(median_finish_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
-        hipLaunchKernelGGL(piece_sums_kernel<0>, dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL(fold_kernel<0>, dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL(piece_sums_kernel<1>, dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL(fold_kernel<1>, dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL(less_stats_kernel<T>, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, final_pass);
+        hipLaunchKernelGGL(median_finish_kernel<T>, dim3(1), dim3(64), 0, s, st, final_pass);
+        hipLaunchKernelGGL((piece_sums_kernel<0, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((fold_kernel<0, T>), dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((piece_sums_kernel<1, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((fold_kernel<1, T>), dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
     };
 
     for (int it = 0; it < iters; it++) {
         stats_pass(0);
         hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, s, st, sigma_lower, sigma_upper);
-        hipLaunchKernelGGL(tile_count_kernel<1>, dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, tcounts);
+        hipLaunchKernelGGL((tile_count_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, tcounts);
         hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
-        hipLaunchKernelGGL(tile_scatter_kernel<1>, dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, toffs);
+        hipLaunchKernelGGL((tile_scatter_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, toffs);
         hipLaunchKernelGGL(commit_kernel<1>, dim3(1), dim3(64), 0, s, st);
         if (int rc = check_launch("sigclip_global: iteration")) return rc;
     }
     // statistics of the survivors (the last iteration's statistics belong to the pre-clip set unless
     // it removed nothing)
     stats_pass(1);
-    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, s, st, stats_out);
+    hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, stats_out);
     return check_launch("sigclip_global: publish");
+}
+
+// F2 helper: float64 difference of two images where neither is flagged bad, NaN elsewhere (the NaNs are
+// dropped, in order, by the finite-value compaction of the global statistics pass).
+template <typename RawT>
+__global__ __launch_bounds__(kBlock) void image_difference_kernel(const RawT *__restrict__ a, const RawT *__restrict__ b,
+                                                                 const uint8_t *__restrict__ bad1, const uint8_t *__restrict__ bad2,
+                                                                 double *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const bool bad = (bad1 && bad1[i]) || (bad2 && bad2[i]);
+        out[i] = bad ? __builtin_nan("") : (double)a[i] - (double)b[i];
+    }
+}
+
+}  // namespace
+
+extern "C" size_t apgpu_sigclip_global_ws_bytes(int64_t n_pixels)
+{
+    if (n_pixels <= 0) return 0;
+    return layout(n_pixels, sizeof(float)).total;
+}
+
+extern "C" size_t apgpu_sigclip_global_f64_ws_bytes(int64_t n_pixels)
+{
+    if (n_pixels <= 0) return 0;
+    return layout(n_pixels, sizeof(double)).total;
+}
+
+extern "C" int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters,
+                                        double *stats_out, void *ws, size_t ws_bytes, void *stream)
+{
+    return run_sigclip_global<float>(data, n_pixels, sigma_lower, sigma_upper, maxiters, stats_out, ws, ws_bytes, stream);
+}
+
+extern "C" int apgpu_sigclip_global_f64(const double *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters,
+                                        double *stats_out, void *ws, size_t ws_bytes, void *stream)
+{
+    return run_sigclip_global<double>(data, n_pixels, sigma_lower, sigma_upper, maxiters, stats_out, ws, ws_bytes, stream);
+}
+
+extern "C" int apgpu_image_difference_f64(const void *a, const void *b, int dtype, const uint8_t *bad1, const uint8_t *bad2,
+                                          double *out, int64_t n_pixels, void *stream)
+{
+    if (!a || !b || !out) return fail(APGPU_EINVAL, "image_difference: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "image_difference: n_pixels = %lld", (long long)n_pixels);
+    int64_t grid = (n_pixels + kBlock - 1) / kBlock;
+    if (grid > kNumCU * 8) grid = kNumCU * 8;
+    hipStream_t s = as_stream(stream);
+    if (dtype == APGPU_F32)
+        hipLaunchKernelGGL(image_difference_kernel<float>, dim3((unsigned)grid), dim3(kBlock), 0, s, (const float *)a, (const float *)b,
+                           bad1, bad2, out, n_pixels);
+    else if (dtype == APGPU_U16)
+        hipLaunchKernelGGL(image_difference_kernel<uint16_t>, dim3((unsigned)grid), dim3(kBlock), 0, s, (const uint16_t *)a,
+                           (const uint16_t *)b, bad1, bad2, out, n_pixels);
+    else
+        return fail(APGPU_EINVAL, "image_difference: bad dtype %d", dtype);
+    return check_launch("image_difference");
 }

@@ -208,19 +208,47 @@ def moments_finalize(moments, want_std=True, out_mean=None):
 def sigclip_global(data, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5):
     """A3 sigma_clipped_stats(data, sigma) with axis=None (ApFindBadPixels.py:191).
 
-    Returns a float64 device tensor [8] = mean, median, std, lo, hi, iterations, survivors, 0."""
+    float32 data -> numpy's float32 statistics; float64 and integer data (widened exactly) -> float64
+    statistics, as numpy computes them.  Returns a float64 device tensor [10] =
+    mean, median, std, lo, hi, iterations, survivors, min, max, 0."""
     _need_cuda(data)
     lib = _lib.load()
-    data = _f32c(data, 'data')
+    if data.dtype == torch.float32:
+        f64 = False
+        data = data.contiguous()
+    else:
+        f64 = True
+        if data.dtype == torch.uint16:
+            data = (data.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float64)
+        else:
+            data = data.to(torch.float64)
+        data = data.contiguous()
     n = data.numel()
-    ws_bytes = lib.apgpu_sigclip_global_ws_bytes(n)
+    ws_bytes = (lib.apgpu_sigclip_global_f64_ws_bytes if f64 else lib.apgpu_sigclip_global_ws_bytes)(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=data.device)
-    stats = torch.empty(8, dtype=torch.float64, device=data.device)
+    stats = torch.empty(10, dtype=torch.float64, device=data.device)
     sl = float(sigma if sigma_lower is None else sigma_lower)
     su = float(sigma if sigma_upper is None else sigma_upper)
-    check(lib.apgpu_sigclip_global_f32(_ptr(data), n, sl, su, -1 if maxiters is None else int(maxiters),
-                                       _ptr(stats), _ptr(ws), ws_bytes, _stream()))
+    fn = lib.apgpu_sigclip_global_f64 if f64 else lib.apgpu_sigclip_global_f32
+    check(fn(_ptr(data), n, sl, su, -1 if maxiters is None else int(maxiters), _ptr(stats), _ptr(ws), ws_bytes, _stream()))
     return stats
+
+
+def image_difference(a, b, bad1=None, bad2=None):
+    """F2 ApImageDifference (ap_calc_read_noise.py:122): float64(a) - float64(b), NaN where bad1|bad2."""
+    _need_cuda(a, b, bad1, bad2)
+    a, b = a.contiguous(), b.contiguous()
+    dt = _raw_dtype(a)
+    if _raw_dtype(b) != dt or a.shape != b.shape:
+        raise RuntimeError('Error, data array shapes do not match: First file=%s, second file=%s' % (tuple(a.shape), tuple(b.shape)))
+    for m in (bad1, bad2):
+        if m is not None and (m.dtype != torch.uint8 or m.shape != a.shape):
+            raise TypeError('bad-pixel masks must be uint8 with the image shape')
+    bad1 = None if bad1 is None else bad1.contiguous()
+    bad2 = None if bad2 is None else bad2.contiguous()
+    out = torch.empty(a.shape, dtype=torch.float64, device=a.device)
+    check(_lib.load().apgpu_image_difference_f64(_ptr(a), _ptr(b), dt, _ptr(bad1), _ptr(bad2), _ptr(out), a.numel(), _stream()))
+    return out
 
 
 def threshold_mask(data, lothresh=0.0, hithresh=0.0, thresholds=None):

@@ -135,13 +135,30 @@ int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_
 /* ---------------------------------------------------------------------------------------------
  * A3  astropy.stats.sigma_clipped_stats(data, sigma) with axis=None as called at
  *     core/ApFindBadPixels.py:191 (astropy/stats/sigma_clipping.py:385-433, numpy nan-functions):
- *     global iterative clip of a float32 image with numpy's float32 arithmetic (exact median by
- *     radix select, float32 pairwise sums).  result_host? no - results stay on the device:
- *     stats_out[8] float64 = { mean, median, std, lo, hi, iterations, survivors, reserved }.
+ *     global iterative clip of an image with numpy's arithmetic reproduced exactly (exact median by
+ *     radix select, numpy-ordered pairwise sums):
+ *       _f32: float32 data, float32 statistics (float32 masters);
+ *       _f64: float64 data and statistics - what numpy computes for integer images (the caller widens
+ *             uint16/int16 pixels exactly) and for float64 data.
+ *     Results stay on the device: stats_out[10] float64 =
+ *       { mean, median, std, lo, hi, iterations, survivors, min, max, reserved }
+ *     (lo/hi = bounds of the last pass; min/max of the survivors).  maxiters < 0 = until convergence.
  * ------------------------------------------------------------------------------------------- */
 size_t apgpu_sigclip_global_ws_bytes(int64_t n_pixels);
 int apgpu_sigclip_global_f32(const float *data, int64_t n_pixels, double sigma_lower, double sigma_upper,
                              int maxiters, double *stats_out, void *ws, size_t ws_bytes, void *stream);
+size_t apgpu_sigclip_global_f64_ws_bytes(int64_t n_pixels);
+int apgpu_sigclip_global_f64(const double *data, int64_t n_pixels, double sigma_lower, double sigma_upper,
+                             int maxiters, double *stats_out, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * F2  ApImageDifference (scripts/ap_calc_read_noise.py:122): out = float64(a) - float64(b) where neither
+ *     bad1 nor bad2 (uint8, non-zero = bad, either may be NULL) flags the pixel, NaN elsewhere; feed
+ *     `out` to apgpu_sigclip_global_f64 (maxiters 1, huge sigma) for np.std/mean/median/min/max of
+ *     diff[good] in numpy's order.  a, b: APGPU_F32 or APGPU_U16.
+ * ------------------------------------------------------------------------------------------- */
+int apgpu_image_difference_f64(const void *a, const void *b, int dtype, const uint8_t *bad1, const uint8_t *bad2,
+                               double *out, int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A4  ApFindBadPixels._generate_sigmaclip_mask (core/ApFindBadPixels.py:194-216):

@@ -287,3 +287,29 @@ def calibrate_stack(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still
                                      _p(mean), _p(cnt))
     assert rc == 0
     return mean, cnt
+
+
+def image_difference(im1, im2, sigmaclip, mask1=None, mask2=None):
+    """F2 ApImageDifference (scripts/ap_calc_read_noise.py:86-370): statistics of float64(im1) - float64(im2)
+    over the pixels that are good in both images.  Returns dict(stddev, min, max, mean, median, numgood,
+    numpix, good)."""
+    im1, im2 = np.asarray(im1), np.asarray(im2)
+    if sigmaclip:
+        goods = []
+        for img in (im1, im2):
+            st = sigclip_global(img, sigma=3.0, maxiters=5)
+            lo, hi = badpix_thresholds(st['median'], st['std'], 3.0)
+            f = img.astype(np.float32)            # numpy 1.26 compares f32 / u16 arrays with a float scalar in float32
+            goods.append((f >= np.float32(lo)) & (f <= np.float32(hi)))
+        good = goods[0] & goods[1]
+    elif mask1 is not None or mask2 is not None:
+        g1 = np.ones(im1.shape, bool) if mask1 is None else (np.asarray(mask1) == 0)
+        g2 = np.ones(im1.shape, bool) if mask2 is None else (np.asarray(mask2) == 0)
+        good = g1 & g2
+    else:
+        good = np.ones(im1.shape, bool)
+    diff = im1.astype(np.float64) - im2.astype(np.float64)
+    sel = np.ascontiguousarray(diff[good])
+    st = sigclip_global(sel, sigma=1e300, maxiters=1)       # float64 path: numpy-ordered mean / median / std
+    return dict(stddev=float(st['std']), min=float(sel.min()), max=float(sel.max()), mean=float(st['mean']),
+                median=float(st['median']), numgood=int(good.sum()), numpix=int(good.size), good=good)

@@ -24,6 +24,7 @@ Fixture groups:
   G6 mad_std/median along N (building blocks of the ccdproc.combine settings used at
                     scripts/ap_combine_darks.py:394-420; ccdproc itself is absent -> unpinned)
   G7 nanmean        np.nanmean of float32 flats (pairwise float32 summation) for _generate_flat
+  G8 read noise     ApImageDifference / ApCalcReadNoise      scripts/ap_calc_read_noise.py:86-688
 """
 import sys, types, importlib, warnings, os, tempfile, shutil, json
 warnings.filterwarnings('ignore')
@@ -391,12 +392,53 @@ def g7_nanmean(tmp):
     save('g7_nanmean.npz', **out)
 
 
+def g8_readnoise(tmp):
+    import importlib.util
+    import matplotlib
+    matplotlib.use('Agg')
+    spec = importlib.util.spec_from_file_location('ref_ap_calc_read_noise',
+                                                  '/root/reference/AstroPhotography/scripts/ap_calc_read_noise.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(808)
+    out = {}
+    H, W = 120, 200
+    for tag, dt in (('u16', np.uint16), ('f32', np.float32)):
+        b1 = rng.normal(1000, 8, (H, W))
+        b2 = rng.normal(1000, 8, (H, W))
+        hot = rng.random((H, W)) < 0.002
+        b1[hot] += 3000
+        b2[rng.random((H, W)) < 0.002] += 2500
+        if dt == np.uint16:
+            b1 = np.clip(np.rint(b1), 0, 65535).astype(dt)
+            b2 = np.clip(np.rint(b2), 0, 65535).astype(dt)
+        else:
+            b1, b2 = b1.astype(dt), b2.astype(dt)
+        out[tag + '_b1'], out[tag + '_b2'] = b1, b2
+        for clip in (True, False):
+            d = mod.ApImageDifference(b1, b2, clip, LOG)
+            ng, nt = d.numpix()
+            out[f'{tag}_clip{int(clip)}_stats'] = np.array([d.stddev(), d.min(), d.max(), d.mean(), d.median(), ng, nt], np.float64)
+            out[f'{tag}_clip{int(clip)}_good'] = np.packbits(d.good_pixel_mask())
+        m1 = (rng.random((H, W)) < 0.01).astype(np.uint8) * 3
+        d = mod.ApImageDifference(b1, b2, False, LOG, mask1=m1, mask2=None)
+        out[tag + '_mask1'] = m1
+        out[tag + '_masked_stats'] = np.array([d.stddev(), d.min(), d.max(), d.mean(), d.median(), d.numpix()[0]], np.float64)
+        p1, p2 = f'{tmp}/rn_{tag}_1.fits', f'{tmp}/rn_{tag}_2.fits'
+        wfits(p1, b1, EGAIN=1.37)
+        wfits(p2, b2, EGAIN=1.37)
+        rn = mod.ApCalcReadNoise(p1, p2, 'EGAIN', LOG).estimate_rn(True)
+        rn2 = mod.ApCalcReadNoise(p1, p2, '2.0', LOG).estimate_rn(False)
+        out[tag + '_readnoise'] = np.array([rn, rn2], np.float64)
+    save('g8_readnoise.npz', **out)
+
+
 if __name__ == '__main__':
     tmp = tempfile.mkdtemp(prefix='apgold_')
     try:
-        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
         for g in which:
             {'g1': g1_calibrate, 'g2': g2_findbadpix, 'g3': g3_fixbadpix, 'g4': g4_imarith,
-             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean}[g](tmp)
+             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean, 'g8': g8_readnoise}[g](tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -109,8 +109,11 @@ def test_apfindbadpixels_golden(tmp_path):
             st = fb.get_stats()
             assert [st['lothresh'], st['hithresh']] == list(g[f'd{ci}_thresh'])
         else:
-            # integer dark: numpy uses float64 statistics, the device float32 ones; the mask still agrees
-            assert (fb.get_mask() != g[f'd{ci}_mask_auto']).sum() == 0
+            # integer dark: numpy's float64 statistics are reproduced exactly on the device
+            assert np.array_equal(fb.get_mask(), g[f'd{ci}_mask_auto'])
+            st = fb.get_stats()
+            assert [float(st['mean']), float(st['median']), float(st['std'])] == list(g[f'd{ci}_stats'])
+            assert [st['lothresh'], st['hithresh']] == list(g[f'd{ci}_thresh'])
         if f'd{ci}_mask_user' in g:
             fb.add_user_badpix(os.path.join(GOLDEN, 'user_badpixels.yml'))
             assert np.array_equal(fb.get_mask(), g[f'd{ci}_mask_user'])
@@ -306,3 +309,33 @@ def test_fits_device_decode_encode(tmp_path):
     _, h = fitsio.read(str(tmp_path / 'f32.fits'))
     fitsio.write_device(str(tmp_path / 'dev.fits'), t, h)
     assert (tmp_path / 'dev.fits').read_bytes() == (tmp_path / 'f32.fits').read_bytes()
+
+
+def test_read_noise_golden(tmp_path, capsys):
+    """F2: ApImageDifference / ApCalcReadNoise against the reference's own numbers (exact float64 equality)."""
+    import astrophotography_amd as ap
+    g = load_golden('g8_readnoise.npz')
+    for tag in ('u16', 'f32'):
+        b1, b2 = g[tag + '_b1'], g[tag + '_b2']
+        for clip in (1, 0):
+            d = ap.ApImageDifference(b1, b2, bool(clip), 'CRITICAL')
+            ref = g[f'{tag}_clip{clip}_stats']
+            ng, nt = d.numpix()
+            assert [d.stddev(), d.min(), d.max(), d.mean(), d.median(), ng, nt] == list(ref), (tag, clip)
+            good = np.unpackbits(g[f'{tag}_clip{clip}_good'])[:b1.size].reshape(b1.shape).astype(bool)
+            assert np.array_equal(d.good_pixel_mask(), good)
+        d = ap.ApImageDifference(b1, b2, False, 'CRITICAL', mask1=g[tag + '_mask1'])
+        assert [d.stddev(), d.min(), d.max(), d.mean(), d.median(), d.numpix()[0]] == list(g[tag + '_masked_stats'])
+        assert np.array_equal(d.data(), b1.astype(np.float64) - b2.astype(np.float64))
+        _wf(tmp_path / f'{tag}1.fits', b1, EGAIN=1.37)
+        _wf(tmp_path / f'{tag}2.fits', b2, EGAIN=1.37)
+        rn = ap.ApCalcReadNoise(str(tmp_path / f'{tag}1.fits'), str(tmp_path / f'{tag}2.fits'), 'EGAIN', 'CRITICAL').estimate_rn(True)
+        rn2 = ap.ApCalcReadNoise(str(tmp_path / f'{tag}1.fits'), str(tmp_path / f'{tag}2.fits'), '2.0', 'CRITICAL').estimate_rn(False)
+        assert [rn, rn2] == list(g[tag + '_readnoise'])
+    from astrophotography_amd.scripts import ap_calc_read_noise
+    assert ap_calc_read_noise.main([str(tmp_path / 'u161.fits'), str(tmp_path / 'u162.fits'), '-l', 'CRITICAL']) == 0
+    assert 'Estimated read noise is %.2f electrons/pixel.' % g['u16_readnoise'][0] in capsys.readouterr().out
+    with pytest.raises(RuntimeError):
+        ap.ApCalcReadNoise(str(tmp_path / 'u161.fits'), str(tmp_path / 'u162.fits'), 'NOGAIN', 'CRITICAL').estimate_rn(True)
+    with pytest.raises(RuntimeError):
+        ap.ApImageDifference(b1, b2[:10], True, 'CRITICAL')

@@ -229,15 +229,17 @@ def test_sigclip_global_and_mask_golden(ops):
     g = load_golden('g2_findbadpix.npz')
     for ci in range(int(g['ncases'])):
         dark = g[f'd{ci}_dark']
-        if dark.dtype != np.float32:
-            continue
         d = dev(dark, ops)
         st = ops.sigclip_global(d, sigma=4.0, maxiters=5)
         s = host(st)
         ref = g[f'd{ci}_stats']
-        assert_biteq(s[:3].astype(np.float32), ref.astype(np.float32), f'stats case {ci}')
-        lo = float(np.float32(s[1])) - 4.0 * float(np.float32(s[2]))
-        hi = float(np.float32(s[1])) + 4.0 * float(np.float32(s[2]))
+        if dark.dtype == np.float32:
+            assert_biteq(s[:3].astype(np.float32), ref.astype(np.float32), f'stats case {ci}')
+        else:                                   # integer dark: numpy's float64 statistics, reproduced exactly
+            assert list(s[:3]) == list(ref), ci
+            d = dev(dark.astype(np.float32), ops)
+        lo = float(s[1]) - 4.0 * float(s[2])
+        hi = float(s[1]) + 4.0 * float(s[2])
         assert [lo, hi] == list(g[f'd{ci}_thresh'])
         mask, nbad = ops.threshold_mask(d, lo, hi)
         assert np.array_equal(host(mask), g[f'd{ci}_mask_auto'])
@@ -423,3 +425,26 @@ def test_config4_bayer_u16_median_pipeline(ops, apref):
     assert np.array_equal(host(planes), apref.bayer_split(raw[0], (0, 1, 3, 2), (256, 256, 256, 256)))
     p = host(planes)
     assert (p[0][1::2] == 0).all() and (p[0][:, 1::2] == 0).all() and (p[2][::2] == 0).all()
+
+
+def test_sigclip_global_f64_vs_oracle(ops, apref):
+    """Integer / float64 images: numpy runs every statistic in float64; same tree, same bits."""
+    rng = np.random.default_rng(43)
+    for n in (5, 1000, 8192 * 2 + 77, 300000):
+        xu = np.clip(np.rint(rng.normal(1000, 8, n)), 0, 65535).astype(np.uint16)
+        xu[rng.random(n) < 0.002] = 5000
+        xd = rng.normal(0, 3, n)
+        xd[rng.random(n) < 0.002] += 100
+        if n > 100:
+            xd[3] = np.nan
+        for x in (xu, xd):
+            for sigma, maxiters in ((3.0, 5), (4.0, None), (1e300, 1)):
+                ref = apref.sigclip_global(x, sigma=sigma, maxiters=maxiters)
+                t = ops.to_device_u16(x) if x.dtype == np.uint16 else torch.from_numpy(x).cuda()
+                s = host(ops.sigclip_global(t, sigma=sigma, maxiters=maxiters))
+                what = f'n={n} {x.dtype} sigma={sigma} maxiters={maxiters}'
+                assert [s[0], s[1], s[2]] == [ref['mean'], ref['median'], ref['std']], what
+                assert int(s[6]) == ref['nkeep'] and int(s[5]) == ref['niter'], what
+                fin = x[np.isfinite(x.astype(np.float64))].astype(np.float64)
+                if sigma > 1e100:
+                    assert s[7] == fin.min() and s[8] == fin.max(), what

@@ -192,3 +192,22 @@ def test_g6_madstd_blocks(golden_dir):
         exp = np.where(keep, cube.astype(np.float64), 0).sum(0) / keep.sum(0)
         np.testing.assert_allclose(c['mean'], exp, rtol=1e-14)
         assert np.array_equal(c['count'], keep.sum(0))
+
+
+# ---- G8: ApImageDifference / ApCalcReadNoise -------------------------------------------------------
+def test_g8_read_noise(golden_dir):
+    import math
+    g = load(golden_dir, 'g8_readnoise.npz')
+    for tag in ('u16', 'f32'):
+        b1, b2 = g[tag + '_b1'], g[tag + '_b2']
+        for clip in (1, 0):
+            r = apref.image_difference(b1, b2, bool(clip))
+            ref = g[f'{tag}_clip{clip}_stats']
+            assert [r['stddev'], r['min'], r['max'], r['mean'], r['median'], r['numgood'], r['numpix']] == list(ref), (tag, clip)
+            good = np.unpackbits(g[f'{tag}_clip{clip}_good'])[:b1.size].reshape(b1.shape).astype(bool)
+            assert np.array_equal(r['good'], good)
+        r = apref.image_difference(b1, b2, False, mask1=g[tag + '_mask1'])
+        assert [r['stddev'], r['min'], r['max'], r['mean'], r['median'], r['numgood']] == list(g[tag + '_masked_stats'])
+        rn = 1.37 * apref.image_difference(b1, b2, True)['stddev'] / math.sqrt(2)
+        rn2 = 2.0 * apref.image_difference(b1, b2, False)['stddev'] / math.sqrt(2)
+        assert [rn, rn2] == list(g[tag + '_readnoise'])
