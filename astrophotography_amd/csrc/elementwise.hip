@@ -41,6 +41,24 @@ __device__ __forceinline__ float calib_one(float x, float ped, bool has_ped, flo
     return x;
 }
 
+// x / nf through y = RN(1 / nf) and two FMA-residual corrections (exact when nothing over/underflows,
+// see stack_kernels.h div_by_recip); anything outside the guarded ranges takes the IEEE sequence.
+__device__ __forceinline__ float guarded_div(float x, float nf, float y, bool nf_ok)
+{
+    const float q0 = x * y;
+    const float r0 = __builtin_fmaf(-nf, q0, x);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-nf, q1, x);
+    const float q = __builtin_fmaf(r1, y, q1);
+    const float aq = fabsf(q);
+    const bool safe = nf_ok && (aq < 0x1p50f) && (aq > 0x1p-50f);     // false for NaN / Inf / 0 as well
+    return safe ? q : __fdiv_rn(x, nf);
+}
+
+// One lane owns 4 consecutive pixels and walks over the N frames: the masters are read once per pixel
+// (not once per frame), the reciprocal of the flat is formed once, and every access is a 16-byte (f32)
+// or 8-byte (u16) coalesced vector.  vec = 0 (P % 4 != 0: frame starts are not 16-byte aligned) sends
+// every pixel through the scalar tail.
 template <typename RawT>
 __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restrict__ raw, const float *__restrict__ bias,
                                                           const float *__restrict__ dark,
@@ -49,43 +67,66 @@ __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restric
                                                           const float *__restrict__ pedestal, int still_biased,
                                                           float *__restrict__ out, int64_t N, int64_t P, int vec)
 {
-    // vec = 0 when P % 4 != 0: frame starts are then not 16-byte aligned and every pixel takes the
-    // scalar tail path.
-    const int64_t groups = vec ? P / 4 : 0;   // 4-pixel groups per frame (vector body)
-    const int64_t total = N * groups;
+    const int64_t groups = vec ? P / 4 : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool has_flat = nflat != nullptr;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const int64_t f = t / groups;
-        const int64_t g = t - f * groups;
-        const float e = exp_ratio[f];
-        const float ped = pedestal ? pedestal[f] : 0.f;
-        const bool has_ped = ped != 0.f;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
         const float4 b4 = reinterpret_cast<const float4 *>(bias)[g];
         const float4 d4 = reinterpret_cast<const float4 *>(dark)[g];
         float4 n4 = make_float4(1.f, 1.f, 1.f, 1.f);
         if (has_flat) n4 = reinterpret_cast<const float4 *>(nflat)[g];
-        float x[4];
-        const RawT *rp = raw + f * P + g * 4;
-        if constexpr (sizeof(RawT) == 4) {
-            const float4 r4 = *reinterpret_cast<const float4 *>(rp);
-            x[0] = r4.x; x[1] = r4.y; x[2] = r4.z; x[3] = r4.w;
-        } else {
-            const ushort4 r4 = *reinterpret_cast<const ushort4 *>(rp);
-            x[0] = (float)r4.x; x[1] = (float)r4.y; x[2] = (float)r4.z; x[3] = (float)r4.w;
-        }
         const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
         const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
         const float nn[4] = {n4.x, n4.y, n4.z, n4.w};
-        float y[4];
+        float D[4], y[4];
+        bool dodiv[4], nf_ok[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float D = still_biased ? dd[k] - bb[k] : dd[k];      // :440-445
-            y[k] = calib_one(x[k], ped, has_ped, bb[k], D, e, has_flat, nn[k]);
+            D[k] = still_biased ? dd[k] - bb[k] : dd[k];               // ApCalibrate.py:440-445
+            dodiv[k] = has_flat && (nn[k] != 0.f);                     // :462 (NaN != 0 -> divide -> NaN)
+            y[k] = __fdiv_rn(1.0f, nn[k]);
+            const float a = fabsf(nn[k]);
+            nf_ok[k] = (a >= 0x1p-40f) && (a <= 0x1p40f);
         }
-        *reinterpret_cast<float4 *>(out + f * P + g * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        // kU frames per trip: all kU loads are issued before the first result is needed, which keeps
+        // kU x 16 bytes per lane in flight (the loop is otherwise one outstanding load per lane).
+        constexpr int kU = 4;
+        for (int64_t f0 = 0; f0 < N; f0 += kU) {
+            float x[kU][4];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int64_t f = f0 + u < N ? f0 + u : N - 1;         // clamped reload, result discarded below
+                const RawT *rp = raw + f * P + g * 4;
+                if constexpr (sizeof(RawT) == 4) {
+                    const float4 r4 = *reinterpret_cast<const float4 *>(rp);
+                    x[u][0] = r4.x; x[u][1] = r4.y; x[u][2] = r4.z; x[u][3] = r4.w;
+                } else {
+                    const ushort4 r4 = *reinterpret_cast<const ushort4 *>(rp);
+                    x[u][0] = (float)r4.x; x[u][1] = (float)r4.y; x[u][2] = (float)r4.z; x[u][3] = (float)r4.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const int64_t f = f0 + u;
+                if (f >= N) break;
+                const float e = exp_ratio[f];
+                const float ped = pedestal ? pedestal[f] : 0.f;
+                const bool has_ped = ped != 0.f;
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float v = x[u][k];
+                    if (has_ped) v = v + ped;                           // ApCalibrate.py:318-326
+                    v = v - bb[k];                                      // :439
+                    const float ds = e * D[k];                          // :450
+                    v = v - ds;                                         // :451
+                    o[k] = dodiv[k] ? guarded_div(v, nn[k], y[k], nf_ok[k]) : v;
+                }
+                *reinterpret_cast<float4 *>(out + f * P + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
     }
-    // tail pixels (P % 4) of every frame
+    // tail pixels (P % 4, or every pixel when vec == 0)
     const int64_t tail0 = groups * 4;
     const int64_t ntail = P - tail0;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * ntail; t += stride) {
@@ -243,19 +284,21 @@ __global__ __launch_bounds__(kBlock) void threshold_mask_kernel(const float *__r
     if (thr_dev) { lo_d = thr_dev[0]; hi_d = thr_dev[1]; }
     const float lo = (float)lo_d, hi = (float)hi_d;     // numpy 1.26 demotes the float64 scalar to float32
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t n4 = n / 4;
+    const int64_t n16 = n / 16;             // 16 pixels per lane: 4 x 16-byte loads, one 16-byte mask store
     unsigned cnt = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        const float4 a = reinterpret_cast<const float4 *>(data)[i];
-        uchar4 m;
-        m.x = (a.x < lo) || (a.x > hi);
-        m.y = (a.y < lo) || (a.y > hi);
-        m.z = (a.z < lo) || (a.z > hi);
-        m.w = (a.w < lo) || (a.w > hi);
-        cnt += m.x + m.y + m.z + m.w;
-        reinterpret_cast<uchar4 *>(mask)[i] = m;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 a = reinterpret_cast<const float4 *>(data)[i * 4 + q];
+            const unsigned b0 = (a.x < lo) || (a.x > hi), b1 = (a.y < lo) || (a.y > hi);
+            const unsigned b2 = (a.z < lo) || (a.z > hi), b3 = (a.w < lo) || (a.w > hi);
+            cnt += b0 + b1 + b2 + b3;
+            w[q] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+        }
+        reinterpret_cast<uint4 *>(mask)[i] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (int64_t i = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint8_t b = (data[i] < lo) || (data[i] > hi);
         mask[i] = b;
         cnt += b;
@@ -406,7 +449,7 @@ extern "C" int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias
     if (!aligned16(raw) || !aligned16(bias) || !aligned16(dark) || !aligned16(out) || (nflat && !aligned16(nflat)))
         return fail(APGPU_EINVAL, "calibrate: buffers must be 16-byte aligned");
     const int vec = (n_pixels % 4) == 0 || n_frames == 1;
-    const unsigned grid = grid_for(n_frames * ((n_pixels + 3) / 4));
+    const unsigned grid = grid_for(vec ? (n_pixels + 3) / 4 : n_frames * n_pixels);
     hipStream_t st = as_stream(stream);
     if (raw_dtype == APGPU_F32)
         hipLaunchKernelGGL(calibrate_kernel<float>, dim3(grid), dim3(kBlock), 0, st, (const float *)raw, bias, dark, nflat,
@@ -456,10 +499,10 @@ extern "C" int apgpu_threshold_mask_f32(const float *data, int64_t n_pixels, dou
 {
     if (!data || !mask || !nbad_out) return fail(APGPU_EINVAL, "threshold_mask: NULL pointer argument");
     if (n_pixels <= 0) return fail(APGPU_EINVAL, "threshold_mask: n_pixels = %lld", (long long)n_pixels);
-    if (!aligned16(data) || (reinterpret_cast<uintptr_t>(mask) & 3)) return fail(APGPU_EINVAL, "threshold_mask: misaligned buffers");
+    if (!aligned16(data) || !aligned16(mask)) return fail(APGPU_EINVAL, "threshold_mask: buffers must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(nbad_out, 0, sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "threshold_mask: memset failed");
-    hipLaunchKernelGGL(threshold_mask_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, data, n_pixels, lothresh,
+    hipLaunchKernelGGL(threshold_mask_kernel, dim3(grid_for(n_pixels / 16 + 1)), dim3(kBlock), 0, st, data, n_pixels, lothresh,
                        hithresh, thresholds_dev, mask, reinterpret_cast<unsigned long long *>(nbad_out));
     return check_launch("threshold_mask");
 }
