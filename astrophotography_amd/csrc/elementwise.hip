@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restric
         }
         // kU frames per trip: all kU loads are issued before the first result is needed, which keeps
         // kU x 16 bytes per lane in flight (the loop is otherwise one outstanding load per lane).
-        constexpr int kU = 4;
+        constexpr int kU = 8;
         for (int64_t f0 = 0; f0 < N; f0 += kU) {
             float x[kU][4];
 #pragma unroll
@@ -122,7 +122,9 @@ __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restric
                     v = v - ds;                                         // :451
                     o[k] = dodiv[k] ? guarded_div(v, nn[k], y[k], nf_ok[k]) : v;
                 }
-                *reinterpret_cast<float4 *>(out + f * P + g * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                float *op = out + f * P + g * 4;                        // streamed once, never re-read: bypass L2 retention
+#pragma unroll
+                for (int k = 0; k < 4; k++) __builtin_nontemporal_store(o[k], op + k);
             }
         }
     }

@@ -266,46 +266,63 @@ __device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st
     }
 }
 
-// astropy.stats.mad_std of the survivors v[a .. b): 1.482602218505602 * median(|x - med|)
-// (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  The deviations are sorted as
-// float32 keys with a second network - rounding is monotone, so the k-th smallest ROUNDED deviation is
-// the rounding of the k-th smallest exact one - and the exact float64 value is then recovered from
-// the (almost always single) element whose key equals it.
+// -------------------------------------------------------------------------------------------------
+// "Rich" kernels (median / std output planes, mad_std deviation): after the sort the column is parked in
+// LDS - row i holds element i of every lane's column - so that a lane reads ITS column with a run-time
+// index (one ds_read_b32, bank = lane: conflict-free) where the lean kernel needs an (NP-1)-select
+// multiplexer tree, and every later phase is a compact run-time loop over LDS instead of NP levels of
+// statically indexed code.  64 KB per workgroup (256 lanes x 64 rows, or 128 lanes x 128 rows).
+// -------------------------------------------------------------------------------------------------
 template <int NP>
-__device__ __forceinline__ double mad_std_range(const float (&v)[NP], int a, int b, double med)
+constexpr int rich_block() { return NP > 64 ? 128 : 256; }
+
+template <int NP, bool RICH>
+struct ColumnLds {
+    __device__ __forceinline__ float *lane_ptr(int) { return nullptr; }
+};
+template <int NP>
+struct ColumnLds<NP, true> {
+    float x[NP][rich_block<NP>()];
+    __device__ __forceinline__ float *lane_ptr(int lane) { return &x[0][lane]; }
+};
+
+template <int NP>
+__device__ __forceinline__ float col_read(const float *col, int i)
 {
-    float dv[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const double d = fabs((double)v[i] - med);
-        dv[i] = (i >= a && i < b) ? (float)d : __builtin_inff();
-    }
-    sort_column<NP>(dv);
+    i = i < 0 ? 0 : (i > NP - 1 ? NP - 1 : i);
+    return col[i * rich_block<NP>()];
+}
+
+// astropy.stats.mad_std of the survivors x[a .. b): 1.482602218505602 * median(|x - med|)
+// (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  No second sort: the column is
+// sorted, so the j+1 deviations nearest to med belong to a contiguous window [L, L+j], and the j-th order
+// statistic of the deviations is  min over L of max(|x_L - med|, |x_(L+j) - med|)  (|x - med| is convex
+// along the sorted column, so a window's largest deviation sits at one of its ends).  Windows leaving
+// [a, b) get an infinite deviation.  Every value is the exact float64 |x - med| the reference sorts.
+template <int NP>
+__device__ __forceinline__ double mad_std_window(const float *col, bool active, int a, int b, double med)
+{
     const int n = b - a;
-    const int k1 = (n - 1) >> 1, k2 = n >> 1;
-    const float D1 = pick_at<NP>(dv, k1), D2 = pick_at<NP>(dv, k2);
-    int less1 = 0, eq1 = 0, less2 = 0, eq2 = 0;
-    double mn1 = __builtin_inf(), mx1 = 0.0, mn2 = __builtin_inf(), mx2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const bool in = (i >= a && i < b);
-        const double d = fabs((double)v[i] - med);
-        const float r = (float)d;
-        const bool e1 = in && (r == D1), e2 = in && (r == D2);
-        less1 += (in && r < D1) ? 1 : 0;
-        less2 += (in && r < D2) ? 1 : 0;
-        eq1 += e1 ? 1 : 0;
-        eq2 += e2 ? 1 : 0;
-        mn1 = (e1 && d < mn1) ? d : mn1;
-        mx1 = (e1 && d > mx1) ? d : mx1;
-        mn2 = (e2 && d < mn2) ? d : mn2;
-        mx2 = (e2 && d > mx2) ? d : mx2;
+    const int k1 = n > 0 ? (n - 1) >> 1 : 0;
+    const bool even = (n & 1) == 0;
+    const int bk = b - k1;                                  // L + k1 < b  <=>  L < bk
+    const float inf = __builtin_inff();
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    double dl_prev = __builtin_inf();
+    for (int L = 0; L < NP; L++) {
+        if (!__any(active && L >= a && L < bk)) {           // no lane has a window starting here
+            dl_prev = __builtin_inf();
+            continue;
+        }
+        const float xl = (L >= a) ? col_read<NP>(col, L) : inf;
+        const float xr = (L < bk) ? col_read<NP>(col, L + k1) : inf;
+        const double dl = fabs((double)xl - med);
+        const double dr = fabs((double)xr - med);
+        m1 = fmin(m1, fmax(dl, dr));                        // window [L, L + k1]
+        m2 = fmin(m2, fmax(dl_prev, dr));                   // window [L - 1, L + k1]
+        dl_prev = dl;
     }
-    // rank inside the group of equal keys: first -> smallest exact value, last -> largest; an interior
-    // rank of a >= 3-way tie (exact values within one float32 ulp of each other) takes the midpoint
-    const int j1 = k1 - less1, j2 = k2 - less2;
-    const double x1 = (j1 <= 0) ? mn1 : ((j1 >= eq1 - 1) ? mx1 : 0.5 * (mn1 + mx1));
-    const double x2 = (j2 <= 0) ? mn2 : ((j2 >= eq2 - 1) ? mx2 : 0.5 * (mn2 + mx2));
+    const double x1 = m1, x2 = even ? m2 : m1;
     return (0.5 * (x1 + x2)) * 1.482602218505602;
 }
 
@@ -461,7 +478,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
         }
     }
     const bool skip = prm.pixmask && prm.pixmask[p];
-    if constexpr (CALIB && FULL && FINITE_ONLY) {
+    if constexpr (CALIB && FULL) {
         bool good;
         if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
         else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
@@ -492,11 +509,9 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
     return n;
 }
 
-// EXTRA = the optional median / std planes are compiled in.  They cost ~100 extra VGPRs (a two-pass
-// std over the column and two more multiplexer trees), so the mean/count/moments-only kernel - the
-// benchmarked path - is a separate, leaner instantiation.
-// Everything after the column is in registers: sort, moments, clipping iterations, outputs.
-template <int NP, bool EXTRA>
+// Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
+// the column load is in registers: sort, moments, clipping iterations, outputs.
+template <int NP>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
     // everything the loop and the epilogue need from the kernel arguments, parked before the sort
@@ -552,31 +567,20 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     st.Thi = 0.0;
     bool active = n > 0;
     int it = 0;
-    const bool use_mad = EXTRA && prm.dev == APGPU_DEV_MAD_STD;
 
     while (__any(active)) {
         const int a0 = st.a, b0 = st.b;
         float m1 = 0.f, m2 = 0.f;
-        if (use_median || use_mad) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
+        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
         const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
-        double mad = 0.0;
-        if constexpr (EXTRA) {
-            if (use_mad) mad = mad_std_range<NP>(v, st.a, st.b, med);
-        }
         if (active) {
             st.nn = (double)(st.b - st.a);
             st.cen = use_median ? med : c + st.S / st.nn;
-            if (use_mad) {
-                st.wscale = 1.0;
-                st.Tlo = sl2 * (mad * mad);
-                st.Thi = su2 * (mad * mad);
-            } else {
-                st.wscale = st.nn;
-                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
-                V = V > 0.0 ? V : 0.0;
-                st.Tlo = sl2 * V;
-                st.Thi = su2 * V;
-            }
+            st.wscale = st.nn;
+            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
+            V = V > 0.0 ? V : 0.0;
+            st.Tlo = sl2 * V;
+            st.Thi = su2 * V;
         }
         trim_low<0, NP>(v, st, active);
         trim_high<NP - 1, NP>(v, st, active);
@@ -607,30 +611,6 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const double ms = S / nf;                                 // mean - c
     if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
     if (out_count) out_count[p] = cnt;
-    if (EXTRA && prm.std) {
-        // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
-        // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
-        double s1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const double dd = (double)v[i] - c;
-            s1 += (i >= a && i < b) ? dd : 0.0;
-        }
-        const double m1 = s1 / nf;
-        double q1 = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const double dd = ((double)v[i] - c) - m1;
-            const double d = (i >= a && i < b) ? dd : 0.0;
-            q1 = fma(d, d, q1);
-        }
-        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
-    }
-    if (EXTRA && prm.median) {
-        const float m1 = pick_at<NP>(v, (a + b - 1) >> 1);
-        const float m2 = pick_at<NP>(v, (a + b) >> 1);
-        prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
-    }
     if (out_moments) {
         const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
         const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
@@ -640,20 +620,187 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     }
 }
 
+// Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and
+// std output planes, (c) the sorted column in LDS (see above).  Arithmetic on S / Q is performed in the
+// same order as in the lean kernel, so both produce identical mean / count / moments.
+template <int NP>
+__device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
+                                                      float *const col)
+{
+    constexpr int B = rich_block<NP>();
+    const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
+    const bool use_mad = prm.dev == APGPU_DEV_MAD_STD;
+    const double sl2 = prm.sl2, su2 = prm.su2;
+    const int maxiters = prm.maxiters;
+    sort_column<NP>(v);
+#pragma unroll
+    for (int i = 0; i < NP; i++) col[i * B] = v[i];
+
+    // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
+    const float cf = n > 0 ? col_read<NP>(col, (n - 1) >> 1) : 0.f;
+    const double c = (double)cf;
+    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const float x = (i < n) ? v[i] : cf;
+        const double d = (double)x - c;
+        Sa[i & 3] += d;
+        Qa[i & 3] = fma(d, d, Qa[i & 3]);
+    }
+    ClipState st;
+    st.S = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+    st.Q = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+    st.c = c;
+    st.a = 0;
+    st.b = n;
+    st.cen = c;
+    st.nn = (double)n;
+    st.wscale = (double)n;
+    st.Tlo = 0.0;
+    st.Thi = 0.0;
+    bool active = n > 0;
+    int it = 0;
+
+    while (__any(active)) {
+        const int a0 = st.a, b0 = st.b;
+        const float m1 = col_read<NP>(col, (st.a + st.b - 1) >> 1);
+        const float m2 = col_read<NP>(col, (st.a + st.b) >> 1);
+        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
+        double mad = 0.0;
+        if (use_mad) mad = mad_std_window<NP>(col, active, st.a, st.b, med);
+        if (active) {
+            st.nn = (double)(st.b - st.a);
+            st.cen = use_median ? med : c + st.S / st.nn;
+            if (use_mad) {
+                st.wscale = 1.0;
+                st.Tlo = sl2 * (mad * mad);
+                st.Thi = su2 * (mad * mad);
+            } else {
+                st.wscale = st.nn;
+                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
+                V = V > 0.0 ? V : 0.0;
+                st.Tlo = sl2 * V;
+                st.Thi = su2 * V;
+            }
+        }
+        // trim from the low end, then from the high end: every lane walks its own cursor
+        for (;;) {
+            const double xd = (double)col_read<NP>(col, st.a);
+            const bool rej = active && (st.a < st.b) && below(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.a++;
+            }
+            if (!__any(rej)) break;
+        }
+        for (;;) {
+            const double xd = (double)col_read<NP>(col, st.b - 1);
+            const bool rej = active && (st.a < st.b) && above(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.b--;
+            }
+            if (!__any(rej)) break;
+        }
+        it++;
+        const bool changed = (st.a != a0) || (st.b != b0);
+        active = active && changed && (maxiters < 0 || it < maxiters);
+    }
+
+    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by an
+    // earlier, tighter pass that lie inside the final bounds are re-admitted (ascending, then descending,
+    // like the lean kernel's chains).
+    if (__any(st.a > 0)) {
+        int a_new = st.a;
+        for (int i = 0; __any(i < st.a); i++) {
+            const double xd = (double)col_read<NP>(col, i);
+            const bool keep = (i < st.a) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                a_new = a_new < i ? a_new : i;
+            }
+        }
+        st.a = a_new;
+    }
+    if (__any(st.b < n)) {
+        int b_new = st.b;
+        for (int i = NP - 1; __any(i >= st.b); i--) {
+            const double xd = (double)col_read<NP>(col, i);
+            const bool keep = (i >= st.b) && (i < n) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                b_new = b_new > i + 1 ? b_new : i + 1;
+            }
+        }
+        st.b = b_new;
+    }
+    const int a = st.a, b = st.b;
+    const double S = st.S, Q = st.Q;
+    const int cnt = b - a;
+    const double nf = (double)cnt;
+    const double nan = __builtin_nan("");
+    const double ms = S / nf;                                 // mean - c
+    if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (prm.count) prm.count[p] = cnt;
+    if (prm.std) {
+        // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
+        // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
+        double s1 = 0.0;
+        for (int i = 0; i < NP; i++) {
+            const bool in = (i >= a && i < b);
+            if (!__any(in)) continue;
+            const float x = in ? col_read<NP>(col, i) : cf;   // a rejected slot contributes exactly 0
+            s1 += (double)x - c;
+        }
+        const double m1 = s1 / nf;
+        double q1 = 0.0;
+        for (int i = 0; i < NP; i++) {
+            const bool in = (i >= a && i < b);
+            if (!__any(in)) continue;
+            const double dd = ((double)col_read<NP>(col, i) - c) - m1;
+            const double d = in ? dd : 0.0;
+            q1 = fma(d, d, q1);
+        }
+        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
+    }
+    if (prm.median) {
+        const float m1 = col_read<NP>(col, (a + b - 1) >> 1);
+        const float m2 = col_read<NP>(col, (a + b) >> 1);
+        prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
+    }
+    if (prm.moments) {
+        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
+        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
+        prm.moments[p] = (float)sum;
+        prm.moments[prm.P + p] = (float)sq;
+        prm.moments[2 * prm.P + p] = (float)cnt;
+    }
+}
+
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
-__global__ __launch_bounds__(256, (NP <= 64 && !EXTRA) ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
+__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
+    __shared__ ColumnLds<NP, EXTRA> cols;        // lane-private columns: no barrier around their use
     if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
 
     float v[NP];
     APGPU_MARK("load_calibrate");
     const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
-    reduce_and_store<NP, EXTRA>(prm, v, n, p);
+    if constexpr (EXTRA) reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
+    else reduce_and_store<NP>(prm, v, n, p);
 }
 
 // Persistent form of the lean kernel for full stacks (N == NP) with fused calibration: every
@@ -728,13 +875,13 @@ __global__ __launch_bounds__(256, 2) void stack_sigclip_persistent_kernel(const 
                 v[f] = ok ? x : __builtin_inff();
             }
         }
-        if (valid) reduce_and_store<NP, false>(prm, v, n, p);
+        if (valid) reduce_and_store<NP>(prm, v, n, p);
         tile = next;
     }
 }
 
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
-template <int NP, typename RawT, bool CALIB>
+template <int NP, typename RawT, bool CALIB, bool FULL>
 __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -744,7 +891,7 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
-    const int n = load_column<NP, RawT, CALIB, false, false>(prm, fs, base, lane, v);
+    const int n = load_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);
     sort_column<NP>(v);
     const float m1 = pick_at<NP>(v, (n - 1) >> 1);
     const float m2 = pick_at<NP>(v, n >> 1);
@@ -756,26 +903,31 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
 template <int NP, typename RawT, bool CALIB>
 int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
 {
-    const int block = 256;
+    const bool rich = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
+    const bool full = prm.N == NP;
+    const int block = rich ? rich_block<NP>() : 256;
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-    if (median_only)
-        hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB>), dim3((unsigned)grid), dim3(block), 0, st, prm);
-    else if (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD)
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
-    else if (prm.N == NP) {
+    const dim3 g((unsigned)grid), b(block);
+    if (median_only) {
+        if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);
+        else hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, false>), g, b, 0, st, prm);
+    } else if (rich) {
+        if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, prm);
+        else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, prm);
+    } else if (full) {
         if constexpr (CALIB) {
             if (prm.persistent && NP >= 2) {
                 const int64_t ntiles = (prm.P + 255) / 256;
-                const int64_t g = ntiles < 2 * kNumCU ? ntiles : 2 * kNumCU;
-                hipLaunchKernelGGL((stack_sigclip_persistent_kernel<NP, RawT>), dim3((unsigned)g), dim3(block), 0, st, prm);
+                const int64_t gp = ntiles < 2 * kNumCU ? ntiles : 2 * kNumCU;
+                hipLaunchKernelGGL((stack_sigclip_persistent_kernel<NP, RawT>), dim3((unsigned)gp), b, 0, st, prm);
                 return check_launch("stack kernel (persistent)");
             }
         }
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), dim3((unsigned)grid), dim3(block), 0, st, prm);
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), g, b, 0, st, prm);
+    } else {
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), g, b, 0, st, prm);
     }
-    else
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), dim3((unsigned)grid), dim3(block), 0, st, prm);
     return check_launch("stack kernel");
 }
 

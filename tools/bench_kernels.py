@@ -41,7 +41,11 @@ def main():
     calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
     rows = []
 
+    only = sys.argv[1] if len(sys.argv) > 1 else ''
+
     def rec(name, bytes_, fn, **kw):
+        if only and only not in name:
+            return
         med, best = timeit(fn, **kw)
         rows.append(dict(kernel=name, ms=med, ms_min=best, GBps=bytes_ / med / 1e6, frac_of_8TBps=bytes_ / med / 1e6 / 8000))
         print('%-46s %8.3f ms  %7.0f GB/s  %5.1f %%' % (name, med, bytes_ / med / 1e6, 100 * bytes_ / med / 1e6 / 8000), flush=True)
@@ -54,6 +58,7 @@ def main():
     rec('stack_sigclip fused, mean+median+std (EXTRA)', 4 * N * P + 24 * P, lambda: ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'median', 'std')), reps=5)
     rec('stack_sigclip plain f32 (A7, no calibration)', 4 * N * P + 4 * P, lambda: ops.stack_sigclip(frames, outputs=('mean',)))
     rec('stack ccdproc config: 1 pass, median/mad_std 5s (A6)', 4 * N * P + 4 * P, lambda: ops.stack_sigclip(frames, sigma=5.0, maxiters=1, stdfunc='mad_std', outputs=('mean',)), reps=3, warm=1)
+    rec('stack_sigclip fused, 48 of 64 slots (non-FULL lean)', 4 * 48 * P + 16 * P, lambda: ops.stack_sigclip(frames[:48], calib=calib, outputs=('mean',)))
     rec('stack_median fused (C4-style, f32)', 4 * N * P + 16 * P, lambda: ops.stack_median(frames, calib=calib))
     f16 = synth.make_frames(N, masters, nflat, config_id=2, dtype=torch.uint16)
     rec('stack_sigclip fused u16 raw', 2 * N * P + 16 * P, lambda: ops.stack_sigclip(f16, calib=calib, outputs=('mean',)))
