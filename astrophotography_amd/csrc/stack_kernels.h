@@ -137,6 +137,18 @@ __device__ __forceinline__ float pick_at(const float (&v)[NP], int idx)
 // few values off either end, so the middle stays within a few slots of NP/2: if every lane of the
 // wave is inside the 8-slot window around NP/2 the multiplexer needs 2 x 7 selects instead of
 // 2 x (NP-1); otherwise the whole wave takes the full tree.
+// 8-slot window [4K, 4K + 8) chosen at run time by a wave-uniform K (static register indices per case).
+template <int K, int NP>
+__device__ __forceinline__ void pick_window(const float (&v)[NP], int k, int i1, int i2, float &m1, float &m2)
+{
+    if (k == K) {
+        m1 = pick_rel<4 * K, 8, NP>(v, i1 - 4 * K);
+        m2 = pick_rel<4 * K, 8, NP>(v, i2 - 4 * K);
+    } else if constexpr (4 * (K + 1) + 8 <= NP) {
+        pick_window<K + 1, NP>(v, k, i1, i2, m1, m2);
+    }
+}
+
 template <int NP>
 __device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2, float &m1, float &m2)
 {
@@ -150,8 +162,17 @@ __device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2
             m1 = pick_rel<WLO, 8, NP>(v, i1 - WLO);
             m2 = pick_rel<WLO, 8, NP>(v, i2 - WLO);
         } else {
-            m1 = pick_at<NP>(v, i1);
-            m2 = pick_at<NP>(v, i2);
+            // stacks with fewer frames than slots (or many rejected values) have their middle elsewhere:
+            // take the 8-slot window around the first lane's middle if it holds every lane's
+            int k = (__builtin_amdgcn_readfirstlane(i1) - 2) >> 2;
+            k = k < 0 ? 0 : (k > NP / 4 - 2 ? NP / 4 - 2 : k);
+            const bool inside_k = (i1 >= 4 * k) && (i2 < 4 * k + 8);
+            if (__all(inside_k)) {
+                pick_window<0, NP>(v, k, i1, i2, m1, m2);
+            } else {
+                m1 = pick_at<NP>(v, i1);
+                m2 = pick_at<NP>(v, i2);
+            }
         }
     }
 }
@@ -218,13 +239,15 @@ template <int I, int NP>
 __device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
 {
     if constexpr (I >= 0) {
-        const double xd = widen(v[I]);
-        const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
-        if (rej) {
-            const double d = xd - st.c;
-            st.S -= d;
-            st.Q = fma(-d, d, st.Q);
-            st.b = I;
+        if (__any(active && (I < st.b))) {                  // padding slots above every lane's range: just step down
+            const double xd = widen(v[I]);
+            const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.b = I;
+            }
         }
         if (__any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
     }
@@ -367,6 +390,7 @@ template <int NP>
 struct FrameScalars {
     float e[NP];
     float ped[NP];
+    float pad[NP];          // -inf for a real frame, +inf for a padding slot (f >= N): v = max(v, pad) pads a column
 };
 
 template <int NP>
@@ -374,8 +398,9 @@ __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, Fram
 {
     for (int t = threadIdx.x; t < NP; t += blockDim.x) {
         const int ff = t < prm.N ? t : prm.N - 1;
-        fs.e[t] = prm.exp_ratio[ff];
+        fs.e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
         fs.ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
+        fs.pad[t] = t < prm.N ? -__builtin_inff() : __builtin_inff();
     }
     __syncthreads();
 }
@@ -385,10 +410,14 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
 {
     // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
     const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
+    // opaque per call: the fast path and its (rare) exact fallback each load the column; sharing the NP
+    // clamped address steps between the two calls would keep 2*NP SGPRs live across the calibration
+    int nframes = prm.N;
+    if constexpr (!FULL) asm volatile("" : "+s"(nframes));
 #pragma unroll
     for (int f = 0; f < NP; f++) {
         raw[f] = fb[lane];
-        if (FULL || f + 1 < prm.N) fb += prm.stride;    // padded slots re-read the last frame (cache hit)
+        if (FULL || f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
         // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
         if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
@@ -478,18 +507,34 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
         }
     }
     const bool skip = prm.pixmask && prm.pixmask[p];
-    if constexpr (CALIB && FULL) {
+    if constexpr (CALIB) {
         bool good;
         if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
         else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
-        if (__all(good && !skip)) return NP;
-        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave
-        load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+        if (__all(good && !skip)) {
+            if constexpr (FULL) return NP;
+            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
+            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
+#pragma unroll
+            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+            return N;
+        }
+        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
+        // redo the column exactly (IEEE division), one frame at a time - no second raw[] column in flight
     }
     int n = 0;
+    const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
+    int nleft = N;
+    asm volatile("" : "+s"(nleft));
 #pragma unroll
     for (int f = 0; f < NP; f++) {
-        float x = to_f32(raw[f]);
+        float x;
+        if constexpr (CALIB) {
+            x = to_f32(*fp);
+            if (FULL || f + 1 < nleft) fp += prm.stride;
+        } else {
+            x = to_f32(raw[f]);
+        }
         if constexpr (CALIB) {
             const float e = fs.e[f];
             const float ped = fs.ped[f];
@@ -793,7 +838,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
     __shared__ ColumnLds<NP, EXTRA> cols;        // lane-private columns: no barrier around their use
-    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
+    if constexpr (CALIB || !FULL) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
 
     float v[NP];
@@ -888,7 +933,7 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
-    if constexpr (CALIB) stage_frame_scalars<NP>(prm, fs);
+    if constexpr (CALIB || !FULL) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
     const int n = load_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);
