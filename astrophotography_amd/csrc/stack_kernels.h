@@ -332,18 +332,27 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
     const float inf = __builtin_inff();
     double m1 = __builtin_inf(), m2 = __builtin_inf();
     double dl_prev = __builtin_inf();
-    for (int L = 0; L < NP; L++) {
-        if (!__any(active && L >= a && L < bk)) {           // no lane has a window starting here
+    constexpr int CH = NP >= 4 ? 4 : NP;                    // windows per trip: 2*CH LDS reads in flight
+    for (int L0 = 0; L0 < NP; L0 += CH) {
+        if (!__any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
             dl_prev = __builtin_inf();
             continue;
         }
-        const float xl = (L >= a) ? col_read<NP>(col, L) : inf;
-        const float xr = (L < bk) ? col_read<NP>(col, L + k1) : inf;
-        const double dl = fabs((double)xl - med);
-        const double dr = fabs((double)xr - med);
-        m1 = fmin(m1, fmax(dl, dr));                        // window [L, L + k1]
-        m2 = fmin(m2, fmax(dl_prev, dr));                   // window [L - 1, L + k1]
-        dl_prev = dl;
+        float xl[CH], xr[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            xl[j] = col_read<NP>(col, L0 + j);
+            xr[j] = col_read<NP>(col, L0 + j + k1);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int L = L0 + j;
+            const double dl = fabs((double)((L >= a) ? xl[j] : inf) - med);
+            const double dr = fabs((double)((L < bk) ? xr[j] : inf) - med);
+            m1 = fmin(m1, fmax(dl, dr));                    // window [L, L + k1]
+            m2 = fmin(m2, fmax(dl_prev, dr));               // window [L - 1, L + k1]
+            dl_prev = dl;
+        }
     }
     const double x1 = m1, x2 = even ? m2 : m1;
     return (0.5 * (x1 + x2)) * 1.482602218505602;
@@ -798,21 +807,33 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     if (prm.std) {
         // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
         // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
+        constexpr int CH = NP >= 8 ? 8 : NP;                  // LDS reads in flight per trip
         double s1 = 0.0;
-        for (int i = 0; i < NP; i++) {
-            const bool in = (i >= a && i < b);
-            if (!__any(in)) continue;
-            const float x = in ? col_read<NP>(col, i) : cf;   // a rejected slot contributes exactly 0
-            s1 += (double)x - c;
+        for (int i0 = 0; i0 < NP; i0 += CH) {
+            if (!__any(i0 + CH > a && i0 < b)) continue;
+            float x[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const bool in = (i0 + j >= a && i0 + j < b);
+                s1 += (double)(in ? x[j] : cf) - c;          // a rejected slot contributes exactly 0
+            }
         }
         const double m1 = s1 / nf;
         double q1 = 0.0;
-        for (int i = 0; i < NP; i++) {
-            const bool in = (i >= a && i < b);
-            if (!__any(in)) continue;
-            const double dd = ((double)col_read<NP>(col, i) - c) - m1;
-            const double d = in ? dd : 0.0;
-            q1 = fma(d, d, q1);
+        for (int i0 = 0; i0 < NP; i0 += CH) {
+            if (!__any(i0 + CH > a && i0 < b)) continue;
+            float x[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const bool in = (i0 + j >= a && i0 + j < b);
+                const double dd = ((double)x[j] - c) - m1;
+                const double d = in ? dd : 0.0;
+                q1 = fma(d, d, q1);
+            }
         }
         prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
     }
