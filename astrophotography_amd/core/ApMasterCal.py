@@ -156,8 +156,15 @@ class ApMasterCal:
             slab = ops.to_device_u16(np.stack(arrs, 0))
         else:
             slab = torch.from_numpy(np.stack([a.astype(np.float32) for a in arrs], 0)).cuda()
-        res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count'))
-        master = res['mean'].cpu().numpy()
+        res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
+                                outputs=('mean', 'count', 'std'))
+        # ccdproc's CCDData product (ap_combine_darks.py:411-439): float64 primary, MASK = pixels with every
+        # input rejected, UNCERT = std of the surviving values / sqrt(their number)
+        master = res['mean'].cpu().numpy().astype(np.float64)
+        count = res['count'].cpu().numpy()
+        all_masked = (count == 0).astype(np.uint8)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            uncert = res['std'].cpu().numpy().astype(np.float64) / np.sqrt(count.astype(np.float64))
         hdr = hdrs[0].copy()
         for k in ('BSCALE', 'BZERO', 'UT', 'TIME-OBS', 'SWOWNER', 'SWCREATE', 'SBSTDVER'):
             if k in hdr:
@@ -167,6 +174,7 @@ class ApMasterCal:
         hdr['BUNIT'] = 'adu'
         for k, v in kw_dict.items():
             hdr[k] = v
-        fitsio.write(str(output_master_file), master, hdr, overwrite=True)
+        fitsio.write(str(output_master_file), master, hdr, overwrite=True,
+                     extensions=[('MASK', all_masked, None), ('UNCERT', uncert, {'UTYPE': ('StdDevUncertainty', '')})])
         self._logger.info(f'Wrote combined calibration file: {output_master_file}')
         return res

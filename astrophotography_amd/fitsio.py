@@ -302,12 +302,7 @@ def getheader(path):
     return read(path, want_data=False)[1]
 
 
-def write(path, data, header=None, overwrite=True):
-    """Writes a primary HDU (+ the extensions `header` was read with, if any)."""
-    if os.path.exists(path) and not overwrite:
-        raise OSError("File '%s' already exists." % path)
-    data = np.asarray(data)
-    hdr = _structural(header if header is not None else Header(), data)
+def _disk_bytes(data):
     dt = data.dtype
     if dt == np.uint16:
         disk = (data ^ np.uint16(0x8000)).view(np.int16).astype('>i2')
@@ -316,16 +311,77 @@ def write(path, data, header=None, overwrite=True):
     else:
         disk = data.astype(dt.newbyteorder('>'))
     payload = disk.tobytes()
-    pad = (-len(payload)) % BLOCK
+    return payload + b'\0' * ((-len(payload)) % BLOCK)
+
+
+def _extension_hdu(name, data, cards=None):
+    """One IMAGE extension (what astropy's CCDData writer emits for the MASK / UNCERT planes)."""
+    data = np.asarray(data)
+    prim = _structural(Header(), data)
+    head = [Card('XTENSION', 'IMAGE', 'Image extension')]
+    head += [c for c in prim.cards if c.key in ('BITPIX', 'NAXIS') or c.key.startswith('NAXIS')]
+    head += [Card('PCOUNT', 0, 'number of parameters'), Card('GCOUNT', 1, 'number of groups')]
+    head += [c for c in prim.cards if c.key in ('BSCALE', 'BZERO')]
+    head.append(Card('EXTNAME', name, 'extension name'))
+    for k, v in (cards or {}).items():
+        head.append(Card(k, *v) if isinstance(v, tuple) else Card(k, v))
+    return Header(head).tostring().encode('ascii') + _disk_bytes(data)
+
+
+def write(path, data, header=None, overwrite=True, extensions=None):
+    """Writes a primary HDU, followed by `extensions` = [(extname, array, {key: value | (value, comment)}), ...]
+    as IMAGE extensions, or else by the extensions `header` was read with, if any."""
+    if os.path.exists(path) and not overwrite:
+        raise OSError("File '%s' already exists." % path)
+    data = np.asarray(data)
+    src = header if header is not None else Header()
+    if extensions and 'EXTEND' not in src:
+        src = src.copy()
+        src['EXTEND'] = True
+    hdr = _structural(src, data)
     tail = getattr(header, '_tail', b'') if header is not None else b''
+    if extensions:
+        tail = b''.join(_extension_hdu(n, a, c) for n, a, c in extensions)
     tmp = str(path) + '.tmp%d' % os.getpid()
     with open(tmp, 'wb') as f:
         f.write(hdr.tostring().encode('ascii'))
-        f.write(payload)
-        f.write(b'\0' * pad)
+        f.write(_disk_bytes(data))
         f.write(tail)
     os.replace(tmp, path)
     return hdr
+
+
+def read_extension(path, extname):
+    """(data, Header) of the first IMAGE extension called `extname` (case-insensitive)."""
+    _, hdr = read(path, want_data=False)
+    raw = hdr._tail
+    pos = 0
+    while pos < len(raw):
+        text = ''
+        start = pos
+        while True:
+            block = raw[pos:pos + BLOCK].decode('ascii', 'replace')
+            if len(block) < BLOCK:
+                raise OSError('%s: extension header is truncated.' % path)
+            pos += BLOCK
+            text += block
+            if any(block[i:i + 8] == 'END     ' for i in range(0, BLOCK, 80)):
+                break
+        eh = Header.fromstring(text)
+        naxis = int(eh.get('NAXIS', 0))
+        shape = tuple(int(eh['NAXIS%d' % i]) for i in range(naxis, 0, -1))
+        bitpix = int(eh['BITPIX'])
+        count = int(np.prod(shape)) if naxis > 0 else 0
+        nbytes = count * abs(bitpix) // 8 + int(eh.get('PCOUNT', 0))
+        if str(eh.get('EXTNAME', '')).strip().upper() == extname.upper() and str(eh.get('XTENSION', '')).strip() == 'IMAGE':
+            arr = np.frombuffer(raw, dtype=_BITPIX_DTYPE[bitpix], count=count, offset=pos).reshape(shape)
+            if bitpix == 16 and eh.get('BZERO', 0) == 32768:
+                return (arr.astype(np.int16).view(np.uint16) ^ np.uint16(0x8000)), eh
+            return arr.astype(arr.dtype.newbyteorder('=')), eh
+        pos += ((nbytes + BLOCK - 1) // BLOCK) * BLOCK
+        if pos <= start:
+            break
+    raise KeyError("Extension '%s' not found in %s." % (extname, path))
 
 
 # ---------------------------------------------------------------------------------------------------

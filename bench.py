@@ -72,9 +72,17 @@ def cpu_baseline(frames, masters, nflat, e, seconds):
         t_total += times[-1]
     times.sort()
     t = times[len(times) // 2]
+    model = 'unknown CPU'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
     return dict(value=N * rows * W / 1e6 / t, unit='Mpixels/s', cores=threads, kind='port',
-                sample='%d frames x %d rows x %d cols f32, median of %d runs (%.1f s of CPU work, OpenMP %d threads, '
-                       'oracle/apref.c fused calibrate + clipped stack)' % (N, rows, W, len(times), t_total, threads))
+                sample='%d frames x %d rows x %d cols f32, median of %d runs (%.1f s of CPU work, OpenMP %d threads on %s, '
+                       'oracle/apref.c fused calibrate + clipped stack)' % (N, rows, W, len(times), t_total, threads, model))
 
 
 def main():
@@ -158,6 +166,24 @@ def main():
         except Exception:
             traffic = None
 
+    # the box's achievable streaming rate beside the nominal peak: device-to-device copy of
+    # 1 GiB, read + write bytes over the best of 10 runs
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        best = 1e9
+        for _ in range(10):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            dst.copy_(src)
+            b.record()
+            torch.cuda.synchronize()
+            best = min(best, a.elapsed_time(b))
+        copy_gbs = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
+        del src, dst
+
     line = None
     if rank == 0:
         line = {
@@ -171,7 +197,8 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'stack_sigclip_kernel<64,%s,calib>' % ('float' if args.dtype == 'f32' else 'u16'),
-                         'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes},
+                         'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes,
+                         'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             if args.dtype == 'f32':

@@ -188,7 +188,13 @@ def test_apmastercal_and_apstack(tmp_path):
     mc.make_master(str(d / 'master_dark.fits'))
     m, h = fitsio.read(str(d / 'master_dark.fits'))
     ref = apref.combine_ccdproc(cube.astype(np.float64), 5.0, 5.0)
-    assert_ulp(m, ref['mean'].astype(np.float32), 1, 'master dark vs ccdproc-style oracle')
+    assert m.dtype == np.float64 and h['BITPIX'] == -64           # CCDData product: float64 primary + MASK + UNCERT
+    assert_ulp(m.astype(np.float32), ref['mean'].astype(np.float32), 1, 'master dark vs ccdproc-style oracle')
+    mask, mh = fitsio.read_extension(str(d / 'master_dark.fits'), 'MASK')
+    unc, uh = fitsio.read_extension(str(d / 'master_dark.fits'), 'UNCERT')
+    assert mask.dtype == np.uint8 and mask.shape == shape and not mask.any()
+    assert uh['UTYPE'] == 'StdDevUncertainty' and unc.dtype == np.float64
+    np.testing.assert_allclose(unc, ref['std'] / np.sqrt(ref['count']), rtol=2e-6, atol=1e-9)
     assert h['IMAGETYP'] == 'MASTER DARK' and h['NCOMBINE'] == N and h['IFILE011'] == 'dark11.fits' and h['BUNIT'] == 'adu'
     # second construction ignores the master it just wrote
     assert len(ap.ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')._values('file')) == N

@@ -86,6 +86,32 @@ def test_fitsio_reads_and_rewrites_astropy_files(tmp_path):
         fitsio.read(str(tmp_path / 'bad.fits'))
 
 
+def test_fitsio_image_extensions(tmp_path):
+    """Primary + IMAGE extensions (the CCDData layout ApMasterCal writes: MASK uint8, UNCERT float64)."""
+    from astrophotography_amd import fitsio
+    rng = np.random.default_rng(5)
+    prim = rng.normal(size=(7, 9))
+    mask = (rng.random((7, 9)) > 0.8).astype(np.uint8)
+    unc = rng.random((7, 9))
+    h = fitsio.Header()
+    h['BUNIT'] = 'adu'
+    out = tmp_path / 'ccd.fits'
+    fitsio.write(str(out), prim, h, extensions=[('MASK', mask, None), ('UNCERT', unc, {'UTYPE': ('StdDevUncertainty', '')})])
+    assert out.stat().st_size % 2880 == 0
+    d, hh = fitsio.read(str(out))
+    assert hh['EXTEND'] is True and hh['BITPIX'] == -64 and np.array_equal(d, prim)
+    m, mh = fitsio.read_extension(str(out), 'mask')
+    assert mh['XTENSION'].strip() == 'IMAGE' and mh['PCOUNT'] == 0 and mh['GCOUNT'] == 1 and mh['BITPIX'] == 8
+    assert m.dtype == np.uint8 and np.array_equal(m, mask)
+    u, uh = fitsio.read_extension(str(out), 'UNCERT')
+    assert uh['UTYPE'] == 'StdDevUncertainty' and np.array_equal(u, unc)
+    with pytest.raises(KeyError):
+        fitsio.read_extension(str(out), 'NOPE')
+    # rewriting the primary with the header it was read with keeps the extensions byte for byte
+    fitsio.write(str(tmp_path / 'again.fits'), d, hh)
+    assert (tmp_path / 'again.fits').read_bytes() == out.read_bytes()
+
+
 def test_fitsio_scaled_integers(tmp_path):
     from astrophotography_amd import fitsio
     h = fitsio.Header()
