@@ -239,6 +239,27 @@ __global__ void select_begin_kernel(GState *st, int final_pass)
     st->max_key = 0;
 }
 
+// Visits src[0 .. m) with 16-byte loads where the pointer allows it (grid-stride over vectors, scalar tail).
+template <typename T, typename F>
+__device__ __forceinline__ void for_each_value(const T *__restrict__ src, long long m, F f)
+{
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T x[V]; };
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    long long done = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const long long nvec = m / V;
+        for (long long i = tid; i < nvec; i += nthreads) {
+            const Vec v = reinterpret_cast<const Vec *>(src)[i];
+#pragma unroll
+            for (int k = 0; k < V; k++) f(v.x[k]);
+        }
+        done = nvec * V;
+    }
+    for (long long i = done + tid; i < m; i += nthreads) f(src[i]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
                                                      GState *__restrict__ st, int pass, int final_pass)
@@ -252,31 +273,54 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const T *__restrict__ b0, 
     __shared__ unsigned h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-        const typename K::type key = K::to(src[i]);
+    for_each_value<T>(src, m, [&](T x) {
+        const typename K::type key = K::to(x);
         const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
-        if (match) atomicAdd(&h[(unsigned)(key >> shift) & 0xffu], 1u);
-    }
+        const unsigned d = (unsigned)(key >> shift) & 0xffu;
+        // A dark frame's values share their leading digits: nearly every lane of a wave hits the same bin and
+        // the LDS atomics serialise.  Up to 4 rounds of "leader adds the population count of its digit",
+        // then plain atomics for whatever is left (the spread-out low digits).
+        unsigned long long todo = __ballot(match);
+        for (int round = 0; round < 4 && todo; round++) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const unsigned dl = (unsigned)__shfl((int)d, leader);
+            const unsigned long long same = __ballot(match && d == dl) & todo;
+            if ((int)(threadIdx.x % kWave) == leader) atomicAdd(&h[dl], (unsigned)__popcll(same));
+            todo &= ~same;
+        }
+        if ((todo >> (threadIdx.x % kWave)) & 1ull) atomicAdd(&h[d], 1u);
+    });
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
 }
 
-__global__ void select_digit_kernel(GState *st, int final_pass)
+__global__ __launch_bounds__(256) void select_digit_kernel(GState *st, int final_pass)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one lane per bin: exclusive prefix over the 256 counts in LDS, the lane whose interval holds rank k wins
+    if (blockIdx.x != 0) return;
     if (!final_pass && st->done) return;
-    long long k = st->k;
-    unsigned d = 0;
-    long long cum = 0;
-    for (d = 0; d < 256; d++) {
-        const long long c = st->hist[d];
-        if (k < cum + c) break;
-        cum += c;
+    __shared__ long long cum[257];
+    __shared__ int digit;
+    const int t = threadIdx.x;
+    const long long c = st->hist[t];
+    cum[t + 1] = c;
+    if (t == 0) { cum[0] = 0; digit = 255; }
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                     // Hillis-Steele inclusive scan over cum[1..256]
+        const long long add = (t + 1 - d >= 1) ? cum[t + 1 - d] : 0;
+        __syncthreads();
+        cum[t + 1] += add;
+        __syncthreads();
     }
-    if (d > 255) d = 255;
-    st->k = k - cum;
-    st->prefix = (st->prefix << 8) | d;
-    for (int i = 0; i < 256; i++) st->hist[i] = 0;
+    const long long k = st->k;
+    if (k >= cum[t] && k < cum[t + 1]) digit = t;           // at most one lane (intervals are disjoint)
+    st->hist[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        const int d = digit;
+        st->k = k - cum[d];
+        st->prefix = (st->prefix << 8) | (unsigned long long)d;
+    }
 }
 
 template <typename T>
@@ -290,12 +334,12 @@ __global__ __launch_bounds__(kBlock) void less_stats_kernel(const T *__restrict_
     const unsigned long long vkey = st->prefix;
     unsigned cnt = 0;
     unsigned long long mx = 0, lo = ~0ull, hi = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long key = K::to(src[i]);
+    for_each_value<T>(src, m, [&](T x) {
+        const unsigned long long key = K::to(x);
         if (key < vkey) { cnt++; mx = key > mx ? key : mx; }
         lo = key < lo ? key : lo;
         hi = key > hi ? key : hi;
-    }
+    });
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
         cnt += __shfl_down(cnt, d);
@@ -305,9 +349,27 @@ __global__ __launch_bounds__(kBlock) void less_stats_kernel(const T *__restrict_
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
+    // block-level combine in LDS: one set of global atomics per workgroup, not per wave
+    __shared__ unsigned s_cnt[kBlock / kWave];
+    __shared__ unsigned long long s_mx[kBlock / kWave], s_lo[kBlock / kWave], s_hi[kBlock / kWave];
+    const int wave = threadIdx.x / kWave;
     if ((threadIdx.x % kWave) == 0) {
-        if (cnt) {
-            atomicAdd(&st->cnt_less, (unsigned long long)cnt);
+        s_cnt[wave] = cnt;
+        s_mx[wave] = mx;
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0;
+        for (int w = 0; w < kBlock / kWave; w++) {
+            c += s_cnt[w];
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+            lo = s_lo[w] < lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+        }
+        if (c) {
+            atomicAdd(&st->cnt_less, c);
             atomicMax(&st->max_less_key, mx);
         }
         if (final_pass && hi >= lo) {
@@ -358,21 +420,48 @@ __device__ T leaf_sum(const T *a, int n, T mean)
     return res;
 }
 
-template <int SQ, typename T>
-__device__ T pairwise_rec(const T *a, int n, T mean)
+// numpy's recursion for a ragged piece (n < 8192; depth <= 7), split in two walks so that the leaves -
+// which are independent - can be summed by different lanes: enumerate the leaves, sum them in parallel,
+// then combine the leaf sums in the recursion's order.
+struct LeafList {
+    int off[256], len[256];
+    int n;
+};
+
+__device__ void enumerate_leaves(LeafList &ll, int off, int n)
 {
-    // numpy's recursion for a ragged piece (n < 8192); depth <= 7
+    if (n < 8 || n <= kLeaf) {
+        ll.off[ll.n] = off;
+        ll.len[ll.n] = n;
+        ll.n++;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    enumerate_leaves(ll, off, n2);
+    enumerate_leaves(ll, off + n2, n - n2);
+}
+
+template <typename T>
+__device__ T combine_leaves(const T *vals, int &next, int n)
+{
+    if (n < 8 || n <= kLeaf) return vals[next++];
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const T l = combine_leaves<T>(vals, next, n2);
+    const T r = combine_leaves<T>(vals, next, n - n2);
+    return l + r;
+}
+
+template <int SQ, typename T>
+__device__ T one_leaf(const T *a, int n, T mean)
+{
     if (n < 8) {
         T res = 0;
         for (int i = 0; i < n; i++) res = res + tr<SQ, T>(a[i], mean);
         return res;
     }
-    if (n <= kLeaf) return leaf_sum<SQ, T>(a, n, mean);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const T l = pairwise_rec<SQ, T>(a, n2, mean);
-    const T r = pairwise_rec<SQ, T>(a + n2, n - n2, mean);
-    return l + r;
+    return leaf_sum<SQ, T>(a, n, mean);
 }
 
 template <typename T>
@@ -408,16 +497,52 @@ template <int SQ, typename T>
 __global__ void fold_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
                             const T *__restrict__ piece_sums, int final_pass)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one workgroup: the piece sums are accumulated sequentially (numpy's order), but fetched by all
+    // lanes into LDS first - a lone lane walking global memory pays a full miss latency per piece
+    if (blockIdx.x != 0) return;
     if (!final_pass && st->done) return;
     const T *src = st->cur ? b1 : b0;
     const long long m = st->m;
     const T mean = SQ ? var_mean<T>(st) : (T)0;
     const long long npieces_full = m / kPiece;
+    constexpr int kStage = 2048;
+    __shared__ T stage[kStage];
     T res = 0;
-    for (long long i = 0; i < npieces_full; i++) res = res + piece_sums[i];
+    for (long long i0 = 0; i0 < npieces_full; i0 += kStage) {
+        const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {                  // 8 LDS reads in flight, then the 8 ordered adds
+                T x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = stage[t + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) res = res + x[k];
+            }
+            for (; t < cnt; t++) res = res + stage[t];
+        }
+        __syncthreads();
+    }
     const int rem = (int)(m - npieces_full * kPiece);
-    if (rem > 0) res = res + pairwise_rec<SQ, T>(src + npieces_full * kPiece, rem, mean);
+    if (rem > 0) {
+        __shared__ LeafList ll;
+        __shared__ T leaf_vals[256];
+        if (threadIdx.x == 0) {
+            ll.n = 0;
+            enumerate_leaves(ll, 0, rem);
+        }
+        __syncthreads();
+        const T *tail = src + npieces_full * kPiece;
+        for (int l = threadIdx.x; l < ll.n; l += blockDim.x) leaf_vals[l] = one_leaf<SQ, T>(tail + ll.off[l], ll.len[l], mean);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int next = 0;
+            res = res + combine_leaves<T>(leaf_vals, next, rem);
+        }
+    }
+    if (threadIdx.x != 0) return;
     if (SQ) {
         st->s2 = (double)res;
         const T var = (T)((double)res / (double)m);         // ret.dtype.type(ret / rcount)
@@ -502,6 +627,8 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     const long long ntiles = (n + kTile - 1) / kTile;
     const unsigned gtile = (unsigned)(ntiles < kNumCU * 8 ? ntiles : kNumCU * 8);
     const unsigned gflat = (unsigned)((n + kBlock - 1) / kBlock < kNumCU * 8 ? (n + kBlock - 1) / kBlock : kNumCU * 8);
+    // histogram / rank scans end in global atomics per workgroup: fewer, fatter workgroups (16-byte loads)
+    const unsigned gscan = gflat < kNumCU * 2 ? gflat : kNumCU * 2;
     const unsigned gpiece = (unsigned)((n / kPiece) / (kBlock / kWave) + 1 < kNumCU * 8 ? (n / kPiece) / (kBlock / kWave) + 1 : kNumCU * 8);
 
     if (hipMemsetAsync(st, 0, sizeof(GState), s) != hipSuccess) return fail(APGPU_ELAUNCH, "sigclip_global: memset failed");
@@ -515,15 +642,15 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     auto stats_pass = [&](int final_pass) {
         hipLaunchKernelGGL(select_begin_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
         for (int pass = 0; pass < K::passes; pass++) {
-            hipLaunchKernelGGL(hist_kernel<T>, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
-            hipLaunchKernelGGL(select_digit_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
+            hipLaunchKernelGGL(hist_kernel<T>, dim3(gscan), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
+            hipLaunchKernelGGL(select_digit_kernel, dim3(1), dim3(256), 0, s, st, final_pass);
         }
-        hipLaunchKernelGGL(less_stats_kernel<T>, dim3(gflat), dim3(kBlock), 0, s, b0, b1, st, final_pass);
+        hipLaunchKernelGGL(less_stats_kernel<T>, dim3(gscan), dim3(kBlock), 0, s, b0, b1, st, final_pass);
         hipLaunchKernelGGL(median_finish_kernel<T>, dim3(1), dim3(64), 0, s, st, final_pass);
         hipLaunchKernelGGL((piece_sums_kernel<0, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL((fold_kernel<0, T>), dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((fold_kernel<0, T>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
         hipLaunchKernelGGL((piece_sums_kernel<1, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL((fold_kernel<1, T>), dim3(1), dim3(64), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((fold_kernel<1, T>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
     };
 
     for (int it = 0; it < iters; it++) {
