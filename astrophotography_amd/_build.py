@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'stack.hip',
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip',
            'stack_inst_f32_calib.hip', 'stack_inst_f32_plain.hip',
            'stack_inst_u16_calib.hip', 'stack_inst_u16_plain.hip']
 HEADERS = ['common.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h')]

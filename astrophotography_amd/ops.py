@@ -355,3 +355,96 @@ def bayer_flat_normalize(flat):
             nflat[r0::2, c0::2] = npl
             norms[r0, c0] = norm[0]
     return nflat, norms
+
+
+# ---------------------------------------------------------------------------------------------------
+# F3: registration resample (what the reference runs SWarp for, scripts/resample_all.sh:123-131, 330-342)
+# ---------------------------------------------------------------------------------------------------
+_LUT_CACHE = {}
+
+
+def lanczos3_table(n_phases=1024, device='cuda'):
+    """[n_phases + 1, 6] float32 device tensor: row p = normalised Lanczos-3 weights of the taps
+    floor(x)-2 .. floor(x)+3 for a fractional offset t = p / n_phases (tap k at distance d = k - 2 - t,
+    L(d) = sinc(d) sinc(d/3) for |d| < 3).  Built once per (n_phases, device) in float64 on the host."""
+    import numpy as np
+    key = (int(n_phases), str(device))
+    if key not in _LUT_CACHE:
+        t = np.arange(n_phases + 1, dtype=np.float64)[:, None] / n_phases
+        d = np.arange(6, dtype=np.float64)[None, :] - 2.0 - t
+        w = np.sinc(d) * np.sinc(d / 3.0)
+        w[np.abs(d) >= 3.0] = 0.0
+        w[np.abs(w) < 1e-12] = 0.0              # np.sinc(integer) is ~1e-17, not 0: whole-pixel offsets are exact copies
+        w /= w.sum(axis=1, keepdims=True)
+        _LUT_CACHE[key] = torch.from_numpy(np.ascontiguousarray(w.astype(np.float32))).to(device)
+    return _LUT_CACHE[key]
+
+
+def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, out=None, weight=True):
+    """Affine Lanczos-3 resample of [N,H,W] (or [H,W]) float32 frames onto a common grid.
+
+    affines: [N,6] float64 (tensor / array / nested list): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps an
+    OUTPUT pixel (x = column, y = row) to INPUT coordinates.  fscale: per-frame flux scale (SWarp's FSCALE,
+    1/EXPTIME in resample_all.sh:298) or None.  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
+    Returns (resampled [N,h,w] float32 with NaN where undefined, weight uint8 [N,h,w] or None).  The co-add is
+    stack_median / stack_sigclip on the result (both skip NaN)."""
+    _need_cuda(frames)
+    frames = _f32c(frames, 'frames')
+    if frames.dim() == 2:
+        frames = frames[None]
+    if frames.dim() != 3:
+        raise ValueError('frames must be [N,H,W] or [H,W]')
+    N, H, W = frames.shape
+    dev = frames.device
+    aff = torch.as_tensor(affines, dtype=torch.float64).reshape(-1, 6)
+    if aff.shape[0] == 1 and N > 1:
+        aff = aff.expand(N, 6)
+    if aff.shape[0] != N:
+        raise ValueError('affines must hold one 2x3 transform per frame')
+    aff = aff.contiguous().to(dev)
+    fs = None
+    if fscale is not None:
+        fs = torch.as_tensor(fscale, dtype=torch.float32).reshape(-1)
+        if fs.numel() == 1 and N > 1:
+            fs = fs.expand(N)
+        if fs.numel() != N:
+            raise ValueError('fscale must hold one value per frame')
+        fs = fs.contiguous().to(dev)
+    mk = None
+    if mask is not None:
+        _need_cuda(mask)
+        if tuple(mask.shape) != (H, W):
+            raise ValueError('mask must be [H,W]')
+        mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
+    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
+    lut = lanczos3_table(n_phases, dev)
+    if out is None:
+        out = torch.empty((N, h, w), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (N, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError('out must be a contiguous float32 [N,h,w] tensor')
+    wt = torch.empty((N, h, w), dtype=torch.uint8, device=dev) if weight else None
+    check(_lib.load().apgpu_resample_affine_f32(_ptr(frames), N, H, W, _ptr(mk) if mk is not None else None, _ptr(aff),
+                                                _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
+                                                _ptr(wt) if wt is not None else None, h, w, _stream()))
+    return out, wt
+
+
+def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024):
+    """Resample + combine: SWarp's COMBINE_TYPE MEDIAN / AVERAGE / SUM (resample_all.sh:262-275 add modes) plus
+    CLIPPED (sigma-clipped mean, median-centred).  Returns dict(image, count) - count = frames contributing."""
+    res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False)
+    combine = combine.upper()
+    if combine == 'MEDIAN':
+        med, cnt = stack_median(res, want_count=True)
+        return dict(image=med, count=cnt)
+    if combine in ('AVERAGE', 'WEIGHTED', 'SUM'):
+        # one pass with bounds nothing can exceed = np.nanmean / np.nansum along N
+        r = stack_sigclip(res, sigma=1e30, maxiters=1, cenfunc='mean',
+                          outputs=('mean', 'count') if combine != 'SUM' else ('moments', 'count'))
+        if combine == 'SUM':
+            return dict(image=r['moments'][0], count=r['count'])
+        return dict(image=r['mean'], count=r['count'])
+    if combine == 'CLIPPED':
+        r = stack_sigclip(res, sigma=sigma, maxiters=maxiters, outputs=('mean', 'count'))
+        return dict(image=r['mean'], count=r['count'])
+    raise ValueError("combine must be one of MEDIAN, AVERAGE, WEIGHTED, SUM, CLIPPED")

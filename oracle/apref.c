@@ -748,3 +748,65 @@ void apref_set_num_threads(int n)
     (void)n;
 #endif
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * F3  Affine Lanczos-3 resample of registered frames (the step SWarp performs for the reference:
+ *     scripts/resample_all.sh:123-131 RESAMPLING_TYPE LANCZOS3, :330-342 the swarp call; FSCALE_DEFAULT =
+ *     1/EXPTIME :298).  No in-tree arithmetic exists - the definition below is this build's own
+ *     (parity with SWarp unpinned); the HIP kernel must match it bit for bit.
+ *
+ *     For output pixel (x, y) (0-based column, row) of frame f with affine A = affines[f][0..5]:
+ *         xin = fma(A0, x, fma(A1, y, A2));  yin = fma(A3, x, fma(A4, y, A5))          (float64)
+ *         ix = floor(xin), px = (int)((xin - ix) * n_phases + 0.5)   (0 .. n_phases), same for y
+ *         wx = lut[px][0..5], wy = lut[py][0..5]      (row p holds the normalised Lanczos-3 weights of the
+ *                                                       taps ix-2 .. ix+3 for a fractional offset p/n_phases)
+ *         r_j = fmaf chain over i of wx[i] * src[iy-2+j][ix-2+i]  (i ascending, first term a product)
+ *         v   = fmaf chain over j of wy[j] * r_j;   out = v * fscale[f]   (float32)
+ *     If any of the 36 taps lies outside the frame, on a masked pixel (mask != 0) or on a non-finite value,
+ *     out = NaN.  weight = 1 where out is not NaN, else 0.
+ * --------------------------------------------------------------------------------------------------- */
+int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
+                              const double *affines, const float *fscale, const float *lut, int n_phases,
+                              float *out, uint8_t *weight_out, long h_out, long w_out)
+{
+    if (!frames || !affines || !lut || !out || n_phases < 1) return -1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (long f = 0; f < n_frames; f++)
+        for (long y = 0; y < h_out; y++) {
+            const float *src = frames + f * h_in * w_in;
+            const double *A = affines + 6 * f;
+            const float fs = fscale ? fscale[f] : 1.0f;
+            for (long x = 0; x < w_out; x++) {
+                const double xin = fma(A[0], (double)x, fma(A[1], (double)y, A[2]));
+                const double yin = fma(A[3], (double)x, fma(A[4], (double)y, A[5]));
+                float res = NAN;
+                uint8_t wt = 0;
+                /* the 6x6 window must lie inside the frame (also rejects NaN / huge coordinates) */
+                if (xin >= 2.0 && yin >= 2.0 && xin < (double)(w_in - 3) && yin < (double)(h_in - 3)) {
+                    const double fx0 = floor(xin), fy0 = floor(yin);
+                    const long ix = (long)fx0, iy = (long)fy0;
+                    const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
+                    const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
+                    const float *wx = lut + 6 * px, *wy = lut + 6 * py;
+                    int ok = 1;
+                    float v = 0.f;
+                    for (int j = 0; j < 6; j++) {
+                        const long row = iy - 2 + j;
+                        const float *s = src + row * w_in + (ix - 2);
+                        float r = 0.f;
+                        for (int i = 0; i < 6; i++) {
+                            const float sv = s[i];
+                            if (!isfinite(sv) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
+                            r = (i == 0) ? wx[0] * sv : fmaf(wx[i], sv, r);
+                        }
+                        v = (j == 0) ? wy[0] * r : fmaf(wy[j], r, v);
+                    }
+                    if (ok && v == v) res = v * fs;
+                    wt = (res == res) ? 1 : 0;       /* weight plane: out is defined */
+                }
+                out[(f * h_out + y) * w_out + x] = res;
+                if (weight_out) weight_out[(f * h_out + y) * w_out + x] = wt;
+            }
+        }
+    return 0;
+}

@@ -313,3 +313,38 @@ def image_difference(im1, im2, sigmaclip, mask1=None, mask2=None):
     st = sigclip_global(sel, sigma=1e300, maxiters=1)       # float64 path: numpy-ordered mean / median / std
     return dict(stddev=float(st['std']), min=float(sel.min()), max=float(sel.max()), mean=float(st['mean']),
                 median=float(st['median']), numgood=int(good.sum()), numpix=int(good.size), good=good)
+
+
+def lanczos3_table(n_phases=1024):
+    """[n_phases + 1, 6] float32: row p = normalised Lanczos-3 weights of the taps ix-2 .. ix+3 for a
+    fractional offset t = p / n_phases (tap k sits at distance d = k - 2 - t; L(d) = sinc(d) sinc(d/3),
+    |d| < 3).  Computed in float64, normalised to sum 1, rounded to float32.  (Same construction as
+    astrophotography_amd.ops.lanczos3_table - kept separate so the oracle does not import the product.)"""
+    t = np.arange(n_phases + 1, dtype=np.float64)[:, None] / n_phases
+    d = np.arange(6, dtype=np.float64)[None, :] - 2.0 - t
+    w = np.sinc(d) * np.sinc(d / 3.0)
+    w[np.abs(d) >= 3.0] = 0.0
+    w[np.abs(w) < 1e-12] = 0.0                  # np.sinc(integer) is ~1e-17, not 0: whole-pixel offsets are exact copies
+    w /= w.sum(axis=1, keepdims=True)
+    return np.ascontiguousarray(w.astype(np.float32))
+
+
+def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, lut=None):
+    """F3: affine Lanczos-3 resample of [N,H,W] float32 frames (definition in apref.c).  affines [N,6] float64
+    map output (x, y) to input (xin, yin).  Returns (out [N,h,w] float32 with NaN where undefined, weight u8)."""
+    frames = _c(np.asarray(frames), np.float32)
+    if frames.ndim == 2:
+        frames = frames[None]
+    N, H, W = frames.shape
+    affines = _c(np.asarray(affines, dtype=np.float64).reshape(N, 6), np.float64)
+    h, w = (H, W) if out_shape is None else out_shape
+    lut = lanczos3_table(n_phases) if lut is None else _c(lut, np.float32)
+    fs = None if fscale is None else _c(np.asarray(fscale, dtype=np.float32).reshape(N), np.float32)
+    mk = None if mask is None else _c(np.asarray(mask), np.uint8)
+    out = np.empty((N, h, w), np.float32)
+    wt = np.empty((N, h, w), np.uint8)
+    rc = lib().apref_resample_affine_f32(_p(frames), C.c_long(N), C.c_long(H), C.c_long(W), _p(mk) if mk is not None else None,
+                                         _p(affines), _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases),
+                                         _p(out), _p(wt), C.c_long(h), C.c_long(w))
+    assert rc == 0
+    return out, wt
