@@ -15,6 +15,7 @@ _LAZY = {
     'ApMasterCal': ('.core.ApMasterCal', 'ApMasterCal'),
     'ApStack': ('.core.ApStack', 'ApStack'),
     'ApCombine': ('.core.ApStack', 'ApCombine'),
+    'ApResample': ('.core.ApResample', 'ApResample'),
     'ApImageDifference': ('.core.ApCalcReadNoise', 'ApImageDifference'),
     'ApCalcReadNoise': ('.core.ApCalcReadNoise', 'ApCalcReadNoise'),
 }

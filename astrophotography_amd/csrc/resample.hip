@@ -5,11 +5,11 @@
 //
 //   xin = fma(A0, x, fma(A1, y, A2)), yin = fma(A3, x, fma(A4, y, A5))           (float64, output -> input)
 //   ix = floor(xin), phase px = (int)((xin - ix) * n_phases + 0.5); taps ix-2 .. ix+3 weighted by lut[px][0..5]
-//   (a host-built table of normalised Lanczos-3 weights), rows combined by lut[py]; fmaf chains in a fixed
-//   order; result * fscale[f].  Any tap outside the frame, masked or non-finite -> NaN, weight 0.
+//   (a host-built table of normalised Lanczos-3 weights), rows combined by lut[py]; even / odd fmaf chains in a
+//   fixed order (= packed float32 arithmetic); result * fscale[f].  Any tap outside the frame, masked or non-finite -> NaN, weight 0.
 //
 // A workgroup produces a 64 x 16 output tile.  For registration-sized transforms (small rotation / shift /
-// scale near 1) the tile's input footprint is ~70 x 22 pixels: it is staged in LDS once (coalesced rows,
+// scale near 1) the tile's input footprint is ~70 x 22 pixels: it is staged in LDS once (coalesced runs,
 // invalid pixels stored as NaN) and the 36 taps of every output pixel are LDS reads, so HBM traffic is one
 // read of the input (+ ~40 % halo, mostly L2 hits) and one write of the output: 8 B per pixel.  A footprint
 // that does not fit (strong shear / large scale) takes the direct-gather path, same arithmetic.
@@ -19,38 +19,84 @@ namespace {
 using namespace apgpu;
 
 constexpr int kTileW = 64, kTileH = 16;
-constexpr int kLdsFloats = 12288;              // 48 KB: three workgroups per CU
+constexpr int kLdsFloats = 4096;               // 16 KB footprint buffer: eight workgroups (all 32 wave slots) per CU
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float fetch_global(const float *__restrict__ src, const uint8_t *__restrict__ mask, int64_t h_in,
-                                              int64_t w_in, int64_t row, int64_t col)
+struct FrameView {
+    const float *src;
+    const uint8_t *mask;
+    int h_in, w_in;
+};
+
+// src[row][col], or NaN if the pixel is outside the frame, masked or not finite
+__device__ __forceinline__ float fetch_global(const FrameView &fv, int row, int col)
 {
-    if (row < 0 || row >= h_in || col < 0 || col >= w_in) return __builtin_nanf("");
-    const int64_t q = row * w_in + col;
-    const float v = src[q];
-    const bool bad = !(fabsf(v) < __builtin_inff()) || (mask && mask[q] != 0);
+    if (row < 0 || row >= fv.h_in || col < 0 || col >= fv.w_in) return __builtin_nanf("");
+    const int64_t q = (int64_t)row * fv.w_in + col;
+    const float v = fv.src[q];
+    const bool bad = !(fabsf(v) < __builtin_inff()) || (fv.mask && fv.mask[q] != 0);
     return bad ? __builtin_nanf("") : v;
 }
 
-template <bool LDS>
+// One output pixel from its 6 x 6 window; `row(j)` returns the 6 samples of window row j as three pairs.
+// Evaluation order (restated in the oracle): per row the even and the odd taps are two fmaf chains, the rows
+// are combined by two fmaf chains over j, and the two halves are added last - which is exactly a sequence of
+// packed float32 operations on (even, odd) pairs: 4 instructions per row for 6 taps.
+struct Weights {
+    v2f wx01, wx23, wx45;       // x taps as (even, odd) pairs
+    v2f wy01, wy23, wy45;
+};
+
+__device__ __forceinline__ Weights load_weights(const float *__restrict__ lut, int px, int py)
+{
+    const v2f *wxp = reinterpret_cast<const v2f *>(lut + 6 * px);
+    const v2f *wyp = reinterpret_cast<const v2f *>(lut + 6 * py);
+    Weights w;
+    w.wx01 = wxp[0]; w.wx23 = wxp[1]; w.wx45 = wxp[2];
+    w.wy01 = wyp[0]; w.wy23 = wyp[1]; w.wy45 = wyp[2];
+    return w;
+}
+
+template <typename RowFn>
+__device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
+{
+    const float wy[6] = {w.wy01.x, w.wy01.y, w.wy23.x, w.wy23.y, w.wy45.x, w.wy45.y};
+    v2f V = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        v2f s01, s23, s45;
+        row(j, s01, s23, s45);
+        v2f acc = w.wx01 * s01;
+        acc = __builtin_elementwise_fma(w.wx23, s23, acc);
+        acc = __builtin_elementwise_fma(w.wx45, s45, acc);
+        const v2f wyj = {wy[j], wy[j]};
+        V = (j == 0) ? wyj * acc : __builtin_elementwise_fma(wyj, acc, V);
+    }
+    return V.x + V.y;
+}
+
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const double *__restrict__ affines,
                                                              const float *__restrict__ fscale, const float *__restrict__ lut,
                                                              int n_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
-                                                             int64_t h_in, int64_t w_in, int64_t h_out, int64_t w_out)
+                                                             int h_in, int w_in, int h_out, int w_out)
 {
-    __shared__ float tile[LDS ? kLdsFloats : 1];
+    __shared__ float tile[kLdsFloats];
     const int64_t f = blockIdx.z;
-    const int64_t x0 = (int64_t)blockIdx.x * kTileW, y0 = (int64_t)blockIdx.y * kTileH;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const double *A = affines + 6 * f;
     const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
     const float fs = fscale ? fscale[f] : 1.0f;
-    const float *src = frames + f * h_in * w_in;
+    FrameView fv;
+    fv.src = frames + f * (int64_t)h_in * w_in;
+    fv.mask = mask;
+    fv.h_in = h_in;
+    fv.w_in = w_in;
 
     // input footprint of the tile: an affine map takes its extremes at the tile corners
-    int64_t bx0 = 0, by0 = 0;
-    int fw = 0;
+    int bx0 = 0, by0 = 0, fw = 0;
     bool staged = false;
-    if constexpr (LDS) {
+    {
         const double xa = (double)x0, xb = (double)(x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1);
         const double ya = (double)y0, yb = (double)(y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1);
         double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
@@ -62,64 +108,108 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
             mny = fmin(mny, yi); mxy = fmax(mxy, yi);
         }
-        const bool sane = (mnx > -1e15) && (mxx < 1e15) && (mny > -1e15) && (mxy < 1e15);   // false for NaN too
+        // clip to the band of coordinates that can produce a defined pixel at all; false for NaN coefficients
+        const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9);
         if (sane) {
-            bx0 = (int64_t)floor(mnx) - 2;
-            by0 = (int64_t)floor(mny) - 2;
-            const int64_t w = (int64_t)floor(mxx) + 3 - bx0 + 1, h = (int64_t)floor(mxy) + 3 - by0 + 1;
+            bx0 = (int)floor(mnx) - 2;
+            by0 = (int)floor(mny) - 2;
+            const int w = (int)floor(mxx) + 3 - bx0 + 1, h = (int)floor(mxy) + 3 - by0 + 1;
             if (w > 0 && h > 0 && w <= kLdsFloats && h <= kLdsFloats && w * h <= kLdsFloats) {
                 staged = true;
-                fw = (int)w;
+                fw = w;
+                // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
+                // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
+                // a trip are in flight together; validity is applied afterwards
                 const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-                for (int r = wave; r < (int)h; r += 256 / kWave)
-                    for (int c = lane; c < fw; c += kWave) tile[r * fw + c] = fetch_global(src, mask, h_in, w_in, by0 + r, bx0 + c);
+                const bool has_mask = mask != nullptr;
+                constexpr int RU = 3;
+                for (int r0 = wave; r0 < h; r0 += 4 * RU) {
+                    for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
+                        float val[RU][2];
+                        uint8_t mk[RU][2];
+#pragma unroll
+                        for (int u = 0; u < RU; u++) {
+                            const int row = by0 + r0 + 4 * u;
+                            const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
+                            const float *rp = fv.src + (int64_t)rc * w_in;
+                            const uint8_t *mp = has_mask ? mask + (int64_t)rc * w_in : nullptr;
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const int col = bx0 + c0 + q * kWave + lane;
+                                const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
+                                val[u][q] = rp[cc];
+                                mk[u][q] = has_mask ? mp[cc] : (uint8_t)0;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < RU; u++) {
+                            const int r = r0 + 4 * u;
+                            const int row = by0 + r;
+                            const bool row_ok = row >= 0 && row < h_in;
+#pragma unroll
+                            for (int q = 0; q < 2; q++) {
+                                const int c = c0 + q * kWave + lane;
+                                const int col = bx0 + c;
+                                const bool good = row_ok && col >= 0 && col < w_in && (fabsf(val[u][q]) < __builtin_inff()) && mk[u][q] == 0;
+                                if (r < h && c < fw) tile[r * fw + c] = good ? val[u][q] : __builtin_nanf("");
+                            }
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
     }
 
     const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
-    const int64_t x = x0 + lx;
+    const int x = x0 + lx;
     if (x >= w_out) return;
+    // coordinates, phases and table rows of the lane's 4 pixels first (branch-free, so the 24 table loads are in
+    // flight together), then the window sums
+    constexpr int NPX = kTileH / 4;
+    bool inside[NPX];
+    int ixs[NPX], iys[NPX];
+    Weights wts[NPX];
 #pragma unroll
-    for (int k = 0; k < kTileH / 4; k++) {
-        const int64_t y = y0 + ly + 4 * k;
-        if (y >= h_out) break;
+    for (int k = 0; k < NPX; k++) {
+        const int y = y0 + ly + 4 * k;
         const double xin = fma(a0, (double)x, fma(a1, (double)y, a2));
         const double yin = fma(a3, (double)x, fma(a4, (double)y, a5));
-        float res = __builtin_nanf("");
-        if (xin >= 2.0 && yin >= 2.0 && xin < (double)(w_in - 3) && yin < (double)(h_in - 3)) {
-            const double fx0 = floor(xin), fy0 = floor(yin);
-            const int64_t ix = (int64_t)fx0, iy = (int64_t)fy0;
-            const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
-            const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
-            const float2 *wxp = reinterpret_cast<const float2 *>(lut + 6 * px);
-            const float2 *wyp = reinterpret_cast<const float2 *>(lut + 6 * py);
-            const float2 wx01 = wxp[0], wx23 = wxp[1], wx45 = wxp[2];
-            const float2 wy01 = wyp[0], wy23 = wyp[1], wy45 = wyp[2];
-            const float wx[6] = {wx01.x, wx01.y, wx23.x, wx23.y, wx45.x, wx45.y};
-            const float wy[6] = {wy01.x, wy01.y, wy23.x, wy23.y, wy45.x, wy45.y};
-            float v = 0.f;
+        inside[k] = (y < h_out) && xin >= 2.0 && yin >= 2.0 && xin < (double)(w_in - 3) && yin < (double)(h_in - 3);
+        const double fx0 = floor(xin), fy0 = floor(yin);
+        const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
+        const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
+        ixs[k] = inside[k] ? (int)fx0 : 0;
+        iys[k] = inside[k] ? (int)fy0 : 0;
+        wts[k] = load_weights(lut, inside[k] ? px : 0, inside[k] ? py : 0);
+    }
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                float s[6];
-                if (LDS && staged) {
-                    const float *t = tile + (int)(iy - 2 + j - by0) * fw + (int)(ix - 2 - bx0);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) s[i] = t[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) s[i] = fetch_global(src, mask, h_in, w_in, iy - 2 + j, ix - 2 + i);
-                }
-                float r = wx[0] * s[0];
-#pragma unroll
-                for (int i = 1; i < 6; i++) r = fmaf(wx[i], s[i], r);
-                v = (j == 0) ? wy[0] * r : fmaf(wy[j], r, v);
-            }
-            // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
-            res = (v == v) ? v * fs : __builtin_nanf("");
+    for (int k = 0; k < NPX; k++) {
+        const int y = y0 + ly + 4 * k;
+        if (y >= h_out) break;
+        const int ix = ixs[k], iy = iys[k];
+        float v;
+        if (staged) {
+            // pixels outside the frame read (and discard) the tile origin
+            const int off = inside[k] ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
+            const float *t = tile + off;
+            const int stride = inside[k] ? fw : 0;
+            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+                const float *r = t + j * stride;
+                s01 = v2f{r[0], r[1]};
+                s23 = v2f{r[2], r[3]};
+                s45 = v2f{r[4], r[5]};
+            });
+        } else {
+            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+                s01 = v2f{fetch_global(fv, iy - 2 + j, ix - 2), fetch_global(fv, iy - 2 + j, ix - 1)};
+                s23 = v2f{fetch_global(fv, iy - 2 + j, ix), fetch_global(fv, iy - 2 + j, ix + 1)};
+                s45 = v2f{fetch_global(fv, iy - 2 + j, ix + 2), fetch_global(fv, iy - 2 + j, ix + 3)};
+            });
         }
-        const int64_t o = (f * h_out + y) * w_out + x;
+        // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
+        const float res = (inside[k] && v == v) ? v * fs : __builtin_nanf("");
+        const int64_t o = (f * h_out + y) * (int64_t)w_out + x;
         out[o] = res;
         if (wout) wout[o] = (res == res) ? 1 : 0;
     }
@@ -134,12 +224,14 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
     if (!frames || !affines || !lut || !out) return fail(APGPU_EINVAL, "resample_affine: NULL pointer argument");
     if (n_frames <= 0 || n_frames > 65535) return fail(APGPU_EINVAL, "resample_affine: n_frames = %d (1..65535)", n_frames);
     if (h_in < 6 || w_in < 6 || h_out <= 0 || w_out <= 0) return fail(APGPU_EINVAL, "resample_affine: bad shape");
+    if (h_in > 0x3fffffff || w_in > 0x3fffffff || h_out > 0x3fffffff || w_out > 0x3fffffff)
+        return fail(APGPU_EUNSUPPORTED, "resample_affine: image sides are limited to 2^30 pixels");
     if (n_phases < 1 || n_phases > (1 << 20)) return fail(APGPU_EINVAL, "resample_affine: n_phases = %d", n_phases);
     if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "resample_affine: lut must be 8-byte aligned");
     const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "resample_affine: output too large");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(resample_affine_kernel<true>, dim3((unsigned)gx, (unsigned)gy, (unsigned)n_frames), dim3(256), 0, st, frames,
-                       mask, affines, fscale, lut, n_phases, out, weight_out, h_in, w_in, h_out, w_out);
+    hipLaunchKernelGGL(resample_affine_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)n_frames), dim3(256), 0, st, frames, mask,
+                       affines, fscale, lut, n_phases, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     return check_launch("resample_affine");
 }

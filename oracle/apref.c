@@ -760,8 +760,10 @@ void apref_set_num_threads(int n)
  *         ix = floor(xin), px = (int)((xin - ix) * n_phases + 0.5)   (0 .. n_phases), same for y
  *         wx = lut[px][0..5], wy = lut[py][0..5]      (row p holds the normalised Lanczos-3 weights of the
  *                                                       taps ix-2 .. ix+3 for a fractional offset p/n_phases)
- *         r_j = fmaf chain over i of wx[i] * src[iy-2+j][ix-2+i]  (i ascending, first term a product)
- *         v   = fmaf chain over j of wy[j] * r_j;   out = v * fscale[f]   (float32)
+ *         e_j = fmaf(wx4, s4, fmaf(wx2, s2, wx0 * s0)), o_j = fmaf(wx5, s5, fmaf(wx3, s3, wx1 * s1)),
+ *                                                     s_i = src[iy-2+j][ix-2+i]   (even / odd taps of row j)
+ *         ve = fmaf chain over j of wy[j] * e_j, vo likewise of o_j (first term a product);
+ *         v = ve + vo;   out = v * fscale[f]          (float32; a packed-pair evaluation order)
  *     If any of the 36 taps lies outside the frame, on a masked pixel (mask != 0) or on a non-finite value,
  *     out = NaN.  weight = 1 where out is not NaN, else 0.
  * --------------------------------------------------------------------------------------------------- */
@@ -789,18 +791,18 @@ int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, lon
                     const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
                     const float *wx = lut + 6 * px, *wy = lut + 6 * py;
                     int ok = 1;
-                    float v = 0.f;
+                    float ve = 0.f, vo = 0.f;
                     for (int j = 0; j < 6; j++) {
                         const long row = iy - 2 + j;
                         const float *s = src + row * w_in + (ix - 2);
-                        float r = 0.f;
-                        for (int i = 0; i < 6; i++) {
-                            const float sv = s[i];
-                            if (!isfinite(sv) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
-                            r = (i == 0) ? wx[0] * sv : fmaf(wx[i], sv, r);
-                        }
-                        v = (j == 0) ? wy[0] * r : fmaf(wy[j], r, v);
+                        for (int i = 0; i < 6; i++)
+                            if (!isfinite(s[i]) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
+                        const float e = fmaf(wx[4], s[4], fmaf(wx[2], s[2], wx[0] * s[0]));   /* even taps */
+                        const float o = fmaf(wx[5], s[5], fmaf(wx[3], s[3], wx[1] * s[1]));   /* odd taps  */
+                        ve = (j == 0) ? wy[0] * e : fmaf(wy[j], e, ve);
+                        vo = (j == 0) ? wy[0] * o : fmaf(wy[j], o, vo);
                     }
+                    const float v = ve + vo;
                     if (ok && v == v) res = v * fs;
                     wt = (res == res) ? 1 : 0;       /* weight plane: out is defined */
                 }

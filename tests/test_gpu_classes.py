@@ -345,3 +345,53 @@ def test_read_noise_golden(tmp_path, capsys):
         ap.ApCalcReadNoise(str(tmp_path / 'u161.fits'), str(tmp_path / 'u162.fits'), 'NOGAIN', 'CRITICAL').estimate_rn(True)
     with pytest.raises(RuntimeError):
         ap.ApImageDifference(b1, b2[:10], True, 'CRITICAL')
+
+
+def test_apresample_files_and_script(tmp_path):
+    """F3 at file level: ApResample / ap_coadd.py (the SWarp step of resample_all.sh) against 'oracle resample,
+    then numpy combine'; FSCALE = 1/EXPOSURE except in SUM mode; weight image = contributing frames."""
+    import warnings
+    import yaml
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    from astrophotography_amd.scripts import ap_coadd
+    from oracle import apref
+    rng = np.random.default_rng(21)
+    N, shape = 6, (48, 72)
+    cube = rng.normal(400, 12, (N,) + shape).astype(np.float32)
+    exps = [60.0, 60.0, 120.0, 120.0, 30.0, 90.0]
+    A = []
+    names = []
+    for i in range(N):
+        th = np.deg2rad(rng.uniform(-0.3, 0.3))
+        A.append([np.cos(th), -np.sin(th), rng.uniform(-2, 2), np.sin(th), np.cos(th), rng.uniform(-2, 2)])
+        kw = dict(EXPOSURE=exps[i]) if i % 2 == 0 else dict(EXPTIME=exps[i])
+        _wf(tmp_path / f'cal{i}.fits', cube[i], **kw)
+        names.append(str(tmp_path / f'cal{i}.fits'))
+    mask = (rng.random(shape) < 0.004).astype(np.uint8)
+    _wf(tmp_path / 'badpix.fits', mask)
+    fs = np.array([1.0 / e for e in exps], np.float32)
+    res_ref, _ = apref.resample_affine(cube, A, fscale=fs, mask=mask)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        med = np.nanmedian(res_ref.astype(np.float64), axis=0).astype(np.float32)
+    rs = ap.ApResample('CRITICAL', combine='MEDIAN')
+    rs.coadd_files(names, A, str(tmp_path / 'coadd.fits'), weight_file=str(tmp_path / 'w.fits'), mask_file=str(tmp_path / 'badpix.fits'))
+    img, h = fitsio.read(str(tmp_path / 'coadd.fits'))
+    wimg, _ = fitsio.read(str(tmp_path / 'w.fits'))
+    assert_ulp(img, med, 1, 'median co-add file')
+    assert np.array_equal(wimg, np.isfinite(res_ref).sum(0).astype(np.float32))
+    assert h['NCOMBINE'] == N and h['COMBINET'] == 'MEDIAN' and h['TEXPTIME'] == sum(exps) and h['IFILE005'] == 'cal5.fits'
+    # SUM mode does not flux-scale (resample_all.sh:305-309)
+    res_sum, _ = apref.resample_affine(cube, A, mask=mask)
+    with open(tmp_path / 't.yml', 'w') as fh:
+        yaml.safe_dump({'transforms': {f'cal{i}.fits': [float(v) for v in A[i]] for i in range(N)}}, fh)
+    assert ap_coadd.main([str(tmp_path / 'sum.fits'), *names, '--transforms', str(tmp_path / 't.yml'), '--combine', 'SUM',
+                          '--badpix', str(tmp_path / 'badpix.fits'), '-l', 'CRITICAL']) == 0
+    s, _ = fitsio.read(str(tmp_path / 'sum.fits'))
+    ok = np.isfinite(res_sum).any(0)
+    assert_ulp(s[ok], np.nansum(res_sum.astype(np.float64), axis=0)[ok].astype(np.float32), 1, 'sum co-add file')
+    with pytest.raises(RuntimeError):
+        rs.coadd_files(names, A[:-1], str(tmp_path / 'x.fits'))
+    with pytest.raises(ValueError):
+        ap.ApResample('CRITICAL', combine='MODE')

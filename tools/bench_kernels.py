@@ -72,6 +72,14 @@ def main():
     rec('fix_badpix 4096^2, delta 2 (A5)', 9 * P, lambda: ops.fix_badpix(img, mask, 2), batch=20)
     print('bad pixel fraction %.4f' % float(mask.float().mean()))
     rec('imarith f32 SUB image 4096^2 (A8)', 12 * P, lambda: ops.imarith(img, 'SUB', masters['bias']), batch=20)
+    import numpy as np
+    rng = np.random.default_rng(5)
+    th = np.deg2rad(rng.uniform(-0.2, 0.2, N))
+    A = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, N), np.sin(th), np.cos(th), rng.uniform(-3, 3, N)], 1)
+    out = torch.empty_like(frames)
+    rec('resample_affine 64x4096^2 f32, Lanczos-3 (F3)', 8 * N * P, lambda: ops.resample_affine(frames, A, out=out, weight=False), reps=5)
+    rec('resample_affine + uint8 weight planes', 9 * N * P, lambda: ops.resample_affine(frames, A, out=out, weight=True), reps=5)
+    del out
     json.dump(rows, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'bench_kernels.json'), 'w'), indent=1)
 
 
