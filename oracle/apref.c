@@ -14,7 +14,9 @@
  * + numpy 1.26.4.  A6 (ccdproc.combine, not installed anywhere in the build container; pinned
  * version ccdproc>=2.1.0, requirements.txt:18) is "parity unpinned": apref_combine_ccdproc()
  * restates ccdproc's published Combiner.sigma_clipping + average_combine algorithm and is
- * anchored only on astropy's median / mad_std building blocks (golden group G6).
+ * anchored only on astropy's median / mad_std building blocks (golden group G6).  F3 (resample, the
+ * reference's external SWarp step) is likewise "parity unpinned": apref_resample_affine_f32() is the
+ * definition the HIP kernel is held to, checked only against closed-form properties.
  *
  * Citations "ref:" are relative to /root/reference/AstroPhotography/; "astropy:" refers to
  * astropy 4.3.1 (astropy/stats/sigma_clipping.py and its C helper src/compute_bounds.c /
