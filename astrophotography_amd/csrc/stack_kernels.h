@@ -966,9 +966,177 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     if (prm.count) prm.count[p] = n;
 }
 
+// -------------------------------------------------------------------------------------------------
+// uint16 median stacks (config 4): order statistics commute with a monotone map.  When every frame has
+// the same exposure ratio and no pedestal (the usual case: one exposure time per set), a pixel's
+// calibration  raw -> ((raw - b) - e*D) / nf  is the same monotone function for all N frames (each float32
+// operation is monotone; nf < 0 merely reverses the order), so the two middle calibrated values are the
+// calibrations of the two middle RAW values: the raw uint16 columns are sorted - two pixels per lane with
+// v_pk_min_u16 / v_pk_max_u16, i.e. half the compare-exchange instructions per pixel, and one 4-byte load
+// per lane per frame - and only two values per pixel are calibrated (exact IEEE path).  uint16 data cannot
+// be NaN, and with a uniform map the calibrated column is all-NaN or NaN-free, so count is N or 0.
+// The kernel verifies the precondition itself (staged scalars, one __syncthreads_or); if it does not hold
+// the workgroup processes its 512 pixels as two ordinary 256-pixel tiles.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cmpx_pk16(uint32_t &x, uint32_t &y)
+{
+    uint32_t lo, hi;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    x = lo;
+    y = hi;
+}
+
+template <int NP, int BASE, int... I>
+__device__ __forceinline__ void net_chunk_pk16(uint32_t (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_net<NP>();
+    (cmpx_pk16(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int NP, int BASE>
+__device__ __forceinline__ void net_from_pk16(uint32_t (&v)[NP])
+{
+    constexpr int total = make_net<NP>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        net_chunk_pk16<NP, BASE>(v, std::make_integer_sequence<int, len>{});
+        net_from_pk16<NP, BASE + len>(v);
+    }
+}
+
+// v[idx] for a wave-uniform idx: binary search with scalar branches, static register indices at the leaves
+template <int LO, int LEN, int NP>
+__device__ __forceinline__ uint32_t pick_uniform(const uint32_t (&v)[NP], int idx)
+{
+    if constexpr (LEN == 1) {
+        return v[LO];
+    } else {
+        constexpr int H = LEN / 2;
+        if (idx < LO + H) return pick_uniform<LO, H, NP>(v, idx);
+        return pick_uniform<LO + H, LEN - H, NP>(v, idx);
+    }
+}
+
+template <bool CALIB>
+__device__ __forceinline__ float calibrate_exact_u16(unsigned raw, float b, float D, float e, float nf, bool dodiv)
+{
+    float x = (float)raw;
+    if constexpr (CALIB) {
+        x = x - b;                                          // ApCalibrate.py:439
+        const float ds = e * D;                             // :450
+        x = x - ds;                                         // :451
+        if (dodiv) x = __fdiv_rn(x, nf);                    // :463
+    }
+    return x;
+}
+
+template <int NP, bool CALIB, bool FULL>
+__global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams prm)
+{
+    __shared__ FrameScalars<NP> fs;
+    const int lane = threadIdx.x;
+    bool monotone = true;
+    if constexpr (CALIB) {
+        stage_frame_scalars<NP>(prm, fs);
+        const bool differs = lane < NP && (!(fs.e[lane] == fs.e[0]) || fs.ped[lane] != 0.f);
+        monotone = !__syncthreads_or(differs);
+    } else if constexpr (!FULL) {
+        stage_frame_scalars<NP>(prm, fs);
+    }
+    const int N = prm.N;
+    if (monotone) {
+        const int64_t p2 = ((int64_t)blockIdx.x * 256 + lane) * 2;     // this lane's pixel pair (P is even here)
+        if (p2 >= prm.P) return;
+        uint32_t w[NP];
+        {
+            const uint32_t *fp = reinterpret_cast<const uint32_t *>(static_cast<const uint16_t *>(prm.frames) + (int64_t)blockIdx.x * 512);
+            const int64_t step = prm.stride / 2;
+            int nframes = N;
+            if constexpr (!FULL) asm volatile("" : "+s"(nframes));     // see load_raw
+#pragma unroll
+            for (int f = 0; f < NP; f++) {
+                w[f] = fp[lane];
+                if (FULL || f + 1 < nframes) fp += step;    // padded slots re-read the last frame
+                if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!FULL) {
+#pragma unroll
+                for (int f = 0; f < NP; f++) w[f] |= (uint32_t)((N - 1 - f) >> 31);  // f >= N: all ones, sorts to the top
+            }
+        }
+        if constexpr (NP > 1) net_from_pk16<NP, 0>(w);
+        const int i1 = FULL ? (NP - 1) >> 1 : (N - 1) >> 1, i2 = FULL ? NP >> 1 : N >> 1;
+        const uint32_t m1 = pick_uniform<0, NP, NP>(w, i1), m2 = pick_uniform<0, NP, NP>(w, i2);
+        float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
+        bool dodiv[2] = {false, false};
+        const float e = CALIB ? fs.e[0] : 0.f;
+        if constexpr (CALIB) {
+            const float2 b2 = *reinterpret_cast<const float2 *>(prm.bias + p2);
+            const float2 d2 = *reinterpret_cast<const float2 *>(prm.dark + p2);
+            bb[0] = b2.x; bb[1] = b2.y;
+            dd[0] = prm.still_biased ? d2.x - b2.x : d2.x;  // ApCalibrate.py:440-445
+            dd[1] = prm.still_biased ? d2.y - b2.y : d2.y;
+            if (prm.nflat) {
+                const float2 n2 = *reinterpret_cast<const float2 *>(prm.nflat + p2);
+                nn[0] = n2.x; nn[1] = n2.y;
+                dodiv[0] = n2.x != 0.f;                     // ApCalibrate.py:462 (NaN != 0 is True)
+                dodiv[1] = n2.y != 0.f;
+            }
+        }
+        float med[2];
+        int cnt[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const unsigned r1 = (m1 >> (16 * h)) & 0xffffu, r2 = (m2 >> (16 * h)) & 0xffffu;
+            const float c1 = calibrate_exact_u16<CALIB>(r1, bb[h], dd[h], e, nn[h], dodiv[h]);
+            const float c2 = calibrate_exact_u16<CALIB>(r2, bb[h], dd[h], e, nn[h], dodiv[h]);
+            const bool skip = prm.pixmask && prm.pixmask[p2 + h];
+            const bool any = (c1 == c1) && (c2 == c2) && !skip;     // a uniform map gives all-NaN or NaN-free columns
+            cnt[h] = any ? N : 0;
+            med[h] = any ? (float)(((double)c1 + (double)c2) / 2.0) : __builtin_nanf("");
+        }
+        if (prm.median) *reinterpret_cast<float2 *>(prm.median + p2) = make_float2(med[0], med[1]);
+        if (prm.count) *reinterpret_cast<int2 *>(prm.count + p2) = make_int2(cnt[0], cnt[1]);
+    } else {
+        // per-frame exposure ratios / pedestals: the ordinary path, two 256-pixel tiles per workgroup
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int64_t base = ((int64_t)blockIdx.x * 2 + half) * 256;
+            const int64_t p = base + lane;
+            if (p >= prm.P) break;
+            float v[NP];
+            const int n = load_column<NP, uint16_t, CALIB, false, FULL>(prm, fs, base, lane, v);
+            sort_column<NP>(v);
+            const float m1 = pick_at<NP>(v, (n - 1) >> 1);
+            const float m2 = pick_at<NP>(v, n >> 1);
+            const double med = ((double)m1 + (double)m2) / 2.0;
+            if (prm.median) prm.median[p] = n > 0 ? (float)med : __builtin_nanf("");
+            if (prm.count) prm.count[p] = n;
+        }
+    }
+}
+
 template <int NP, typename RawT, bool CALIB>
 int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
 {
+    if constexpr (sizeof(RawT) == 2) {
+        // uint16 median: pixel pairs per lane need 4-byte aligned frame rows and 8-byte aligned planes
+        const bool pairs = median_only && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
+                           ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
+                           ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
+                             reinterpret_cast<uintptr_t>(prm.nflat) | reinterpret_cast<uintptr_t>(prm.median) |
+                             reinterpret_cast<uintptr_t>(prm.count)) & 7) == 0;
+        if (pairs) {
+            const int64_t grid = (prm.P + 511) / 512;
+            if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+            if (prm.N == NP) hipLaunchKernelGGL((stack_median_u16_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            else hipLaunchKernelGGL((stack_median_u16_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            return check_launch("stack median kernel (uint16 pairs)");
+        }
+    }
+
     const bool rich = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
     const bool full = prm.N == NP;
     const int block = rich ? rich_block<NP>() : 256;

@@ -448,3 +448,49 @@ def test_sigclip_global_f64_vs_oracle(ops, apref):
                 fin = x[np.isfinite(x.astype(np.float64))].astype(np.float64)
                 if sigma > 1e100:
                     assert s[7] == fin.min() and s[8] == fin.max(), what
+
+
+def test_stack_median_u16_pairs_paths(ops, apref):
+    """uint16 median stacks: the packed two-pixels-per-lane kernel (raw columns sorted, only the two middle
+    values calibrated - valid because a uniform calibration is monotone) against 'oracle calibrate, then
+    oracle median', with every special value of the masters; and the cases that must take the ordinary path
+    (per-frame exposure ratios, pedestals, odd pixel counts)."""
+    rng = np.random.default_rng(77)
+    shape = (12, 86)                                        # P = 1032: even -> pairs
+    bias, dark, flat = synth_masters(rng, shape)
+    nflat = (flat / np.float32(30000.0)).astype(np.float32)
+    nflat[0, :8] = [0.0, np.nan, -1.25, np.inf, -np.inf, 1e-30, -0.0, 2.0]
+    bias[1, :3] = [np.nan, np.inf, -np.inf]
+    dark[2, :3] = [np.nan, np.inf, -np.inf]
+    pixmask = (rng.random(shape) < 0.01).astype(np.uint8)
+    for N in (1, 2, 5, 16, 37, 64, 100):
+        cube = synth_cube(rng, N, shape, dtype=np.uint16)
+        cube[:, 3, :4] = [0, 65535, 1, 65534]               # extremes; identical columns
+        for sb in (False, True):
+            for e_kind in ('uniform', 'perframe', 'pedestal'):
+                e = np.full(N, 0.4, np.float32)
+                ped = None
+                if e_kind == 'perframe' and N > 1:
+                    e = rng.uniform(0.2, 0.6, N).astype(np.float32)
+                if e_kind == 'pedestal':
+                    ped = np.zeros(N, np.float32)
+                    ped[N // 2] = -100.0
+                cal = apref.calibrate(cube, bias, dark, nflat, e, pedestal=ped, dark_still_biased=sb)
+                ref = apref.stack_median(cal)
+                nref = (~np.isnan(cal)).sum(0).astype(np.int32)
+                ref[pixmask != 0] = np.nan
+                nref[pixmask != 0] = 0
+                calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=dev(e, ops),
+                             pedestal=None if ped is None else dev(ped, ops), dark_still_biased=sb)
+                med, cnt = ops.stack_median(dev(cube, ops), calib=calib, pixmask=dev(pixmask, ops), want_count=True)
+                assert np.array_equal(host(cnt), nref), (N, sb, e_kind)
+                assert_ulp(host(med), ref.astype(np.float32), 0 if N % 2 else 1, f'u16 median N={N} sb={sb} {e_kind}')
+        # plain (no calibration) and an odd pixel count (ordinary kernel)
+        med = ops.stack_median(dev(cube, ops))
+        assert_ulp(host(med), apref.stack_median(cube.astype(np.float32)).astype(np.float32), 0, f'plain u16 median N={N}')
+        odd = np.ascontiguousarray(cube[:, :, :85])
+        calib = dict(bias=dev(np.ascontiguousarray(bias[:, :85]), ops), dark=dev(np.ascontiguousarray(dark[:, :85]), ops),
+                     nflat=dev(np.ascontiguousarray(nflat[:, :85]), ops), exp_ratio=0.4)
+        cal = apref.calibrate(odd, bias[:, :85], dark[:, :85], nflat[:, :85], np.full(N, 0.4, np.float32))
+        assert_ulp(host(ops.stack_median(dev(odd, ops), calib=calib)), apref.stack_median(cal).astype(np.float32),
+                   0 if N % 2 else 1, f'odd-P u16 median N={N}')
