@@ -25,6 +25,9 @@ Fixture groups:
                     scripts/ap_combine_darks.py:394-420; ccdproc itself is absent -> unpinned)
   G7 nanmean        np.nanmean of float32 flats (pairwise float32 summation) for _generate_flat
   G8 read noise     ApImageDifference / ApCalcReadNoise      scripts/ap_calc_read_noise.py:86-688
+  G9 Bayer stamps   the known-answer tables of the reference's own RawConv.split test
+                    (test/AstroPhotography/test_core.py:47-259: 14x14 R/G1/B/G2 stamps, with and without
+                    black-level subtraction) - numbers only, read by calling the test class's accessor
 """
 import sys, types, importlib, warnings, os, tempfile, shutil, json
 warnings.filterwarnings('ignore')
@@ -433,12 +436,31 @@ def g8_readnoise(tmp):
     save('g8_readnoise.npz', **out)
 
 
+def g9_bayer_stamps(tmp):
+    """The reference's hand-checked split() stamps (the CR2 they were cut from is not in the checkout)."""
+    sys.path.insert(0, '/root/reference/test/AstroPhotography')
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_test_core', '/root/reference/test/AstroPhotography/test_core.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    t = mod.RawConvTest()
+    out = dict(versions=json.dumps(VERSIONS), channels=json.dumps(['R', 'G1', 'B', 'G2']))
+    for black in (False, True):
+        for ch in ('R', 'G1', 'B', 'G2'):
+            oct_ind, meanval, stdval, minval, maxval, sumval, img = t._get_split_data(ch, black)
+            tag = '%s_%s' % (ch, 'black' if black else 'noblack')
+            out[tag] = np.asarray(img, np.int64)
+            out[tag + '_octind'] = np.asarray(oct_ind, np.int64)
+            out[tag + '_stats'] = np.asarray([meanval, stdval, minval, maxval, sumval], np.int64)
+    save('g9_bayer_stamps.npz', **out)
+
+
 if __name__ == '__main__':
     tmp = tempfile.mkdtemp(prefix='apgold_')
     try:
-        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
         for g in which:
             {'g1': g1_calibrate, 'g2': g2_findbadpix, 'g3': g3_fixbadpix, 'g4': g4_imarith,
-             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean, 'g8': g8_readnoise}[g](tmp)
+             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean, 'g8': g8_readnoise, 'g9': g9_bayer_stamps}[g](tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

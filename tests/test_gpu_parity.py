@@ -326,6 +326,17 @@ def test_bayer_split_vs_oracle(ops, apref):
         assert np.array_equal(host(out), ref)
 
 
+def test_bayer_split_reference_stamps(ops):
+    """The reference's RawConv.split known-answer stamps (golden G9) through the HIP kernel."""
+    g = load_golden('g9_bayer_stamps.npz')
+    chans = ('R', 'G1', 'B', 'G2')
+    raw = sum(g[c + '_noblack'] for c in chans).astype(np.uint16)
+    out = host(ops.bayer_split(dev(raw, ops), (0, 1, 3, 2)))
+    outb = host(ops.bayer_split(dev(raw, ops), (0, 1, 3, 2), (256, 256, 256, 256)))
+    for k, c in enumerate(chans):
+        assert np.array_equal(out[k], g[c + '_noblack']) and np.array_equal(outb[k], g[c + '_black']), c
+
+
 def test_errors_are_loud(ops):
     from astrophotography_amd._lib import ApGpuError
     with pytest.raises(ApGpuError):

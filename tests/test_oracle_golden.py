@@ -211,3 +211,22 @@ def test_g8_read_noise(golden_dir):
         rn = 1.37 * apref.image_difference(b1, b2, True)['stddev'] / math.sqrt(2)
         rn2 = 2.0 * apref.image_difference(b1, b2, False)['stddev'] / math.sqrt(2)
         assert [rn, rn2] == list(g[tag + '_readnoise'])
+
+
+def test_g9_bayer_stamps(golden_dir):
+    """A9: the reference's own known-answer vectors for RawConv.split (test_core.py:47-259, 14x14 stamps of an
+    RGGB mosaic starting at an even row / even column, black level 256): the raw stamp is the sum of the four
+    zero-filled channel planes; the split must give back every plane, with and without black subtraction."""
+    g = load(golden_dir, 'g9_bayer_stamps.npz')
+    chans = ('R', 'G1', 'B', 'G2')                          # plane order of bayer_split
+    raw = sum(g[c + '_noblack'] for c in chans).astype(np.uint16)
+    assert raw.shape == (14, 14) and (raw > 0).all()
+    planes = apref.bayer_split(raw, pattern=(0, 1, 3, 2))
+    for k, c in enumerate(chans):
+        assert np.array_equal(planes[k], g[c + '_noblack']), c
+        mean, std, mn, mx, total = g[c + '_noblack_stats']
+        assert planes[k].sum() == total and planes[k].max() == mx and planes[k].min() == mn
+    planes = apref.bayer_split(raw, pattern=(0, 1, 3, 2), black=(256, 256, 256, 256))
+    for k, c in enumerate(chans):
+        assert np.array_equal(planes[k], g[c + '_black']), c
+        assert planes[k].sum() == g[c + '_black_stats'][4]
