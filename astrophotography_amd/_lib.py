@@ -75,9 +75,10 @@ def load():
     """Loads libapgpu.so; raises ImportError (no CPU fallback) if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get('APGPU_LIBRARY', LIB_PATH)      # development: a variant build (tools/variant_lib.sh)
+        if not os.path.exists(path):
             raise ImportError('%s is missing: build it with `python -m astrophotography_amd._build` '
-                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+                              '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
         # PyTorch-ROCm bundles its own libamdhip64.so; it must be in the process BEFORE libapgpu.so so
         # that both resolve to ONE HIP runtime (stream handles are only valid inside the runtime that
         # created them).
@@ -85,7 +86,7 @@ def load():
             import torch  # noqa: F401
         except ImportError:      # symbol-only use without torch (no device work possible then)
             pass
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype = res

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                 // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
                 // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
                 // a trip are in flight together; validity is applied afterwards
-                const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
                 const bool has_mask = mask != nullptr;
                 constexpr int RU = 3;
                 for (int r0 = wave; r0 < h; r0 += 4 * RU) {
@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const int y = y0 + ly + 4 * k;
         const double xin = fma(a0, (double)x, fma(a1, (double)y, a2));
         const double yin = fma(a3, (double)x, fma(a4, (double)y, a5));
-        inside[k] = (y < h_out) && xin >= 2.0 && yin >= 2.0 && xin < (double)(w_in - 3) && yin < (double)(h_in - 3);
         const double fx0 = floor(xin), fy0 = floor(yin);
+        // 2 <= xin < w_in - 3  <=>  2 <= floor(xin) <= w_in - 4 (integer bounds); v_cvt_i32_f64 saturates huge
+        // values and maps NaN to 0, both of which fail the unsigned range test
+        inside[k] = (y < h_out) && (unsigned)((int)fx0 - 2) < (unsigned)(w_in - 5) && (unsigned)((int)fy0 - 2) < (unsigned)(h_in - 5);
         const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
         const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
         ixs[k] = inside[k] ? (int)fx0 : 0;
@@ -194,11 +196,19 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             const int off = inside[k] ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
             const float *t = tile + off;
             const int stride = inside[k] ? fw : 0;
-            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+            // all 18 ds_read2_b32 of the window are issued before the first product
+            v2f smp[6][3];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
                 const float *r = t + j * stride;
-                s01 = v2f{r[0], r[1]};
-                s23 = v2f{r[2], r[3]};
-                s45 = v2f{r[4], r[5]};
+                smp[j][0] = v2f{r[0], r[1]};
+                smp[j][1] = v2f{r[2], r[3]};
+                smp[j][2] = v2f{r[4], r[5]};
+            }
+            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+                s01 = smp[j][0];
+                s23 = smp[j][1];
+                s45 = smp[j][2];
             });
         } else {
             v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {

@@ -38,6 +38,10 @@ def parse():
     ap.add_argument('--height', type=int, default=4096)
     ap.add_argument('--width', type=int, default=4096)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'u16'])
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
+                    help='c2 (default, the BASELINE metric): fused calibrate + clipped mean; c4: uint16 Bayer frames, per-channel '
+                         'flat + fused calibrate + median stack (use --height 6248 --width 4176); c5: bad-pixel mask + per-frame '
+                         'affine Lanczos-3 resample + 5-iteration clipped mean (use --frames 16 --height 8192 --width 8192)')
     ap.add_argument('--stripes', type=int, default=8, help='row stripes for collective/compute overlap (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-collective', action='store_true', help='run the striped all-reduce path even with one rank (testing)')
@@ -113,13 +117,42 @@ def main():
     masters = synth.make_masters(H, W, config_id=2, device=dev)
     nflat, _ = ops.flat_normalize(masters['flat'])
     tdtype = torch.float32 if args.dtype == 'f32' else torch.uint16
-    frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=rank * N)
+    wl = args.workload
+    frames = None
+    if wl != 'c4':
+        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=rank * N)
     e = synth.EXP_RATIO
     calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat,
                  exp_ratio=torch.full((N,), e, dtype=torch.float32, device=dev), dark_still_biased=False)
     torch.cuda.synchronize()
 
+    if wl == 'c4':
+        if world > 1:
+            raise SystemExit('workload c4 is a single-GPU configuration')
+        nflat4, _ = ops.bayer_flat_normalize(masters['flat'])
+        frames = synth.make_frames(N, masters, nflat4, config_id=4, dtype=torch.uint16, first_frame=0)
+        calib = dict(calib, nflat=nflat4)
+    if wl == 'c5':
+        import numpy as np
+        rng = np.random.default_rng(5000 + rank)
+        th = np.deg2rad(rng.uniform(-0.2, 0.2, N))
+        affines = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, N), np.sin(th), np.cos(th), rng.uniform(-3, 3, N)], 1)
+        cal = ops.calibrate(frames, masters['bias'], masters['dark'], nflat, e)
+        del frames
+        frames = cal
+        st = ops.sigclip_global(masters['dark'], sigma=4.0, maxiters=5)
+        badmask, _ = ops.threshold_mask(masters['dark'], thresholds=st[3:5].contiguous())     # lo, hi of the clip, read on the device
+        resampled = torch.empty_like(frames)
+    torch.cuda.synchronize()
+
     def step():
+        if wl == 'c4':
+            return ops.stack_median(frames, calib=calib)
+        if wl == 'c5':
+            ops.resample_affine(frames, affines, mask=badmask, out=resampled, weight=False)
+            if world == 1:
+                return ops.stack_sigclip(resampled, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
+            return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=args.stripes)
         if world == 1 and not args.force_collective:
             return ops.stack_sigclip(frames, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', calib=calib,
                                      outputs=('mean',))['mean']
@@ -157,10 +190,24 @@ def main():
     esize = 4 if args.dtype == 'f32' else 2
     out_planes = 1 if world == 1 else 3
     algo_bytes = esize * N * P + 12 * P + 4 * out_planes * P       # frames + bias/dark/nflat read, outputs written
+    kernel_name = 'stack_sigclip_kernel<64,%s,calib>' % ('float' if args.dtype == 'f32' else 'u16')
+    metric = 'Mpixels/sec calibrate+sigma-clip-stack'
+    workload = 'C2: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean' % (N, H, W, args.dtype)
+    if wl == 'c4':
+        algo_bytes = 2 * N * P + 12 * P + 4 * P
+        args.dtype = 'u16'
+        kernel_name = 'stack_median_u16_kernel<%d,calib>' % N
+        metric = 'Mpixels/sec calibrate+median-stack (uint16 Bayer)'
+        workload = 'C4: %dx%dx%d u16 RGGB mosaic, per-channel flat normalisation, fused bias/dark/flat + median stack' % (N, H, W)
+    if wl == 'c5':
+        algo_bytes = (8 * N * P + P) + (4 * N * P + 4 * out_planes * P)     # resample read+write (+mask), stack read + outputs
+        kernel_name = 'resample_affine_kernel + stack_sigclip_kernel<%d,float,plain> (step = both launches)' % N
+        metric = 'Mpixels/sec mask+affine-resample+sigma-clip-stack'
+        workload = 'C5 (per-GPU share): %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (N, H, W)
     achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tfile) and world == 1 and (N, H, W, args.dtype) == (64, 4096, 4096, 'f32'):
+    if os.path.exists(tfile) and world == 1 and (N, H, W, args.dtype, wl) == (64, 4096, 4096, 'f32', 'c2'):
         try:
             traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
         except Exception:
@@ -187,21 +234,20 @@ def main():
     line = None
     if rank == 0:
         line = {
-            'metric': 'Mpixels/sec calibrate+sigma-clip-stack', 'value': value, 'unit': 'Mpixels/s',
+            'metric': metric, 'value': value, 'unit': 'Mpixels/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'C2: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean'
-                                   % (N, H, W, args.dtype),
+            'config': {'workload': workload,
                        'frames_per_gpu': N, 'height': H, 'width': W,
                        'parallelism': 'single GPU' if world == 1 else 'N-shard x%d, %d-stripe all-reduce of sum/sumsq/count' % (world, args.stripes)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'stack_sigclip_kernel<64,%s,calib>' % ('float' if args.dtype == 'f32' else 'u16'),
+                         'kernel': kernel_name,
                          'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes,
                          'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None},
         }
         if world == 1 and not args.no_cpu_baseline:
-            if args.dtype == 'f32':
+            if args.dtype == 'f32' and wl == 'c2':
                 line['cpu_baseline'] = cpu_baseline(frames, masters, nflat, e, args.cpu_seconds)
             else:
                 line['cpu_baseline'] = None
