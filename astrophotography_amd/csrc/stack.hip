@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(const float *__re
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const float s = mom[p], q = mom[P + p], n = mom[2 * P + p];
+    const float s = mom[p], n = mom[P + p];                   // planes: sum, count, sum of squares
+    const float q = std ? mom[2 * P + p] : 0.f;               // the third plane is only touched if std is wanted
     const float m = s / n;                                    // n == 0 -> NaN
     if (mean) mean[p] = n > 0.f ? m : __builtin_nanf("");
     if (std) {

@@ -668,9 +668,9 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     if (out_moments) {
         const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
         const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        out_moments[p] = (float)sum;
-        out_moments[Pn + p] = (float)sq;
-        out_moments[2 * Pn + p] = (float)cnt;
+        out_moments[p] = (float)sum;                      // plane order: sum, count, sum of squares - the first
+        out_moments[Pn + p] = (float)cnt;                  // two are all a mean needs, so an N-shard exchange that
+        out_moments[2 * Pn + p] = (float)sq;               // does not want std all-reduces a contiguous [2][P] prefix
     }
 }
 
@@ -846,8 +846,8 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
         const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
         prm.moments[p] = (float)sum;
-        prm.moments[prm.P + p] = (float)sq;
-        prm.moments[2 * prm.P + p] = (float)cnt;
+        prm.moments[prm.P + p] = (float)cnt;
+        prm.moments[2 * prm.P + p] = (float)sq;
     }
 }
 

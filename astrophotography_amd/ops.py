@@ -188,7 +188,8 @@ def stack_median(frames, calib=None, pixmask=None, want_count=False):
 
 
 def moments_finalize(moments, want_std=True, out_mean=None):
-    """mean = sum/cnt, std = sqrt(sumsq/cnt - mean^2) from (all-reduced) moments[3, ...]."""
+    """mean = sum/cnt, std = sqrt(sumsq/cnt - mean^2) from (all-reduced) moments[3, ...] = (sum, cnt, sumsq);
+    with want_std=False a [2, ...] tensor (sum, cnt) is enough."""
     _need_cuda(moments)
     lib = _lib.load()
     moments = _f32c(moments, 'moments')

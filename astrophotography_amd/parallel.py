@@ -64,12 +64,29 @@ def _default_finalize(moments, out_mean):
     ops.moments_finalize(moments, want_std=False, out_mean=out_mean)
 
 
+_COMM_STREAMS = {}
+
+
+def _comm_stream(device):
+    """One side stream per device for the stripe all-reduces (created once, not per call)."""
+    key = (device.type, device.index)
+    if key not in _COMM_STREAMS:
+        _COMM_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COMM_STREAMS[key]
+
+
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
-                 n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False):
+                 n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
+                 exchange_sumsq=None):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank.
 
-    One all-reduce per stripe on a side stream, overlapped with the reduction of the next stripe.
+    One all-reduce per stripe on a side stream, overlapped with the reduction of the next stripe.  The
+    moments are laid out (sum, count, sum of squares); the mean needs only the first two, so unless
+    `exchange_sumsq` (default: `return_moments`) asks for the full set the collective carries the contiguous
+    [2, stripe, W] prefix - 8 instead of 12 bytes per pixel over xGMI.
     """
+    if exchange_sumsq is None:
+        exchange_sumsq = return_moments
     local_moments = local_moments or _default_local_moments
     finalize = finalize or _default_finalize
     world, _ = _world(group)
@@ -79,17 +96,20 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     collective = (world > 1) or (force_collective and dist.is_available() and dist.is_initialized())
     stripes = stripe_rows(H, n_stripes if collective else 1)
     parts = []
+    mean = torch.empty((H, W), dtype=torch.float32, device=frames_local.device)
     if collective and on_gpu:
-        comm = torch.cuda.Stream()
+        comm = _comm_stream(frames_local.device)
         main = torch.cuda.current_stream()
-        works = []
+        comm.wait_stream(main)
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip)
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(comm):
+                # exchange and finalise stripe k on the side stream while the main stream reduces stripe k + 1
                 comm.wait_event(ev)
-                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(m if exchange_sumsq else m[:2], op=dist.ReduceOp.SUM, group=group)
+                finalize(m, mean[r0:r1])
                 m.record_stream(comm)
             parts.append(m)
         main.wait_stream(comm)
@@ -97,11 +117,9 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip)
             if collective:
-                dist.all_reduce(m, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(m if exchange_sumsq else m[:2], op=dist.ReduceOp.SUM, group=group)
+            finalize(m, mean[r0:r1])
             parts.append(m)
-    mean = torch.empty((H, W), dtype=torch.float32, device=frames_local.device)
-    for (r0, r1), m in zip(stripes, parts):
-        finalize(m, mean[r0:r1])
     if return_moments:
         return mean, (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1))
     return mean

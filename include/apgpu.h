@@ -93,7 +93,7 @@ int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias, const flo
  *     sigma_lower = sigma_upper = 5 this is the ccdproc.combine configuration of
  *     scripts/ap_combine_darks.py:394-420.
  *     Outputs (each may be NULL): mean/median/std [P] float32, count [P] int32 survivors,
- *     and the N-shard partial moments sum/sumsq/cnt packed as moments[3][P] float32
+ *     and the N-shard partial moments sum/cnt/sumsq packed as moments[3][P] float32
  *     (all-reduced over ranks, then apgpu_moments_finalize).
  * ------------------------------------------------------------------------------------------- */
 typedef struct apgpu_stack_args {
@@ -118,7 +118,8 @@ typedef struct apgpu_stack_args {
     float *median;               /* [P] or NULL */
     float *std;                  /* [P] or NULL */
     int32_t *count;              /* [P] or NULL */
-    float *moments;              /* [3][P] or NULL: sum, sum of squares, count of survivors */
+    float *moments;              /* [3][P] or NULL: sum, count, sum of squares of the survivors (in this order:
+                                    a mean-only exchange all-reduces the contiguous [2][P] prefix) */
     int64_t frame_stride;        /* elements between the starts of consecutive frames; 0 = n_pixels.
                                     > n_pixels lets a call reduce a row stripe of a larger slab */
 } apgpu_stack_args;
@@ -128,7 +129,8 @@ int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 /* Plain median along N (np.nanmedian(axis=0)); config 4.  Optional fused calibration as above. */
 int apgpu_stack_median(const apgpu_stack_args *args, void *stream);
 
-/* mean = sum / cnt, std = sqrt(max(sumsq / cnt - mean^2, 0)) from all-reduced moments[3][P];
+/* mean = sum / cnt, std = sqrt(max(sumsq / cnt - mean^2, 0)) from all-reduced moments[3][P] = sum, cnt, sumsq
+ * (with std == NULL only the first two planes are read);
  * cnt == 0 -> NaN.  mean/std may be NULL. */
 int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_t n_pixels, void *stream);
 

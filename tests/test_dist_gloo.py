@@ -34,12 +34,12 @@ def _oracle_local_moments(frames, calib, r0, r1, clip):
     r = apref.stack_sigclip(sub, sigma=clip['sigma'], maxiters=clip['maxiters'], cenfunc=clip['cenfunc'],
                             stdfunc=clip['stdfunc'], want=('keep', 'count'))
     kept = np.where(r['keep'], sub.astype(np.float64), 0.0)
-    mom = np.stack([kept.sum(0), (kept * kept).sum(0), r['count'].astype(np.float64)]).astype(np.float32)
+    mom = np.stack([kept.sum(0), r['count'].astype(np.float64), (kept * kept).sum(0)]).astype(np.float32)    # sum, count, sumsq
     return torch.from_numpy(mom)
 
 
 def _cpu_finalize(moments, out_mean):
-    out_mean.copy_(moments[0] / moments[2])
+    out_mean.copy_(moments[0] / moments[1])
 
 
 def _worker(rank, world, port, n_total, shape, out_dir):
@@ -57,6 +57,10 @@ def _worker(rank, world, port, n_total, shape, out_dir):
     calib = dict(bias=torch.from_numpy(bias), dark=torch.from_numpy(dark), nflat=None, exp_ratio=0.4)
     mean, mom = parallel.stack_nshard(torch.from_numpy(cube[lo:hi]), calib, sigma=3.0, maxiters=5, n_stripes=3,
                                       local_moments=_oracle_local_moments, finalize=_cpu_finalize, return_moments=True)
+    # the mean-only exchange all-reduces just the (sum, count) prefix of the moments: same mean
+    mean2 = parallel.stack_nshard(torch.from_numpy(cube[lo:hi]), calib, sigma=3.0, maxiters=5, n_stripes=4,
+                                  local_moments=_oracle_local_moments, finalize=_cpu_finalize)
+    assert torch.equal(mean, mean2)
     np.save(os.path.join(out_dir, f'mean{rank}.npy'), mean.numpy())
     np.save(os.path.join(out_dir, f'mom{rank}.npy'), mom.numpy())
     dist.barrier()
@@ -87,6 +91,6 @@ def test_nshard_allreduce_world2(tmp_path):
         rr = apref.stack_sigclip(cal[lo:hi], sigma=3.0, maxiters=5, want=('keep', 'count'))
         tot += np.where(rr['keep'], cal[lo:hi].astype(np.float64), 0).sum(0)
         cnt += rr['count']
-    assert np.array_equal(moms[0][2], cnt.astype(np.float32))
+    assert np.array_equal(moms[0][1], cnt.astype(np.float32))                           # planes: sum, count, sumsq
     np.testing.assert_allclose(means[0], tot / cnt, rtol=3e-7)
     assert cnt.min() >= 16 and cnt.max() == 24 and (cnt < 24).any()                     # outliers were clipped

@@ -148,10 +148,10 @@ def test_stack_sigclip_vs_oracle(ops, apref, N):
         assert_ulp(host(r['median']), ref['median'].astype(np.float32), 1, 'median ' + what)
         assert_ulp(host(r['std']), ref['std'].astype(np.float32), 2, 'std ' + what)
         mom = host(r['moments'])
-        assert np.array_equal(mom[2], ref['count'].astype(np.float32)), what
+        assert np.array_equal(mom[1], ref['count'].astype(np.float32)), what      # planes: sum, count, sumsq
         kept = np.where(ref['keep'], cube.astype(np.float64), 0.0)
         np.testing.assert_allclose(mom[0], kept.sum(0), rtol=3e-7, atol=1e-30)
-        np.testing.assert_allclose(mom[1], (kept * kept).sum(0), rtol=3e-7, atol=1e-30)
+        np.testing.assert_allclose(mom[2], (kept * kept).sum(0), rtol=3e-7, atol=1e-30)
 
 
 def test_stack_u16_and_pixmask(ops, apref):
