@@ -67,9 +67,9 @@ def _default_finalize(moments, out_mean):
 _COMM_STREAMS = {}
 
 
-def _comm_stream(device):
-    """One side stream per device for the stripe all-reduces (created once, not per call)."""
-    key = (device.type, device.index)
+def _comm_stream(device, role='comm'):
+    """Side streams per device (stripe all-reduces, alternating compute lanes), created once, not per call."""
+    key = (device.type, device.index, role)
     if key not in _COMM_STREAMS:
         _COMM_STREAMS[key] = torch.cuda.Stream(device=device)
     return _COMM_STREAMS[key]
@@ -98,21 +98,30 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     parts = []
     mean = torch.empty((H, W), dtype=torch.float32, device=frames_local.device)
     if collective and on_gpu:
-        comm = _comm_stream(frames_local.device)
+        dev = frames_local.device
+        comm = _comm_stream(dev)
         main = torch.cuda.current_stream()
-        comm.wait_stream(main)
-        for (r0, r1) in stripes:
-            m = local_moments(frames_local, calib, r0, r1, clip)
-            ev = torch.cuda.Event()
-            ev.record(main)
+        # two alternating compute streams: stripe k + 1 starts filling the CUs that stripe k's last workgroups
+        # leave idle (kernels on ONE stream serialise, and every stripe has a drain phase)
+        lanes = [_comm_stream(dev, 'compute0'), _comm_stream(dev, 'compute1')]
+        for st in lanes + [comm]:
+            st.wait_stream(main)
+        for k, (r0, r1) in enumerate(stripes):
+            cs = lanes[k % 2]
+            with torch.cuda.stream(cs):
+                m = local_moments(frames_local, calib, r0, r1, clip)
+                ev = torch.cuda.Event()
+                ev.record(cs)
+                m.record_stream(cs)
             with torch.cuda.stream(comm):
-                # exchange and finalise stripe k on the side stream while the main stream reduces stripe k + 1
+                # exchange and finalise stripe k on the side stream while the compute streams reduce the next stripes
                 comm.wait_event(ev)
                 dist.all_reduce(m if exchange_sumsq else m[:2], op=dist.ReduceOp.SUM, group=group)
                 finalize(m, mean[r0:r1])
                 m.record_stream(comm)
             parts.append(m)
-        main.wait_stream(comm)
+        for st in lanes + [comm]:
+            main.wait_stream(st)
     else:
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip)

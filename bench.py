@@ -42,7 +42,7 @@ def parse():
                     help='c2 (default, the BASELINE metric): fused calibrate + clipped mean; c4: uint16 Bayer frames, per-channel '
                          'flat + fused calibrate + median stack (use --height 6248 --width 4176); c5: bad-pixel mask + per-frame '
                          'affine Lanczos-3 resample + 5-iteration clipped mean (use --frames 16 --height 8192 --width 8192)')
-    ap.add_argument('--stripes', type=int, default=4, help='row stripes for collective/compute overlap (N > 1)')
+    ap.add_argument('--stripes', type=int, default=8, help='row stripes for collective/compute overlap (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-collective', action='store_true', help='run the striped all-reduce path even with one rank (testing)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
