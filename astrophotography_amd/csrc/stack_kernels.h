@@ -565,7 +565,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP>
+template <int NP, bool PRESORTED = false>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
     // everything the loop and the epilogue need from the kernel arguments, parked before the sort
@@ -577,7 +577,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const int maxiters = park_in_vgpr(prm.maxiters);
     const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
     APGPU_MARK("sort");
-    sort_column<NP>(v);
+    if constexpr (!PRESORTED) sort_column<NP>(v);           // PRESORTED: ascending, sentinels last (uint16 pair kernel)
     APGPU_MARK("moments");
 
     // pivot: the lower median of the finite values
@@ -1118,6 +1118,164 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
     }
 }
 
+// One pixel of the uint16 pair kernel: its sorted raw column arrives packed two values per register.
+template <int NP, bool CALIB, bool FULL>
+__device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm, const FrameScalars<NP> &fs,
+                                                         const uint32_t (&cur)[NP >= 2 ? NP / 2 : 1], float b, float D, float nf,
+                                                         bool dv, int64_t p)
+{
+    constexpr int HP = NP >= 2 ? NP / 2 : 1;
+    const int N = prm.N;
+    const bool skip = prm.pixmask && prm.pixmask[p];
+    float v[NP];
+    int n = N;
+    bool fast = !skip;
+    float rawf[NP];
+    if constexpr (NP >= 2) {
+#pragma unroll
+        for (int k = 0; k < HP; k++) {
+            rawf[2 * k] = (float)(cur[k] & 0xffffu);
+            rawf[2 * k + 1] = (float)(cur[k] >> 16);
+        }
+    } else {
+        rawf[0] = (float)cur[0];
+    }
+    if constexpr (CALIB) {
+        // non-decreasing map: finite masters and a positive (or unused) flat
+        const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
+        const bool good = calibrate_fast<NP, float, false>(fs, rawf, b, D, nf, dv, v);
+        fast = fast && good && increasing;
+    } else {
+#pragma unroll
+        for (int f = 0; f < NP; f++) v[f] = rawf[f];
+    }
+    if (__all(fast)) {
+        if constexpr (!FULL) {
+#pragma unroll
+            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+        }
+    } else {
+        // rare: exact IEEE calibration of every value (frame order is irrelevant: the per-frame scalars are
+        // uniform), non-finite results and padding become sentinels, and the column is sorted the ordinary way.
+        // The raw values are re-read from memory: the sorted copy has left the registers.
+        n = 0;
+        const float e = CALIB ? fs.e[0] : 0.f;
+        const uint16_t *fp = static_cast<const uint16_t *>(prm.frames) + p;
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            const float x = calibrate_exact_u16<CALIB>(*fp, b, D, e, nf, dv);
+            if (FULL || f + 1 < N) fp += prm.stride;
+            const bool ok = (fabsf(x) < __builtin_inff()) && (FULL || f < N) && !skip;
+            n += ok ? 1 : 0;
+            v[f] = ok ? x : __builtin_inff();
+        }
+        sort_column<NP>(v);
+    }
+    reduce_and_store<NP, true>(prm, v, n, p);
+}
+
+// -------------------------------------------------------------------------------------------------
+// uint16 clipped stacks, two pixels per lane.  Same observation as for the median kernel: with one exposure
+// ratio for all frames, no pedestal and a positive flat, calibration is one non-decreasing function per pixel,
+// so sorting the RAW uint16 column sorts the calibrated column.  The raw columns of two neighbouring pixels
+// are sorted together with packed 16-bit compare-exchanges (543 v_pk_min_u16 + 543 v_pk_max_u16 for BOTH
+// pixels - half the sort cost per pixel, and one 4-byte load per lane per frame); each pixel's sorted raw
+// column is then calibrated (same packed fast path and guards as the lean kernel) and reduced WITHOUT a
+// second sort.  Lanes that do not meet the precondition (flat <= 0 / non-finite masters / guard hit) take the
+// exact per-value path followed by the ordinary sort; workgroups whose per-frame scalars are not uniform run
+// the ordinary kernel body on their 512 pixels.  Results are bit-identical to the one-pixel-per-lane kernel:
+// the survivors are summed in sorted order in both.
+// -------------------------------------------------------------------------------------------------
+template <int NP, bool CALIB, bool FULL>
+__global__ __launch_bounds__(256, NP <= 64 ? 2 : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
+{
+    __shared__ FrameScalars<NP> fs;
+    const int lane = threadIdx.x;
+    bool monotone = true;
+    if constexpr (CALIB) {
+        stage_frame_scalars<NP>(prm, fs);
+        const bool differs = lane < NP && (!(fs.e[lane] == fs.e[0]) || fs.ped[lane] != 0.f);
+        monotone = !__syncthreads_or(differs);
+    } else if constexpr (!FULL) {
+        stage_frame_scalars<NP>(prm, fs);
+    }
+    const int N = prm.N;
+    if (!monotone) {
+        // per-frame exposure ratios / pedestals: the ordinary path, two 256-pixel tiles per workgroup
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            const int64_t base = ((int64_t)blockIdx.x * 2 + half) * 256;
+            const int64_t p = base + lane;
+            if (p >= prm.P) break;
+            float v[NP];
+            const int n = load_column<NP, uint16_t, CALIB, true, FULL>(prm, fs, base, lane, v);
+            reduce_and_store<NP>(prm, v, n, p);
+        }
+        return;
+    }
+    const int64_t p2 = ((int64_t)blockIdx.x * 256 + lane) * 2;         // this lane's pixel pair (P is even here)
+    if (p2 >= prm.P) return;
+    uint32_t w[NP];
+    {
+        const uint32_t *fp = reinterpret_cast<const uint32_t *>(static_cast<const uint16_t *>(prm.frames) + (int64_t)blockIdx.x * 512);
+        const int64_t step = prm.stride / 2;
+        int nframes = N;
+        if constexpr (!FULL) asm volatile("" : "+s"(nframes));         // see load_raw
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            w[f] = fp[lane];
+            if (FULL || f + 1 < nframes) fp += step;        // padded slots re-read the last frame
+            if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!FULL) {
+#pragma unroll
+            for (int f = 0; f < NP; f++) w[f] |= (uint32_t)((N - 1 - f) >> 31);  // f >= N: all ones, sorts to the top
+        }
+    }
+    if constexpr (NP > 1) net_from_pk16<NP, 0>(w);
+
+    // Re-pack the two sorted columns: cur[k] = (raw[2k], raw[2k+1]) of the first pixel stays in registers, the
+    // second pixel's column is parked in LDS (NP/2 dwords per lane, bank = lane) while the first is reduced, so
+    // only one column is register-resident at a time.
+    constexpr int HP = NP >= 2 ? NP / 2 : 1;
+    __shared__ uint32_t parked[HP][256];
+    uint32_t cur[HP];
+    if constexpr (NP >= 2) {
+#pragma unroll
+        for (int k = 0; k < HP; k++) {
+            cur[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16);
+            parked[k][lane] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u);
+        }
+    } else {
+        cur[0] = w[0] & 0xffffu;
+        parked[0][lane] = w[0] >> 16;
+    }
+
+    float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
+    bool dodiv[2] = {false, false};
+    if constexpr (CALIB) {
+        const float2 b2 = *reinterpret_cast<const float2 *>(prm.bias + p2);
+        const float2 d2 = *reinterpret_cast<const float2 *>(prm.dark + p2);
+        bb[0] = b2.x; bb[1] = b2.y;
+        dd[0] = prm.still_biased ? d2.x - b2.x : d2.x;      // ApCalibrate.py:440-445
+        dd[1] = prm.still_biased ? d2.y - b2.y : d2.y;
+        if (prm.nflat) {
+            const float2 n2 = *reinterpret_cast<const float2 *>(prm.nflat + p2);
+            nn[0] = n2.x; nn[1] = n2.y;
+            dodiv[0] = n2.x != 0.f;                         // ApCalibrate.py:462 (NaN != 0 is True)
+            dodiv[1] = n2.y != 0.f;
+        }
+    }
+    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[0], dd[0], nn[0], dodiv[0], p2);
+    // the parked column takes over the registers (through an opaque pointer: otherwise the compiler forwards the
+    // stored values to these loads, i.e. keeps the column in NP/2 registers across the whole first reduction)
+    int slot = lane;
+    asm volatile("" : "+v"(slot) : : "memory");             // opaque index: no store-to-load forwarding in registers
+#pragma unroll
+    for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
+    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1);
+}
+
 template <int NP, typename RawT, bool CALIB>
 int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
 {
@@ -1128,6 +1286,18 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
                            ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
                              reinterpret_cast<uintptr_t>(prm.nflat) | reinterpret_cast<uintptr_t>(prm.median) |
                              reinterpret_cast<uintptr_t>(prm.count)) & 7) == 0;
+        const bool rich_out = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
+        const bool pairs_clip = !median_only && !rich_out && !prm.persistent && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
+                                ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
+                                ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
+                                  reinterpret_cast<uintptr_t>(prm.nflat)) & 7) == 0;
+        if (pairs_clip) {
+            const int64_t grid = (prm.P + 511) / 512;
+            if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+            if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            else hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            return check_launch("stack kernel (uint16 pairs)");
+        }
         if (pairs) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);

@@ -505,3 +505,57 @@ def test_stack_median_u16_pairs_paths(ops, apref):
         cal = apref.calibrate(odd, bias[:, :85], dark[:, :85], nflat[:, :85], np.full(N, 0.4, np.float32))
         assert_ulp(host(ops.stack_median(dev(odd, ops), calib=calib)), apref.stack_median(cal).astype(np.float32),
                    0 if N % 2 else 1, f'odd-P u16 median N={N}')
+
+
+def test_stack_sigclip_u16_pairs_paths(ops, apref):
+    """uint16 clipped stacks through the two-pixels-per-lane kernel (raw columns sorted with packed 16-bit
+    compare-exchanges, then calibrated): counts equal to / means within 1 ulp of 'oracle calibrate, oracle clip',
+    and bit-identical to the one-pixel-per-lane kernel fed the same values as float32 - for every special value
+    of the masters (flat 0 / NaN / negative / inf, non-finite bias and dark), pixel masks, padded stacks, and the
+    cases that must take the ordinary path (per-frame exposure ratios, pedestals, odd pixel counts)."""
+    rng = np.random.default_rng(78)
+    shape = (10, 90)                                        # P = 900: even -> pairs
+    bias, dark, flat = synth_masters(rng, shape)
+    nflat = (flat / np.float32(30000.0)).astype(np.float32)
+    nflat[0, :8] = [0.0, np.nan, -1.25, np.inf, -np.inf, 1e-30, -0.0, 2.0]
+    bias[1, :3] = [np.nan, np.inf, -np.inf]
+    dark[2, :3] = [np.nan, np.inf, -np.inf]
+    pixmask = (rng.random(shape) < 0.01).astype(np.uint8)
+    for N in (1, 3, 8, 16, 37, 64, 100):
+        cube = synth_cube(rng, N, shape, dtype=np.uint16)
+        cube[:, 3, :4] = [0, 65535, 1, 65534]
+        for sb, e_kind in ((False, 'uniform'), (True, 'uniform'), (False, 'perframe'), (False, 'pedestal')):
+            e = np.full(N, 0.4, np.float32)
+            ped = None
+            if e_kind == 'perframe' and N > 1:
+                e = rng.uniform(0.2, 0.6, N).astype(np.float32)
+            if e_kind == 'pedestal':
+                ped = np.zeros(N, np.float32)
+                ped[N // 2] = -100.0
+            cal = apref.calibrate(cube, bias, dark, nflat, e, pedestal=ped, dark_still_biased=sb)
+            with np.errstate(all='ignore'):
+                ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5)
+            mref, nref = ref['mean'].astype(np.float32), ref['count'].copy()
+            mref[pixmask != 0] = np.nan
+            nref[pixmask != 0] = 0
+            calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=dev(e, ops),
+                         pedestal=None if ped is None else dev(ped, ops), dark_still_biased=sb)
+            what = f'u16 pairs N={N} sb={sb} {e_kind}'
+            r = ops.stack_sigclip(dev(cube, ops), sigma=3.0, maxiters=5, calib=calib, pixmask=dev(pixmask, ops),
+                                  outputs=('mean', 'count', 'moments'))
+            assert np.array_equal(host(r['count']), nref), what
+            assert_ulp(host(r['mean']), mref, 1, what)
+            rf = ops.stack_sigclip(dev(cube.astype(np.float32), ops), sigma=3.0, maxiters=5, calib=calib,
+                                   pixmask=dev(pixmask, ops), outputs=('mean', 'count', 'moments'))
+            assert_biteq(host(r['mean']), host(rf['mean']), what + ' vs float32 kernel')
+            assert_biteq(host(r['moments']), host(rf['moments']), what + ' moments vs float32 kernel')
+        # plain (no calibration), mean-centred, and an odd pixel count (ordinary kernel)
+        with np.errstate(all='ignore'):
+            ref = apref.stack_sigclip(cube.astype(np.float32), sigma=2.5, maxiters=None, cenfunc='mean')
+        r = ops.stack_sigclip(dev(cube, ops), sigma=2.5, maxiters=None, cenfunc='mean', outputs=('mean', 'count'))
+        assert np.array_equal(host(r['count']), ref['count']) and True
+        assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, f'plain u16 pairs N={N}')
+        odd = np.ascontiguousarray(cube[:, :, :89])
+        ro = ops.stack_sigclip(dev(odd, ops), sigma=3.0, maxiters=5, outputs=('mean',))
+        rfo = ops.stack_sigclip(dev(odd.astype(np.float32), ops), sigma=3.0, maxiters=5, outputs=('mean',))
+        assert_biteq(host(ro['mean']), host(rfo['mean']), f'odd-P u16 N={N}')
