@@ -1006,16 +1006,18 @@ __device__ __forceinline__ void net_from_pk16(uint32_t (&v)[NP])
     }
 }
 
-// v[idx] for a wave-uniform idx: binary search with scalar branches, static register indices at the leaves
+// v[LO + rel] for rel in [0, LEN): select tree with static register indices (a branchy binary search over the
+// registers gets turned into a run-time indexed array by the compiler, i.e. the column is demoted to scratch).
 template <int LO, int LEN, int NP>
-__device__ __forceinline__ uint32_t pick_uniform(const uint32_t (&v)[NP], int idx)
+__device__ __forceinline__ uint32_t pick_rel_u32(const uint32_t (&v)[NP], int rel)
 {
     if constexpr (LEN == 1) {
         return v[LO];
     } else {
         constexpr int H = LEN / 2;
-        if (idx < LO + H) return pick_uniform<LO, H, NP>(v, idx);
-        return pick_uniform<LO + H, LEN - H, NP>(v, idx);
+        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
+        const uint32_t hi = pick_rel_u32<LO + H, H, NP>(v, rel);
+        return (rel & H) ? hi : lo;
     }
 }
 
@@ -1068,7 +1070,8 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
         }
         if constexpr (NP > 1) net_from_pk16<NP, 0>(w);
         const int i1 = FULL ? (NP - 1) >> 1 : (N - 1) >> 1, i2 = FULL ? NP >> 1 : N >> 1;
-        const uint32_t m1 = pick_uniform<0, NP, NP>(w, i1), m2 = pick_uniform<0, NP, NP>(w, i2);
+        const uint32_t m1 = FULL ? w[(NP - 1) >> 1] : pick_rel_u32<0, NP, NP>(w, i1);
+        const uint32_t m2 = FULL ? w[NP >> 1] : pick_rel_u32<0, NP, NP>(w, i2);
         float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
         bool dodiv[2] = {false, false};
         const float e = CALIB ? fs.e[0] : 0.f;
@@ -1107,7 +1110,9 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
             const int64_t p = base + lane;
             if (p >= prm.P) break;
             float v[NP];
-            const int n = load_column<NP, uint16_t, CALIB, false, FULL>(prm, fs, base, lane, v);
+            StackParams q = prm;
+            asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
+            const int n = load_column<NP, uint16_t, CALIB, false, FULL>(q, fs, base, lane, v);
             sort_column<NP>(v);
             const float m1 = pick_at<NP>(v, (n - 1) >> 1);
             const float m2 = pick_at<NP>(v, n >> 1);
@@ -1187,7 +1192,7 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
 // the survivors are summed in sorted order in both.
 // -------------------------------------------------------------------------------------------------
 template <int NP, bool CALIB, bool FULL>
-__global__ __launch_bounds__(256, NP <= 64 ? 2 : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
+__global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
 {
     __shared__ FrameScalars<NP> fs;
     const int lane = threadIdx.x;
@@ -1208,7 +1213,9 @@ __global__ __launch_bounds__(256, NP <= 64 ? 2 : 1) void stack_sigclip_u16_pairs
             const int64_t p = base + lane;
             if (p >= prm.P) break;
             float v[NP];
-            const int n = load_column<NP, uint16_t, CALIB, true, FULL>(prm, fs, base, lane, v);
+            StackParams q = prm;
+            asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
+            const int n = load_column<NP, uint16_t, CALIB, true, FULL>(q, fs, base, lane, v);
             reduce_and_store<NP>(prm, v, n, p);
         }
         return;
