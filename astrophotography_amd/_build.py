@@ -14,9 +14,27 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip',
-           'stack_inst_f32_calib.hip', 'stack_inst_f32_plain.hip',
-           'stack_inst_u16_calib.hip', 'stack_inst_u16_plain.hip']
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip'] + [
+    'stack_inst_f32_calib_e.hip',
+    'stack_inst_f32_plain_e.hip',
+    'stack_inst_u16_calib_e.hip',
+    'stack_inst_u16_plain_e.hip',
+    'stack_inst_f32_calib_d.hip',
+    'stack_inst_f32_plain_d.hip',
+    'stack_inst_u16_calib_d.hip',
+    'stack_inst_u16_plain_d.hip',
+    'stack_inst_f32_calib_c.hip',
+    'stack_inst_f32_plain_c.hip',
+    'stack_inst_u16_calib_c.hip',
+    'stack_inst_u16_plain_c.hip',
+    'stack_inst_f32_calib_b.hip',
+    'stack_inst_f32_plain_b.hip',
+    'stack_inst_u16_calib_b.hip',
+    'stack_inst_u16_plain_b.hip',
+    'stack_inst_f32_calib_a.hip',
+    'stack_inst_f32_plain_a.hip',
+    'stack_inst_u16_calib_a.hip',
+    'stack_inst_u16_plain_a.hip']
 HEADERS = ['common.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h')]
 
 # -ffp-contract=off: the reference's NumPy expressions round after every operation, so no FMA

@@ -1,15 +1,9 @@
 // stack.hip - argument checking and dispatch for the stack reductions (kernels: stack_kernels.h,
-// instantiated per raw dtype / fused-calibration flag in stack_inst_*.hip so they build in parallel).
+// instantiated per raw dtype / fused-calibration flag / slot-count group in stack_inst_*.hip so that they
+// build in parallel).
 #include "stack_kernels.h"
 
 #include <cstdlib>
-
-namespace apgpu_stack {
-extern template int launch_np<float, true>(const StackParams &, bool, hipStream_t);
-extern template int launch_np<float, false>(const StackParams &, bool, hipStream_t);
-extern template int launch_np<uint16_t, true>(const StackParams &, bool, hipStream_t);
-extern template int launch_np<uint16_t, false>(const StackParams &, bool, hipStream_t);
-}  // namespace apgpu_stack
 
 namespace {
 using namespace apgpu;

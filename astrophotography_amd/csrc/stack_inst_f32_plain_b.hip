@@ -1,0 +1,7 @@
+// Explicit instantiation: raw dtype float, fused calibration false, slot counts 32, 48.
+#define APGPU_STACK_INSTANTIATE
+#include "stack_kernels.h"
+namespace apgpu_stack {
+template int launch_one<32, float, false>(const StackParams &, bool, hipStream_t);
+template int launch_one<48, float, false>(const StackParams &, bool, hipStream_t);
+}

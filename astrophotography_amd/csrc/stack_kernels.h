@@ -42,7 +42,9 @@ using namespace apgpu;
 #endif
 
 // -------------------------------------------------------------------------------------------------
-// Batcher odd-even merge sorting network for NP = 2^k inputs, generated at compile time.
+// Batcher odd-even merge sorting network, generated at compile time.  For NP that is not a power of two the
+// network of the next power of two is pruned to its first NP wires: the missing inputs are +inf, which never
+// move from the top wires, so every compare-exchange that touches one of them is a no-op and can be dropped.
 // -------------------------------------------------------------------------------------------------
 struct CE {
     unsigned char a, b;
@@ -54,17 +56,25 @@ struct Net {
     int n;
 };
 
+constexpr int next_pow2(int n)
+{
+    int p = 1;
+    while (p < n) p *= 2;
+    return p;
+}
+
 template <int NP>
 constexpr Net<NP> make_net()
 {
+    constexpr int P2 = next_pow2(NP);
     Net<NP> net{};
     int c = 0;
-    for (int p = 1; p < NP; p *= 2)
+    for (int p = 1; p < P2; p *= 2)
         for (int k = p; k >= 1; k /= 2)
-            for (int j = k % p; j <= NP - 1 - k; j += 2 * k) {
-                int lim = (k - 1 < NP - j - k - 1) ? k - 1 : NP - j - k - 1;
+            for (int j = k % p; j <= P2 - 1 - k; j += 2 * k) {
+                int lim = (k - 1 < P2 - j - k - 1) ? k - 1 : P2 - j - k - 1;
                 for (int i = 0; i <= lim; i++)
-                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2)) {
+                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2) && i + j + k < NP) {
                         net.ce[c].a = (unsigned char)(i + j);
                         net.ce[c].b = (unsigned char)(i + j + k);
                         c++;
@@ -118,11 +128,16 @@ __device__ __forceinline__ float pick_rel(const float (&v)[NP], int rel)
 {
     if constexpr (LEN == 1) {
         return v[LO];
-    } else {
+    } else if constexpr ((LEN & (LEN - 1)) == 0) {
         constexpr int H = LEN / 2;
         float lo = pick_rel<LO, H, NP>(v, rel);
         float hi = pick_rel<LO + H, H, NP>(v, rel);
         return (rel & H) ? hi : lo;
+    } else {
+        constexpr int H = next_pow2(LEN) / 2;               // 48 = 32 + 16, 96 = 64 + 32, 24 = 16 + 8, 12 = 8 + 4
+        float lo = pick_rel<LO, H, NP>(v, rel);
+        float hi = pick_rel<LO + H, LEN - H, NP>(v, rel - H);
+        return (rel >= H) ? hi : lo;
     }
 }
 
@@ -1013,11 +1028,16 @@ __device__ __forceinline__ uint32_t pick_rel_u32(const uint32_t (&v)[NP], int re
 {
     if constexpr (LEN == 1) {
         return v[LO];
-    } else {
+    } else if constexpr ((LEN & (LEN - 1)) == 0) {
         constexpr int H = LEN / 2;
         const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
         const uint32_t hi = pick_rel_u32<LO + H, H, NP>(v, rel);
         return (rel & H) ? hi : lo;
+    } else {
+        constexpr int H = next_pow2(LEN) / 2;
+        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
+        const uint32_t hi = pick_rel_u32<LO + H, LEN - H, NP>(v, rel - H);
+        return (rel >= H) ? hi : lo;
     }
 }
 
@@ -1327,8 +1347,8 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
         if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, prm);
         else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, prm);
     } else if (full) {
-        if constexpr (CALIB) {
-            if (prm.persistent && NP >= 2) {
+        if constexpr (CALIB && NP >= 2 && NP <= 64) {       // two columns in flight: register budget of <= 64 slots
+            if (prm.persistent) {
                 const int64_t ntiles = (prm.P + 255) / 256;
                 const int64_t gp = ntiles < 2 * kNumCU ? ntiles : 2 * kNumCU;
                 hipLaunchKernelGGL((stack_sigclip_persistent_kernel<NP, RawT>), dim3((unsigned)gp), b, 0, st, prm);
@@ -1342,16 +1362,35 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
     return check_launch("stack kernel");
 }
 
+// launch_one<NP, RawT, CALIB> is explicitly instantiated in the stack_inst_*.hip translation units (one group of
+// slot counts each, so that the build parallelises); everybody else only sees these declarations.
+#ifndef APGPU_STACK_INSTANTIATE
+#define APGPU_DECLARE_LAUNCH(NP)                                                                          \
+    extern template int launch_one<NP, float, true>(const StackParams &, bool, hipStream_t);              \
+    extern template int launch_one<NP, float, false>(const StackParams &, bool, hipStream_t);             \
+    extern template int launch_one<NP, uint16_t, true>(const StackParams &, bool, hipStream_t);           \
+    extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t);
+APGPU_DECLARE_LAUNCH(1) APGPU_DECLARE_LAUNCH(4) APGPU_DECLARE_LAUNCH(8) APGPU_DECLARE_LAUNCH(12) APGPU_DECLARE_LAUNCH(16)
+APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(96)
+APGPU_DECLARE_LAUNCH(128)
+#undef APGPU_DECLARE_LAUNCH
+#endif
+
 template <typename RawT, bool CALIB>
 int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
 {
     const int N = prm.N;
+    // slot counts: powers of two and their 3/4 points (pruned networks), so padding wastes at most a third
     if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st);
     if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st);
     if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st);
+    if (N <= 12) return launch_one<12, RawT, CALIB>(prm, median_only, st);
     if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st);
+    if (N <= 24) return launch_one<24, RawT, CALIB>(prm, median_only, st);
     if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st);
+    if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st);
     if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st);
+    if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st);
     return launch_one<128, RawT, CALIB>(prm, median_only, st);
 }
 

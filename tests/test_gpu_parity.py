@@ -559,3 +559,39 @@ def test_stack_sigclip_u16_pairs_paths(ops, apref):
         ro = ops.stack_sigclip(dev(odd, ops), sigma=3.0, maxiters=5, outputs=('mean',))
         rfo = ops.stack_sigclip(dev(odd.astype(np.float32), ops), sigma=3.0, maxiters=5, outputs=('mean',))
         assert_biteq(host(ro['mean']), host(rfo['mean']), f'odd-P u16 N={N}')
+
+
+@pytest.mark.parametrize('N', [9, 12, 20, 24, 40, 48, 70, 96])
+def test_stack_three_quarter_slot_sizes(ops, apref, N):
+    """Slot counts 12 / 24 / 48 / 96 use Batcher networks pruned to their first NP wires and non-power-of-two
+    multiplexer trees: full (N = NP) and padded stacks, lean and rich outputs, median, float32 and uint16."""
+    rng = np.random.default_rng(900 + N)
+    shape = (6, 128)
+    cube = synth_cube(rng, N, shape, nan_frac=0.01)
+    bias, dark, flat = synth_masters(rng, shape)
+    nflat = (flat / np.float32(30000.0)).astype(np.float32)
+    e = np.full(N, 0.4, np.float32)
+    cal = apref.calibrate(cube, bias, dark, nflat, e)
+    calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=dev(e, ops))
+    for cen, dv, sig, mi in (('median', 'std', 3.0, 5), ('mean', 'std', 2.5, None), ('median', 'mad_std', 5.0, 1)):
+        with np.errstate(all='ignore'):
+            ref = apref.stack_sigclip(cal, sigma=sig, maxiters=mi, cenfunc=cen, stdfunc=dv)
+        what = f'N={N} {cen}/{dv}'
+        r = ops.stack_sigclip(dev(cube, ops), sigma=sig, maxiters=mi, cenfunc=cen, stdfunc=dv, calib=calib,
+                              outputs=('mean', 'count') if dv == 'std' else ('mean', 'count', 'median', 'std'))
+        assert np.array_equal(host(r['count']), ref['count']), what
+        assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, what)
+        if 'median' in r:
+            assert_ulp(host(r['median']), ref['median'].astype(np.float32), 1, what + ' median plane')
+            assert_ulp(host(r['std']), ref['std'].astype(np.float32), 2, what + ' std plane')
+    med = ops.stack_median(dev(cube, ops), calib=calib)
+    assert_ulp(host(med), apref.stack_median(cal).astype(np.float32), 0 if N % 2 else 1, f'median N={N}')
+    u16 = synth_cube(rng, N, shape, dtype=np.uint16)
+    calu = apref.calibrate(u16, bias, dark, nflat, e)
+    with np.errstate(all='ignore'):
+        ref = apref.stack_sigclip(calu, sigma=3.0, maxiters=5)
+    r = ops.stack_sigclip(dev(u16, ops), sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
+    assert np.array_equal(host(r['count']), ref['count']), f'u16 N={N}'
+    assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, f'u16 N={N}')
+    assert_ulp(host(ops.stack_median(dev(u16, ops), calib=calib)), apref.stack_median(calu).astype(np.float32),
+               0 if N % 2 else 1, f'u16 median N={N}')
