@@ -244,16 +244,42 @@ __global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const float *__
     }
 }
 
-__global__ void flat_norm_kernel(const float *__restrict__ flat, int64_t n, const float *__restrict__ piece_sums,
-                                 const unsigned long long *__restrict__ nan_count, float *__restrict__ norm_out)
+__global__ __launch_bounds__(kBlock) void flat_norm_kernel(const float *__restrict__ flat, int64_t n,
+                                                          const float *__restrict__ piece_sums,
+                                                          const unsigned long long *__restrict__ nan_count,
+                                                          float *__restrict__ norm_out)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    // One workgroup.  The piece sums are accumulated sequentially (numpy's order) by lane 0, but all lanes fetch
+    // them - and the ragged last piece - into LDS first: a lone lane walking global memory pays a full miss
+    // latency per element.
+    if (blockIdx.x != 0) return;
+    constexpr int kStage = 2048;
+    __shared__ float stage[kPiece > kStage ? kPiece : kStage];
     const int64_t npieces_full = n / kPiece;
     float res = 0.f;
-    for (int64_t i = 0; i < npieces_full; i++) res = res + piece_sums[i];
-    int nans = 0;
+    for (int64_t i0 = 0; i0 < npieces_full; i0 += kStage) {
+        const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (; t + 8 <= cnt; t += 8) {                  // 8 LDS reads in flight, then the 8 ordered adds
+                float x[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[k] = stage[t + k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) res = res + x[k];
+            }
+            for (; t < cnt; t++) res = res + stage[t];
+        }
+        __syncthreads();
+    }
     const int rem = (int)(n - npieces_full * kPiece);
-    if (rem > 0) res = res + pairwise_generic(flat + npieces_full * kPiece, rem, nans);
+    for (int t = threadIdx.x; t < rem; t += blockDim.x) stage[t] = flat[npieces_full * kPiece + t];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int nans = 0;
+    if (rem > 0) res = res + pairwise_generic(stage, rem, nans);
     const unsigned long long bad = *nan_count + (unsigned long long)nans;
     const double cnt = (double)(n - (int64_t)bad);
     norm_out[0] = (float)((double)res / cnt);          // numpy 1.26: float32 / int -> float64 -> float32
@@ -486,7 +512,7 @@ extern "C" int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *
         hipLaunchKernelGGL(flat_piece_sums_kernel, dim3(grid), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count);
         if (int rc = check_launch("flat_piece_sums")) return rc;
     }
-    hipLaunchKernelGGL(flat_norm_kernel, dim3(1), dim3(64), 0, st, flat, n_pixels, piece_sums, nan_count, norm_out);
+    hipLaunchKernelGGL(flat_norm_kernel, dim3(1), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count, norm_out);
     if (int rc = check_launch("flat_norm")) return rc;
     if (nflat) {
         hipLaunchKernelGGL(divide_by_scalar_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, flat, norm_out, nflat,

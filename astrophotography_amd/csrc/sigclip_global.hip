@@ -534,7 +534,11 @@ __global__ void fold_kernel(const T *__restrict__ b0, const T *__restrict__ b1, 
             enumerate_leaves(ll, 0, rem);
         }
         __syncthreads();
-        const T *tail = src + npieces_full * kPiece;
+        // the ragged piece goes through LDS as well: a leaf is up to 128 elements walked by one lane
+        __shared__ T ragged[kPiece];
+        for (int t = threadIdx.x; t < rem; t += blockDim.x) ragged[t] = src[npieces_full * kPiece + t];
+        __syncthreads();
+        const T *tail = ragged;
         for (int l = threadIdx.x; l < ll.n; l += blockDim.x) leaf_vals[l] = one_leaf<SQ, T>(tail + ll.off[l], ll.len[l], mean);
         __syncthreads();
         if (threadIdx.x == 0) {
