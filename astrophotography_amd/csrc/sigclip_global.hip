@@ -250,7 +250,18 @@ __device__ __forceinline__ void for_each_value(const T *__restrict__ src, long l
     long long done = 0;
     if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
         const long long nvec = m / V;
-        for (long long i = tid; i < nvec; i += nthreads) {
+        constexpr int U = 4;                                // 4 x 16 bytes in flight per lane: these scans run with few,
+        long long i = tid;                                  // fat workgroups and are latency-bound otherwise
+        for (; i + (U - 1) * nthreads < nvec; i += U * nthreads) {
+            Vec v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = reinterpret_cast<const Vec *>(src)[i + u * nthreads];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int k = 0; k < V; k++) f(v[u].x[k]);
+        }
+        for (; i < nvec; i += nthreads) {
             const Vec v = reinterpret_cast<const Vec *>(src)[i];
 #pragma unroll
             for (int k = 0; k < V; k++) f(v.x[k]);
