@@ -1,0 +1,143 @@
+"""Randomised parity sweep (fixed seeds): many small stacks of random shape / frame count / dtype / options through
+every kernel family (lean, rich, median; one- and two-pixel-per-lane uint16 paths; full and padded slot counts;
+row stripes of a larger slab) against the oracle.  Catches dispatch and alignment corner cases."""
+import numpy as np
+import pytest
+
+from tests.util import assert_ulp, synth_cube, synth_masters
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from astrophotography_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope='module')
+def apref():
+    from oracle import apref as _a
+    return _a
+
+
+def _dev(a, ops):
+    a = np.ascontiguousarray(a)
+    return ops.to_device_u16(a) if a.dtype == np.uint16 else torch.from_numpy(a).cuda()
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_stack_configs(ops, apref, seed):
+    rng = np.random.default_rng(10_000 + seed)
+    N = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 16, 17, 23, 24, 25, 31, 32, 33, 47, 48, 49, 63, 64, 65, 95, 96, 97, 127, 128]))
+    H, W = int(rng.integers(1, 9)), int(rng.integers(1, 300))
+    u16 = bool(rng.integers(0, 2))
+    cube = synth_cube(rng, N, (H, W), nan_frac=0.0 if u16 else 0.02, dtype=np.uint16 if u16 else np.float32)
+    use_calib = bool(rng.integers(0, 4) > 0)
+    bias, dark, flat = synth_masters(rng, (H, W))
+    nflat = (flat / np.float32(30000.0)).astype(np.float32) if rng.integers(0, 3) > 0 else None
+    if nflat is not None and W > 3:
+        nflat[0, :3] = [0.0, -1.5, np.nan]
+    e_uniform = bool(rng.integers(0, 3) > 0)
+    e = np.full(N, 0.4, np.float32) if e_uniform else rng.uniform(0.2, 0.6, N).astype(np.float32)
+    sb = bool(rng.integers(0, 2))
+    if use_calib:
+        cal = apref.calibrate(cube, bias, dark, nflat, e, dark_still_biased=sb)
+        calib = dict(bias=_dev(bias, ops), dark=_dev(dark, ops), nflat=None if nflat is None else _dev(nflat, ops),
+                     exp_ratio=_dev(e, ops), dark_still_biased=sb)
+    else:
+        cal = cube.astype(np.float32)
+        calib = None
+    pixmask = (rng.random((H, W)) < 0.05).astype(np.uint8) if rng.integers(0, 2) else None
+    pm = None if pixmask is None else _dev(pixmask, ops)
+    sigma = float(rng.choice([2.0, 3.0, 5.0]))
+    maxiters = rng.choice([1, 5, None])
+    maxiters = None if maxiters is None else int(maxiters)
+    cen = str(rng.choice(['median', 'mean']))
+    dv = str(rng.choice(['std', 'std', 'mad_std']))
+    what = f'seed={seed} N={N} {H}x{W} u16={u16} calib={use_calib} flat={nflat is not None} e_uniform={e_uniform} {cen}/{dv} s={sigma} it={maxiters}'
+    with np.errstate(all='ignore'):
+        ref = apref.stack_sigclip(cal, sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv)
+    mref, nref = ref['mean'].astype(np.float32), ref['count'].copy()
+    if pixmask is not None:
+        mref[pixmask != 0] = np.nan
+        nref[pixmask != 0] = 0
+    outs = ('mean', 'count') if dv == 'std' and rng.integers(0, 2) else ('mean', 'count', 'median', 'std')
+    r = ops.stack_sigclip(_dev(cube, ops), sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv, calib=calib, pixmask=pm,
+                          outputs=outs)
+    assert np.array_equal(r['count'].cpu().numpy(), nref), what
+    assert_ulp(r['mean'].cpu().numpy(), mref, 1, what)
+    med, cnt = ops.stack_median(_dev(cube, ops), calib=calib, pixmask=pm, want_count=True)
+    mm = apref.stack_median(cal).astype(np.float32)
+    nn = (~np.isnan(cal)).sum(0).astype(np.int32)
+    if pixmask is not None:
+        mm[pixmask != 0] = np.nan
+        nn[pixmask != 0] = 0
+    assert np.array_equal(cnt.cpu().numpy(), nn), what
+    assert_ulp(med.cpu().numpy(), mm, 1, 'median ' + what)
+    # a row stripe of the slab (frame_stride > stripe pixels), as the N-shard path uses it
+    if H >= 3:
+        r0, r1 = 1, H - 1
+        sub = _dev(cube, ops)[:, r0:r1]
+        c2 = None
+        if calib is not None:
+            c2 = dict(calib)
+            for k in ('bias', 'dark', 'nflat'):
+                if c2.get(k) is not None:
+                    c2[k] = c2[k][r0:r1]
+        rs = ops.stack_sigclip(sub, sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv, calib=c2,
+                               pixmask=None if pm is None else pm[r0:r1], outputs=('mean', 'count'))
+        assert np.array_equal(rs['count'].cpu().numpy(), nref[r0:r1]), 'stripe ' + what
+        assert_ulp(rs['mean'].cpu().numpy(), mref[r0:r1], 1, 'stripe ' + what)
+
+
+def test_too_many_frames_is_refused(ops):
+    from astrophotography_amd._lib import ApGpuError
+    with pytest.raises(ApGpuError):
+        ops.stack_sigclip(torch.zeros((129, 2, 8), device='cuda'))
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_image_kernels(ops, apref, seed):
+    """Streaming / statistics kernels on random (often awkward) shapes: vector tails, sizes below one reduction
+    piece, ragged last pieces, masks that are empty or full."""
+    rng = np.random.default_rng(20_000 + seed)
+    H, W = int(rng.integers(1, 70)), int(rng.integers(1, 400))
+    N = int(rng.integers(1, 6))
+    img = rng.normal(50, 6, (H, W)).astype(np.float32)
+    img[rng.random((H, W)) < 0.01] += 500
+    bias, dark, flat = synth_masters(rng, (H, W))
+    nflat_ref, norm_ref = apref.flat_normalize(flat)
+    nflat, norm = ops.flat_normalize(_dev(flat, ops))
+    assert np.float32(norm.item()) == norm_ref and np.array_equal(nflat.cpu().numpy(), nflat_ref), (seed, H, W)
+    u16 = bool(rng.integers(0, 2))
+    raw = synth_cube(rng, N, (H, W), dtype=np.uint16 if u16 else np.float32)
+    e = rng.uniform(0.2, 0.6, N).astype(np.float32)
+    ped = rng.choice([0.0, -100.0], N).astype(np.float32) if rng.integers(0, 2) else None
+    ref = apref.calibrate(raw, bias, dark, nflat_ref, e, pedestal=ped)
+    got = ops.calibrate(_dev(raw, ops), _dev(bias, ops), _dev(dark, ops), nflat, _dev(e, ops), None if ped is None else _dev(ped, ops))
+    assert np.array_equal(got.cpu().numpy(), ref, equal_nan=True), ('calibrate', seed, H, W, N, u16)
+    # global clip + threshold mask + repair
+    st_ref = apref.sigclip_global(img, sigma=4.0, maxiters=5)
+    st = ops.sigclip_global(_dev(img, ops), sigma=4.0, maxiters=5).cpu().numpy()
+    for k, name in enumerate(('mean', 'median', 'std')):
+        assert np.float32(st[k]) == np.float32(st_ref[name]), (name, seed, H, W, st[k], st_ref[name])
+    lo, hi = apref.badpix_thresholds(st_ref['median'], st_ref['std'], 4.0)
+    mref = apref.threshold_mask(img, lo, hi)
+    mask, nbad = ops.threshold_mask(_dev(img, ops), lo, hi)
+    mref_arr = mref[0] if isinstance(mref, tuple) else mref
+    assert np.array_equal(mask.cpu().numpy(), mref_arr) and int(nbad.item()) == int(mref_arr.sum())
+    delta = int(rng.integers(1, 4))
+    fref = apref.fix_badpix(img, mref_arr, delta)
+    fgot = ops.fix_badpix(_dev(img, ops), mask, delta)
+    fref_arr = fref[0] if isinstance(fref, tuple) else fref
+    fgot_arr = fgot[0] if isinstance(fgot, tuple) else fgot
+    assert np.array_equal(fgot_arr.cpu().numpy(), fref_arr, equal_nan=True), ('fix_badpix', seed, H, W, delta)
+    # image arithmetic
+    for op in ('ADD', 'SUB', 'MUL', 'DIV'):
+        with np.errstate(all='ignore'):
+            assert np.array_equal(ops.imarith(_dev(img, ops), op, _dev(bias, ops)).cpu().numpy(), apref.imarith(img, op, bias), equal_nan=True)
