@@ -75,6 +75,7 @@ __device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
     return V.x + V.y;
 }
 
+template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const double *__restrict__ affines,
                                                              const float *__restrict__ fscale, const float *__restrict__ lut,
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const float fs = fscale ? fscale[f] : 1.0f;
     FrameView fv;
     fv.src = frames + f * (int64_t)h_in * w_in;
-    fv.mask = mask;
+    fv.mask = HAS_MASK ? mask : nullptr;
     fv.h_in = h_in;
     fv.w_in = w_in;
 
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                 // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
                 // a trip are in flight together; validity is applied afterwards
                 const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-                const bool has_mask = mask != nullptr;
+                // HAS_MASK is a template flag: as a run-time test every mask load became a branch followed by a
+                // full wait, which serialised the whole batch of loads
                 constexpr int RU = 3;
                 for (int r0 = wave; r0 < h; r0 += 4 * RU) {
                     for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
@@ -132,13 +134,14 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                             const int row = by0 + r0 + 4 * u;
                             const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
                             const float *rp = fv.src + (int64_t)rc * w_in;
-                            const uint8_t *mp = has_mask ? mask + (int64_t)rc * w_in : nullptr;
+                            const uint8_t *mp = HAS_MASK ? mask + (int64_t)rc * w_in : nullptr;
 #pragma unroll
                             for (int q = 0; q < 2; q++) {
                                 const int col = bx0 + c0 + q * kWave + lane;
                                 const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
                                 val[u][q] = rp[cc];
-                                mk[u][q] = has_mask ? mp[cc] : (uint8_t)0;
+                                if constexpr (HAS_MASK) mk[u][q] = mp[cc];
+                                else mk[u][q] = 0;
                             }
                         }
 #pragma unroll
@@ -241,7 +244,12 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
     const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "resample_affine: output too large");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(resample_affine_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)n_frames), dim3(256), 0, st, frames, mask,
-                       affines, fscale, lut, n_phases, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
+    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
+    if (mask)
+        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, fscale, lut, n_phases, out,
+                           weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
+    else
+        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, fscale, lut, n_phases, out,
+                           weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     return check_launch("resample_affine");
 }
