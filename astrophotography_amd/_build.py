@@ -35,7 +35,7 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_a.hip',
     'stack_inst_u16_calib_a.hip',
     'stack_inst_u16_plain_a.hip']
-HEADERS = ['common.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h')]
+HEADERS = ['common.h', 'stack_sort.h', 'stack_calibrate.h', 'stack_reduce.h', 'stack_kernels.h', os.path.join(ROOT, 'include', 'apgpu.h')]
 
 # -ffp-contract=off: the reference's NumPy expressions round after every operation, so no FMA
 # contraction anywhere; fused operations are written explicitly (fma()) where wanted.

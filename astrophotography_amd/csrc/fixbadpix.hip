@@ -8,7 +8,7 @@
 //   float32(a + b) / 2 through np.mean), else unchanged.  np.median returns NaN if a good value is NaN.
 // HBM traffic: 4P + P read, 4P written; the gathers hit L2 (neighbouring rows were just streamed).
 #include "common.h"
-#include "stack_kernels.h"
+#include "stack_sort.h"
 
 namespace {
 using namespace apgpu;

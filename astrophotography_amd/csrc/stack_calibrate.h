@@ -1,0 +1,214 @@
+// stack_calibrate.h - kernel parameters, per-frame scalars, column loads and the fused calibration (core/ApCalibrate.py:439-464) of the stack kernels.
+#pragma once
+#include "stack_sort.h"
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+struct StackParams {
+    const void *frames;
+    const float *bias, *dark, *nflat, *exp_ratio, *pedestal;
+    const uint8_t *pixmask;
+    float *mean, *median, *std, *moments;
+    int32_t *count;
+    int64_t P;
+    int64_t stride;         // elements between frames
+    double sl2, su2;        // sigma_lower^2, sigma_upper^2
+    int N;
+    int still_biased;
+    int center;             // 0 median, 1 mean
+    int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
+    int maxiters;           // < 0: until convergence
+    int persistent;         // use the persistent, load/compute-overlapped kernel where available
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
+
+// x / nf for a per-pixel divisor with y = RN(1 / nf) precomputed: two Newton steps on the quotient with
+// exact FMA residuals (Markstein): q0 = RN(x*y) is within 1.5 ulp, q1 is faithful, q2 = RN(x / nf)
+// provided nothing over/underflows - the caller guards the ranges and falls back to IEEE division.
+// 5 instructions instead of the 12 of the IEEE sequence (v_div_scale x2, v_rcp, 6 FMA, v_div_fmas,
+// v_div_fixup), 64 times per pixel.
+__device__ __forceinline__ float div_by_recip(float x, float nf, float y)
+{
+    const float q0 = x * y;
+    const float r0 = __builtin_fmaf(-nf, q0, x);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-nf, q1, x);
+    return __builtin_fmaf(r1, y, q1);
+}
+
+// Per-frame scalars (exposure ratio, pedestal) staged in LDS once per workgroup: as SGPR values the
+// 2*NP scalars exceed the 102-SGPR budget and get spilled to VGPR lanes; from LDS they arrive as
+// broadcast ds_read_b128 (4 frames per instruction) just before use.
+template <int NP>
+struct FrameScalars {
+    float e[NP];
+    float ped[NP];
+    float pad[NP];          // -inf for a real frame, +inf for a padding slot (f >= N): v = max(v, pad) pads a column
+};
+
+template <int NP>
+__device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, FrameScalars<NP> &fs)
+{
+    for (int t = threadIdx.x; t < NP; t += blockDim.x) {
+        const int ff = t < prm.N ? t : prm.N - 1;
+        fs.e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
+        fs.ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
+        fs.pad[t] = t < prm.N ? -__builtin_inff() : __builtin_inff();
+    }
+    __syncthreads();
+}
+
+template <int NP, typename RawT, bool FULL>
+__device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[NP])
+{
+    // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
+    const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
+    // opaque per call: the fast path and its (rare) exact fallback each load the column; sharing the NP
+    // clamped address steps between the two calls would keep 2*NP SGPRs live across the calibration
+    int nframes = prm.N;
+    if constexpr (!FULL) asm volatile("" : "+s"(nframes));
+#pragma unroll
+    for (int f = 0; f < NP; f++) {
+        raw[f] = fb[lane];
+        if (FULL || f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
+        // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
+        if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Fast calibration of a full column (N == NP): reciprocal division, no per-value fix-ups.  Returns
+// true if the lane's results are exact AND all finite; otherwise the wave redoes the column exactly.
+// Frames are processed in pairs with 2-wide vector arithmetic so that the backend emits the packed
+// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 forms: the kernel is bound by VALU issue slots (one
+// wave64 instruction per 4 cycles per SIMD) and a packed instruction retires two values per slot.
+// Each lane of a packed operation is an ordinary IEEE float32 operation, so results do not change.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int NP, typename RawT, bool HAS_PED>
+__device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[NP], float b, float D, float nf,
+                                               bool dodiv, float (&v)[NP])
+{
+    // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
+    // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
+    const float nfe = dodiv ? nf : 1.0f;
+    const float y = __fdiv_rn(1.0f, nfe);
+    const float anf = fabsf(nfe);
+    const bool nf_ok = (anf >= 0x1p-40f && anf <= 0x1p40f);
+    float mx = 0.f, mn = __builtin_inff();
+    if constexpr (NP >= 2) {
+        v2f acc = {0.f, 0.f};
+        const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NP; f += 2) {
+            v2f x = {to_f32(raw[f]), to_f32(raw[f + 1])};
+            if constexpr (HAS_PED) {
+                const v2f ped = {fs.ped[f], fs.ped[f + 1]};
+                x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
+            }                                                // which changes nothing but the sign of a -0.0 input
+            const v2f e2 = {fs.e[f], fs.e[f + 1]};
+            x = x - b2;                                      // :439
+            const v2f ds = e2 * D2;                          // :450
+            x = x - ds;                                      // :451
+            const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
+            const v2f r0 = __builtin_elementwise_fma(nf2, q0, x);
+            const v2f q1 = __builtin_elementwise_fma(r0, y2, q0);
+            const v2f r1 = __builtin_elementwise_fma(nf2, q1, x);
+            const v2f q = __builtin_elementwise_fma(r1, y2, q1);
+            v[f] = q.x;
+            v[f + 1] = q.y;
+            acc = __builtin_elementwise_fma(q, zero2, acc);  // NaN iff some value is not finite
+            mx = fmaxf(fmaxf(mx, fabsf(q.x)), fabsf(q.y));
+            mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
+        }
+        const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
+        return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
+    } else {
+        float x = to_f32(raw[0]);
+        if constexpr (HAS_PED) x = x + fs.ped[0];
+        x = x - b;
+        const float ds = fs.e[0] * D;
+        x = x - ds;
+        const float q = div_by_recip(x, nfe, y);
+        v[0] = q;
+        const float acc = __builtin_fmaf(q, 0.0f, 0.0f);
+        const bool range_ok = !dodiv || (fabsf(q) < 0x1p50f && fabsf(q) > 0x1p-50f);
+        return nf_ok && range_ok && (acc == 0.f);
+    }
+}
+
+// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
+// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
+// FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
+// wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes).
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+__device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
+                                           float (&v)[NP])
+{
+    const int N = prm.N;
+    const int64_t p = base + lane;
+    RawT raw[NP];
+    load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+    float b = 0.f, D = 0.f, nf = 1.f;
+    bool dodiv = false;
+    if constexpr (CALIB) {
+        b = prm.bias[p];
+        const float d = prm.dark[p];
+        D = prm.still_biased ? d - b : d;                    // ApCalibrate.py:440-445
+        if (prm.nflat) {
+            nf = prm.nflat[p];
+            dodiv = (nf != 0.f);                             // ApCalibrate.py:462 (NaN != 0 is True)
+        }
+    }
+    const bool skip = prm.pixmask && prm.pixmask[p];
+    if constexpr (CALIB) {
+        bool good;
+        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
+        else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
+        if (__all(good && !skip)) {
+            if constexpr (FULL) return NP;
+            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
+            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
+#pragma unroll
+            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+            return N;
+        }
+        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
+        // redo the column exactly (IEEE division), one frame at a time - no second raw[] column in flight
+    }
+    int n = 0;
+    const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
+    int nleft = N;
+    asm volatile("" : "+s"(nleft));
+#pragma unroll
+    for (int f = 0; f < NP; f++) {
+        float x;
+        if constexpr (CALIB) {
+            x = to_f32(*fp);
+            if (FULL || f + 1 < nleft) fp += prm.stride;
+        } else {
+            x = to_f32(raw[f]);
+        }
+        if constexpr (CALIB) {
+            const float e = fs.e[f];
+            const float ped = fs.ped[f];
+            if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
+            x = x - b;                                       // :439
+            const float ds = e * D;                          // :450
+            x = x - ds;                                      // :451
+            if (dodiv) x = __fdiv_rn(x, nf);                 // :463
+        }
+        bool ok;
+        if constexpr (FINITE_ONLY) ok = fabsf(x) < __builtin_inff();
+        else ok = (x == x);
+        ok = ok && (FULL || f < N) && !skip;
+        n += ok ? 1 : 0;
+        v[f] = ok ? x : __builtin_inff();
+    }
+    return n;
+}
+
+}  // namespace apgpu_stack

@@ -26,845 +26,11 @@
 // 4 per requested output plane written.  No LDS, no cross-lane traffic: the kernel is a pure
 // stream-in / reduce-in-registers / stream-out design, bounded by HBM when the VALU work hides.
 #pragma once
-#include "common.h"
-
-#include <utility>
+#include "stack_reduce.h"
 
 namespace apgpu_stack {
 
 using namespace apgpu;
-
-// zero-cost section markers in the generated assembly (tools/isa_sections.py counts instructions per section)
-#ifdef APGPU_PROFILE_SECTIONS
-#define APGPU_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; APGPU_SECTION " name); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define APGPU_MARK(name) asm volatile("; APGPU_SECTION " name)
-#endif
-
-// -------------------------------------------------------------------------------------------------
-// Batcher odd-even merge sorting network, generated at compile time.  For NP that is not a power of two the
-// network of the next power of two is pruned to its first NP wires: the missing inputs are +inf, which never
-// move from the top wires, so every compare-exchange that touches one of them is a no-op and can be dropped.
-// -------------------------------------------------------------------------------------------------
-struct CE {
-    unsigned char a, b;
-};
-
-template <int NP>
-struct Net {
-    CE ce[NP * 12 + 1]; // NP=128 needs 1471 < 1536
-    int n;
-};
-
-constexpr int next_pow2(int n)
-{
-    int p = 1;
-    while (p < n) p *= 2;
-    return p;
-}
-
-template <int NP>
-constexpr Net<NP> make_net()
-{
-    constexpr int P2 = next_pow2(NP);
-    Net<NP> net{};
-    int c = 0;
-    for (int p = 1; p < P2; p *= 2)
-        for (int k = p; k >= 1; k /= 2)
-            for (int j = k % p; j <= P2 - 1 - k; j += 2 * k) {
-                int lim = (k - 1 < P2 - j - k - 1) ? k - 1 : P2 - j - k - 1;
-                for (int i = 0; i <= lim; i++)
-                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2) && i + j + k < NP) {
-                        net.ce[c].a = (unsigned char)(i + j);
-                        net.ce[c].b = (unsigned char)(i + j + k);
-                        c++;
-                    }
-            }
-    net.n = c;
-    return net;
-}
-
-// Compare-exchange.  Written as the two machine instructions: through fminf/fmaxf the compiler has to
-// quiet possible signalling NaNs first (IEEE mode) and adds a v_max_f32 x, x, x canonicalisation per
-// network input (~120 instructions per column); the columns are NaN-free by construction here.
-__device__ __forceinline__ void cmpx(float &x, float &y)
-{
-    float lo, hi;
-    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
-    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
-    x = lo;
-    y = hi;
-}
-
-template <int NP, int BASE, int... I>
-__device__ __forceinline__ void net_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
-{
-    constexpr Net<NP> net = make_net<NP>();
-    (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
-}
-
-template <int NP, int BASE>
-__device__ __forceinline__ void net_from(float (&v)[NP])
-{
-    constexpr int total = make_net<NP>().n;
-    constexpr int CH = 64;
-    if constexpr (BASE < total) {
-        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
-        net_chunk<NP, BASE>(v, std::make_integer_sequence<int, len>{});
-        net_from<NP, BASE + len>(v);
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void sort_column(float (&v)[NP])
-{
-    if constexpr (NP > 1) net_from<NP, 0>(v);
-}
-
-// v[LO + rel] for a per-lane rel in [0, LEN): binary multiplexer tree (LEN-1 v_cndmask), static
-// register indices only (a runtime-indexed register array would be demoted to scratch memory).
-template <int LO, int LEN, int NP>
-__device__ __forceinline__ float pick_rel(const float (&v)[NP], int rel)
-{
-    if constexpr (LEN == 1) {
-        return v[LO];
-    } else if constexpr ((LEN & (LEN - 1)) == 0) {
-        constexpr int H = LEN / 2;
-        float lo = pick_rel<LO, H, NP>(v, rel);
-        float hi = pick_rel<LO + H, H, NP>(v, rel);
-        return (rel & H) ? hi : lo;
-    } else {
-        constexpr int H = next_pow2(LEN) / 2;               // 48 = 32 + 16, 96 = 64 + 32, 24 = 16 + 8, 12 = 8 + 4
-        float lo = pick_rel<LO, H, NP>(v, rel);
-        float hi = pick_rel<LO + H, LEN - H, NP>(v, rel - H);
-        return (rel >= H) ? hi : lo;
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ float pick_at(const float (&v)[NP], int idx)
-{
-    idx = idx < 0 ? 0 : (idx > NP - 1 ? NP - 1 : idx);
-    return pick_rel<0, NP, NP>(v, idx);
-}
-
-// The two middle elements v[i1], v[i2] (i2 = i1 or i1 + 1) of the survivor range.  The clip trims a
-// few values off either end, so the middle stays within a few slots of NP/2: if every lane of the
-// wave is inside the 8-slot window around NP/2 the multiplexer needs 2 x 7 selects instead of
-// 2 x (NP-1); otherwise the whole wave takes the full tree.
-// 8-slot window [4K, 4K + 8) chosen at run time by a wave-uniform K (static register indices per case).
-template <int K, int NP>
-__device__ __forceinline__ void pick_window(const float (&v)[NP], int k, int i1, int i2, float &m1, float &m2)
-{
-    if (k == K) {
-        m1 = pick_rel<4 * K, 8, NP>(v, i1 - 4 * K);
-        m2 = pick_rel<4 * K, 8, NP>(v, i2 - 4 * K);
-    } else if constexpr (4 * (K + 1) + 8 <= NP) {
-        pick_window<K + 1, NP>(v, k, i1, i2, m1, m2);
-    }
-}
-
-template <int NP>
-__device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2, float &m1, float &m2)
-{
-    if constexpr (NP <= 8) {
-        m1 = pick_at<NP>(v, i1);
-        m2 = pick_at<NP>(v, i2);
-    } else {
-        constexpr int WLO = NP / 2 - 4;
-        const bool inside = (i1 >= WLO) && (i2 < WLO + 8);
-        if (__all(inside)) {
-            m1 = pick_rel<WLO, 8, NP>(v, i1 - WLO);
-            m2 = pick_rel<WLO, 8, NP>(v, i2 - WLO);
-        } else {
-            // stacks with fewer frames than slots (or many rejected values) have their middle elsewhere:
-            // take the 8-slot window around the first lane's middle if it holds every lane's
-            int k = (__builtin_amdgcn_readfirstlane(i1) - 2) >> 2;
-            k = k < 0 ? 0 : (k > NP / 4 - 2 ? NP / 4 - 2 : k);
-            const bool inside_k = (i1 >= 4 * k) && (i2 < 4 * k + 8);
-            if (__all(inside_k)) {
-                pick_window<0, NP>(v, k, i1, i2, m1, m2);
-            } else {
-                m1 = pick_at<NP>(v, i1);
-                m2 = pick_at<NP>(v, i2);
-            }
-        }
-    }
-}
-
-// Per-lane state of the clipping loop.  Survivors are v[a .. b) of the sorted column.
-struct ClipState {
-    double S, Q;            // sum(x - c), sum((x - c)^2) over the survivors
-    double c;               // pivot
-    double cen, nn;         // centre and count the last bounds were computed with
-    double wscale;          // scale of the bound test: n (std mode, T = sigma^2 n^2 var) or 1 (mad_std mode)
-    double Tlo, Thi;        // sigma^2 * (n*Q - S^2): squared, n^2-scaled half-widths of the bounds
-    int a, b;
-};
-
-__device__ __forceinline__ bool below(const ClipState &st, double xd)
-{
-    const double w = st.wscale * (xd - st.cen);
-    return (w < 0.0) && (w * w > st.Tlo);
-}
-
-__device__ __forceinline__ bool above(const ClipState &st, double xd)
-{
-    const double w = st.wscale * (xd - st.cen);
-    return (w > 0.0) && (w * w > st.Thi);
-}
-
-// Moves a wave-uniform value into VGPRs.  The kernel arguments arrive in 40 SGPRs; whatever stays live
-// across the clipping loop is spilled to VGPR lanes and re-read (v_readlane) on every iteration, so the
-// handful of values needed inside / after the loop are parked in VGPRs once instead.
-template <typename T>
-__device__ __forceinline__ T park_in_vgpr(T x)
-{
-    asm volatile("" : "+v"(x));
-    return x;
-}
-
-// float -> double of a column element, opaque to the optimiser: without the barrier LLVM hoists and
-// CSEs the 64 conversions out of the clipping loop and keeps 64 doubles (128 VGPRs) live.
-__device__ __forceinline__ double widen(float x)
-{
-    asm volatile("" : "+v"(x));
-    return (double)x;
-}
-
-// Trim rejected values from the low end: element I, then (only if some lane still has its cut
-// above I) element I+1, ...  Static recursion keeps every register index a compile-time constant.
-template <int I, int NP>
-__device__ __forceinline__ void trim_low(const float (&v)[NP], ClipState &st, bool active)
-{
-    if constexpr (I < NP) {
-        const double xd = widen(v[I]);
-        const bool rej = active && (I >= st.a) && (I < st.b) && below(st, xd);
-        if (rej) {
-            const double d = xd - st.c;
-            st.S -= d;
-            st.Q = fma(-d, d, st.Q);
-            st.a = I + 1;
-        }
-        if (__any(active && (st.a > I))) trim_low<I + 1, NP>(v, st, active);
-    }
-}
-
-template <int I, int NP>
-__device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
-{
-    if constexpr (I >= 0) {
-        if (__any(active && (I < st.b))) {                  // padding slots above every lane's range: just step down
-            const double xd = widen(v[I]);
-            const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
-            if (rej) {
-                const double d = xd - st.c;
-                st.S -= d;
-                st.Q = fma(-d, d, st.Q);
-                st.b = I;
-            }
-        }
-        if (__any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
-    }
-}
-
-template <int I, int NP>
-__device__ __forceinline__ void readmit_low(const float (&v)[NP], ClipState &st, int &a_new)
-{
-    if constexpr (I < NP) {
-        if (__any(I < st.a)) {
-            const double xd = widen(v[I]);
-            const bool keep = (I < st.a) && !below(st, xd) && !above(st, xd);
-            if (keep) {
-                const double d = xd - st.c;
-                st.S += d;
-                st.Q = fma(d, d, st.Q);
-                a_new = a_new < I ? a_new : I;
-            }
-            readmit_low<I + 1, NP>(v, st, a_new);
-        }
-    }
-}
-
-template <int I, int NP>
-__device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new)
-{
-    if constexpr (I >= 0) {
-        if (__any(I >= st.b)) {
-            const double xd = widen(v[I]);
-            const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
-            if (keep) {
-                const double d = xd - st.c;
-                st.S += d;
-                st.Q = fma(d, d, st.Q);
-                b_new = b_new > I + 1 ? b_new : I + 1;
-            }
-            readmit_high<I - 1, NP>(v, st, n, b_new);
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// "Rich" kernels (median / std output planes, mad_std deviation): after the sort the column is parked in
-// LDS - row i holds element i of every lane's column - so that a lane reads ITS column with a run-time
-// index (one ds_read_b32, bank = lane: conflict-free) where the lean kernel needs an (NP-1)-select
-// multiplexer tree, and every later phase is a compact run-time loop over LDS instead of NP levels of
-// statically indexed code.  64 KB per workgroup (256 lanes x 64 rows, or 128 lanes x 128 rows).
-// -------------------------------------------------------------------------------------------------
-template <int NP>
-constexpr int rich_block() { return NP > 64 ? 128 : 256; }
-
-template <int NP, bool RICH>
-struct ColumnLds {
-    __device__ __forceinline__ float *lane_ptr(int) { return nullptr; }
-};
-template <int NP>
-struct ColumnLds<NP, true> {
-    float x[NP][rich_block<NP>()];
-    __device__ __forceinline__ float *lane_ptr(int lane) { return &x[0][lane]; }
-};
-
-template <int NP>
-__device__ __forceinline__ float col_read(const float *col, int i)
-{
-    i = i < 0 ? 0 : (i > NP - 1 ? NP - 1 : i);
-    return col[i * rich_block<NP>()];
-}
-
-// astropy.stats.mad_std of the survivors x[a .. b): 1.482602218505602 * median(|x - med|)
-// (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  No second sort: the column is
-// sorted, so the j+1 deviations nearest to med belong to a contiguous window [L, L+j], and the j-th order
-// statistic of the deviations is  min over L of max(|x_L - med|, |x_(L+j) - med|)  (|x - med| is convex
-// along the sorted column, so a window's largest deviation sits at one of its ends).  Windows leaving
-// [a, b) get an infinite deviation.  Every value is the exact float64 |x - med| the reference sorts.
-template <int NP>
-__device__ __forceinline__ double mad_std_window(const float *col, bool active, int a, int b, double med)
-{
-    const int n = b - a;
-    const int k1 = n > 0 ? (n - 1) >> 1 : 0;
-    const bool even = (n & 1) == 0;
-    const int bk = b - k1;                                  // L + k1 < b  <=>  L < bk
-    const float inf = __builtin_inff();
-    double m1 = __builtin_inf(), m2 = __builtin_inf();
-    double dl_prev = __builtin_inf();
-    constexpr int CH = NP >= 4 ? 4 : NP;                    // windows per trip: 2*CH LDS reads in flight
-    for (int L0 = 0; L0 < NP; L0 += CH) {
-        if (!__any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
-            dl_prev = __builtin_inf();
-            continue;
-        }
-        float xl[CH], xr[CH];
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            xl[j] = col_read<NP>(col, L0 + j);
-            xr[j] = col_read<NP>(col, L0 + j + k1);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int L = L0 + j;
-            const double dl = fabs((double)((L >= a) ? xl[j] : inf) - med);
-            const double dr = fabs((double)((L < bk) ? xr[j] : inf) - med);
-            m1 = fmin(m1, fmax(dl, dr));                    // window [L, L + k1]
-            m2 = fmin(m2, fmax(dl_prev, dr));               // window [L - 1, L + k1]
-            dl_prev = dl;
-        }
-    }
-    const double x1 = m1, x2 = even ? m2 : m1;
-    return (0.5 * (x1 + x2)) * 1.482602218505602;
-}
-
-struct StackParams {
-    const void *frames;
-    const float *bias, *dark, *nflat, *exp_ratio, *pedestal;
-    const uint8_t *pixmask;
-    float *mean, *median, *std, *moments;
-    int32_t *count;
-    int64_t P;
-    int64_t stride;         // elements between frames
-    double sl2, su2;        // sigma_lower^2, sigma_upper^2
-    int N;
-    int still_biased;
-    int center;             // 0 median, 1 mean
-    int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
-    int maxiters;           // < 0: until convergence
-    int persistent;         // use the persistent, load/compute-overlapped kernel where available
-};
-
-__device__ __forceinline__ float to_f32(float x) { return x; }
-__device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
-
-// x / nf for a per-pixel divisor with y = RN(1 / nf) precomputed: two Newton steps on the quotient with
-// exact FMA residuals (Markstein): q0 = RN(x*y) is within 1.5 ulp, q1 is faithful, q2 = RN(x / nf)
-// provided nothing over/underflows - the caller guards the ranges and falls back to IEEE division.
-// 5 instructions instead of the 12 of the IEEE sequence (v_div_scale x2, v_rcp, 6 FMA, v_div_fmas,
-// v_div_fixup), 64 times per pixel.
-__device__ __forceinline__ float div_by_recip(float x, float nf, float y)
-{
-    const float q0 = x * y;
-    const float r0 = __builtin_fmaf(-nf, q0, x);
-    const float q1 = __builtin_fmaf(r0, y, q0);
-    const float r1 = __builtin_fmaf(-nf, q1, x);
-    return __builtin_fmaf(r1, y, q1);
-}
-
-// Per-frame scalars (exposure ratio, pedestal) staged in LDS once per workgroup: as SGPR values the
-// 2*NP scalars exceed the 102-SGPR budget and get spilled to VGPR lanes; from LDS they arrive as
-// broadcast ds_read_b128 (4 frames per instruction) just before use.
-template <int NP>
-struct FrameScalars {
-    float e[NP];
-    float ped[NP];
-    float pad[NP];          // -inf for a real frame, +inf for a padding slot (f >= N): v = max(v, pad) pads a column
-};
-
-template <int NP>
-__device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, FrameScalars<NP> &fs)
-{
-    for (int t = threadIdx.x; t < NP; t += blockDim.x) {
-        const int ff = t < prm.N ? t : prm.N - 1;
-        fs.e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
-        fs.ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
-        fs.pad[t] = t < prm.N ? -__builtin_inff() : __builtin_inff();
-    }
-    __syncthreads();
-}
-
-template <int NP, typename RawT, bool FULL>
-__device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[NP])
-{
-    // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
-    const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
-    // opaque per call: the fast path and its (rare) exact fallback each load the column; sharing the NP
-    // clamped address steps between the two calls would keep 2*NP SGPRs live across the calibration
-    int nframes = prm.N;
-    if constexpr (!FULL) asm volatile("" : "+s"(nframes));
-#pragma unroll
-    for (int f = 0; f < NP; f++) {
-        raw[f] = fb[lane];
-        if (FULL || f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
-        // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
-        if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Fast calibration of a full column (N == NP): reciprocal division, no per-value fix-ups.  Returns
-// true if the lane's results are exact AND all finite; otherwise the wave redoes the column exactly.
-// Frames are processed in pairs with 2-wide vector arithmetic so that the backend emits the packed
-// v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 forms: the kernel is bound by VALU issue slots (one
-// wave64 instruction per 4 cycles per SIMD) and a packed instruction retires two values per slot.
-// Each lane of a packed operation is an ordinary IEEE float32 operation, so results do not change.
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int NP, typename RawT, bool HAS_PED>
-__device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[NP], float b, float D, float nf,
-                                               bool dodiv, float (&v)[NP])
-{
-    // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
-    // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
-    const float nfe = dodiv ? nf : 1.0f;
-    const float y = __fdiv_rn(1.0f, nfe);
-    const float anf = fabsf(nfe);
-    const bool nf_ok = (anf >= 0x1p-40f && anf <= 0x1p40f);
-    float mx = 0.f, mn = __builtin_inff();
-    if constexpr (NP >= 2) {
-        v2f acc = {0.f, 0.f};
-        const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
-#pragma unroll
-        for (int f = 0; f < NP; f += 2) {
-            v2f x = {to_f32(raw[f]), to_f32(raw[f + 1])};
-            if constexpr (HAS_PED) {
-                const v2f ped = {fs.ped[f], fs.ped[f + 1]};
-                x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
-            }                                                // which changes nothing but the sign of a -0.0 input
-            const v2f e2 = {fs.e[f], fs.e[f + 1]};
-            x = x - b2;                                      // :439
-            const v2f ds = e2 * D2;                          // :450
-            x = x - ds;                                      // :451
-            const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
-            const v2f r0 = __builtin_elementwise_fma(nf2, q0, x);
-            const v2f q1 = __builtin_elementwise_fma(r0, y2, q0);
-            const v2f r1 = __builtin_elementwise_fma(nf2, q1, x);
-            const v2f q = __builtin_elementwise_fma(r1, y2, q1);
-            v[f] = q.x;
-            v[f + 1] = q.y;
-            acc = __builtin_elementwise_fma(q, zero2, acc);  // NaN iff some value is not finite
-            mx = fmaxf(fmaxf(mx, fabsf(q.x)), fabsf(q.y));
-            mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
-        }
-        const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
-        return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
-    } else {
-        float x = to_f32(raw[0]);
-        if constexpr (HAS_PED) x = x + fs.ped[0];
-        x = x - b;
-        const float ds = fs.e[0] * D;
-        x = x - ds;
-        const float q = div_by_recip(x, nfe, y);
-        v[0] = q;
-        const float acc = __builtin_fmaf(q, 0.0f, 0.0f);
-        const bool range_ok = !dodiv || (fabsf(q) < 0x1p50f && fabsf(q) > 0x1p-50f);
-        return nf_ok && range_ok && (acc == 0.f);
-    }
-}
-
-// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
-// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
-// FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
-// wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
-__device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
-                                           float (&v)[NP])
-{
-    const int N = prm.N;
-    const int64_t p = base + lane;
-    RawT raw[NP];
-    load_raw<NP, RawT, FULL>(prm, base, lane, raw);
-    float b = 0.f, D = 0.f, nf = 1.f;
-    bool dodiv = false;
-    if constexpr (CALIB) {
-        b = prm.bias[p];
-        const float d = prm.dark[p];
-        D = prm.still_biased ? d - b : d;                    // ApCalibrate.py:440-445
-        if (prm.nflat) {
-            nf = prm.nflat[p];
-            dodiv = (nf != 0.f);                             // ApCalibrate.py:462 (NaN != 0 is True)
-        }
-    }
-    const bool skip = prm.pixmask && prm.pixmask[p];
-    if constexpr (CALIB) {
-        bool good;
-        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
-        else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
-        if (__all(good && !skip)) {
-            if constexpr (FULL) return NP;
-            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
-            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
-#pragma unroll
-            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
-            return N;
-        }
-        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
-        // redo the column exactly (IEEE division), one frame at a time - no second raw[] column in flight
-    }
-    int n = 0;
-    const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
-    int nleft = N;
-    asm volatile("" : "+s"(nleft));
-#pragma unroll
-    for (int f = 0; f < NP; f++) {
-        float x;
-        if constexpr (CALIB) {
-            x = to_f32(*fp);
-            if (FULL || f + 1 < nleft) fp += prm.stride;
-        } else {
-            x = to_f32(raw[f]);
-        }
-        if constexpr (CALIB) {
-            const float e = fs.e[f];
-            const float ped = fs.ped[f];
-            if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
-            x = x - b;                                       // :439
-            const float ds = e * D;                          // :450
-            x = x - ds;                                      // :451
-            if (dodiv) x = __fdiv_rn(x, nf);                 // :463
-        }
-        bool ok;
-        if constexpr (FINITE_ONLY) ok = fabsf(x) < __builtin_inff();
-        else ok = (x == x);
-        ok = ok && (FULL || f < N) && !skip;
-        n += ok ? 1 : 0;
-        v[f] = ok ? x : __builtin_inff();
-    }
-    return n;
-}
-
-// Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
-// the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP, bool PRESORTED = false>
-__device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
-{
-    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
-    float *const out_mean = park_in_vgpr(prm.mean);
-    int32_t *const out_count = park_in_vgpr(prm.count);
-    float *const out_moments = park_in_vgpr(prm.moments);
-    const int64_t Pn = park_in_vgpr(prm.P);
-    const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
-    const int maxiters = park_in_vgpr(prm.maxiters);
-    const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
-    APGPU_MARK("sort");
-    if constexpr (!PRESORTED) sort_column<NP>(v);           // PRESORTED: ascending, sentinels last (uint16 pair kernel)
-    APGPU_MARK("moments");
-
-    // pivot: the lower median of the finite values
-    float cf, cf2;
-    pick_middle<NP>(v, (n - 1) >> 1, (n - 1) >> 1, cf, cf2);
-    cf = n > 0 ? cf : 0.f;
-    const double c = (double)cf;
-    // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
-    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
-    if (__all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const double d = (double)v[i] - c;
-            Sa[i & 3] += d;
-            Qa[i & 3] = fma(d, d, Qa[i & 3]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            const float x = (i < n) ? v[i] : cf;
-            const double d = widen(x) - c;      // opaque: keeps this rare path from sharing (and hoisting)
-            Sa[i & 3] += d;                     // the 64 conversions of the common path above
-            Qa[i & 3] = fma(d, d, Qa[i & 3]);
-        }
-    }
-    const double S0 = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
-    const double Q0 = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
-
-    APGPU_MARK("clip_loop");
-    ClipState st;
-    st.S = S0;
-    st.Q = Q0;
-    st.c = c;
-    st.a = 0;
-    st.b = n;
-    // parameters of the last bounds computed for this lane
-    st.cen = c;
-    st.nn = (double)n;
-    st.wscale = (double)n;
-    st.Tlo = 0.0;
-    st.Thi = 0.0;
-    bool active = n > 0;
-    int it = 0;
-
-    while (__any(active)) {
-        const int a0 = st.a, b0 = st.b;
-        float m1 = 0.f, m2 = 0.f;
-        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
-        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
-        if (active) {
-            st.nn = (double)(st.b - st.a);
-            st.cen = use_median ? med : c + st.S / st.nn;
-            st.wscale = st.nn;
-            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
-            V = V > 0.0 ? V : 0.0;
-            st.Tlo = sl2 * V;
-            st.Thi = su2 * V;
-        }
-        trim_low<0, NP>(v, st, active);
-        trim_high<NP - 1, NP>(v, st, active);
-        it++;
-        const bool changed = (st.a != a0) || (st.b != b0);
-        active = active && changed && (maxiters < 0 || it < maxiters);
-    }
-
-    APGPU_MARK("readmit_output");
-    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by
-    // an earlier, tighter pass that lie inside the final bounds are re-admitted.
-    if (__any(st.a > 0)) {
-        int a_new = st.a;
-        readmit_low<0, NP>(v, st, a_new);
-        st.a = a_new;
-    }
-    if (__any(st.b < n)) {
-        int b_new = st.b;
-        readmit_high<NP - 1, NP>(v, st, n, b_new);
-        st.b = b_new;
-    }
-    const int a = st.a, b = st.b;
-    const double S = st.S, Q = st.Q;
-
-    const int cnt = b - a;
-    const double nf = (double)cnt;
-    const double nan = __builtin_nan("");
-    const double ms = S / nf;                                 // mean - c
-    if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
-    if (out_count) out_count[p] = cnt;
-    if (out_moments) {
-        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
-        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        out_moments[p] = (float)sum;                      // plane order: sum, count, sum of squares - the first
-        out_moments[Pn + p] = (float)cnt;                  // two are all a mean needs, so an N-shard exchange that
-        out_moments[2 * Pn + p] = (float)sq;               // does not want std all-reduces a contiguous [2][P] prefix
-    }
-}
-
-// Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and
-// std output planes, (c) the sorted column in LDS (see above).  Arithmetic on S / Q is performed in the
-// same order as in the lean kernel, so both produce identical mean / count / moments.
-template <int NP>
-__device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
-                                                      float *const col)
-{
-    constexpr int B = rich_block<NP>();
-    const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
-    const bool use_mad = prm.dev == APGPU_DEV_MAD_STD;
-    const double sl2 = prm.sl2, su2 = prm.su2;
-    const int maxiters = prm.maxiters;
-    sort_column<NP>(v);
-#pragma unroll
-    for (int i = 0; i < NP; i++) col[i * B] = v[i];
-
-    // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
-    const float cf = n > 0 ? col_read<NP>(col, (n - 1) >> 1) : 0.f;
-    const double c = (double)cf;
-    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const float x = (i < n) ? v[i] : cf;
-        const double d = (double)x - c;
-        Sa[i & 3] += d;
-        Qa[i & 3] = fma(d, d, Qa[i & 3]);
-    }
-    ClipState st;
-    st.S = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
-    st.Q = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
-    st.c = c;
-    st.a = 0;
-    st.b = n;
-    st.cen = c;
-    st.nn = (double)n;
-    st.wscale = (double)n;
-    st.Tlo = 0.0;
-    st.Thi = 0.0;
-    bool active = n > 0;
-    int it = 0;
-
-    while (__any(active)) {
-        const int a0 = st.a, b0 = st.b;
-        const float m1 = col_read<NP>(col, (st.a + st.b - 1) >> 1);
-        const float m2 = col_read<NP>(col, (st.a + st.b) >> 1);
-        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
-        double mad = 0.0;
-        if (use_mad) mad = mad_std_window<NP>(col, active, st.a, st.b, med);
-        if (active) {
-            st.nn = (double)(st.b - st.a);
-            st.cen = use_median ? med : c + st.S / st.nn;
-            if (use_mad) {
-                st.wscale = 1.0;
-                st.Tlo = sl2 * (mad * mad);
-                st.Thi = su2 * (mad * mad);
-            } else {
-                st.wscale = st.nn;
-                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
-                V = V > 0.0 ? V : 0.0;
-                st.Tlo = sl2 * V;
-                st.Thi = su2 * V;
-            }
-        }
-        // trim from the low end, then from the high end: every lane walks its own cursor
-        for (;;) {
-            const double xd = (double)col_read<NP>(col, st.a);
-            const bool rej = active && (st.a < st.b) && below(st, xd);
-            if (rej) {
-                const double d = xd - st.c;
-                st.S -= d;
-                st.Q = fma(-d, d, st.Q);
-                st.a++;
-            }
-            if (!__any(rej)) break;
-        }
-        for (;;) {
-            const double xd = (double)col_read<NP>(col, st.b - 1);
-            const bool rej = active && (st.a < st.b) && above(st, xd);
-            if (rej) {
-                const double d = xd - st.c;
-                st.S -= d;
-                st.Q = fma(-d, d, st.Q);
-                st.b--;
-            }
-            if (!__any(rej)) break;
-        }
-        it++;
-        const bool changed = (st.a != a0) || (st.b != b0);
-        active = active && changed && (maxiters < 0 || it < maxiters);
-    }
-
-    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by an
-    // earlier, tighter pass that lie inside the final bounds are re-admitted (ascending, then descending,
-    // like the lean kernel's chains).
-    if (__any(st.a > 0)) {
-        int a_new = st.a;
-        for (int i = 0; __any(i < st.a); i++) {
-            const double xd = (double)col_read<NP>(col, i);
-            const bool keep = (i < st.a) && !below(st, xd) && !above(st, xd);
-            if (keep) {
-                const double d = xd - st.c;
-                st.S += d;
-                st.Q = fma(d, d, st.Q);
-                a_new = a_new < i ? a_new : i;
-            }
-        }
-        st.a = a_new;
-    }
-    if (__any(st.b < n)) {
-        int b_new = st.b;
-        for (int i = NP - 1; __any(i >= st.b); i--) {
-            const double xd = (double)col_read<NP>(col, i);
-            const bool keep = (i >= st.b) && (i < n) && !below(st, xd) && !above(st, xd);
-            if (keep) {
-                const double d = xd - st.c;
-                st.S += d;
-                st.Q = fma(d, d, st.Q);
-                b_new = b_new > i + 1 ? b_new : i + 1;
-            }
-        }
-        st.b = b_new;
-    }
-    const int a = st.a, b = st.b;
-    const double S = st.S, Q = st.Q;
-    const int cnt = b - a;
-    const double nf = (double)cnt;
-    const double nan = __builtin_nan("");
-    const double ms = S / nf;                                 // mean - c
-    if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
-    if (prm.count) prm.count[p] = cnt;
-    if (prm.std) {
-        // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
-        // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
-        constexpr int CH = NP >= 8 ? 8 : NP;                  // LDS reads in flight per trip
-        double s1 = 0.0;
-        for (int i0 = 0; i0 < NP; i0 += CH) {
-            if (!__any(i0 + CH > a && i0 < b)) continue;
-            float x[CH];
-#pragma unroll
-            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                const bool in = (i0 + j >= a && i0 + j < b);
-                s1 += (double)(in ? x[j] : cf) - c;          // a rejected slot contributes exactly 0
-            }
-        }
-        const double m1 = s1 / nf;
-        double q1 = 0.0;
-        for (int i0 = 0; i0 < NP; i0 += CH) {
-            if (!__any(i0 + CH > a && i0 < b)) continue;
-            float x[CH];
-#pragma unroll
-            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
-#pragma unroll
-            for (int j = 0; j < CH; j++) {
-                const bool in = (i0 + j >= a && i0 + j < b);
-                const double dd = ((double)x[j] - c) - m1;
-                const double d = in ? dd : 0.0;
-                q1 = fma(d, d, q1);
-            }
-        }
-        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
-    }
-    if (prm.median) {
-        const float m1 = col_read<NP>(col, (a + b - 1) >> 1);
-        const float m2 = col_read<NP>(col, (a + b) >> 1);
-        prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
-    }
-    if (prm.moments) {
-        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
-        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        prm.moments[p] = (float)sum;
-        prm.moments[prm.P + p] = (float)cnt;
-        prm.moments[2 * prm.P + p] = (float)sq;
-    }
-}
 
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
 __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
@@ -993,54 +159,6 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
 // The kernel verifies the precondition itself (staged scalars, one __syncthreads_or); if it does not hold
 // the workgroup processes its 512 pixels as two ordinary 256-pixel tiles.
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cmpx_pk16(uint32_t &x, uint32_t &y)
-{
-    uint32_t lo, hi;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
-    asm("v_pk_max_u16 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
-    x = lo;
-    y = hi;
-}
-
-template <int NP, int BASE, int... I>
-__device__ __forceinline__ void net_chunk_pk16(uint32_t (&v)[NP], std::integer_sequence<int, I...>)
-{
-    constexpr Net<NP> net = make_net<NP>();
-    (cmpx_pk16(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
-}
-
-template <int NP, int BASE>
-__device__ __forceinline__ void net_from_pk16(uint32_t (&v)[NP])
-{
-    constexpr int total = make_net<NP>().n;
-    constexpr int CH = 64;
-    if constexpr (BASE < total) {
-        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
-        net_chunk_pk16<NP, BASE>(v, std::make_integer_sequence<int, len>{});
-        net_from_pk16<NP, BASE + len>(v);
-    }
-}
-
-// v[LO + rel] for rel in [0, LEN): select tree with static register indices (a branchy binary search over the
-// registers gets turned into a run-time indexed array by the compiler, i.e. the column is demoted to scratch).
-template <int LO, int LEN, int NP>
-__device__ __forceinline__ uint32_t pick_rel_u32(const uint32_t (&v)[NP], int rel)
-{
-    if constexpr (LEN == 1) {
-        return v[LO];
-    } else if constexpr ((LEN & (LEN - 1)) == 0) {
-        constexpr int H = LEN / 2;
-        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
-        const uint32_t hi = pick_rel_u32<LO + H, H, NP>(v, rel);
-        return (rel & H) ? hi : lo;
-    } else {
-        constexpr int H = next_pow2(LEN) / 2;
-        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
-        const uint32_t hi = pick_rel_u32<LO + H, LEN - H, NP>(v, rel - H);
-        return (rel >= H) ? hi : lo;
-    }
-}
-
 template <bool CALIB>
 __device__ __forceinline__ float calibrate_exact_u16(unsigned raw, float b, float D, float e, float nf, bool dodiv)
 {

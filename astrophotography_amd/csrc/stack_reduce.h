@@ -1,0 +1,479 @@
+// stack_reduce.h - per-pixel sigma-clipped reduction of a sorted column: clip state and trim chains, the lean (register) and rich (LDS)
+// reductions (astropy sigma_clipping.py:298-383, 924-937; mad_std funcs.py:844-850).
+#pragma once
+#include "stack_calibrate.h"
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+// Per-lane state of the clipping loop.  Survivors are v[a .. b) of the sorted column.
+struct ClipState {
+    double S, Q;            // sum(x - c), sum((x - c)^2) over the survivors
+    double c;               // pivot
+    double cen, nn;         // centre and count the last bounds were computed with
+    double wscale;          // scale of the bound test: n (std mode, T = sigma^2 n^2 var) or 1 (mad_std mode)
+    double Tlo, Thi;        // sigma^2 * (n*Q - S^2): squared, n^2-scaled half-widths of the bounds
+    int a, b;
+};
+
+__device__ __forceinline__ bool below(const ClipState &st, double xd)
+{
+    const double w = st.wscale * (xd - st.cen);
+    return (w < 0.0) && (w * w > st.Tlo);
+}
+
+__device__ __forceinline__ bool above(const ClipState &st, double xd)
+{
+    const double w = st.wscale * (xd - st.cen);
+    return (w > 0.0) && (w * w > st.Thi);
+}
+
+// Moves a wave-uniform value into VGPRs.  The kernel arguments arrive in 40 SGPRs; whatever stays live
+// across the clipping loop is spilled to VGPR lanes and re-read (v_readlane) on every iteration, so the
+// handful of values needed inside / after the loop are parked in VGPRs once instead.
+template <typename T>
+__device__ __forceinline__ T park_in_vgpr(T x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// float -> double of a column element, opaque to the optimiser: without the barrier LLVM hoists and
+// CSEs the 64 conversions out of the clipping loop and keeps 64 doubles (128 VGPRs) live.
+__device__ __forceinline__ double widen(float x)
+{
+    asm volatile("" : "+v"(x));
+    return (double)x;
+}
+
+// Trim rejected values from the low end: element I, then (only if some lane still has its cut
+// above I) element I+1, ...  Static recursion keeps every register index a compile-time constant.
+template <int I, int NP>
+__device__ __forceinline__ void trim_low(const float (&v)[NP], ClipState &st, bool active)
+{
+    if constexpr (I < NP) {
+        const double xd = widen(v[I]);
+        const bool rej = active && (I >= st.a) && (I < st.b) && below(st, xd);
+        if (rej) {
+            const double d = xd - st.c;
+            st.S -= d;
+            st.Q = fma(-d, d, st.Q);
+            st.a = I + 1;
+        }
+        if (__any(active && (st.a > I))) trim_low<I + 1, NP>(v, st, active);
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
+{
+    if constexpr (I >= 0) {
+        if (__any(active && (I < st.b))) {                  // padding slots above every lane's range: just step down
+            const double xd = widen(v[I]);
+            const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.b = I;
+            }
+        }
+        if (__any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void readmit_low(const float (&v)[NP], ClipState &st, int &a_new)
+{
+    if constexpr (I < NP) {
+        if (__any(I < st.a)) {
+            const double xd = widen(v[I]);
+            const bool keep = (I < st.a) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                a_new = a_new < I ? a_new : I;
+            }
+            readmit_low<I + 1, NP>(v, st, a_new);
+        }
+    }
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new)
+{
+    if constexpr (I >= 0) {
+        if (__any(I >= st.b)) {
+            const double xd = widen(v[I]);
+            const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                b_new = b_new > I + 1 ? b_new : I + 1;
+            }
+            readmit_high<I - 1, NP>(v, st, n, b_new);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// "Rich" kernels (median / std output planes, mad_std deviation): after the sort the column is parked in
+// LDS - row i holds element i of every lane's column - so that a lane reads ITS column with a run-time
+// index (one ds_read_b32, bank = lane: conflict-free) where the lean kernel needs an (NP-1)-select
+// multiplexer tree, and every later phase is a compact run-time loop over LDS instead of NP levels of
+// statically indexed code.  64 KB per workgroup (256 lanes x 64 rows, or 128 lanes x 128 rows).
+// -------------------------------------------------------------------------------------------------
+template <int NP>
+constexpr int rich_block() { return NP > 64 ? 128 : 256; }
+
+template <int NP, bool RICH>
+struct ColumnLds {
+    __device__ __forceinline__ float *lane_ptr(int) { return nullptr; }
+};
+template <int NP>
+struct ColumnLds<NP, true> {
+    float x[NP][rich_block<NP>()];
+    __device__ __forceinline__ float *lane_ptr(int lane) { return &x[0][lane]; }
+};
+
+template <int NP>
+__device__ __forceinline__ float col_read(const float *col, int i)
+{
+    i = i < 0 ? 0 : (i > NP - 1 ? NP - 1 : i);
+    return col[i * rich_block<NP>()];
+}
+
+// astropy.stats.mad_std of the survivors x[a .. b): 1.482602218505602 * median(|x - med|)
+// (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  No second sort: the column is
+// sorted, so the j+1 deviations nearest to med belong to a contiguous window [L, L+j], and the j-th order
+// statistic of the deviations is  min over L of max(|x_L - med|, |x_(L+j) - med|)  (|x - med| is convex
+// along the sorted column, so a window's largest deviation sits at one of its ends).  Windows leaving
+// [a, b) get an infinite deviation.  Every value is the exact float64 |x - med| the reference sorts.
+template <int NP>
+__device__ __forceinline__ double mad_std_window(const float *col, bool active, int a, int b, double med)
+{
+    const int n = b - a;
+    const int k1 = n > 0 ? (n - 1) >> 1 : 0;
+    const bool even = (n & 1) == 0;
+    const int bk = b - k1;                                  // L + k1 < b  <=>  L < bk
+    const float inf = __builtin_inff();
+    double m1 = __builtin_inf(), m2 = __builtin_inf();
+    double dl_prev = __builtin_inf();
+    constexpr int CH = NP >= 4 ? 4 : NP;                    // windows per trip: 2*CH LDS reads in flight
+    for (int L0 = 0; L0 < NP; L0 += CH) {
+        if (!__any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
+            dl_prev = __builtin_inf();
+            continue;
+        }
+        float xl[CH], xr[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            xl[j] = col_read<NP>(col, L0 + j);
+            xr[j] = col_read<NP>(col, L0 + j + k1);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int L = L0 + j;
+            const double dl = fabs((double)((L >= a) ? xl[j] : inf) - med);
+            const double dr = fabs((double)((L < bk) ? xr[j] : inf) - med);
+            m1 = fmin(m1, fmax(dl, dr));                    // window [L, L + k1]
+            m2 = fmin(m2, fmax(dl_prev, dr));               // window [L - 1, L + k1]
+            dl_prev = dl;
+        }
+    }
+    const double x1 = m1, x2 = even ? m2 : m1;
+    return (0.5 * (x1 + x2)) * 1.482602218505602;
+}
+
+// Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
+// the column load is in registers: sort, moments, clipping iterations, outputs.
+template <int NP, bool PRESORTED = false>
+__device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
+{
+    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
+    float *const out_mean = park_in_vgpr(prm.mean);
+    int32_t *const out_count = park_in_vgpr(prm.count);
+    float *const out_moments = park_in_vgpr(prm.moments);
+    const int64_t Pn = park_in_vgpr(prm.P);
+    const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
+    const int maxiters = park_in_vgpr(prm.maxiters);
+    const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
+    APGPU_MARK("sort");
+    if constexpr (!PRESORTED) sort_column<NP>(v);           // PRESORTED: ascending, sentinels last (uint16 pair kernel)
+    APGPU_MARK("moments");
+
+    // pivot: the lower median of the finite values
+    float cf, cf2;
+    pick_middle<NP>(v, (n - 1) >> 1, (n - 1) >> 1, cf, cf2);
+    cf = n > 0 ? cf : 0.f;
+    const double c = (double)cf;
+    // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
+    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
+    if (__all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const double d = (double)v[i] - c;
+            Sa[i & 3] += d;
+            Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const float x = (i < n) ? v[i] : cf;
+            const double d = widen(x) - c;      // opaque: keeps this rare path from sharing (and hoisting)
+            Sa[i & 3] += d;                     // the 64 conversions of the common path above
+            Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        }
+    }
+    const double S0 = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+    const double Q0 = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+
+    APGPU_MARK("clip_loop");
+    ClipState st;
+    st.S = S0;
+    st.Q = Q0;
+    st.c = c;
+    st.a = 0;
+    st.b = n;
+    // parameters of the last bounds computed for this lane
+    st.cen = c;
+    st.nn = (double)n;
+    st.wscale = (double)n;
+    st.Tlo = 0.0;
+    st.Thi = 0.0;
+    bool active = n > 0;
+    int it = 0;
+
+    while (__any(active)) {
+        const int a0 = st.a, b0 = st.b;
+        float m1 = 0.f, m2 = 0.f;
+        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
+        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
+        if (active) {
+            st.nn = (double)(st.b - st.a);
+            st.cen = use_median ? med : c + st.S / st.nn;
+            st.wscale = st.nn;
+            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
+            V = V > 0.0 ? V : 0.0;
+            st.Tlo = sl2 * V;
+            st.Thi = su2 * V;
+        }
+        trim_low<0, NP>(v, st, active);
+        trim_high<NP - 1, NP>(v, st, active);
+        it++;
+        const bool changed = (st.a != a0) || (st.b != b0);
+        active = active && changed && (maxiters < 0 || it < maxiters);
+    }
+
+    APGPU_MARK("readmit_output");
+    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by
+    // an earlier, tighter pass that lie inside the final bounds are re-admitted.
+    if (__any(st.a > 0)) {
+        int a_new = st.a;
+        readmit_low<0, NP>(v, st, a_new);
+        st.a = a_new;
+    }
+    if (__any(st.b < n)) {
+        int b_new = st.b;
+        readmit_high<NP - 1, NP>(v, st, n, b_new);
+        st.b = b_new;
+    }
+    const int a = st.a, b = st.b;
+    const double S = st.S, Q = st.Q;
+
+    const int cnt = b - a;
+    const double nf = (double)cnt;
+    const double nan = __builtin_nan("");
+    const double ms = S / nf;                                 // mean - c
+    if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (out_count) out_count[p] = cnt;
+    if (out_moments) {
+        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
+        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
+        out_moments[p] = (float)sum;                      // plane order: sum, count, sum of squares - the first
+        out_moments[Pn + p] = (float)cnt;                  // two are all a mean needs, so an N-shard exchange that
+        out_moments[2 * Pn + p] = (float)sq;               // does not want std all-reduces a contiguous [2][P] prefix
+    }
+}
+
+// Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and
+// std output planes, (c) the sorted column in LDS (see above).  Arithmetic on S / Q is performed in the
+// same order as in the lean kernel, so both produce identical mean / count / moments.
+template <int NP>
+__device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
+                                                      float *const col)
+{
+    constexpr int B = rich_block<NP>();
+    const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
+    const bool use_mad = prm.dev == APGPU_DEV_MAD_STD;
+    const double sl2 = prm.sl2, su2 = prm.su2;
+    const int maxiters = prm.maxiters;
+    sort_column<NP>(v);
+#pragma unroll
+    for (int i = 0; i < NP; i++) col[i * B] = v[i];
+
+    // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
+    const float cf = n > 0 ? col_read<NP>(col, (n - 1) >> 1) : 0.f;
+    const double c = (double)cf;
+    double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const float x = (i < n) ? v[i] : cf;
+        const double d = (double)x - c;
+        Sa[i & 3] += d;
+        Qa[i & 3] = fma(d, d, Qa[i & 3]);
+    }
+    ClipState st;
+    st.S = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+    st.Q = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+    st.c = c;
+    st.a = 0;
+    st.b = n;
+    st.cen = c;
+    st.nn = (double)n;
+    st.wscale = (double)n;
+    st.Tlo = 0.0;
+    st.Thi = 0.0;
+    bool active = n > 0;
+    int it = 0;
+
+    while (__any(active)) {
+        const int a0 = st.a, b0 = st.b;
+        const float m1 = col_read<NP>(col, (st.a + st.b - 1) >> 1);
+        const float m2 = col_read<NP>(col, (st.a + st.b) >> 1);
+        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
+        double mad = 0.0;
+        if (use_mad) mad = mad_std_window<NP>(col, active, st.a, st.b, med);
+        if (active) {
+            st.nn = (double)(st.b - st.a);
+            st.cen = use_median ? med : c + st.S / st.nn;
+            if (use_mad) {
+                st.wscale = 1.0;
+                st.Tlo = sl2 * (mad * mad);
+                st.Thi = su2 * (mad * mad);
+            } else {
+                st.wscale = st.nn;
+                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
+                V = V > 0.0 ? V : 0.0;
+                st.Tlo = sl2 * V;
+                st.Thi = su2 * V;
+            }
+        }
+        // trim from the low end, then from the high end: every lane walks its own cursor
+        for (;;) {
+            const double xd = (double)col_read<NP>(col, st.a);
+            const bool rej = active && (st.a < st.b) && below(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.a++;
+            }
+            if (!__any(rej)) break;
+        }
+        for (;;) {
+            const double xd = (double)col_read<NP>(col, st.b - 1);
+            const bool rej = active && (st.a < st.b) && above(st, xd);
+            if (rej) {
+                const double d = xd - st.c;
+                st.S -= d;
+                st.Q = fma(-d, d, st.Q);
+                st.b--;
+            }
+            if (!__any(rej)) break;
+        }
+        it++;
+        const bool changed = (st.a != a0) || (st.b != b0);
+        active = active && changed && (maxiters < 0 || it < maxiters);
+    }
+
+    // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by an
+    // earlier, tighter pass that lie inside the final bounds are re-admitted (ascending, then descending,
+    // like the lean kernel's chains).
+    if (__any(st.a > 0)) {
+        int a_new = st.a;
+        for (int i = 0; __any(i < st.a); i++) {
+            const double xd = (double)col_read<NP>(col, i);
+            const bool keep = (i < st.a) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                a_new = a_new < i ? a_new : i;
+            }
+        }
+        st.a = a_new;
+    }
+    if (__any(st.b < n)) {
+        int b_new = st.b;
+        for (int i = NP - 1; __any(i >= st.b); i--) {
+            const double xd = (double)col_read<NP>(col, i);
+            const bool keep = (i >= st.b) && (i < n) && !below(st, xd) && !above(st, xd);
+            if (keep) {
+                const double d = xd - st.c;
+                st.S += d;
+                st.Q = fma(d, d, st.Q);
+                b_new = b_new > i + 1 ? b_new : i + 1;
+            }
+        }
+        st.b = b_new;
+    }
+    const int a = st.a, b = st.b;
+    const double S = st.S, Q = st.Q;
+    const int cnt = b - a;
+    const double nf = (double)cnt;
+    const double nan = __builtin_nan("");
+    const double ms = S / nf;                                 // mean - c
+    if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (prm.count) prm.count[p] = cnt;
+    if (prm.std) {
+        // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
+        // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
+        constexpr int CH = NP >= 8 ? 8 : NP;                  // LDS reads in flight per trip
+        double s1 = 0.0;
+        for (int i0 = 0; i0 < NP; i0 += CH) {
+            if (!__any(i0 + CH > a && i0 < b)) continue;
+            float x[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const bool in = (i0 + j >= a && i0 + j < b);
+                s1 += (double)(in ? x[j] : cf) - c;          // a rejected slot contributes exactly 0
+            }
+        }
+        const double m1 = s1 / nf;
+        double q1 = 0.0;
+        for (int i0 = 0; i0 < NP; i0 += CH) {
+            if (!__any(i0 + CH > a && i0 < b)) continue;
+            float x[CH];
+#pragma unroll
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+#pragma unroll
+            for (int j = 0; j < CH; j++) {
+                const bool in = (i0 + j >= a && i0 + j < b);
+                const double dd = ((double)x[j] - c) - m1;
+                const double d = in ? dd : 0.0;
+                q1 = fma(d, d, q1);
+            }
+        }
+        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
+    }
+    if (prm.median) {
+        const float m1 = col_read<NP>(col, (a + b - 1) >> 1);
+        const float m2 = col_read<NP>(col, (a + b) >> 1);
+        prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
+    }
+    if (prm.moments) {
+        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
+        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
+        prm.moments[p] = (float)sum;
+        prm.moments[prm.P + p] = (float)cnt;
+        prm.moments[2 * prm.P + p] = (float)sq;
+    }
+}
+
+}  // namespace apgpu_stack

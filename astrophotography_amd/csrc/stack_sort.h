@@ -1,0 +1,220 @@
+// stack_sort.h - compile-time sorting networks (float32 and packed uint16) and static-index multiplexers for register-resident columns.
+// Part of the stack kernels (see stack_kernels.h for the overall design).
+#pragma once
+#include "common.h"
+
+#include <utility>
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+
+// zero-cost section markers in the generated assembly (tools/isa_sections.py counts instructions per section)
+#ifdef APGPU_PROFILE_SECTIONS
+#define APGPU_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; APGPU_SECTION " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define APGPU_MARK(name) asm volatile("; APGPU_SECTION " name)
+#endif
+
+// -------------------------------------------------------------------------------------------------
+// Batcher odd-even merge sorting network, generated at compile time.  For NP that is not a power of two the
+// network of the next power of two is pruned to its first NP wires: the missing inputs are +inf, which never
+// move from the top wires, so every compare-exchange that touches one of them is a no-op and can be dropped.
+// -------------------------------------------------------------------------------------------------
+struct CE {
+    unsigned char a, b;
+};
+
+template <int NP>
+struct Net {
+    CE ce[NP * 12 + 1]; // NP=128 needs 1471 < 1536
+    int n;
+};
+
+constexpr int next_pow2(int n)
+{
+    int p = 1;
+    while (p < n) p *= 2;
+    return p;
+}
+
+template <int NP>
+constexpr Net<NP> make_net()
+{
+    constexpr int P2 = next_pow2(NP);
+    Net<NP> net{};
+    int c = 0;
+    for (int p = 1; p < P2; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= P2 - 1 - k; j += 2 * k) {
+                int lim = (k - 1 < P2 - j - k - 1) ? k - 1 : P2 - j - k - 1;
+                for (int i = 0; i <= lim; i++)
+                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2) && i + j + k < NP) {
+                        net.ce[c].a = (unsigned char)(i + j);
+                        net.ce[c].b = (unsigned char)(i + j + k);
+                        c++;
+                    }
+            }
+    net.n = c;
+    return net;
+}
+
+// Compare-exchange.  Written as the two machine instructions: through fminf/fmaxf the compiler has to
+// quiet possible signalling NaNs first (IEEE mode) and adds a v_max_f32 x, x, x canonicalisation per
+// network input (~120 instructions per column); the columns are NaN-free by construction here.
+__device__ __forceinline__ void cmpx(float &x, float &y)
+{
+    float lo, hi;
+    asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    x = lo;
+    y = hi;
+}
+
+template <int NP, int BASE, int... I>
+__device__ __forceinline__ void net_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_net<NP>();
+    (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int NP, int BASE>
+__device__ __forceinline__ void net_from(float (&v)[NP])
+{
+    constexpr int total = make_net<NP>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        net_chunk<NP, BASE>(v, std::make_integer_sequence<int, len>{});
+        net_from<NP, BASE + len>(v);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void sort_column(float (&v)[NP])
+{
+    if constexpr (NP > 1) net_from<NP, 0>(v);
+}
+
+// v[LO + rel] for a per-lane rel in [0, LEN): binary multiplexer tree (LEN-1 v_cndmask), static
+// register indices only (a runtime-indexed register array would be demoted to scratch memory).
+template <int LO, int LEN, int NP>
+__device__ __forceinline__ float pick_rel(const float (&v)[NP], int rel)
+{
+    if constexpr (LEN == 1) {
+        return v[LO];
+    } else if constexpr ((LEN & (LEN - 1)) == 0) {
+        constexpr int H = LEN / 2;
+        float lo = pick_rel<LO, H, NP>(v, rel);
+        float hi = pick_rel<LO + H, H, NP>(v, rel);
+        return (rel & H) ? hi : lo;
+    } else {
+        constexpr int H = next_pow2(LEN) / 2;               // 48 = 32 + 16, 96 = 64 + 32, 24 = 16 + 8, 12 = 8 + 4
+        float lo = pick_rel<LO, H, NP>(v, rel);
+        float hi = pick_rel<LO + H, LEN - H, NP>(v, rel - H);
+        return (rel >= H) ? hi : lo;
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ float pick_at(const float (&v)[NP], int idx)
+{
+    idx = idx < 0 ? 0 : (idx > NP - 1 ? NP - 1 : idx);
+    return pick_rel<0, NP, NP>(v, idx);
+}
+
+// The two middle elements v[i1], v[i2] (i2 = i1 or i1 + 1) of the survivor range.  The clip trims a
+// few values off either end, so the middle stays within a few slots of NP/2: if every lane of the
+// wave is inside the 8-slot window around NP/2 the multiplexer needs 2 x 7 selects instead of
+// 2 x (NP-1); otherwise the whole wave takes the full tree.
+// 8-slot window [4K, 4K + 8) chosen at run time by a wave-uniform K (static register indices per case).
+template <int K, int NP>
+__device__ __forceinline__ void pick_window(const float (&v)[NP], int k, int i1, int i2, float &m1, float &m2)
+{
+    if (k == K) {
+        m1 = pick_rel<4 * K, 8, NP>(v, i1 - 4 * K);
+        m2 = pick_rel<4 * K, 8, NP>(v, i2 - 4 * K);
+    } else if constexpr (4 * (K + 1) + 8 <= NP) {
+        pick_window<K + 1, NP>(v, k, i1, i2, m1, m2);
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2, float &m1, float &m2)
+{
+    if constexpr (NP <= 8) {
+        m1 = pick_at<NP>(v, i1);
+        m2 = pick_at<NP>(v, i2);
+    } else {
+        constexpr int WLO = NP / 2 - 4;
+        const bool inside = (i1 >= WLO) && (i2 < WLO + 8);
+        if (__all(inside)) {
+            m1 = pick_rel<WLO, 8, NP>(v, i1 - WLO);
+            m2 = pick_rel<WLO, 8, NP>(v, i2 - WLO);
+        } else {
+            // stacks with fewer frames than slots (or many rejected values) have their middle elsewhere:
+            // take the 8-slot window around the first lane's middle if it holds every lane's
+            int k = (__builtin_amdgcn_readfirstlane(i1) - 2) >> 2;
+            k = k < 0 ? 0 : (k > NP / 4 - 2 ? NP / 4 - 2 : k);
+            const bool inside_k = (i1 >= 4 * k) && (i2 < 4 * k + 8);
+            if (__all(inside_k)) {
+                pick_window<0, NP>(v, k, i1, i2, m1, m2);
+            } else {
+                m1 = pick_at<NP>(v, i1);
+                m2 = pick_at<NP>(v, i2);
+            }
+        }
+    }
+}
+
+// Packed uint16 compare-exchange network: two columns (the two halves of every register) sorted at once.
+__device__ __forceinline__ void cmpx_pk16(uint32_t &x, uint32_t &y)
+{
+    uint32_t lo, hi;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    x = lo;
+    y = hi;
+}
+
+template <int NP, int BASE, int... I>
+__device__ __forceinline__ void net_chunk_pk16(uint32_t (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_net<NP>();
+    (cmpx_pk16(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int NP, int BASE>
+__device__ __forceinline__ void net_from_pk16(uint32_t (&v)[NP])
+{
+    constexpr int total = make_net<NP>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        net_chunk_pk16<NP, BASE>(v, std::make_integer_sequence<int, len>{});
+        net_from_pk16<NP, BASE + len>(v);
+    }
+}
+
+// v[LO + rel] for rel in [0, LEN): select tree with static register indices (a branchy binary search over the
+// registers gets turned into a run-time indexed array by the compiler, i.e. the column is demoted to scratch).
+template <int LO, int LEN, int NP>
+__device__ __forceinline__ uint32_t pick_rel_u32(const uint32_t (&v)[NP], int rel)
+{
+    if constexpr (LEN == 1) {
+        return v[LO];
+    } else if constexpr ((LEN & (LEN - 1)) == 0) {
+        constexpr int H = LEN / 2;
+        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
+        const uint32_t hi = pick_rel_u32<LO + H, H, NP>(v, rel);
+        return (rel & H) ? hi : lo;
+    } else {
+        constexpr int H = next_pow2(LEN) / 2;
+        const uint32_t lo = pick_rel_u32<LO, H, NP>(v, rel);
+        const uint32_t hi = pick_rel_u32<LO + H, LEN - H, NP>(v, rel - H);
+        return (rel >= H) ? hi : lo;
+    }
+}
+
+}  // namespace apgpu_stack
