@@ -41,7 +41,7 @@ with open(dst + '/pmc_stack_kernel.csv', 'w', newline='') as fh:
 shutil.copy(src + '/summary_%s.json' % tag, dst + '/summary_%s.json' % tag)
 shutil.copy(src + '/bench_trace.json', dst + '/bench_line_under_rocprof.json')
 for name in ('bench_line.json', 'bench_c4.json', 'bench_c5.json', 'bench_collective_1rank.json', 'bench_kernels.json',
-             'bench_kernels.txt', 'bench_u16_sizes.txt'):
+             'bench_kernels.txt', 'bench_kernels_cpu.txt', 'bench_u16_sizes.txt'):
     p = os.path.join(root, 'gpurun_out', name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, name))

@@ -31,6 +31,61 @@ def timeit(fn, reps=10, warm=2, batch=1):
     return ts[len(ts) // 2], ts[0]
 
 
+def cpu_side(frames, masters, nflat, calib, rows):
+    """The oracle (the CPU restatement of the reference arithmetic, oracle/apref.c; OpenMP where it has it) on a
+    bounded sample of the same data, beside the GPU numbers: Mpixels/s of input frame-pixels for the slab kernels,
+    of image pixels for the image kernels."""
+    import numpy as np
+    from oracle import apref
+    thr = apref.num_threads()
+    rowsN = 256                                                  # sample: 64 frames x 256 rows x 4096 columns
+    raw = frames[:, :rowsN].cpu().numpy()
+    b, d, nf = masters['bias'][:rowsN].cpu().numpy(), masters['dark'][:rowsN].cpu().numpy(), nflat[:rowsN].cpu().numpy()
+    img = frames[0].cpu().numpy()
+    dark = masters['dark'].cpu().numpy()
+    bias_full = masters['bias'].cpu().numpy()
+
+    def t(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    def out(name, npix, sec, gpu_name):
+        g = next((r for r in rows if r['kernel'].startswith(gpu_name)), None)
+        gpu_rate = None
+        if g is not None:
+            gpu_pix = {True: 64 * 4096 * 4096, False: 4096 * 4096}[gpu_name.startswith(('calibrate', 'stack', 'resample'))]
+            gpu_rate = gpu_pix / (g['ms'] * 1e-3) / 1e6
+        rows.append(dict(kernel='CPU oracle: ' + name, cpu_Mpix_s=npix / sec / 1e6, threads=thr, gpu_Mpix_s=gpu_rate))
+        print('CPU %-44s %10.1f Mpix/s (%d threads)   GPU %s Mpix/s' % (name, npix / sec / 1e6, thr,
+              '%.0f' % gpu_rate if gpu_rate else '-'), flush=True)
+
+    n_in = raw.size
+    out('calibrate (A2)', n_in, t(lambda: apref.calibrate(raw, b, d, nf, synth.EXP_RATIO)), 'calibrate')
+    out('fused calibrate + clipped mean (A2+A7)', n_in, t(lambda: apref.calibrate_stack(raw, b, d, nf, synth.EXP_RATIO)), 'stack_sigclip fused, mean (A2')
+    cal = apref.calibrate(raw, b, d, nf, synth.EXP_RATIO)
+    out('clipped mean/median/std planes (A7)', n_in, t(lambda: apref.stack_sigclip(cal, sigma=3.0, maxiters=5)), 'stack_sigclip fused, mean+median')
+    out('ccdproc configuration (A6)', n_in, t(lambda: apref.combine_ccdproc(cal.astype(np.float64), 5.0, 5.0), reps=1), 'stack ccdproc')
+    out('median stack', n_in, t(lambda: apref.stack_median(cal)), 'stack_median fused (C4')
+    out('flat_normalize (A1)', img.size, t(lambda: apref.flat_normalize(masters['flat'].cpu().numpy())), 'flat_normalize')
+    out('sigclip_global (A3)', img.size, t(lambda: apref.sigclip_global(dark, sigma=4.0, maxiters=5), reps=1), 'sigclip_global')
+    st = apref.sigclip_global(dark, sigma=4.0, maxiters=5)
+    lo, hi = apref.badpix_thresholds(st['median'], st['std'], 4.0)
+    out('threshold_mask (A4)', img.size, t(lambda: apref.threshold_mask(dark, lo, hi)), 'threshold_mask')
+    m = apref.threshold_mask(dark, 5.0, 35.0)[0]
+    out('fix_badpix delta 2 (A5)', img.size, t(lambda: apref.fix_badpix(img, m, 2)), 'fix_badpix')
+    out('imarith SUB (A8)', img.size, t(lambda: apref.imarith(img, 'SUB', bias_full)), 'imarith')
+    rng = np.random.default_rng(5)
+    th = np.deg2rad(rng.uniform(-0.2, 0.2, 4))
+    A = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, 4), np.sin(th), np.cos(th), rng.uniform(-3, 3, 4)], 1)
+    f4 = frames[:4].cpu().numpy()
+    out('resample_affine Lanczos-3 (F3)', f4.size, t(lambda: apref.resample_affine(f4, A), reps=1), 'resample_affine 64')
+
+
 def main():
     H = W = 4096
     P = H * W
@@ -41,7 +96,7 @@ def main():
     calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
     rows = []
 
-    only = sys.argv[1] if len(sys.argv) > 1 else ''
+    only = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else ''
 
     def rec(name, bytes_, fn, **kw):
         if only and only not in name:
@@ -80,6 +135,8 @@ def main():
     rec('resample_affine 64x4096^2 f32, Lanczos-3 (F3)', 8 * N * P, lambda: ops.resample_affine(frames, A, out=out, weight=False), reps=5)
     rec('resample_affine + uint8 weight planes', 9 * N * P, lambda: ops.resample_affine(frames, A, out=out, weight=True), reps=5)
     del out
+    if '--cpu' in sys.argv:
+        cpu_side(frames, masters, nflat, calib, rows)
     json.dump(rows, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'bench_kernels.json'), 'w'), indent=1)
 
 
