@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restric
         }
         // kU frames per trip: all kU loads are issued before the first result is needed, which keeps
         // kU x 16 bytes per lane in flight (the loop is otherwise one outstanding load per lane).
-        constexpr int kU = 8;
+        constexpr int kU = 16;                             // 16 x 16 B per lane in flight: 1.91 -> 1.78 ms against 8 on C2
         for (int64_t f0 = 0; f0 < N; f0 += kU) {
             float x[kU][4];
 #pragma unroll
