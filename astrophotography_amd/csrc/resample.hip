@@ -181,13 +181,14 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const double xin = fma(a0, (double)x, fma(a1, (double)y, a2));
         const double yin = fma(a3, (double)x, fma(a4, (double)y, a5));
         const double fx0 = floor(xin), fy0 = floor(yin);
-        // 2 <= xin < w_in - 3  <=>  2 <= floor(xin) <= w_in - 4 (integer bounds); v_cvt_i32_f64 saturates huge
-        // values and maps NaN to 0, both of which fail the unsigned range test
-        inside[k] = (y < h_out) && (unsigned)((int)fx0 - 2) < (unsigned)(w_in - 5) && (unsigned)((int)fy0 - 2) < (unsigned)(h_in - 5);
+        // 2 <= xin < w_in - 3  <=>  2 <= floor(xin) <= w_in - 4 (integer bounds).  The clamp keeps the conversion
+        // defined for huge or NaN coordinates (fmax / fmin return the finite operand), which then fail the test.
+        const int jx = (int)fmin(fmax(fx0, -4.0), 2147483000.0), jy = (int)fmin(fmax(fy0, -4.0), 2147483000.0);
+        inside[k] = (y < h_out) && (unsigned)(jx - 2) < (unsigned)(w_in - 5) && (unsigned)(jy - 2) < (unsigned)(h_in - 5);
         const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
         const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
-        ixs[k] = inside[k] ? (int)fx0 : 0;
-        iys[k] = inside[k] ? (int)fy0 : 0;
+        ixs[k] = inside[k] ? jx : 0;
+        iys[k] = inside[k] ? jy : 0;
         wts[k] = load_weights(lut, inside[k] ? px : 0, inside[k] ? py : 0);
     }
 #pragma unroll
