@@ -6,7 +6,8 @@ filter, derives a flux scale ``FSCALE = 1/EXPOSURE`` per file (:283-312; 1.0 in 
 262-275, 330-342).  ``ApResample`` keeps that contract on the GPU for frames whose registration is a 2x3 affine
 transform per frame (output pixel -> input pixel): Lanczos-3 resampling onto the common grid
 (``ops.resample_affine``), the flux scaling, the combine, and a weight image (= number of frames that
-contributed to each pixel).  Sky projections (SWarp's TAN) are not affine over wide fields and are out of scope.
+contributed to each pixel).  Files that carry a TAN WCS (astrometry.net) are registered through the sky with one
+affine per 16 x 64 output tile (wcs.tile_affines); distortion polynomials (SIP / TPV) are not supported.
 """
 from datetime import datetime, timezone
 from pathlib import Path
@@ -40,16 +41,23 @@ class ApResample:
                 return float(hdr[kw])
         raise RuntimeError(f'Error, could not find EXPOSURE keyword in {fname}.')
 
-    def coadd_files(self, input_files, affines, output_file, weight_file=None, mask_file=None, out_shape=None):
-        """Resamples and combines FITS files.  `affines`: one [a00, a01, a02, a10, a11, a12] per file.
+    def coadd_files(self, input_files, affines, output_file, weight_file=None, mask_file=None, out_shape=None,
+                    center=None, pixscale=None):
+        """Resamples and combines FITS files.  `affines`: one [a00, a01, a02, a10, a11, a12] per file, or None to
+        register through the files' celestial WCS (RA---TAN / DEC--TAN headers, as astrometry.net writes them):
+        the output grid is then north-up TAN at `center` = (ra, dec) degrees with `pixscale` arcsec per pixel and
+        `out_shape` pixels - SWarp's -CENTER / -PIXEL_SCALE / -IMAGE_SIZE (resample_all.sh:334-338) - or, without
+        `center`, the first file's own WCS and shape.
         Flux scale per file = 1 / EXPOSURE (or EXPTIME), except 1.0 for SUM (resample_all.sh:298, 305-309)."""
         import torch
         input_files = [str(f) for f in input_files]
         if not input_files:
             raise RuntimeError('No input files to resample.')
-        affines = np.asarray(affines, dtype=np.float64).reshape(-1, 6)
-        if len(affines) != len(input_files):
-            raise RuntimeError(f'Error, {len(affines)} transforms given for {len(input_files)} files.')
+        use_wcs = affines is None
+        if not use_wcs:
+            affines = np.asarray(affines, dtype=np.float64).reshape(-1, 6)
+            if len(affines) != len(input_files):
+                raise RuntimeError(f'Error, {len(affines)} transforms given for {len(input_files)} files.')
         arrs, hdrs, fscale, texp = [], [], [], 0.0
         for f in input_files:
             data, hdr, _ = _common.read_fits(self._logger, f)
@@ -67,6 +75,19 @@ class ApResample:
             if m.shape != arrs[0].shape:
                 raise RuntimeError(f'Error, mask shape {m.shape} differs from the image shape {arrs[0].shape}.')
             mask = torch.from_numpy((np.asarray(m) != 0).astype(np.uint8)).cuda()
+        out_wcs = None
+        if use_wcs:
+            from .. import wcs as apwcs
+            in_wcs = [apwcs.TanWcs.from_header(h) for h in hdrs]
+            if center is not None:
+                if pixscale is None or out_shape is None:
+                    raise RuntimeError('Error, center needs pixscale and out_shape as well.')
+                out_wcs = apwcs.TanWcs.from_center(float(center[0]), float(center[1]), float(pixscale), out_shape)
+            else:
+                out_wcs = in_wcs[0]
+                out_shape = out_shape or arrs[0].shape
+            affines = np.stack([apwcs.tile_affines(out_wcs, w, out_shape) for w in in_wcs], 0)
+            self._logger.info(f'Registered {len(in_wcs)} files through their TAN WCS onto a {out_shape[1]}x{out_shape[0]} grid.')
         slab = torch.from_numpy(np.stack(arrs, 0)).cuda()
         res = self.coadd(slab, affines, fscale=np.asarray(fscale, np.float32), mask=mask, out_shape=out_shape)
         hdr = hdrs[0].copy()
@@ -76,6 +97,12 @@ class ApResample:
         hdr['NCOMBINE'] = (len(input_files), 'Number of frames combined')
         hdr['COMBINET'] = (self.combine, 'Co-add combine type')
         hdr['RESAMPT'] = ('LANCZOS3', 'Resampling kernel')
+        if out_wcs is not None:
+            for k in ('CD1_1', 'CD1_2', 'CD2_1', 'CD2_2', 'CDELT1', 'CDELT2', 'CROTA1', 'CROTA2', 'PC1_1', 'PC1_2', 'PC2_1', 'PC2_2'):
+                if k in hdr:
+                    del hdr[k]
+            for k, v in out_wcs.header_cards().items():
+                hdr[k] = v
         hdr['TEXPTIME'] = (texp, '[s] Total exposure of the inputs')
         if self.combine != 'SUM':
             hdr['BUNIT'] = ('adu/s', 'Pixel value units (flux scaled by 1/EXPOSURE)')

@@ -385,7 +385,8 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
     """Affine Lanczos-3 resample of [N,H,W] (or [H,W]) float32 frames onto a common grid.
 
     affines: [N,6] float64 (tensor / array / nested list): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps an
-    OUTPUT pixel (x = column, y = row) to INPUT coordinates.  fscale: per-frame flux scale (SWarp's FSCALE,
+    OUTPUT pixel (x = column, y = row) to INPUT coordinates; or [N, tiles_y, tiles_x, 6] with one transform per
+    16 x 64 output tile (wcs.tile_affines: a piecewise-affine TAN -> TAN registration).  fscale: per-frame flux scale (SWarp's FSCALE,
     1/EXPTIME in resample_all.sh:298) or None.  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
     Returns (resampled [N,h,w] float32 with NaN where undefined, weight uint8 [N,h,w] or None).  The co-add is
     stack_median / stack_sigclip on the result (both skip NaN)."""
@@ -397,11 +398,19 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
         raise ValueError('frames must be [N,H,W] or [H,W]')
     N, H, W = frames.shape
     dev = frames.device
-    aff = torch.as_tensor(affines, dtype=torch.float64).reshape(-1, 6)
-    if aff.shape[0] == 1 and N > 1:
-        aff = aff.expand(N, 6)
-    if aff.shape[0] != N:
-        raise ValueError('affines must hold one 2x3 transform per frame')
+    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
+    aff = torch.as_tensor(affines, dtype=torch.float64)
+    per_tile = aff.dim() == 4
+    if per_tile:
+        ty, tx = (h + 15) // 16, (w + 63) // 64
+        if tuple(aff.shape) != (N, ty, tx, 6):
+            raise ValueError('per-tile affines must be [N, %d, %d, 6] for a %d x %d output' % (ty, tx, h, w))
+    else:
+        aff = aff.reshape(-1, 6)
+        if aff.shape[0] == 1 and N > 1:
+            aff = aff.expand(N, 6)
+        if aff.shape[0] != N:
+            raise ValueError('affines must hold one 2x3 transform per frame')
     aff = aff.contiguous().to(dev)
     fs = None
     if fscale is not None:
@@ -417,7 +426,6 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
         if tuple(mask.shape) != (H, W):
             raise ValueError('mask must be [H,W]')
         mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
-    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
     lut = lanczos3_table(n_phases, dev)
     if out is None:
         out = torch.empty((N, h, w), dtype=torch.float32, device=dev)
@@ -425,7 +433,7 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
         raise ValueError('out must be a contiguous float32 [N,h,w] tensor')
     wt = torch.empty((N, h, w), dtype=torch.uint8, device=dev) if weight else None
     check(_lib.load().apgpu_resample_affine_f32(_ptr(frames), N, H, W, _ptr(mk) if mk is not None else None, _ptr(aff),
-                                                _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
+                                                int(per_tile), _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
                                                 _ptr(wt) if wt is not None else None, h, w, _stream()))
     return out, wt
 

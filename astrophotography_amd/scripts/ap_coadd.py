@@ -15,7 +15,10 @@ def command_line_opts(argv):
     parser = argparse.ArgumentParser(prog='ap_coadd', description='Resample registered frames onto one grid and combine them.')
     parser.add_argument('output_image', metavar='OUTPUT_IMAGE.FITS', help='Output co-added image (overwritten).')
     parser.add_argument('input_images', metavar='INPUT_IMAGE.FITS', nargs='+', help='Calibrated frames to combine.')
-    parser.add_argument('--transforms', required=True, metavar='TRANSFORMS.YML', help='Per-file 2x3 affine transforms.')
+    parser.add_argument('--transforms', default=None, metavar='TRANSFORMS.YML',
+                        help='Per-file 2x3 affine transforms. Default: register through the TAN WCS of the file headers.')
+    parser.add_argument('--center', default=None, metavar='RA,DEC', help='Output tangent point in degrees (WCS mode).')
+    parser.add_argument('--pixelscale', default=None, type=float, metavar='ARCSEC', help='Output pixel scale (WCS mode).')
     parser.add_argument('--combine', default='MEDIAN', choices=['MEDIAN', 'AVERAGE', 'WEIGHTED', 'SUM', 'CLIPPED'],
                         help='Combine type (resample_all.sh add modes 0/1/2 = MEDIAN/WEIGHTED/SUM). Default: MEDIAN')
     parser.add_argument('--weight_image', default=None, metavar='WEIGHTS.FITS', help='Optional output weight image.')
@@ -31,11 +34,14 @@ def main(args=None):
     p = command_line_opts(args)
     import yaml
     from astrophotography_amd.core.ApResample import ApResample
-    with open(p.transforms) as fh:
-        doc = yaml.safe_load(fh) or {}
-    table = doc.get('transforms') or {}
-    affines = []
-    for f in p.input_images:
+    affines = None
+    table = None
+    if p.transforms is not None:
+        with open(p.transforms) as fh:
+            doc = yaml.safe_load(fh) or {}
+        table = doc.get('transforms') or {}
+        affines = []
+    for f in (p.input_images if table is not None else []):
         key = f if f in table else os.path.basename(f)
         if key not in table:
             raise RuntimeError(f'Error, no transform for {f} in {p.transforms}.')
@@ -47,7 +53,11 @@ def main(args=None):
         nx, ny = (int(v) for v in p.image_size.split(','))
         out_shape = (ny, nx)
     rs = ApResample(p.loglevel, combine=p.combine, sigma=p.sigma, maxiters=None if p.maxiters < 0 else p.maxiters)
-    rs.coadd_files(p.input_images, affines, p.output_image, weight_file=p.weight_image, mask_file=p.badpix, out_shape=out_shape)
+    center = None
+    if p.center:
+        center = tuple(float(v) for v in p.center.split(','))
+    rs.coadd_files(p.input_images, affines, p.output_image, weight_file=p.weight_image, mask_file=p.badpix, out_shape=out_shape,
+                   center=center, pixscale=p.pixelscale)
     return 0
 
 

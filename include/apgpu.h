@@ -220,7 +220,10 @@ int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, vo
  *     (scripts/resample_all.sh:123-131 RESAMPLING_TYPE LANCZOS3; :298 FSCALE = 1/EXPTIME; :330-342 the call).
  *     frames [n_frames, h_in, w_in] float32; mask [h_in, w_in] uint8 shared by all frames, or NULL;
  *     affines [n_frames][6] float64 (device): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps OUTPUT
- *     pixel (x = column, y = row, 0-based) to INPUT coordinates; fscale [n_frames] float32 or NULL (= 1);
+ *     pixel (x = column, y = row, 0-based) to INPUT coordinates.  With affines_per_tile != 0 the array is
+ *     [n_frames][tiles_y][tiles_x][6], one transform per APGPU_RESAMPLE_TILE_H x APGPU_RESAMPLE_TILE_W tile of the
+ *     output (tiles_y = ceil(h_out / TILE_H), tiles_x = ceil(w_out / TILE_W); x, y stay absolute): a piecewise-
+ *     affine form of a smooth non-linear registration such as TAN -> TAN through the sky (wcs.tile_affines); fscale [n_frames] float32 or NULL (= 1);
  *     lut [n_phases + 1][6] float32 (device, 8-byte aligned): row p = normalised Lanczos-3 weights of the
  *     taps floor(xin)-2 .. floor(xin)+3 for the fractional offset p / n_phases (ops.lanczos3_table).
  *     out [n_frames, h_out, w_out] float32 = NaN where any of the 36 taps is outside the frame, masked or
@@ -228,9 +231,11 @@ int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, vo
  *     (COMBINE_TYPE MEDIAN / AVERAGE / SUM / CLIPPED) is apgpu_stack_median / apgpu_stack_sigclip on `out`:
  *     both skip the NaN pixels.  Exact definition: oracle/apref.c apref_resample_affine_f32.
  * ------------------------------------------------------------------------------------------- */
+#define APGPU_RESAMPLE_TILE_H 16
+#define APGPU_RESAMPLE_TILE_W 64
 int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask,
-                              const double *affines, const float *fscale, const float *lut, int32_t n_phases,
-                              float *out, uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream);
+                              const double *affines, int32_t affines_per_tile, const float *fscale, const float *lut,
+                              int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream);
 
 #ifdef __cplusplus
 }

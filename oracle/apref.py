@@ -336,15 +336,19 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
     if frames.ndim == 2:
         frames = frames[None]
     N, H, W = frames.shape
-    affines = _c(np.asarray(affines, dtype=np.float64).reshape(N, 6), np.float64)
     h, w = (H, W) if out_shape is None else out_shape
+    affines = np.asarray(affines, dtype=np.float64)
+    per_tile = affines.ndim == 4
+    affines = _c(affines if per_tile else affines.reshape(N, 6), np.float64)
+    if per_tile:
+        assert affines.shape == (N, (h + 15) // 16, (w + 63) // 64, 6)
     lut = lanczos3_table(n_phases) if lut is None else _c(lut, np.float32)
     fs = None if fscale is None else _c(np.asarray(fscale, dtype=np.float32).reshape(N), np.float32)
     mk = None if mask is None else _c(np.asarray(mask), np.uint8)
     out = np.empty((N, h, w), np.float32)
     wt = np.empty((N, h, w), np.uint8)
     rc = lib().apref_resample_affine_f32(_p(frames), C.c_long(N), C.c_long(H), C.c_long(W), _p(mk) if mk is not None else None,
-                                         _p(affines), _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases),
+                                         _p(affines), C.c_int(int(per_tile)), _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases),
                                          _p(out), _p(wt), C.c_long(h), C.c_long(w))
     assert rc == 0
     return out, wt

@@ -25,6 +25,9 @@ Fixture groups:
                     scripts/ap_combine_darks.py:394-420; ccdproc itself is absent -> unpinned)
   G7 nanmean        np.nanmean of float32 flats (pairwise float32 summation) for _generate_flat
   G8 read noise     ApImageDifference / ApCalcReadNoise      scripts/ap_calc_read_noise.py:86-688
+  G10 TAN WCS       astropy.wcs.WCS pixel <-> sky for RA---TAN / DEC--TAN headers (CD matrix, CDELT + CROTA2,
+                    CDELT + PC): pins astrophotography_amd/wcs.py, the registration input of the resample step
+                    (scripts/resample_all.sh:123-131 PROJECTION_TYPE TAN)
   G9 Bayer stamps   the known-answer tables of the reference's own RawConv.split test
                     (test/AstroPhotography/test_core.py:47-259: 14x14 R/G1/B/G2 stamps, with and without
                     black-level subtraction) - numbers only, read by calling the test class's accessor
@@ -455,12 +458,39 @@ def g9_bayer_stamps(tmp):
     save('g9_bayer_stamps.npz', **out)
 
 
+def g10_wcs(tmp):
+    from astropy.wcs import WCS
+    rng = np.random.default_rng(1010)
+    cases = [
+        dict(CTYPE1='RA---TAN', CTYPE2='DEC--TAN', CRPIX1=960.5, CRPIX2=540.5, CRVAL1=303.0272359, CRVAL2=38.3549333,
+             CD1_1=-4.9e-4, CD1_2=1.2e-5, CD2_1=1.3e-5, CD2_2=4.95e-4),
+        dict(CTYPE1='RA---TAN', CTYPE2='DEC--TAN', CRPIX1=2048.0, CRPIX2=2048.0, CRVAL1=10.68, CRVAL2=-41.27,
+             CDELT1=-2.5e-4, CDELT2=2.5e-4, CROTA2=12.5),
+        dict(CTYPE1='RA---TAN', CTYPE2='DEC--TAN', CRPIX1=100.25, CRPIX2=-20.5, CRVAL1=359.9, CRVAL2=85.0,
+             CDELT1=-5e-4, CDELT2=5e-4, PC1_1=0.8, PC1_2=-0.6, PC2_1=0.6, PC2_2=0.8),
+    ]
+    out = dict(versions=json.dumps(VERSIONS), ncases=len(cases))
+    for i, c in enumerate(cases):
+        h = fits.Header()
+        for k, v in c.items():
+            h[k] = v
+        w = WCS(h)
+        pix = np.column_stack([rng.uniform(-50, 4200, 200), rng.uniform(-50, 4200, 200)])
+        sky = w.all_pix2world(pix, 0)
+        back = w.all_world2pix(sky, 0)
+        out['hdr%d' % i] = json.dumps(c)
+        out['pix%d' % i] = pix
+        out['sky%d' % i] = sky
+        out['back%d' % i] = back
+    save('g10_wcs.npz', **out)
+
+
 if __name__ == '__main__':
     tmp = tempfile.mkdtemp(prefix='apgold_')
     try:
-        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+        which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
         for g in which:
             {'g1': g1_calibrate, 'g2': g2_findbadpix, 'g3': g3_fixbadpix, 'g4': g4_imarith,
-             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean, 'g8': g8_readnoise, 'g9': g9_bayer_stamps}[g](tmp)
+             'g5': g5_stack, 'g6': g6_madstd, 'g7': g7_nanmean, 'g8': g8_readnoise, 'g9': g9_bayer_stamps, 'g10': g10_wcs}[g](tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

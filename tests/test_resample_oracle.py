@@ -77,3 +77,21 @@ def test_frames_use_their_own_transform():
     for k in range(3):
         ok, wk = apref.resample_affine(cube[k], [A[k]], out_shape=(20, 22))
         assert np.array_equal(o[k], ok[0], equal_nan=True) and np.array_equal(w[k], wk[0])
+
+
+def test_per_tile_affines_reduce_to_per_frame():
+    rng = np.random.default_rng(2)
+    cube = rng.normal(50, 5, (2, 40, 150)).astype(np.float32)
+    A = np.array([[1.0, 0.001, 0.4, -0.001, 1.0, 0.3], [0.999, 0.0, -1.2, 0.0, 1.001, 0.8]])
+    tiles = np.broadcast_to(A[:, None, None, :], (2, 3, 3, 6)).copy()
+    o1, w1 = apref.resample_affine(cube, A)
+    o2, w2 = apref.resample_affine(cube, tiles)
+    assert np.array_equal(o1, o2, equal_nan=True) and np.array_equal(w1, w2)
+    # a different transform in one tile changes that tile only
+    tiles[0, 1, 2] = [1.0, 0.0, 2.0, 0.0, 1.0, 0.0]
+    o3, _ = apref.resample_affine(cube, tiles)
+    same = np.ones((40, 150), bool)
+    same[16:32, 128:150] = False
+    assert np.array_equal(o3[0][same], o1[0][same], equal_nan=True)
+    yy, xx = np.mgrid[16:32, 128:145]
+    assert np.array_equal(o3[0][yy, xx], cube[0][yy, xx + 2])
