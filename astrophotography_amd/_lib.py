@@ -65,8 +65,8 @@ SIGNATURES = {
     'apgpu_fits_encode_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_bayer_split_u16': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'apgpu_resample_affine_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
-                                            C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
-                                            C.c_void_p]),
+                                            C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_int64, C.c_void_p]),
 }
 
 _lib = None

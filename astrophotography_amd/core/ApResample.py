@@ -21,19 +21,20 @@ COMBINE_TYPES = ('MEDIAN', 'AVERAGE', 'WEIGHTED', 'SUM', 'CLIPPED')
 
 
 class ApResample:
-    def __init__(self, loglevel='INFO', combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024):
+    def __init__(self, loglevel='INFO', combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024, conserve_flux=True):
         self._name = 'ApResample'
         self._logger = _common.make_logger(self._name, loglevel)
         combine = str(combine).upper()
         if combine not in COMBINE_TYPES:
             raise ValueError(f'Error, combine type {combine} is not one of the allowed types: {COMBINE_TYPES}')
         self.combine, self.sigma, self.maxiters, self.n_phases = combine, sigma, maxiters, n_phases
+        self.conserve_flux = bool(conserve_flux)            # FSCALASTRO_TYPE VARIABLE (resample_all.sh:129)
 
     def coadd(self, frames, affines, fscale=None, mask=None, out_shape=None):
         """frames [N,H,W] float32 device tensor -> dict(image, count) device tensors."""
         from .. import ops
         return ops.coadd(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, combine=self.combine,
-                         sigma=self.sigma, maxiters=self.maxiters, n_phases=self.n_phases)
+                         sigma=self.sigma, maxiters=self.maxiters, n_phases=self.n_phases, conserve_flux=self.conserve_flux)
 
     def _exposure(self, hdr, fname):
         for kw in ('EXPOSURE', 'EXPTIME'):                   # same order as resample_all.sh:283-297

@@ -77,7 +77,7 @@ __device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
 
 template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
-                                                             const double *__restrict__ affines, int per_tile,
+                                                             const double *__restrict__ affines, int per_tile, int conserve_flux,
                                                              const float *__restrict__ fscale, const float *__restrict__ lut,
                                                              int n_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out)
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     // one transform per frame, or one per output tile (= per workgroup)
     const double *A = affines + 6 * (per_tile ? (f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x : f);
     const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
-    const float fs = fscale ? fscale[f] : 1.0f;
+    float fs = fscale ? fscale[f] : 1.0f;
+    if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // output pixel area in input pixels
     FrameView fv;
     fv.src = frames + f * (int64_t)h_in * w_in;
     fv.mask = HAS_MASK ? mask : nullptr;
@@ -236,9 +237,9 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
 }  // namespace
 
 extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask,
-                                         const double *affines, int32_t affines_per_tile, const float *fscale, const float *lut,
-                                         int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out, int64_t w_out,
-                                         void *stream)
+                                         const double *affines, int32_t affines_per_tile, int32_t conserve_flux,
+                                         const float *fscale, const float *lut, int32_t n_phases, float *out,
+                                         uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream)
 {
     if (!frames || !affines || !lut || !out) return fail(APGPU_EINVAL, "resample_affine: NULL pointer argument");
     if (n_frames <= 0 || n_frames > 65535) return fail(APGPU_EINVAL, "resample_affine: n_frames = %d (1..65535)", n_frames);
@@ -252,10 +253,10 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
     if (mask)
-        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, fscale, lut, n_phases, out,
+        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, n_phases, out,
                            weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     else
-        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, fscale, lut, n_phases, out,
+        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, n_phases, out,
                            weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     return check_launch("resample_affine");
 }

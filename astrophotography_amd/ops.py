@@ -381,13 +381,15 @@ def lanczos3_table(n_phases=1024, device='cuda'):
     return _LUT_CACHE[key]
 
 
-def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, out=None, weight=True):
+def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, out=None, weight=True,
+                    conserve_flux=False):
     """Affine Lanczos-3 resample of [N,H,W] (or [H,W]) float32 frames onto a common grid.
 
     affines: [N,6] float64 (tensor / array / nested list): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps an
     OUTPUT pixel (x = column, y = row) to INPUT coordinates; or [N, tiles_y, tiles_x, 6] with one transform per
     16 x 64 output tile (wcs.tile_affines: a piecewise-affine TAN -> TAN registration).  fscale: per-frame flux scale (SWarp's FSCALE,
-    1/EXPTIME in resample_all.sh:298) or None.  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
+    1/EXPTIME in resample_all.sh:298) or None.  conserve_flux: also scale by the local pixel-area ratio |det A| (SWarp's
+    FSCALASTRO_TYPE VARIABLE, resample_all.sh:129).  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
     Returns (resampled [N,h,w] float32 with NaN where undefined, weight uint8 [N,h,w] or None).  The co-add is
     stack_median / stack_sigclip on the result (both skip NaN)."""
     _need_cuda(frames)
@@ -433,15 +435,17 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
         raise ValueError('out must be a contiguous float32 [N,h,w] tensor')
     wt = torch.empty((N, h, w), dtype=torch.uint8, device=dev) if weight else None
     check(_lib.load().apgpu_resample_affine_f32(_ptr(frames), N, H, W, _ptr(mk) if mk is not None else None, _ptr(aff),
-                                                int(per_tile), _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
+                                                int(per_tile), int(bool(conserve_flux)), _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
                                                 _ptr(wt) if wt is not None else None, h, w, _stream()))
     return out, wt
 
 
-def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024):
+def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024,
+          conserve_flux=False):
     """Resample + combine: SWarp's COMBINE_TYPE MEDIAN / AVERAGE / SUM (resample_all.sh:262-275 add modes) plus
     CLIPPED (sigma-clipped mean, median-centred).  Returns dict(image, count) - count = frames contributing."""
-    res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False)
+    res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False,
+                             conserve_flux=conserve_flux)
     combine = combine.upper()
     if combine == 'MEDIAN':
         med, cnt = stack_median(res, want_count=True)

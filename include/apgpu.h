@@ -223,7 +223,9 @@ int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, vo
  *     pixel (x = column, y = row, 0-based) to INPUT coordinates.  With affines_per_tile != 0 the array is
  *     [n_frames][tiles_y][tiles_x][6], one transform per APGPU_RESAMPLE_TILE_H x APGPU_RESAMPLE_TILE_W tile of the
  *     output (tiles_y = ceil(h_out / TILE_H), tiles_x = ceil(w_out / TILE_W); x, y stay absolute): a piecewise-
- *     affine form of a smooth non-linear registration such as TAN -> TAN through the sky (wcs.tile_affines); fscale [n_frames] float32 or NULL (= 1);
+ *     affine form of a smooth non-linear registration such as TAN -> TAN through the sky (wcs.tile_affines).
+ *     conserve_flux != 0 multiplies every pixel by |A0*A4 - A1*A3|, the area of an output pixel in input pixels
+ *     (SWarp's FSCALASTRO_TYPE VARIABLE, resample_all.sh:129: total flux, not surface brightness, is preserved); fscale [n_frames] float32 or NULL (= 1);
  *     lut [n_phases + 1][6] float32 (device, 8-byte aligned): row p = normalised Lanczos-3 weights of the
  *     taps floor(xin)-2 .. floor(xin)+3 for the fractional offset p / n_phases (ops.lanczos3_table).
  *     out [n_frames, h_out, w_out] float32 = NaN where any of the 36 taps is outside the frame, masked or
@@ -234,8 +236,9 @@ int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, vo
 #define APGPU_RESAMPLE_TILE_H 16
 #define APGPU_RESAMPLE_TILE_W 64
 int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask,
-                              const double *affines, int32_t affines_per_tile, const float *fscale, const float *lut,
-                              int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream);
+                              const double *affines, int32_t affines_per_tile, int32_t conserve_flux, const float *fscale,
+                              const float *lut, int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out,
+                              int64_t w_out, void *stream);
 
 #ifdef __cplusplus
 }

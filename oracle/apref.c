@@ -770,7 +770,8 @@ void apref_set_num_threads(int n)
  *     out = NaN.  weight = 1 where out is not NaN, else 0.
  * --------------------------------------------------------------------------------------------------- */
 int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
-                              const double *affines, int per_tile, const float *fscale, const float *lut, int n_phases,
+                              const double *affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
+                              int n_phases,
                               float *out, uint8_t *weight_out, long h_out, long w_out)
 {
     if (!frames || !affines || !lut || !out || n_phases < 1) return -1;
@@ -778,11 +779,13 @@ int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, lon
     for (long f = 0; f < n_frames; f++)
         for (long y = 0; y < h_out; y++) {
             const float *src = frames + f * h_in * w_in;
-            const float fs = fscale ? fscale[f] : 1.0f;
+            const float fs0 = fscale ? fscale[f] : 1.0f;
             const long tiles_x = (w_out + 63) / 64, tiles_y = (h_out + 15) / 16;
             for (long x = 0; x < w_out; x++) {
                 /* one transform per frame, or one per 16 x 64 output tile (piecewise-affine registration) */
                 const double *A = affines + 6 * (per_tile ? (f * tiles_y + y / 16) * tiles_x + x / 64 : f);
+                /* FSCALASTRO_TYPE VARIABLE: output pixel area in input pixels */
+                const float fs = conserve_flux ? (float)((double)fs0 * fabs(fma(A[0], A[4], -(A[1] * A[3])))) : fs0;
                 const double xin = fma(A[0], (double)x, fma(A[1], (double)y, A[2]));
                 const double yin = fma(A[3], (double)x, fma(A[4], (double)y, A[5]));
                 float res = NAN;

@@ -329,7 +329,7 @@ def lanczos3_table(n_phases=1024):
     return np.ascontiguousarray(w.astype(np.float32))
 
 
-def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, lut=None):
+def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, lut=None, conserve_flux=False):
     """F3: affine Lanczos-3 resample of [N,H,W] float32 frames (definition in apref.c).  affines [N,6] float64
     map output (x, y) to input (xin, yin).  Returns (out [N,h,w] float32 with NaN where undefined, weight u8)."""
     frames = _c(np.asarray(frames), np.float32)
@@ -348,7 +348,7 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
     out = np.empty((N, h, w), np.float32)
     wt = np.empty((N, h, w), np.uint8)
     rc = lib().apref_resample_affine_f32(_p(frames), C.c_long(N), C.c_long(H), C.c_long(W), _p(mk) if mk is not None else None,
-                                         _p(affines), C.c_int(int(per_tile)), _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases),
+                                         _p(affines), C.c_int(int(per_tile)), C.c_int(int(bool(conserve_flux))), _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases),
                                          _p(out), _p(wt), C.c_long(h), C.c_long(w))
     assert rc == 0
     return out, wt

@@ -371,7 +371,7 @@ def test_apresample_files_and_script(tmp_path):
     mask = (rng.random(shape) < 0.004).astype(np.uint8)
     _wf(tmp_path / 'badpix.fits', mask)
     fs = np.array([1.0 / e for e in exps], np.float32)
-    res_ref, _ = apref.resample_affine(cube, A, fscale=fs, mask=mask)
+    res_ref, _ = apref.resample_affine(cube, A, fscale=fs, mask=mask, conserve_flux=True)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         med = np.nanmedian(res_ref.astype(np.float64), axis=0).astype(np.float32)
@@ -383,7 +383,7 @@ def test_apresample_files_and_script(tmp_path):
     assert np.array_equal(wimg, np.isfinite(res_ref).sum(0).astype(np.float32))
     assert h['NCOMBINE'] == N and h['COMBINET'] == 'MEDIAN' and h['TEXPTIME'] == sum(exps) and h['IFILE005'] == 'cal5.fits'
     # SUM mode does not flux-scale (resample_all.sh:305-309)
-    res_sum, _ = apref.resample_affine(cube, A, mask=mask)
+    res_sum, _ = apref.resample_affine(cube, A, mask=mask, conserve_flux=True)
     with open(tmp_path / 't.yml', 'w') as fh:
         yaml.safe_dump({'transforms': {f'cal{i}.fits': [float(v) for v in A[i]] for i in range(N)}}, fh)
     assert ap_coadd.main([str(tmp_path / 'sum.fits'), *names, '--transforms', str(tmp_path / 't.yml'), '--combine', 'SUM',
