@@ -231,6 +231,14 @@ def main():
         copy_gbs = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
         del src, dst
 
+    c4file = os.path.join(ROOT, 'profiles', 'r01', 'pmc_c4.json')
+    if wl == 'c4' and os.path.exists(c4file) and (N, H, W) == (64, 6248, 4176):
+        try:
+            d = json.load(open(c4file))
+            traffic = d['hbm_read_bytes_fetch_size_x2'] + d['hbm_write_bytes']
+        except Exception:
+            traffic = None
+
     line = None
     if rank == 0:
         line = {
