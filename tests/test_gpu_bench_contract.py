@@ -1,0 +1,45 @@
+"""bench.py contract: one JSON line on stdout with the agreed keys (small sizes, so this takes seconds)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--height', '256', '--width', '512',
+           '--cpu-seconds', '0.5', *extra]
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                          # exactly one line, and it is the JSON
+    return json.loads(lines[0])
+
+
+def test_default_workload_line():
+    d = _run('--frames', '16')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert d['unit'] == 'Mpixels/s' and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    rf = d['roofline']
+    assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
+    assert rf['algorithmic_bytes'] == 4 * 16 * 256 * 512 + 16 * 256 * 512 and rf['avg_launch_ms'] > 0
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
+    assert abs(d['value'] - 16 * 256 * 512 / 1e6 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+
+
+def test_other_workloads_run():
+    d = _run('--workload', 'c4', '--frames', '16', '--no-cpu-baseline')
+    assert d['dtype'] == 'u16' and 'median' in d['metric'] and 'cpu_baseline' not in d
+    d = _run('--workload', 'c5', '--frames', '4', '--no-cpu-baseline')
+    assert 'resample' in d['metric']
+    d = _run('--frames', '16', '--force-collective', '--no-cpu-baseline', '--stripes', '3')
+    assert d['n_gpus'] == 1 and d['value'] > 0
