@@ -75,9 +75,6 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
     prm.center = args->center;
     prm.dev = median_only ? 0 : args->dev;
     prm.maxiters = args->maxiters;
-    // opt-in: the persistent, load/compute-overlapped variant (not faster while the kernel is
-    // VALU-bound and the chip power-throttles, kept for when the instruction count drops further)
-    prm.persistent = getenv("APGPU_PERSISTENT") ? 1 : 0;
 #ifdef APGPU_DEVELOPMENT                                     // measurement knobs, never in a release build
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;      // all frames alias frame 0: compute-only timing
     if (const char *e = getenv("APGPU_DEBUG_MAXITERS")) prm.maxiters = atoi(e);

@@ -20,7 +20,6 @@ struct StackParams {
     int center;             // 0 median, 1 mean
     int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
     int maxiters;           // < 0: until convergence
-    int persistent;         // use the persistent, load/compute-overlapped kernel where available
 };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -62,19 +61,21 @@ __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, Fram
     __syncthreads();
 }
 
-template <int NP, typename RawT, bool FULL>
-__device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[NP])
+// F0 / CNT: the slots F0 .. F0+CNT-1 of the column (large slot counts are loaded and calibrated in two halves so that
+// only half of the raw values sit in registers next to v[]); F0 > 0 is a real frame for every N that selects this NP.
+template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP>
+__device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[CNT])
 {
     // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
-    const RawT *fb = static_cast<const RawT *>(prm.frames) + base;
+    const RawT *fb = static_cast<const RawT *>(prm.frames) + base + (int64_t)F0 * prm.stride;
     // opaque per call: the fast path and its (rare) exact fallback each load the column; sharing the NP
     // clamped address steps between the two calls would keep 2*NP SGPRs live across the calibration
     int nframes = prm.N;
     if constexpr (!FULL) asm volatile("" : "+s"(nframes));
 #pragma unroll
-    for (int f = 0; f < NP; f++) {
+    for (int f = 0; f < CNT; f++) {
         raw[f] = fb[lane];
-        if (FULL || f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
+        if (FULL || F0 + f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
         // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
         if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
@@ -88,8 +89,8 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
 // Each lane of a packed operation is an ordinary IEEE float32 operation, so results do not change.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int NP, typename RawT, bool HAS_PED>
-__device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[NP], float b, float D, float nf,
+template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP>
+__device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
                                                bool dodiv, float (&v)[NP])
 {
     // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
@@ -103,8 +104,9 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
         v2f acc = {0.f, 0.f};
         const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
 #pragma unroll
-        for (int f = 0; f < NP; f += 2) {
-            v2f x = {to_f32(raw[f]), to_f32(raw[f + 1])};
+        for (int g = 0; g < CNT; g += 2) {
+            const int f = F0 + g;
+            v2f x = {to_f32(raw[g]), to_f32(raw[g + 1])};
             if constexpr (HAS_PED) {
                 const v2f ped = {fs.ped[f], fs.ped[f + 1]};
                 x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
@@ -150,8 +152,9 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 {
     const int N = prm.N;
     const int64_t p = base + lane;
-    RawT raw[NP];
-    load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+    constexpr bool HALVES = CALIB && NP >= 112;           // 112 / 128 slots: two half columns (register budget: 2 waves/SIMD)
+    RawT raw[HALVES ? 1 : NP];
+    if constexpr (!HALVES) load_raw<NP, RawT, FULL>(prm, base, lane, raw);
     float b = 0.f, D = 0.f, nf = 1.f;
     bool dodiv = false;
     if constexpr (CALIB) {
@@ -166,8 +169,20 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
     const bool skip = prm.pixmask && prm.pixmask[p];
     if constexpr (CALIB) {
         bool good;
-        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
-        else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
+        if constexpr (HALVES) {
+            constexpr int HN = NP / 2;
+            RawT half[HN];
+            load_raw<NP, RawT, FULL, 0, HN>(prm, base, lane, half);
+            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN>(fs, half, b, D, nf, dodiv, v)
+                                : calibrate_fast<NP, RawT, false, 0, HN>(fs, half, b, D, nf, dodiv, v);
+            load_raw<NP, RawT, FULL, HN, HN>(prm, base, lane, half);
+            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN>(fs, half, b, D, nf, dodiv, v)
+                                            : calibrate_fast<NP, RawT, false, HN, HN>(fs, half, b, D, nf, dodiv, v);
+            good = good && good2;
+        } else {
+            if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
+            else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
+        }
         if (__all(good && !skip)) {
             if constexpr (FULL) return NP;
             // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with

@@ -50,83 +50,6 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
     else reduce_and_store<NP>(prm, v, n, p);
 }
 
-// Persistent form of the lean kernel for full stacks (N == NP) with fused calibration: every
-// workgroup walks over tiles of 256 pixels; as soon as the calibrated column of tile t is in v[] the
-// loads of tile t + gridDim.x are issued into the (now dead) raw registers, so the HBM-bound load
-// phase of the next tile runs underneath the VALU-bound sort / clip of the current one.  Without this
-// the two phases of co-resident workgroups stay in lockstep (identical work) and add up.
-// Register budget: raw[NP] (in flight) + v[NP] + ~50 temporaries -> 2 waves per SIMD, which is enough
-// for a kernel bound by VALU issue (one wave64 instruction per 4 cycles per SIMD).
-template <int NP, typename RawT>
-__global__ __launch_bounds__(256, 2) void stack_sigclip_persistent_kernel(const StackParams prm)
-{
-    __shared__ FrameScalars<NP> fs;
-    stage_frame_scalars<NP>(prm, fs);
-    const int lane = threadIdx.x;
-    const int64_t ntiles = (prm.P + 255) / 256;
-    int64_t tile = blockIdx.x;
-    RawT raw[NP];
-    float b = 0.f, d = 0.f, nf = 1.f;
-    const bool has_flat = prm.nflat != nullptr;
-    auto issue = [&](int64_t t) {
-        const int64_t base = t * 256;
-        int64_t pc = base + lane;
-        pc = pc < prm.P ? pc : prm.P - 1;                   // lanes past the end re-read the last pixel
-        b = prm.bias[pc];
-        d = prm.dark[pc];
-        if (has_flat) nf = prm.nflat[pc];
-        const RawT *fp = static_cast<const RawT *>(prm.frames) + pc;
-#pragma unroll
-        for (int f = 0; f < NP; f++) {
-            raw[f] = *fp;
-            fp += prm.stride;
-            if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (tile < ntiles) issue(tile);
-    while (tile < ntiles) {
-        const int64_t base = tile * 256;
-        const int64_t p = base + lane;
-        const bool valid = p < prm.P;
-        const int64_t pc = valid ? p : prm.P - 1;
-        float v[NP];
-        APGPU_MARK("p_calibrate");
-        const float D = prm.still_biased ? d - b : d;       // ApCalibrate.py:440-445
-        const bool dodiv = has_flat && (nf != 0.f);         // ApCalibrate.py:462 (NaN != 0 is True)
-        const bool skip = prm.pixmask && prm.pixmask[pc];
-        const float cb = b, cnf = nf;
-        bool good;
-        if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, cb, D, cnf, dodiv, v);
-        else good = calibrate_fast<NP, RawT, false>(fs, raw, cb, D, cnf, dodiv, v);
-        // raw[] is dead now: start the next tile's loads, they complete under the reduction below
-        const int64_t next = tile + gridDim.x;
-        if (next < ntiles) issue(next);
-        int n = NP;
-        if (!__all(good && !skip)) {
-            // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
-            // redo the column exactly (IEEE division), one frame at a time
-            n = 0;
-            const RawT *fp = static_cast<const RawT *>(prm.frames) + pc;
-#pragma unroll
-            for (int f = 0; f < NP; f++) {
-                float x = to_f32(*fp);
-                fp += prm.stride;
-                const float ped = fs.ped[f];
-                if (ped != 0.f) x = x + ped;
-                x = x - cb;
-                const float ds = fs.e[f] * D;
-                x = x - ds;
-                if (dodiv) x = __fdiv_rn(x, cnf);
-                const bool ok = (fabsf(x) < __builtin_inff()) && !skip;
-                n += ok ? 1 : 0;
-                v[f] = ok ? x : __builtin_inff();
-            }
-        }
-        if (valid) reduce_and_store<NP>(prm, v, n, p);
-        tile = next;
-    }
-}
-
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
 template <int NP, typename RawT, bool CALIB, bool FULL>
 __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm)
@@ -432,7 +355,7 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
                              reinterpret_cast<uintptr_t>(prm.nflat) | reinterpret_cast<uintptr_t>(prm.median) |
                              reinterpret_cast<uintptr_t>(prm.count)) & 7) == 0;
         const bool rich_out = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
-        const bool pairs_clip = !median_only && !rich_out && !prm.persistent && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
+        const bool pairs_clip = !median_only && !rich_out && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
                                   reinterpret_cast<uintptr_t>(prm.nflat)) & 7) == 0;
@@ -465,14 +388,6 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
         if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, prm);
         else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, prm);
     } else if (full) {
-        if constexpr (CALIB && NP >= 2 && NP <= 64) {       // two columns in flight: register budget of <= 64 slots
-            if (prm.persistent) {
-                const int64_t ntiles = (prm.P + 255) / 256;
-                const int64_t gp = ntiles < 2 * kNumCU ? ntiles : 2 * kNumCU;
-                hipLaunchKernelGGL((stack_sigclip_persistent_kernel<NP, RawT>), dim3((unsigned)gp), b, 0, st, prm);
-                return check_launch("stack kernel (persistent)");
-            }
-        }
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), g, b, 0, st, prm);
     } else {
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), g, b, 0, st, prm);
@@ -489,8 +404,8 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
     extern template int launch_one<NP, uint16_t, true>(const StackParams &, bool, hipStream_t);           \
     extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t);
 APGPU_DECLARE_LAUNCH(1) APGPU_DECLARE_LAUNCH(4) APGPU_DECLARE_LAUNCH(8) APGPU_DECLARE_LAUNCH(12) APGPU_DECLARE_LAUNCH(16)
-APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(96)
-APGPU_DECLARE_LAUNCH(128)
+APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(40) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(56)
+APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(128)
 #undef APGPU_DECLARE_LAUNCH
 #endif
 
@@ -498,7 +413,7 @@ template <typename RawT, bool CALIB>
 int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
 {
     const int N = prm.N;
-    // slot counts: powers of two and their 3/4 points (pruned networks), so padding wastes at most a third
+    // slot counts: powers of two, their 3/4 points and, from 32 up, the 5/8 and 7/8 points (pruned networks)
     if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st);
     if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st);
     if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st);
@@ -506,9 +421,13 @@ int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
     if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st);
     if (N <= 24) return launch_one<24, RawT, CALIB>(prm, median_only, st);
     if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st);
+    if (N <= 40) return launch_one<40, RawT, CALIB>(prm, median_only, st);
     if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st);
+    if (N <= 56) return launch_one<56, RawT, CALIB>(prm, median_only, st);
     if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st);
+    if (N <= 80) return launch_one<80, RawT, CALIB>(prm, median_only, st);
     if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st);
+    if (N <= 112) return launch_one<112, RawT, CALIB>(prm, median_only, st);
     return launch_one<128, RawT, CALIB>(prm, median_only, st);
 }
 

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Fused float32 clipped mean / median across slot counts (development aid)."""
+import os
+import sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+sys.path.insert(0, os.path.join(root, 'tools'))
+import torch
+from astrophotography_amd import ops, synth
+from bench_kernels import timeit
+
+H = W = 4096
+masters = synth.make_masters(H, W, config_id=2, device='cuda')
+nflat, _ = ops.flat_normalize(masters['flat'])
+frames = synth.make_frames(128, masters, nflat, config_id=2)
+calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
+for n in (128, 112, 100, 96, 80, 72, 64, 56, 52, 48, 40, 36, 32, 24, 16, 8):
+    med, _ = timeit(lambda: ops.stack_sigclip(frames[:n], calib=calib, outputs=('mean',)), reps=5)
+    gbs = (4 * n + 16) * H * W / med / 1e6
+    med2, _ = timeit(lambda: ops.stack_median(frames[:n], calib=calib), reps=5)
+    print('N=%3d  clipped mean %.3f ms (%5.0f GB/s, %.1f us per frame)   median %.3f ms' % (n, med, gbs, 1e3 * med / n, med2))
