@@ -561,9 +561,9 @@ def test_stack_sigclip_u16_pairs_paths(ops, apref):
         assert_biteq(host(ro['mean']), host(rfo['mean']), f'odd-P u16 N={N}')
 
 
-@pytest.mark.parametrize('N', [9, 12, 20, 24, 40, 48, 70, 96])
+@pytest.mark.parametrize('N', [9, 12, 20, 24, 36, 40, 48, 52, 56, 70, 80, 96, 100, 112])
 def test_stack_three_quarter_slot_sizes(ops, apref, N):
-    """Slot counts 12 / 24 / 48 / 96 use Batcher networks pruned to their first NP wires and non-power-of-two
+    """Slot counts 12 / 24 / 40 / 48 / 56 / 80 / 96 / 112 use Batcher networks pruned to their first NP wires and non-power-of-two
     multiplexer trees: full (N = NP) and padded stacks, lean and rich outputs, median, float32 and uint16."""
     rng = np.random.default_rng(900 + N)
     shape = (6, 128)
