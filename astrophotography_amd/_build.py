@@ -15,6 +15,18 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
 SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip'] + [
+    'stack_inst_f32_calib_h.hip',
+    'stack_inst_f32_plain_h.hip',
+    'stack_inst_u16_calib_h.hip',
+    'stack_inst_u16_plain_h.hip',
+    'stack_inst_f32_calib_g.hip',
+    'stack_inst_f32_plain_g.hip',
+    'stack_inst_u16_calib_g.hip',
+    'stack_inst_u16_plain_g.hip',
+    'stack_inst_f32_calib_f.hip',
+    'stack_inst_f32_plain_f.hip',
+    'stack_inst_u16_calib_f.hip',
+    'stack_inst_u16_plain_f.hip',
     'stack_inst_f32_calib_e.hip',
     'stack_inst_f32_plain_e.hip',
     'stack_inst_u16_calib_e.hip',
