@@ -359,11 +359,16 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
                                 ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
                                   reinterpret_cast<uintptr_t>(prm.nflat)) & 7) == 0;
-        if (pairs_clip) {
+        // register budget: two sorted columns + a calibrated one fit two wavefronts per SIMD up to 96 slots (and 112 full
+        // slots); beyond that the one-pixel-per-lane kernel with half-column loads is the faster one
+        constexpr bool kPairsFit = NP <= 112;
+        if (kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-            if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
-            else hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            if constexpr (kPairsFit) {
+                if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+                else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
+            }
             return check_launch("stack kernel (uint16 pairs)");
         }
         if (pairs) {
