@@ -33,6 +33,7 @@ class StackArgs(C.Structure):
         ('dev', C.c_int32), ('maxiters', C.c_int32), ('sigma_lower', C.c_double), ('sigma_upper', C.c_double),
         ('pixmask', C.c_void_p), ('mean', C.c_void_p), ('median', C.c_void_p), ('std', C.c_void_p),
         ('count', C.c_void_p), ('moments', C.c_void_p), ('frame_stride', C.c_int64),
+        ('mean_f64', C.c_void_p), ('std_f64', C.c_void_p), ('moments_f64', C.c_int32), ('reserved0', C.c_int32),
     ]
 
 
@@ -46,7 +47,10 @@ SIGNATURES = {
                                   C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'apgpu_stack_sigclip': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     'apgpu_stack_median': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
+    'apgpu_stack_kernel_name': (C.c_int, [C.POINTER(StackArgs), C.c_int, C.c_char_p, C.c_size_t]),
     'apgpu_moments_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_moments_finalize_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int64, C.c_void_p]),
     'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
     'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -14,18 +14,33 @@ __global__ __launch_bounds__(256) void moments_finalize_kernel(const float *__re
 {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const float s = mom[p], n = mom[P + p];                   // planes: sum, count, sum of squares
-    const float q = std ? mom[2 * P + p] : 0.f;               // the third plane is only touched if std is wanted
+    const float s = mom[p], n = mom[P + p];                   // planes: sum, count (, sum of squares: not used here)
     const float m = s / n;                                    // n == 0 -> NaN
     if (mean) mean[p] = n > 0.f ? m : __builtin_nanf("");
-    if (std) {
-        float var = q / n - m * m;
-        var = var > 0.f ? var : 0.f;
-        std[p] = n > 0.f ? sqrtf(var) : __builtin_nanf("");
+}
+
+__global__ __launch_bounds__(256) void moments_finalize_f64_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq,
+                                                                  const int32_t *__restrict__ count, float *mean, float *std,
+                                                                  double *mean64, double *std64, int64_t P)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int cnt = count[p];
+    const double n = (double)cnt;
+    const double nan = __builtin_nan("");
+    const double m = cnt > 0 ? sum[p] / n : nan;
+    if (mean) mean[p] = (float)m;
+    if (mean64) mean64[p] = m;
+    if (sumsq && (std || std64)) {
+        double var = sumsq[p] / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        const double sd = cnt > 0 ? sqrt(var) : nan;
+        if (std) std[p] = (float)sd;
+        if (std64) std64[p] = sd;
     }
 }
 
-int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
+int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream, char *describe = nullptr)
 {
     if (!args) return fail(APGPU_EINVAL, "stack: args is NULL");
     if (!args->frames) return fail(APGPU_EINVAL, "stack: frames is NULL");
@@ -48,8 +63,11 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
         if (args->maxiters == 0) return fail(APGPU_EINVAL, "stack: maxiters must be >= 1 or < 0");
         if (!(args->sigma_lower >= 0.0) || !(args->sigma_upper >= 0.0))
             return fail(APGPU_EINVAL, "stack: sigma must be >= 0");
-        if (!args->mean && !args->median && !args->std && !args->count && !args->moments)
+        if (!args->mean && !args->median && !args->std && !args->count && !args->moments && !args->mean_f64 && !args->std_f64)
             return fail(APGPU_EINVAL, "stack: no output requested");
+        if (args->moments && args->moments_f64 && (reinterpret_cast<uintptr_t>(args->moments) & 7))
+            return fail(APGPU_EINVAL, "stack: float64 moments must be 8-byte aligned");
+        if (args->reserved0 != 0) return fail(APGPU_EINVAL, "stack: reserved0 must be 0");
     } else if (!args->median) {
         return fail(APGPU_EINVAL, "stack_median: median output is NULL");
     }
@@ -75,14 +93,17 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream)
     prm.center = args->center;
     prm.dev = median_only ? 0 : args->dev;
     prm.maxiters = args->maxiters;
+    prm.moments64 = median_only ? 0 : args->moments_f64;
+    prm.mean64 = median_only ? nullptr : args->mean_f64;
+    prm.std64 = median_only ? nullptr : args->std_f64;
 #ifdef APGPU_DEVELOPMENT                                     // measurement knobs, never in a release build
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;      // all frames alias frame 0: compute-only timing
     if (const char *e = getenv("APGPU_DEBUG_MAXITERS")) prm.maxiters = atoi(e);
 #endif
     hipStream_t st = as_stream(stream);
     if (args->dtype == APGPU_F32)
-        return calib ? launch_np<float, true>(prm, median_only, st) : launch_np<float, false>(prm, median_only, st);
-    return calib ? launch_np<uint16_t, true>(prm, median_only, st) : launch_np<uint16_t, false>(prm, median_only, st);
+        return calib ? launch_np<float, true>(prm, median_only, st, describe) : launch_np<float, false>(prm, median_only, st, describe);
+    return calib ? launch_np<uint16_t, true>(prm, median_only, st, describe) : launch_np<uint16_t, false>(prm, median_only, st, describe);
 }
 
 }  // namespace
@@ -97,12 +118,36 @@ extern "C" int apgpu_stack_median(const apgpu_stack_args *args, void *stream)
     return stack_dispatch(args, true, stream);
 }
 
+extern "C" int apgpu_stack_kernel_name(const apgpu_stack_args *args, int median_only, char *name_host, size_t name_bytes)
+{
+    if (!name_host || name_bytes == 0) return fail(APGPU_EINVAL, "stack_kernel_name: no buffer");
+    char buf[256] = {0};
+    const int rc = stack_dispatch(args, median_only != 0, nullptr, buf);
+    if (rc != APGPU_OK) return rc;
+    snprintf(name_host, name_bytes, "%s", buf);
+    return APGPU_OK;
+}
+
 extern "C" int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_t n_pixels, void *stream)
 {
     if (!moments || n_pixels <= 0) return fail(APGPU_EINVAL, "moments_finalize: bad arguments");
+    if (std) return fail(APGPU_EUNSUPPORTED, "moments_finalize: no standard deviation from float32 moments (sumsq/n - mean^2 "
+                         "cancels); use the float64 moment layout and apgpu_moments_finalize_f64");
     const int block = 256;
     const int64_t grid = (n_pixels + block - 1) / block;
     hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)grid), dim3(block), 0, as_stream(stream), moments, mean,
                        std, n_pixels);
     return check_launch("moments_finalize");
+}
+
+extern "C" int apgpu_moments_finalize_f64(const double *sum, const double *sumsq, const int32_t *count, float *mean, float *std,
+                                          double *mean_f64, double *std_f64, int64_t n_pixels, void *stream)
+{
+    if (!sum || !count || n_pixels <= 0) return fail(APGPU_EINVAL, "moments_finalize_f64: bad arguments");
+    if ((std || std_f64) && !sumsq) return fail(APGPU_EINVAL, "moments_finalize_f64: std wanted but sumsq is NULL");
+    const int block = 256;
+    const int64_t grid = (n_pixels + block - 1) / block;
+    hipLaunchKernelGGL(moments_finalize_f64_kernel, dim3((unsigned)grid), dim3(block), 0, as_stream(stream), sum, sumsq, count,
+                       mean, std, mean_f64, std_f64, n_pixels);
+    return check_launch("moments_finalize_f64");
 }

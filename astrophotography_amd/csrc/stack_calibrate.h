@@ -10,7 +10,8 @@ struct StackParams {
     const void *frames;
     const float *bias, *dark, *nflat, *exp_ratio, *pedestal;
     const uint8_t *pixmask;
-    float *mean, *median, *std, *moments;
+    float *mean, *median, *std;
+    void *moments;          // float[3][P] (sum, count, sumsq) or, with moments64, double[2][P] (sum, sumsq) + int32[P] (count)
     int32_t *count;
     int64_t P;
     int64_t stride;         // elements between frames
@@ -20,6 +21,8 @@ struct StackParams {
     int center;             // 0 median, 1 mean
     int dev;                // 0 std, 1 mad_std (EXTRA kernels only)
     int maxiters;           // < 0: until convergence
+    int moments64;          // layout of `moments` (see above)
+    double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
 };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }

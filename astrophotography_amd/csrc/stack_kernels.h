@@ -344,9 +344,14 @@ __global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs
     reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1);
 }
 
+// `describe` != nullptr: write the name of the kernel variant this call would launch (as rocprofv3 prints it, without
+// the namespace) into describe[0..255] and launch nothing - the bench line and the profiles name the dominant kernel
+// from the dispatch itself instead of a literal.
 template <int NP, typename RawT, bool CALIB>
-int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
+int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *describe)
 {
+    const char *rawname = sizeof(RawT) == 2 ? "unsigned short" : "float";
+    const char *tf[2] = {"false", "true"};
     if constexpr (sizeof(RawT) == 2) {
         // uint16 median: pixel pairs per lane need 4-byte aligned frame rows and 8-byte aligned planes
         const bool pairs = median_only && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
@@ -354,7 +359,7 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
                            ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
                              reinterpret_cast<uintptr_t>(prm.nflat) | reinterpret_cast<uintptr_t>(prm.median) |
                              reinterpret_cast<uintptr_t>(prm.count)) & 7) == 0;
-        const bool rich_out = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
+        const bool rich_out = !median_only && (prm.median || prm.std || prm.mean64 || prm.std64 || prm.dev == APGPU_DEV_MAD_STD);
         const bool pairs_clip = !median_only && !rich_out && (prm.P % 2 == 0) && (prm.stride % 2 == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
@@ -365,6 +370,10 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
         if (kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+            if (describe) {
+                snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
+                return APGPU_OK;
+            }
             if constexpr (kPairsFit) {
                 if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
                 else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
@@ -374,17 +383,26 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
         if (pairs) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+            if (describe) {
+                snprintf(describe, 256, "stack_median_u16_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
+                return APGPU_OK;
+            }
             if (prm.N == NP) hipLaunchKernelGGL((stack_median_u16_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
             else hipLaunchKernelGGL((stack_median_u16_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
             return check_launch("stack median kernel (uint16 pairs)");
         }
     }
 
-    const bool rich = !median_only && (prm.median || prm.std || prm.dev == APGPU_DEV_MAD_STD);
+    const bool rich = !median_only && (prm.median || prm.std || prm.mean64 || prm.std64 || prm.dev == APGPU_DEV_MAD_STD);
     const bool full = prm.N == NP;
     const int block = rich ? rich_block<NP>() : 256;
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    if (describe) {
+        if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
+        else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
+        return APGPU_OK;
+    }
     const dim3 g((unsigned)grid), b(block);
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);
@@ -404,10 +422,10 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st)
 // slot counts each, so that the build parallelises); everybody else only sees these declarations.
 #ifndef APGPU_STACK_INSTANTIATE
 #define APGPU_DECLARE_LAUNCH(NP)                                                                          \
-    extern template int launch_one<NP, float, true>(const StackParams &, bool, hipStream_t);              \
-    extern template int launch_one<NP, float, false>(const StackParams &, bool, hipStream_t);             \
-    extern template int launch_one<NP, uint16_t, true>(const StackParams &, bool, hipStream_t);           \
-    extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t);
+    extern template int launch_one<NP, float, true>(const StackParams &, bool, hipStream_t, char *);      \
+    extern template int launch_one<NP, float, false>(const StackParams &, bool, hipStream_t, char *);     \
+    extern template int launch_one<NP, uint16_t, true>(const StackParams &, bool, hipStream_t, char *);   \
+    extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t, char *);
 APGPU_DECLARE_LAUNCH(1) APGPU_DECLARE_LAUNCH(4) APGPU_DECLARE_LAUNCH(8) APGPU_DECLARE_LAUNCH(12) APGPU_DECLARE_LAUNCH(16)
 APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(40) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(56)
 APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(128)
@@ -415,25 +433,25 @@ APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU
 #endif
 
 template <typename RawT, bool CALIB>
-int launch_np(const StackParams &prm, bool median_only, hipStream_t st)
+int launch_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe = nullptr)
 {
     const int N = prm.N;
     // slot counts: powers of two, their 3/4 points and, from 32 up, the 5/8 and 7/8 points (pruned networks)
-    if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st);
-    if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st);
-    if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st);
-    if (N <= 12) return launch_one<12, RawT, CALIB>(prm, median_only, st);
-    if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st);
-    if (N <= 24) return launch_one<24, RawT, CALIB>(prm, median_only, st);
-    if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st);
-    if (N <= 40) return launch_one<40, RawT, CALIB>(prm, median_only, st);
-    if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st);
-    if (N <= 56) return launch_one<56, RawT, CALIB>(prm, median_only, st);
-    if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st);
-    if (N <= 80) return launch_one<80, RawT, CALIB>(prm, median_only, st);
-    if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st);
-    if (N <= 112) return launch_one<112, RawT, CALIB>(prm, median_only, st);
-    return launch_one<128, RawT, CALIB>(prm, median_only, st);
+    if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 12) return launch_one<12, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 24) return launch_one<24, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 40) return launch_one<40, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 56) return launch_one<56, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 80) return launch_one<80, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 112) return launch_one<112, RawT, CALIB>(prm, median_only, st, describe);
+    return launch_one<128, RawT, CALIB>(prm, median_only, st, describe);
 }
 
 

@@ -188,6 +188,29 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
     return (0.5 * (x1 + x2)) * 1.482602218505602;
 }
 
+// N-shard partial moments of the survivors: sum(x) = n c + S, sum(x^2) = Q + 2 c S + n c^2 (exact identities, float64).
+//   float32 layout  [3][P]: sum, count, sum of squares - the first two are all a mean needs, so an exchange that does
+//                           not want std all-reduces a contiguous [2][P] prefix (8 bytes per pixel);
+//   float64 layout: double sum[P], double sumsq[P], int32 count[P] - the combine of SURVEY 8(e) "f64 sum + i32 count":
+//                           ranks add float64 sums, so the combined mean is the float64 mean rounded once.
+__device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t Pn, int64_t p, int cnt, double c, double S, double Q)
+{
+    const double nf = (double)cnt;
+    const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
+    const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
+    if (f64_layout) {
+        double *d = static_cast<double *>(out);
+        d[p] = sum;
+        d[Pn + p] = sq;
+        reinterpret_cast<int32_t *>(d + 2 * Pn)[p] = cnt;
+    } else {
+        float *f = static_cast<float *>(out);
+        f[p] = (float)sum;
+        f[Pn + p] = (float)cnt;
+        f[2 * Pn + p] = (float)sq;
+    }
+}
+
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
 template <int NP, bool PRESORTED = false>
@@ -196,7 +219,8 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     // everything the loop and the epilogue need from the kernel arguments, parked before the sort
     float *const out_mean = park_in_vgpr(prm.mean);
     int32_t *const out_count = park_in_vgpr(prm.count);
-    float *const out_moments = park_in_vgpr(prm.moments);
+    void *const out_moments = park_in_vgpr(prm.moments);
+    const int mom64 = park_in_vgpr(prm.moments64);
     const int64_t Pn = park_in_vgpr(prm.P);
     const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
     const int maxiters = park_in_vgpr(prm.maxiters);
@@ -290,13 +314,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const double ms = S / nf;                                 // mean - c
     if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
     if (out_count) out_count[p] = cnt;
-    if (out_moments) {
-        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
-        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        out_moments[p] = (float)sum;                      // plane order: sum, count, sum of squares - the first
-        out_moments[Pn + p] = (float)cnt;                  // two are all a mean needs, so an N-shard exchange that
-        out_moments[2 * Pn + p] = (float)sq;               // does not want std all-reduces a contiguous [2][P] prefix
-    }
+    if (out_moments) store_moments(out_moments, mom64, Pn, p, cnt, c, S, Q);
 }
 
 // Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and
@@ -428,8 +446,9 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     const double nan = __builtin_nan("");
     const double ms = S / nf;                                 // mean - c
     if (prm.mean) prm.mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
+    if (prm.mean64) prm.mean64[p] = cnt > 0 ? c + ms : nan;
     if (prm.count) prm.count[p] = cnt;
-    if (prm.std) {
+    if (prm.std || prm.std64) {
         // np.nanstd of the survivors: two passes like numpy (a column of identical survivors must give
         // exactly 0, which the running S/Q - updated by subtraction - cannot guarantee).
         constexpr int CH = NP >= 8 ? 8 : NP;                  // LDS reads in flight per trip
@@ -460,20 +479,16 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
                 q1 = fma(d, d, q1);
             }
         }
-        prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
+        const double sd = cnt > 0 ? sqrt(q1 > 0.0 ? q1 / nf : 0.0) : nan;
+        if (prm.std) prm.std[p] = (float)sd;
+        if (prm.std64) prm.std64[p] = sd;
     }
     if (prm.median) {
         const float m1 = col_read<NP>(col, (a + b - 1) >> 1);
         const float m2 = col_read<NP>(col, (a + b) >> 1);
         prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
     }
-    if (prm.moments) {
-        const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
-        const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-        prm.moments[p] = (float)sum;
-        prm.moments[prm.P + p] = (float)cnt;
-        prm.moments[2 * prm.P + p] = (float)sq;
-    }
+    if (prm.moments) store_moments(prm.moments, prm.moments64, prm.P, p, cnt, c, S, Q);
 }
 
 }  // namespace apgpu_stack

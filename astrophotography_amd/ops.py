@@ -145,7 +145,10 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
     (sigma_clipping.py:298-383, 924-937), optionally fused with the calibration of each value.
 
     calib: None or dict(bias, dark, nflat=None, exp_ratio, pedestal=None, dark_still_biased=False).
-    outputs: any of 'mean', 'median', 'std', 'count', 'moments' -> dict of device tensors.
+    outputs: any of 'mean', 'median', 'std', 'count' (float32 / int32 planes), 'mean_f64', 'std_f64' (the unrounded
+    float64 statistics, as ccdproc.combine keeps them), 'moments' (float32 [3, ...]: sum, count, sumsq) or
+    'moments_f64' (dict(sum, sumsq: float64 planes, count: int32 plane) - views of one 20-byte-per-pixel buffer)
+    -> dict of device tensors.
     """
     _need_cuda(frames)
     lib = _lib.load()
@@ -162,13 +165,48 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
             res[k] = torch.empty(shp, dtype=torch.float32, device=dev)
         elif k == 'count':
             res[k] = torch.empty(shp, dtype=torch.int32, device=dev)
+        elif k in ('mean_f64', 'std_f64'):
+            res[k] = torch.empty(shp, dtype=torch.float64, device=dev)
         elif k == 'moments':
+            if 'moments_f64' in outputs:
+                raise ValueError("ask for either 'moments' or 'moments_f64'")
             res[k] = torch.empty((3,) + shp, dtype=torch.float32, device=dev)
+        elif k == 'moments_f64':
+            res[k] = alloc_moments_f64(shp, dev)
+            a.moments = res[k]['buffer'].data_ptr()
+            a.moments_f64 = 1
+            continue
         else:
             raise ValueError('unknown output %r' % (k,))
         setattr(a, k, res[k].data_ptr())
     check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
     return res
+
+
+def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std'):
+    """Name of the kernel variant the library dispatches for such a stack call (apgpu_stack_kernel_name): what the
+    bench line and the profiles call the dominant kernel.  Needs no device."""
+    lib = _lib.load()
+    a = StackArgs()
+    a.frames = 0x1000                                     # placeholders: aligned, never dereferenced by the query
+    a.dtype = APGPU_F32 if dtype in ('f32', torch.float32) else APGPU_U16
+    a.n_frames = int(n_frames)
+    a.n_pixels = 1 << 20
+    a.frame_stride = 1 << 20
+    if calibrated:
+        a.bias = a.dark = a.nflat = a.exp_ratio = 0x1000
+    a.center, a.dev, a.maxiters = 0, _lib.DEV[stdfunc], 5
+    a.sigma_lower = a.sigma_upper = 3.0
+    if median_only:
+        a.median = 0x1000
+    for k in outputs:
+        if k == 'moments_f64':
+            a.moments, a.moments_f64 = 0x1000, 1
+        else:
+            setattr(a, k, 0x1000)
+    buf = C.create_string_buffer(256)
+    check(lib.apgpu_stack_kernel_name(C.byref(a), int(bool(median_only)), buf, 256))
+    return buf.value.decode()
 
 
 def stack_median(frames, calib=None, pixmask=None, want_count=False):
@@ -187,11 +225,55 @@ def stack_median(frames, calib=None, pixmask=None, want_count=False):
     return (med, cnt) if want_count else med
 
 
-def moments_finalize(moments, want_std=True, out_mean=None):
-    """mean = sum/cnt, std = sqrt(sumsq/cnt - mean^2) from (all-reduced) moments[3, ...] = (sum, cnt, sumsq);
-    with want_std=False a [2, ...] tensor (sum, cnt) is enough."""
-    _need_cuda(moments)
+def alloc_moments_f64(shape, device):
+    """The float64 moment layout of include/apgpu.h: one buffer = double sum[P], double sumsq[P], int32 count[P];
+    returns dict(sum, sumsq, count, buffer) of views with the image shape."""
+    shape = tuple(shape)
+    P = int(np.prod(shape)) if shape else 1
+    buf = torch.empty(2 * P + (P + 1) // 2, dtype=torch.float64, device=device)
+    return dict(sum=buf[:P].view(shape), sumsq=buf[P:2 * P].view(shape),
+                count=buf[2 * P:].view(torch.int32)[:P].view(shape), buffer=buf)
+
+
+def moments_finalize(moments, want_std=None, out_mean=None, want_f64=False):
+    """Mean (and std) of the survivors from (all-reduced) partial moments.
+
+    moments: the float32 tensor [2 or 3, ...] = (sum, cnt[, sumsq]) -> mean = sum / cnt in float32; no std from this
+    layout (sumsq / cnt - mean^2 of float32 sums about zero cancels: ask for 'moments_f64' instead); or the dict
+    stack_sigclip(..., outputs=('moments_f64',)) returns -> mean = sum / cnt, std = sqrt(sumsq / cnt - mean^2)
+    evaluated in float64 and rounded once (want_f64: also return the float64 planes)."""
     lib = _lib.load()
+    if want_std is None:
+        want_std = isinstance(moments, dict) and moments.get('sumsq') is not None
+    if isinstance(moments, dict):
+        sm, sq, cnt = moments['sum'], moments.get('sumsq'), moments['count']
+        _need_cuda(sm, sq, cnt)
+        shp = tuple(sm.shape)
+        P = sm.numel()
+        for t, dt, nm in ((sm, torch.float64, 'sum'), (sq, torch.float64, 'sumsq'), (cnt, torch.int32, 'count')):
+            if t is not None and (t.dtype != dt or t.numel() != P or not t.is_contiguous()):
+                raise TypeError('moments_f64[%r] must be a contiguous %s plane' % (nm, dt))
+        if want_std and sq is None:
+            raise ValueError('std needs the sumsq plane')
+        if out_mean is None:
+            mean = torch.empty(shp, dtype=torch.float32, device=sm.device)
+        else:
+            mean = out_mean
+            if mean.dtype != torch.float32 or mean.numel() != P or not mean.is_contiguous():
+                raise TypeError('out_mean must be a contiguous float32 tensor with one entry per pixel')
+        std = torch.empty(shp, dtype=torch.float32, device=sm.device) if want_std else None
+        m64 = torch.empty(shp, dtype=torch.float64, device=sm.device) if want_f64 else None
+        s64 = torch.empty(shp, dtype=torch.float64, device=sm.device) if (want_f64 and want_std) else None
+        check(lib.apgpu_moments_finalize_f64(_ptr(sm), _ptr(sq) if want_std else None, _ptr(cnt), _ptr(mean), _ptr(std),
+                                             _ptr(m64), _ptr(s64), P, _stream()))
+        out = (mean, std) if want_std else mean
+        if want_f64:
+            return out, ((m64, s64) if want_std else m64)
+        return out
+    _need_cuda(moments)
+    if want_std:
+        raise ValueError("no standard deviation from float32 moments (sumsq/cnt - mean^2 cancels for CCD-range data): "
+                         "use outputs=('moments_f64',)")
     moments = _f32c(moments, 'moments')
     shp = tuple(moments.shape[1:])
     P = moments[0].numel()

@@ -3,20 +3,29 @@
 Two partitionings of a stack job:
 
 * ``stack_nshard`` - the north-star layout: frames are sharded on the N axis, every rank reduces its
-  own frames to per-pixel partial moments (sum, sum of squares, count of the locally clipped
-  survivors), ONE all-reduce(sum) combines them and ``mean = sum / count``.  Semantics are
-  *hierarchical* clipping (clip against the statistics of the rank's own frames, then combine):
-  median-centred clipping is not decomposable over N shards, so for world_size > 1 the result is
-  defined by "sigma_clipped_stats per shard, moments summed" - which is what the tests check - and
-  equals the single-GPU result for world_size == 1.  The image is cut into row stripes; the
-  all-reduce of stripe k runs on a communication stream while stripe k+1 is being reduced, so the
-  collective hides behind the HBM-bound kernel instead of following it.
-* ``stack_rowshard`` - exact for any centre/deviation function and needs no collective: every rank
-  holds all N frames of a row block and reduces it on its own (use dist.all_gather afterwards if one
-  rank wants the whole image).
+  own frames to per-pixel partial moments of the locally clipped survivors, ONE all-reduce(sum) per row
+  stripe combines them and ``mean = sum / count``.  Semantics are *hierarchical* clipping (clip against
+  the statistics of the rank's own frames, then combine): median-centred clipping is not decomposable
+  over N shards, so for world_size > 1 the result is defined by "sigma_clipped_stats per shard,
+  moments summed" - which is what the tests check - and equals the single-GPU result for
+  world_size == 1.  The image is cut into row stripes; the all-reduce of stripe k runs on a
+  communication stream while stripe k+1 is being reduced, so the collective hides behind the kernel
+  instead of following it.
 
-The kernels are reached through ``astrophotography_amd.ops``; tests substitute CPU stand-ins for the
-two device functions to run the collective plumbing under gloo.
+  Two exchange payloads (``exchange=``):
+    'f64' (default)  float64 sum + int32 count per pixel (12 bytes; + float64 sum of squares = 20 bytes
+                     when a std is wanted): the ranks' float64 partial sums are added in float64, so the
+                     combined mean is the float64 combine of SURVEY 8(e) rounded ONCE to float32;
+    'f32'            float32 sum + float32 count (8 bytes): every rank rounds its sum to float32 and
+                     RCCL adds in float32 - about 1e-7 relative per rank, mean only (no std: float32
+                     sums of squares about zero cancel catastrophically for CCD-range data).
+
+* ``stack_rowshard`` - exact for any centre/deviation function and needs no data-path collective:
+  every rank holds all N frames of its row block (``row_block``) and reduces it on its own;
+  ``gather_rows`` assembles the image on every rank when one is wanted.
+
+The kernels are reached through ``astrophotography_amd.ops``; the CPU tests substitute stand-ins for
+the two device functions to run the collective plumbing under gloo.
 """
 import torch
 import torch.distributed as dist
@@ -47,21 +56,61 @@ def shard_frames(n_total, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def _default_local_moments(frames, calib, r0, r1, clip):
+def row_block(H, world_size, rank):
+    """Row range of `rank` in the row-sharded layout (contiguous blocks, the first H % world get one more)."""
+    return shard_frames(H, world_size, rank)
+
+
+def _slice_calib(calib, r0, r1):
+    if calib is None:
+        return None
+    c = dict(calib)
+    for k in ('bias', 'dark', 'nflat'):
+        if c.get(k) is not None:
+            c[k] = c[k][r0:r1]
+    return c
+
+
+def _default_local_moments(frames, calib, r0, r1, clip, exchange):
+    """Partial moments of rows [r0, r1): dict(sum, count[, sumsq]) of [r1 - r0, W] planes."""
     from . import ops
     sub = frames[:, r0:r1]
-    c = None
-    if calib is not None:
-        c = dict(calib)
-        for k in ('bias', 'dark', 'nflat'):
-            if c.get(k) is not None:
-                c[k] = c[k][r0:r1]
-    return ops.stack_sigclip(sub, calib=c, outputs=('moments',), **clip)['moments']
+    c = _slice_calib(calib, r0, r1)
+    if exchange == 'f32':
+        m = ops.stack_sigclip(sub, calib=c, outputs=('moments',), **clip)['moments']
+        return dict(sum=m[0], count=m[1], prefix=m[:2])         # (sum, count) is one contiguous float32 block
+    m = ops.stack_sigclip(sub, calib=c, outputs=('moments_f64',), **clip)['moments_f64']
+    return dict(sum=m['sum'], count=m['count'], sumsq=m['sumsq'], buffer=m['buffer'])
 
 
-def _default_finalize(moments, out_mean):
+def _default_finalize(m, out_mean, out_std, exchange):
     from . import ops
-    ops.moments_finalize(moments, want_std=False, out_mean=out_mean)
+    if exchange == 'f32':
+        ops.moments_finalize(m['prefix'], want_std=False, out_mean=out_mean)
+        return
+    if out_std is None:
+        ops.moments_finalize(dict(sum=m['sum'], count=m['count']), want_std=False, out_mean=out_mean)
+    else:
+        _, std = ops.moments_finalize(dict(sum=m['sum'], sumsq=m['sumsq'], count=m['count']), want_std=True, out_mean=out_mean)
+        out_std.copy_(std)
+
+
+def _exchange(m, exchange, want_std, group):
+    """The all-reduce(s) of one stripe: float32 (sum, count) block, or float64 sum (+ sumsq) and int32 count."""
+    if exchange == 'f32':
+        dist.all_reduce(m['prefix'], op=dist.ReduceOp.SUM, group=group)
+        return
+    dist.all_reduce(m['sum'], op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(m['count'], op=dist.ReduceOp.SUM, group=group)
+    if want_std:
+        dist.all_reduce(m['sumsq'], op=dist.ReduceOp.SUM, group=group)
+
+
+def exchange_bytes_per_pixel(exchange='f64', want_std=False):
+    """Bytes per output pixel each rank contributes to the all-reduce(s)."""
+    if exchange == 'f32':
+        return 8
+    return 20 if want_std else 12
 
 
 _COMM_STREAMS = {}
@@ -75,18 +124,26 @@ def _comm_stream(device, role='comm'):
     return _COMM_STREAMS[key]
 
 
+def _record(m, stream):
+    for t in m.values():
+        if torch.is_tensor(t):
+            t.record_stream(stream)
+
+
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
                  n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
-                 exchange_sumsq=None):
-    """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank.
+                 exchange='f64', want_std=False):
+    """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank
+    (want_std: (mean, std)).
 
-    One all-reduce per stripe on a side stream, overlapped with the reduction of the next stripe.  The
-    moments are laid out (sum, count, sum of squares); the mean needs only the first two, so unless
-    `exchange_sumsq` (default: `return_moments`) asks for the full set the collective carries the contiguous
-    [2, stripe, W] prefix - 8 instead of 12 bytes per pixel over xGMI.
+    One exchange per stripe on a side stream, overlapped with the reduction of the next stripes.  `exchange`
+    selects the payload (module docstring); want_std needs 'f64'.  return_moments appends the combined per-stripe
+    moment dicts (sum, count[, sumsq]) for inspection.
     """
-    if exchange_sumsq is None:
-        exchange_sumsq = return_moments
+    if exchange not in ('f64', 'f32'):
+        raise ValueError("exchange must be 'f64' or 'f32'")
+    if want_std and exchange != 'f64':
+        raise ValueError("a standard deviation needs exchange='f64' (float32 sums of squares cancel)")
     local_moments = local_moments or _default_local_moments
     finalize = finalize or _default_finalize
     world, _ = _world(group)
@@ -97,6 +154,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     stripes = stripe_rows(H, n_stripes if collective else 1)
     parts = []
     mean = torch.empty((H, W), dtype=torch.float32, device=frames_local.device)
+    std = torch.empty((H, W), dtype=torch.float32, device=frames_local.device) if want_std else None
     if collective and on_gpu:
         dev = frames_local.device
         comm = _comm_stream(dev)
@@ -109,33 +167,63 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
         for k, (r0, r1) in enumerate(stripes):
             cs = lanes[k % 2]
             with torch.cuda.stream(cs):
-                m = local_moments(frames_local, calib, r0, r1, clip)
+                m = local_moments(frames_local, calib, r0, r1, clip, exchange)
                 ev = torch.cuda.Event()
                 ev.record(cs)
-                m.record_stream(cs)
+                _record(m, cs)
             with torch.cuda.stream(comm):
                 # exchange and finalise stripe k on the side stream while the compute streams reduce the next stripes
                 comm.wait_event(ev)
-                dist.all_reduce(m if exchange_sumsq else m[:2], op=dist.ReduceOp.SUM, group=group)
-                finalize(m, mean[r0:r1])
-                m.record_stream(comm)
+                _exchange(m, exchange, want_std, group)
+                finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, exchange)
+                _record(m, comm)
             parts.append(m)
         for st in lanes + [comm]:
             main.wait_stream(st)
     else:
         for (r0, r1) in stripes:
-            m = local_moments(frames_local, calib, r0, r1, clip)
+            m = local_moments(frames_local, calib, r0, r1, clip, exchange)
             if collective:
-                dist.all_reduce(m if exchange_sumsq else m[:2], op=dist.ReduceOp.SUM, group=group)
-            finalize(m, mean[r0:r1])
+                _exchange(m, exchange, want_std, group)
+            finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, exchange)
             parts.append(m)
+    out = (mean, std) if want_std else mean
     if return_moments:
-        return mean, (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1))
-    return mean
+        return out, parts
+    return out
 
 
-def stack_rowshard(frames_rows, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', outputs=('mean',)):
-    """Exact path: this rank's row block frames_rows[N, h, W] (all N frames) -> its block of the result."""
+def stack_rowshard(frames_rows, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', outputs=('mean',),
+                   method='sigclip'):
+    """Exact path: this rank's row block frames_rows[N, h, W] (all N frames; masters in `calib` cut to the same
+    rows) -> its block of the result.  No collective: every output pixel depends only on its own column."""
     from . import ops
+    if method == 'median':
+        return dict(median=ops.stack_median(frames_rows, calib=calib))
     return ops.stack_sigclip(frames_rows, sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc,
                              calib=calib, outputs=outputs)
+
+
+def gather_rows(block, H, group=None):
+    """All-gather of the ranks' row blocks block[h_r, W] (row_block layout) into the full [H, W] image on every rank.
+    This is output assembly (4 bytes per pixel, once), not part of the reduction."""
+    world, rank = _world(group)
+    if world == 1:
+        return block
+    W = block.shape[1]
+    lo, hi = row_block(H, world, rank)
+    if block.shape[0] != hi - lo:
+        raise ValueError('rank %d holds %d rows, the row_block layout expects %d' % (rank, block.shape[0], hi - lo))
+    full = torch.empty((H, W), dtype=block.dtype, device=block.device)
+    if H % world == 0:
+        dist.all_gather_into_tensor(full, block.contiguous(), group=group)
+        return full
+    hmax = -(-H // world)                                   # ragged blocks: pad to the tallest, gather, cut
+    padded = torch.zeros((hmax, W), dtype=block.dtype, device=block.device)
+    padded[:hi - lo] = block
+    allb = torch.empty((world * hmax, W), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(allb, padded, group=group)
+    for r in range(world):
+        a, b = row_block(H, world, r)
+        full[a:b] = allb[r * hmax:r * hmax + (b - a)]
+    return full

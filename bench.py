@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the calibrate + sigma-clip-stack hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--parallelism nshard|rowshard]
 
-A step = one pass of the hot path over one batch of synthetic frames already resident in HBM:
-fused bias/dark/flat calibration + 3-sigma (maxiters 5, median-centred) clipped mean along N of a
-64 x 4096 x 4096 float32 slab per GPU (BASELINE.json configs[1], "C2").  With N > 1 GPUs every rank
-holds its own 64 frames (weak scaling: the global stack is 64*N frames sharded on the N axis), reduces
-them to per-pixel moments and one RCCL all-reduce per row stripe combines them (parallel.stack_nshard).
+A step = one pass of the hot path over one batch of synthetic frames already resident in HBM: fused
+bias/dark/flat calibration + 3-sigma (maxiters 5, median-centred) clipped mean along N.
 
-Prints ONE JSON line (rank 0) with the whole-job Mpixels/s, the HBM roofline of the dominant kernel
-(measured live with HIP events on the launch stream) and a CPU baseline (the oracle, OpenMP, bounded
-sample) timed beside it.
+  N = 1 (default)        BASELINE.json configs[1] "C2": 64 x 4096 x 4096 float32, one launch of the fused kernel.
+  N > 1, --scaling weak  (default) every rank holds its own 64 x 4096 x 4096 frames: the global stack is 64*N frames
+                         sharded on the N axis (parallel.stack_nshard: per-rank partial moments, one RCCL all-reduce
+                         per row stripe overlapped with the reduction of the next stripes).
+  N > 1, --scaling strong  BASELINE.json configs[2] "C3": --total-frames (256) x 4096 x 4096 in total, 256/N per rank.
+  --parallelism rowshard   the exact partition: every rank reduces ALL frames of its own row block, no data-path
+                         collective (weak: 4096 rows per rank, strong: 4096/N rows per rank).
+
+Launch: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, before anything in the
+parent touches the GPU) unless it already runs under a launcher (torchrun sets WORLD_SIZE); the ranks rendezvous over
+RCCL (torch.distributed backend "nccl") on 127.0.0.1.  The run fails (non-zero exit) if the process group's world size
+differs from --gpus.
+
+Prints ONE JSON line (rank 0) with the whole-job Mpixels/s, the HBM roofline of the dominant kernel (measured live
+with HIP events on the launch stream) and the CPU baselines timed beside it (the C/OpenMP oracle and the NumPy path).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,21 +34,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6.3 TB/s is the achievable copy rate
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--frames', type=int, default=64, help='frames per GPU (C2: 64)')
+    ap.add_argument('--frames', type=int, default=64, help='frames per GPU (weak scaling; C2: 64)')
+    ap.add_argument('--total-frames', type=int, default=256, help='frames of the whole job with --scaling strong (C3: 256)')
     ap.add_argument('--height', type=int, default=4096)
     ap.add_argument('--width', type=int, default=4096)
     ap.add_argument('--dtype', default='f32', choices=['f32', 'u16'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--parallelism', default='nshard', choices=['nshard', 'rowshard'])
+    ap.add_argument('--exchange', default='f64', choices=['f64', 'f32'],
+                    help='N-shard all-reduce payload: f64 sum + i32 count (12 B/pixel, float64 combine) or f32 sum + count (8 B/pixel)')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
                     help='c2 (default, the BASELINE metric): fused calibrate + clipped mean; c4: uint16 Bayer frames, per-channel '
                          'flat + fused calibrate + median stack (use --height 6248 --width 4176); c5: bad-pixel mask + per-frame '
@@ -45,13 +58,69 @@ def parse():
     ap.add_argument('--stripes', type=int, default=8, help='row stripes for collective/compute overlap (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-collective', action='store_true', help='run the striped all-reduce path even with one rank (testing)')
-    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='target CPU time of the cpu_baseline sample')
-    return ap.parse_args()
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU time of each cpu_baseline leg')
+    ap.add_argument('--master-port', type=int, default=0, help='rendezvous port of the built-in launcher (0 = pick a free one)')
+    ap.add_argument('--selftest-cpu', action='store_true',
+                    help='launcher/rendezvous/reporting self-test on CPU: gloo backend, a trivial stand-in step, no kernels '
+                         '(tests/test_bench_launcher.py); the JSON line is marked "selftest": true and carries no roofline')
+    return ap.parse_args(argv)
+
+
+# -------------------------------------------------------------------------------------------------------------
+# built-in launcher: N fresh child processes, one per GPU.  Runs before torch is imported in this process, so the
+# parent never initialises the GPU (and nothing is exec'ed from a process that did).
+# -------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    port = args.master_port or _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), APGPU_BENCH_CHILD='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC (RCCL across processes on this pool)
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is not None:
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    deadline = time.time() + 30.0               # one rank failed: give the others 30 s, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in alive:
+                p.kill()                                        # exactly the PIDs started above
+            break
+        time.sleep(0.05)
+    return rc if rc >= 0 else 1
+
+
+def cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
 
 
 def cpu_baseline(frames, masters, nflat, e, seconds):
-    """Times the oracle's fused calibrate + clipped stack (oracle/apref.c, OpenMP) on a row sample."""
-    import numpy as np
+    """Times the oracle's fused calibrate + clipped stack (oracle/apref.c, OpenMP: all threads, and one thread) on a
+    row sample, and the NumPy path (oracle/numpy_ref.py: single process and multiprocessing) in a child process."""
     from oracle import apref
     N, H, W = frames.shape
     threads = apref.num_threads()
@@ -64,63 +133,154 @@ def cpu_baseline(frames, masters, nflat, e, seconds):
         apref.calibrate_stack(raw, b, d, nf, e, None, False, sigma=3.0, maxiters=5)
         return time.perf_counter() - t0
 
-    pilot_rows = min(H, 64)
-    run(pilot_rows)                                   # warm (library load, page faults, thread pool)
-    t = run(pilot_rows)
-    rate = N * pilot_rows * W / max(t, 1e-6)          # input pixels / s
-    rows = int(max(pilot_rows, min(H, 0.25 * seconds * rate / (N * W))))
-    times = []
-    t_total = 0.0
-    while t_total < seconds and len(times) < 50:
-        times.append(run(rows))
-        t_total += times[-1]
-    times.sort()
-    t = times[len(times) // 2]
-    model = 'unknown CPU'
+    def leg(seconds):
+        pilot_rows = min(H, 64)
+        run(pilot_rows)                                   # warm (library load, page faults, thread pool)
+        t = run(pilot_rows)
+        rate = N * pilot_rows * W / max(t, 1e-6)          # input pixels / s
+        rows = int(max(pilot_rows, min(H, 0.25 * seconds * rate / (N * W))))
+        times = []
+        t_total = 0.0
+        while t_total < seconds and len(times) < 50:
+            times.append(run(rows))
+            t_total += times[-1]
+        times.sort()
+        return rows, times[len(times) // 2], len(times), t_total
+
+    model = cpu_model()
+    rows, t, nruns, t_total = leg(seconds)
+    out = dict(value=N * rows * W / 1e6 / t, unit='Mpixels/s', cores=threads, kind='port',
+               sample='%d frames x %d rows x %d cols f32, median of %d runs (%.1f s of CPU work, OpenMP %d threads on %s, '
+                      'oracle/apref.c fused calibrate + clipped stack)' % (N, rows, W, nruns, t_total, threads, model))
+    if threads > 1:
+        apref.set_num_threads(1)
+        rows1, t1, nruns1, tt1 = leg(min(seconds, 6.0))
+        apref.set_num_threads(threads)
+        out['single_thread'] = dict(value=N * rows1 * W / 1e6 / t1, unit='Mpixels/s', cores=1,
+                                    sample='%d rows, median of %d runs (%.1f s)' % (rows1, nruns1, tt1))
+    # the NumPy path the north star names, in a fresh child process (it forks workers; this process holds the GPU)
     try:
-        for ln in open('/proc/cpuinfo'):
-            if ln.startswith('model name'):
-                model = ln.split(':', 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return dict(value=N * rows * W / 1e6 / t, unit='Mpixels/s', cores=threads, kind='port',
-                sample='%d frames x %d rows x %d cols f32, median of %d runs (%.1f s of CPU work, OpenMP %d threads on %s, '
-                       'oracle/apref.c fused calibrate + clipped stack)' % (N, rows, W, len(times), t_total, threads, model))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'oracle', 'numpy_ref.py'), '--frames', str(N), '--width', str(W),
+                            '--seconds', str(min(seconds, 10.0))], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+        nr = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        out['numpy'] = dict(single_process=nr['single'], multiprocessing=nr.get('multi'), cpu=nr['cpu'], numpy=nr['numpy'],
+                            kind='port',
+                            sample='oracle/numpy_ref.py: ApCalibrate.py:439-464 per frame + sigma_clipped_stats(axis=0) in NumPy '
+                                   '(nanmedian/nanstd along N), %d-frame row blocks' % N)
+    except Exception as exc:                                  # the baseline is a report, never a reason to lose the bench line
+        out['numpy'] = dict(error=repr(exc))
+    return out
 
 
-def main():
-    args = parse()
+def selftest_cpu(args, world, rank):
+    """Launcher / rendezvous / timing / reporting on CPU (gloo): no kernels, a stand-in step."""
+    import torch
+    import torch.distributed as dist
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)                                 # gloo chats on the C-level stdout: keep it for the JSON line
+    os.dup2(2, 1)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    x = torch.full((256, 256), float(rank + 1))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = (x * 2).sum()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    rworld = 1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        lst = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(lst, t)
+        per_rank = [float(v.item()) for v in lst]
+        tot = torch.tensor([float(y)])
+        dist.all_reduce(tot)
+        rworld = dist.get_world_size()
+        assert float(tot) == sum(2.0 * 65536 * (r + 1) for r in range(world))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rworld != args.gpus:
+        print('error: world size %d != --gpus %d' % (rworld, args.gpus), file=sys.stderr)
+        return 3
+    if rank == 0:
+        os.write(saved_stdout, (json.dumps({'selftest': True, 'n_gpus': world, 'rccl_world_size': rworld, 'steps': args.steps,
+                                            'per_rank_ms': [1e3 * t / args.steps for t in per_rank], 'backend': 'gloo'}) + '\n').encode())
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    under_launcher = 'WORLD_SIZE' in os.environ
+    if args.gpus > 1 and not under_launcher:
+        return launch_ranks(args, argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        print('error: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world), file=sys.stderr)
+        return 3
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank)
+
     # Only the JSON line may appear on stdout: RCCL prints a version banner to the C-level stdout at
     # exit, so everything else (C and Python) is routed to stderr until the final print.
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1 or args.force_collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    rccl_world = dist.get_world_size() if dist.is_initialized() else 1
+    if rccl_world != args.gpus:
+        print('error: process group has %d ranks, --gpus %d' % (rccl_world, args.gpus), file=sys.stderr)
+        return 3
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
     from astrophotography_amd import ops, synth, parallel
 
-    N, H, W = args.frames, args.height, args.width
+    wl = args.workload
+    rowshard = args.parallelism == 'rowshard'
+    strong = args.scaling == 'strong'
+    H_glob, W = args.height, args.width
+    if rowshard:
+        # every rank: all N frames of its row block.  weak: H rows per rank (a world*H-row mosaic), strong: H/world rows
+        N = args.total_frames if strong else args.frames
+        if strong:
+            r0, r1 = parallel.row_block(H_glob, world, rank)
+            H = r1 - r0
+        else:
+            H = H_glob
+        n_total = N
+    else:
+        if strong:
+            f0, f1 = parallel.shard_frames(args.total_frames, world, rank)
+            N = f1 - f0
+            n_total = args.total_frames
+        else:
+            N = args.frames
+            f0 = rank * N
+            n_total = world * N
+        H = H_glob
     P = H * W
+    if wl != 'c2' and (strong or rowshard):
+        print('error: --scaling strong / --parallelism rowshard are defined for workload c2', file=sys.stderr)
+        return 2
     masters = synth.make_masters(H, W, config_id=2, device=dev)
     nflat, _ = ops.flat_normalize(masters['flat'])
     tdtype = torch.float32 if args.dtype == 'f32' else torch.uint16
-    wl = args.workload
     frames = None
     if wl != 'c4':
-        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=rank * N)
+        first = (rank * 1000) if rowshard else f0               # distinct synthetic frames per rank
+        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=first)
     e = synth.EXP_RATIO
     calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat,
                  exp_ratio=torch.full((N,), e, dtype=torch.float32, device=dev), dark_still_biased=False)
@@ -128,7 +288,8 @@ def main():
 
     if wl == 'c4':
         if world > 1:
-            raise SystemExit('workload c4 is a single-GPU configuration')
+            print('error: workload c4 is a single-GPU configuration', file=sys.stderr)
+            return 2
         nflat4, _ = ops.bayer_flat_normalize(masters['flat'])
         frames = synth.make_frames(N, masters, nflat4, config_id=4, dtype=torch.uint16, first_frame=0)
         calib = dict(calib, nflat=nflat4)
@@ -145,6 +306,8 @@ def main():
         resampled = torch.empty_like(frames)
     torch.cuda.synchronize()
 
+    single_launch = (world == 1 and not args.force_collective) or rowshard
+
     def step():
         if wl == 'c4':
             return ops.stack_median(frames, calib=calib)
@@ -152,11 +315,12 @@ def main():
             ops.resample_affine(frames, affines, mask=badmask, out=resampled, weight=False)
             if world == 1:
                 return ops.stack_sigclip(resampled, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
-            return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=args.stripes)
-        if world == 1 and not args.force_collective:
-            return ops.stack_sigclip(frames, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', calib=calib,
-                                     outputs=('mean',))['mean']
-        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=args.stripes, force_collective=args.force_collective)
+            return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=args.stripes, exchange=args.exchange)
+        if single_launch:
+            return parallel.stack_rowshard(frames, calib, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
+                                           outputs=('mean',))['mean']
+        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=args.stripes,
+                                     force_collective=args.force_collective, exchange=args.exchange)
 
     for _ in range(args.warmup):
         out = step()
@@ -172,44 +336,61 @@ def main():
         out = step()
         evs[k][1].record()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0                    # this rank's own time for the K steps
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [1e3 * local_elapsed / args.steps]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([local_elapsed], dtype=torch.float64, device=dev)
+        allt = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allt, mine)
+        per_rank_ms = [1e3 * float(v) / args.steps for v in allt.cpu()]
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * N * P / 1e6 / (elapsed / args.steps)
+    value = world * N * P / 1e6 / (elapsed / args.steps)       # input frame pixels of ALL ranks per second
 
-    # dominant kernel (stack_sigclip_kernel): device time per launch from HIP events on the launch stream.
-    # For world == 1 a step is exactly one launch of it.
+    # dominant kernel: device time per step from HIP events on the launch stream; for a single-launch step this is
+    # exactly one launch of the stack kernel, whose name the library reports for the variant it dispatched.
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
     avg_kernel_ms = sum(kern_ms) / len(kern_ms)
     esize = 4 if args.dtype == 'f32' else 2
-    out_planes = 1 if world == 1 else 3
-    algo_bytes = esize * N * P + 12 * P + 4 * out_planes * P       # frames + bias/dark/nflat read, outputs written
-    kernel_name = 'stack_sigclip_kernel<64,%s,calib>' % ('float' if args.dtype == 'f32' else 'u16')
+    nshard_multi = not single_launch
+    out_bytes = 4 if single_launch else (20 if args.exchange == 'f64' else 12)     # mean plane | moment planes written
+    algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
+    kernel_name = ops.stack_kernel_name(N, args.dtype, calibrated=True,
+                                        outputs=('mean',) if single_launch else (('moments_f64',) if args.exchange == 'f64' else ('moments',)))
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
-    workload = 'C2: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean' % (N, H, W, args.dtype)
+    cfg_name = 'C2' if (world == 1 or not strong) else 'C3'
+    workload = '%s: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean' % (
+        cfg_name, N, H, W, args.dtype)
     if wl == 'c4':
         algo_bytes = 2 * N * P + 12 * P + 4 * P
         args.dtype = 'u16'
-        kernel_name = 'stack_median_u16_kernel<%d,calib>' % N
+        kernel_name = ops.stack_kernel_name(N, 'u16', calibrated=True, median_only=True)
         metric = 'Mpixels/sec calibrate+median-stack (uint16 Bayer)'
         workload = 'C4: %dx%dx%d u16 RGGB mosaic, per-channel flat normalisation, fused bias/dark/flat + median stack' % (N, H, W)
     if wl == 'c5':
-        algo_bytes = (8 * N * P + P) + (4 * N * P + 4 * out_planes * P)     # resample read+write (+mask), stack read + outputs
-        kernel_name = 'resample_affine_kernel + stack_sigclip_kernel<%d,float,plain> (step = both launches)' % N
+        algo_bytes = (8 * N * P + P) + (4 * N * P + out_bytes * P)     # resample read+write (+mask), stack read + outputs
+        kernel_name = 'resample_affine_kernel + ' + ops.stack_kernel_name(N, 'f32', calibrated=False) + ' (step = both launches)'
         metric = 'Mpixels/sec mask+affine-resample+sigma-clip-stack'
         workload = 'C5 (per-GPU share): %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (N, H, W)
     achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
+
+    # HBM traffic per launch from the PMC counters: collected by profiles/run_profile.sh (separate --pmc passes of THIS
+    # command under rocprofv3; counters cannot be read from inside the process) and looked up by workload key.
     traffic = None
+    tkey = '%s:%dx%dx%d:%s:%s' % (wl, N, H, W, args.dtype, 'single' if single_launch else args.exchange)
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tfile) and world == 1 and (N, H, W, args.dtype, wl) == (64, 4096, 4096, 'f32', 'c2'):
+    if os.path.exists(tfile) and world == 1:
         try:
-            traffic = json.load(open(tfile)).get('hbm_bytes_per_launch')
+            td = json.load(open(tfile))
+            ent = td.get('workloads', {}).get(tkey)
+            if ent:
+                traffic = ent.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
 
@@ -231,29 +412,33 @@ def main():
         copy_gbs = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
         del src, dst
 
-    c4file = os.path.join(ROOT, 'profiles', 'r01', 'pmc_c4.json')
-    if wl == 'c4' and os.path.exists(c4file) and (N, H, W) == (64, 6248, 4176):
-        try:
-            d = json.load(open(c4file))
-            traffic = d['hbm_read_bytes_fetch_size_x2'] + d['hbm_write_bytes']
-        except Exception:
-            traffic = None
-
     line = None
     if rank == 0:
+        if world == 1:
+            par = 'single GPU'
+        elif rowshard:
+            par = 'row-shard x%d (every rank: all %d frames of %d rows; no data-path collective)' % (world, N, H)
+        else:
+            par = 'N-shard x%d (%d of %d frames per rank), %d-stripe all-reduce of %s' % (
+                world, N, n_total, args.stripes,
+                'float64 sum + int32 count (12 B/pixel)' if args.exchange == 'f64' else 'float32 sum + count (8 B/pixel)')
         line = {
             'metric': metric, 'value': value, 'unit': 'Mpixels/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': workload,
-                       'frames_per_gpu': N, 'height': H, 'width': W,
-                       'parallelism': 'single GPU' if world == 1 else 'N-shard x%d, %d-stripe all-reduce of sum/sumsq/count' % (world, args.stripes)},
+            'n_gpus': world, 'rccl_world_size': rccl_world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'per_rank_ms': per_rank_ms,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': workload, 'frames_per_gpu': N, 'frames_total': n_total if not rowshard else N,
+                       'height': H, 'width': W, 'parallelism': par},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': kernel_name,
                          'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes,
                          'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None},
         }
+        if nshard_multi:
+            line['roofline']['note'] = ('step = %d stripe kernels + all-reduces on side streams; achieved = per-rank algorithmic '
+                                        'bytes / step time on the launch stream' % args.stripes)
+            line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(args.exchange)
         if world == 1 and not args.no_cpu_baseline:
             if args.dtype == 'f32' and wl == 'c2':
                 line['cpu_baseline'] = cpu_baseline(frames, masters, nflat, e, args.cpu_seconds)
@@ -273,7 +458,8 @@ def main():
         os.write(1, (json.dumps(line) + '\n').encode())
     # keep late C-level chatter (library destructors) off stdout
     os.dup2(2, 1)
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define APGPU_VERSION 100           /* 0.1.0 */
+#define APGPU_VERSION 110           /* 0.1.1 */
 
 /* error codes */
 #define APGPU_OK            0
@@ -93,8 +93,14 @@ int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias, const flo
  *     sigma_lower = sigma_upper = 5 this is the ccdproc.combine configuration of
  *     scripts/ap_combine_darks.py:394-420.
  *     Outputs (each may be NULL): mean/median/std [P] float32, count [P] int32 survivors,
- *     and the N-shard partial moments sum/cnt/sumsq packed as moments[3][P] float32
- *     (all-reduced over ranks, then apgpu_moments_finalize).
+ *     mean_f64/std_f64 [P] float64 (the unrounded statistics: ccdproc.combine and CCDData.write keep float64,
+ *     scripts/ap_combine_darks.py:411-439), and the N-shard partial moments of the survivors
+ *     (all-reduced over ranks, then apgpu_moments_finalize[_f64]) in one of two layouts:
+ *       moments_f64 == 0: float32 moments[3][P] = sum, count, sum of squares (a mean-only exchange all-reduces
+ *                         the contiguous [2][P] prefix, 8 bytes per pixel; the float32 sums round per rank);
+ *       moments_f64 != 0: double sum[P], double sumsq[P], int32 count[P] laid out back to back in `moments`
+ *                         (20 P bytes, 8-byte aligned): ranks add float64 sums and int32 counts, the combined
+ *                         mean is the float64 combine rounded once to float32 (12 bytes per pixel mean-only).
  * ------------------------------------------------------------------------------------------- */
 typedef struct apgpu_stack_args {
     const void *frames;          /* [N][P] APGPU_F32 or APGPU_U16 */
@@ -118,10 +124,13 @@ typedef struct apgpu_stack_args {
     float *median;               /* [P] or NULL */
     float *std;                  /* [P] or NULL */
     int32_t *count;              /* [P] or NULL */
-    float *moments;              /* [3][P] or NULL: sum, count, sum of squares of the survivors (in this order:
-                                    a mean-only exchange all-reduces the contiguous [2][P] prefix) */
+    void *moments;               /* NULL, or the partial moments of the survivors in the layout moments_f64 selects */
     int64_t frame_stride;        /* elements between the starts of consecutive frames; 0 = n_pixels.
                                     > n_pixels lets a call reduce a row stripe of a larger slab */
+    double *mean_f64;            /* [P] or NULL */
+    double *std_f64;             /* [P] or NULL */
+    int32_t moments_f64;         /* layout of `moments`, see above */
+    int32_t reserved0;           /* must be 0 */
 } apgpu_stack_args;
 
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
@@ -129,10 +138,21 @@ int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 /* Plain median along N (np.nanmedian(axis=0)); config 4.  Optional fused calibration as above. */
 int apgpu_stack_median(const apgpu_stack_args *args, void *stream);
 
-/* mean = sum / cnt, std = sqrt(max(sumsq / cnt - mean^2, 0)) from all-reduced moments[3][P] = sum, cnt, sumsq
- * (with std == NULL only the first two planes are read);
- * cnt == 0 -> NaN.  mean/std may be NULL. */
+/* Name of the kernel variant apgpu_stack_sigclip (median_only == 0) / apgpu_stack_median (!= 0) dispatches for `args`
+ * (slot count, raw type, fused calibration, rich / lean, full / padded), as rocprofv3 prints it without the namespace,
+ * e.g. "stack_sigclip_kernel<64, float, true, false, true>".  Launches nothing; name_host is a HOST buffer. */
+int apgpu_stack_kernel_name(const apgpu_stack_args *args, int median_only, char *name_host, size_t name_bytes);
+
+/* mean = sum / cnt from all-reduced float32 moments (planes sum, cnt; cnt == 0 -> NaN).  `std` must be NULL:
+ * sumsq / cnt - mean^2 from float32 sums about zero cancels catastrophically for CCD-range data (APGPU_EUNSUPPORTED);
+ * use the float64 layout for a standard deviation. */
 int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_t n_pixels, void *stream);
+
+/* The float64 layout: mean = sum / cnt and std = sqrt(max(sumsq / cnt - mean^2, 0)) evaluated in float64, stored as
+ * float32 (mean, std) and/or float64 (mean_f64, std_f64); every output may be NULL; sumsq may be NULL if no std is
+ * wanted; cnt == 0 -> NaN. */
+int apgpu_moments_finalize_f64(const double *sum, const double *sumsq, const int32_t *count, float *mean, float *std,
+                               double *mean_f64, double *std_f64, int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A3  astropy.stats.sigma_clipped_stats(data, sigma) with axis=None as called at

@@ -1,54 +1,39 @@
 #!/usr/bin/env python3
-"""Copies the judged summaries of a profiling run (profiles/run_profile.sh <tag> via gpurun, plus the bench
-lines written next to it) from gpurun_out/ into profiles/<tag>/:  python profiles/collect.py r01"""
-import csv
-import glob
+"""Copies the judged summaries of ONE profiling run (profiles/run_profile.sh <tag> via gpurun) from gpurun_out/ into
+profiles/<tag>/ and refreshes profiles/pmc_traffic.json (the measured HBM bytes per launch bench.py reports as
+roofline.traffic for the same workload key):  python profiles/collect.py r02"""
 import json
 import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(root, 'profiles', tag)
 os.makedirs(dst, exist_ok=True)
-
-f = sorted(glob.glob(src + '/trace/*/*kernel_stats.csv'))[-1]
-rows = list(csv.reader(open(f)))
-with open(dst + '/kernel_stats_top.csv', 'w', newline='') as fh:
-    w = csv.writer(fh)
-    for r in rows[:13]:
-        r[0] = r[0][:120]
-        w.writerow(r)
-f = sorted(glob.glob(src + '/trace/*/*kernel_trace.csv'))[-1]
-keep = ['Kernel_Name', 'Start_Timestamp', 'End_Timestamp', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'Scratch_Size',
-        'LDS_Block_Size', 'Workgroup_Size', 'Grid_Size']
-with open(dst + '/stack_kernel_dispatches.csv', 'w', newline='') as fh:
-    w = csv.writer(fh)
-    w.writerow(keep + ['Duration_ns'])
-    for r in csv.DictReader(open(f)):
-        if 'stack_sigclip' in r['Kernel_Name']:
-            w.writerow([r.get(k, '')[:110] for k in keep] + [int(r['End_Timestamp']) - int(r['Start_Timestamp'])])
-with open(dst + '/pmc_stack_kernel.csv', 'w', newline='') as fh:
-    w = csv.writer(fh)
-    w.writerow(['pass', 'Kernel_Name', 'Counter_Name', 'Counter_Value'])
-    for p in ('pmc_fetch', 'pmc_write'):
-        for f in glob.glob(src + '/' + p + '/*/*counter_collection.csv'):
-            for r in csv.DictReader(open(f)):
-                if 'stack_sigclip' in r['Kernel_Name']:
-                    w.writerow([p, r['Kernel_Name'][:110], r['Counter_Name'], r['Counter_Value']])
-shutil.copy(src + '/summary_%s.json' % tag, dst + '/summary_%s.json' % tag)
-shutil.copy(src + '/bench_trace.json', dst + '/bench_line_under_rocprof.json')
-for name in ('bench_line.json', 'bench_c4.json', 'bench_c5.json', 'bench_collective_1rank.json', 'bench_kernels.json',
-             'bench_kernels.txt', 'bench_kernels_cpu.txt', 'bench_u16_sizes.txt'):
-    p = os.path.join(root, 'gpurun_out', name)
+for name in ('summary_%s.json' % tag, 'kernel_stats_top.csv', 'dominant_kernel_dispatches.csv', 'pmc_dominant_kernel.csv',
+             'bench_line.json', 'bench_trace.json'):
+    p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
-        shutil.copy(p, os.path.join(dst, name))
-s = json.load(open(src + '/summary_%s.json' % tag))
-json.dump({'tag': tag, 'kernel': 'stack_sigclip_kernel<64,float,calib,lean,full>', 'hbm_bytes_per_launch': s['hbm_bytes_per_launch'],
-           'read_bytes_fetch_size_x2': s['hbm_read_bytes_corrected'], 'write_bytes': s['hbm_write_bytes'],
-           'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KiB units; FETCH_SIZE doubled per '
-                   'MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)'},
-          open(os.path.join(root, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
+        shutil.copy(p, os.path.join(dst, 'bench_line_under_rocprof.json' if name == 'bench_trace.json' else name))
+s = json.load(open(os.path.join(src, 'summary_%s.json' % tag)))
+line = s.get('bench_line') or s.get('bench_line_under_rocprof') or {}
+cfg = line.get('config', {})
+if 'hbm_bytes_per_launch' in s and cfg:
+    wl = cfg['workload'].split(':')[0].lower()
+    single = line.get('n_gpus', 1) == 1
+    key = '%s:%dx%dx%d:%s:%s' % (wl, cfg['frames_per_gpu'], cfg['height'], cfg['width'], line['dtype'], 'single' if single else 'nshard')
+    tfile = os.path.join(root, 'profiles', 'pmc_traffic.json')
+    try:
+        td = json.load(open(tfile))
+        if 'workloads' not in td:
+            td = {'workloads': {}}
+    except Exception:
+        td = {'workloads': {}}
+    td['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command (profiles/run_profile.sh); KiB '
+                  'units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)')
+    td['workloads'][key] = {'tag': tag, 'kernel': s.get('dominant_kernel'), 'hbm_bytes_per_launch': s['hbm_bytes_per_launch'],
+                            'read_bytes_fetch_size_x2': s['hbm_read_bytes_corrected'], 'write_bytes': s['hbm_write_bytes']}
+    json.dump(td, open(tfile, 'w'), indent=1)
 print(sorted(os.listdir(dst)))

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Condenses a rocprofv3 output directory (profiles/run_profile.sh) into small text/JSON summaries."""
+"""Condenses one profiles/run_profile.sh output directory (all passes of ONE gpurun call) into a single summary:
+summary_<tag>.json (+ kernel_stats_top.csv, dominant_kernel_dispatches.csv, pmc_dominant_kernel.csv) written next to
+the raw rocprofv3 output; profiles/collect.py copies them into profiles/<tag>/."""
 import csv
 import glob
 import json
@@ -14,40 +16,84 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
-lines = []
+def load_line(name):
+    try:
+        txt = open(os.path.join(out, name)).read().strip().splitlines()
+        return json.loads(txt[-1])
+    except Exception:
+        return None
+
+
+line = load_line('bench_line.json')
+traced = load_line('bench_trace.json')
+res['bench_line'] = line
+res['bench_line_under_rocprof'] = traced
+kern = (line or traced or {}).get('roofline', {}).get('kernel', 'stack_sigclip')
+key = kern.split(' + ')[-1].split(' (')[0]                 # the library's own name of the dispatched variant
+res['dominant_kernel'] = key
+
+stats = []
 for f in find('trace/**/*kernel_stats.csv'):
-    rows = list(csv.DictReader(open(f)))
-    for r in rows[:12]:
-        r['Name'] = r.get('Name', '')[:100]
-        lines.append(r)
-res['kernel_stats'] = lines
-durs = []
-regs = None
-for f in find('trace/**/*kernel_trace.csv'):
-    for r in csv.DictReader(open(f)):
-        if 'stack_sigclip' in r.get('Kernel_Name', ''):
-            durs.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-            regs = {k: r.get(k) for k in ('VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'Scratch_Size', 'LDS_Block_Size',
-                                          'Workgroup_Size', 'Grid_Size')}
-if durs:
-    res['stack_kernel'] = {'dispatches': len(durs), 'avg_ns': sum(durs) / len(durs), 'min_ns': min(durs), 'max_ns': max(durs),
-                           'resources': regs}
-for name, pat in (('FETCH_SIZE', 'pmc_fetch/**/*counter_collection.csv'), ('WRITE_SIZE', 'pmc_write/**/*counter_collection.csv')):
-    vals = []
-    for f in find(pat):
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(out, 'kernel_stats_top.csv'), 'w', newline='') as fh:
+        w = csv.writer(fh)
+        for r in rows[:13]:
+            r[0] = r[0][:140]
+            w.writerow(r)
+    for r in list(csv.DictReader(open(f)))[:12]:
+        r['Name'] = r.get('Name', '')[:140]
+        stats.append(r)
+res['kernel_stats'] = stats
+
+durs, regs = [], None
+keep = ['Kernel_Name', 'Start_Timestamp', 'End_Timestamp', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count', 'Scratch_Size',
+        'LDS_Block_Size', 'Workgroup_Size', 'Grid_Size']
+with open(os.path.join(out, 'dominant_kernel_dispatches.csv'), 'w', newline='') as fh:
+    w = csv.writer(fh)
+    w.writerow(keep + ['Duration_ns'])
+    for f in find('trace/**/*kernel_trace.csv'):
         for r in csv.DictReader(open(f)):
-            if 'stack_sigclip' in r.get('Kernel_Name', '') and r.get('Counter_Name') == name:
-                vals.append(float(r['Counter_Value']))
-    if vals:
-        res[name] = {'dispatches': len(vals), 'avg_raw': sum(vals) / len(vals)}
-if 'FETCH_SIZE' in res and 'WRITE_SIZE' in res:
+            if key in r.get('Kernel_Name', ''):
+                d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+                durs.append(d)
+                regs = {k: r.get(k) for k in keep[3:]}
+                w.writerow([r.get(k, '')[:140] for k in keep] + [d])
+if durs:
+    res['dominant_kernel_trace'] = {'dispatches': len(durs), 'avg_ns': sum(durs) / len(durs), 'min_ns': min(durs),
+                                    'max_ns': max(durs), 'rocprof_resources': regs,
+                                    'note': 'rocprofv3 prints VGPR_Count = allocated VGPRs / 2 on gfx950 (allocation granule 8 '
+                                            'reported in units of 4): 76 here = 152 registers in the code object metadata'}
+
+counters = {}
+with open(os.path.join(out, 'pmc_dominant_kernel.csv'), 'w', newline='') as fh:
+    w = csv.writer(fh)
+    w.writerow(['pass', 'Kernel_Name', 'Counter_Name', 'Counter_Value'])
+    for f in find('pmc_*/**/*counter_collection.csv'):
+        p = os.path.relpath(f, out).split(os.sep)[0]
+        for r in csv.DictReader(open(f)):
+            if key in r.get('Kernel_Name', ''):
+                counters.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+                w.writerow([p, r['Kernel_Name'][:140], r['Counter_Name'], r['Counter_Value']])
+avg = {k: sum(v) / len(v) for k, v in counters.items()}
+res['pmc_avg_per_dispatch'] = avg
+res['pmc_dispatches'] = {k: len(v) for k, v in counters.items()}
+if 'FETCH_SIZE' in avg and 'WRITE_SIZE' in avg:
     # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream (x2)
-    fetch_b = res['FETCH_SIZE']['avg_raw'] * 1024 * 2
-    write_b = res['WRITE_SIZE']['avg_raw'] * 1024
+    fetch_b = avg['FETCH_SIZE'] * 1024 * 2
+    write_b = avg['WRITE_SIZE'] * 1024
     res['hbm_bytes_per_launch'] = fetch_b + write_b
     res['hbm_read_bytes_corrected'] = fetch_b
     res['hbm_write_bytes'] = write_b
+if 'SQ_INSTS_VALU' in avg and avg.get('SQ_WAVES'):
+    res['valu_insts_per_wave'] = avg['SQ_INSTS_VALU'] / avg['SQ_WAVES']
+    for k in ('SQ_INSTS_SALU', 'SQ_INSTS_VMEM_RD', 'SQ_INSTS_LDS'):
+        if k in avg:
+            res[k.lower().replace('sq_insts_', '') + '_insts_per_wave'] = avg[k] / avg['SQ_WAVES']
+if 'GRBM_GUI_ACTIVE' in avg and durs:
+    res['gpu_clock_ghz_during_kernel'] = avg['GRBM_GUI_ACTIVE'] / (sum(durs) / len(durs))
+if 'SQ_WAVE_CYCLES' in avg and avg.get('SQ_BUSY_CYCLES'):
+    res['sq_wave_cycles_over_busy_cycles'] = avg['SQ_WAVE_CYCLES'] / avg['SQ_BUSY_CYCLES']
 json.dump(res, open(os.path.join(out, 'summary_%s.json' % tag), 'w'), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k != 'kernel_stats'}, indent=1))
-for r in lines[:8]:
+print(json.dumps({k: v for k, v in res.items() if k not in ('kernel_stats', 'bench_line', 'bench_line_under_rocprof')}, indent=1))
+for r in stats[:8]:
     print(r)

@@ -1,8 +1,9 @@
-"""world_size-2 gloo test (CPU) of the N-shard collective plumbing in astrophotography_amd.parallel.
+"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing in astrophotography_amd.parallel.
 
 The per-rank partial moments and the finalisation are HIP kernels in the product; here CPU stand-ins
-built on the oracle are injected so that sharding, striping, the all-reduce and the assembly of the
-result run for real under torch.distributed (gloo)."""
+built on the oracle are injected so that sharding, striping, the all-reduces (both exchange payloads) and
+the assembly of the result run for real under torch.distributed (gloo).  The row-shard test exercises the
+partition / gather helpers the same way."""
 import os
 import socket
 import sys
@@ -24,7 +25,8 @@ def _free_port():
     return p
 
 
-def _oracle_local_moments(frames, calib, r0, r1, clip):
+def _oracle_local_moments(frames, calib, r0, r1, clip, exchange):
+    """Stand-in for ops.stack_sigclip(outputs=('moments' | 'moments_f64')): the same planes, computed by the oracle."""
     from oracle import apref
     sub = frames[:, r0:r1].numpy()
     if calib is not None:
@@ -34,12 +36,32 @@ def _oracle_local_moments(frames, calib, r0, r1, clip):
     r = apref.stack_sigclip(sub, sigma=clip['sigma'], maxiters=clip['maxiters'], cenfunc=clip['cenfunc'],
                             stdfunc=clip['stdfunc'], want=('keep', 'count'))
     kept = np.where(r['keep'], sub.astype(np.float64), 0.0)
-    mom = np.stack([kept.sum(0), r['count'].astype(np.float64), (kept * kept).sum(0)]).astype(np.float32)    # sum, count, sumsq
-    return torch.from_numpy(mom)
+    if exchange == 'f32':
+        mom = torch.from_numpy(np.stack([kept.sum(0), r['count'].astype(np.float64)]).astype(np.float32))
+        return dict(sum=mom[0], count=mom[1], prefix=mom)
+    return dict(sum=torch.from_numpy(kept.sum(0)), sumsq=torch.from_numpy((kept * kept).sum(0)),
+                count=torch.from_numpy(r['count'].astype(np.int32)))
 
 
-def _cpu_finalize(moments, out_mean):
-    out_mean.copy_(moments[0] / moments[1])
+def _cpu_finalize(m, out_mean, out_std, exchange):
+    if exchange == 'f32':
+        out_mean.copy_(m['sum'] / m['count'])
+        return
+    n = m['count'].double()
+    mean = m['sum'] / n
+    out_mean.copy_(mean.float())
+    if out_std is not None:
+        out_std.copy_((m['sumsq'] / n - mean * mean).clamp_min(0).sqrt().float())
+
+
+def _data(n_total, shape):
+    rng = np.random.default_rng(42)                                  # same data on every rank
+    cube = rng.normal(50000, 30, (n_total,) + shape).astype(np.float32)   # CCD-range values: float32 sums of squares would cancel
+    hits = rng.random(cube.shape) < 0.03
+    cube[hits] += 3000
+    bias = rng.normal(100, 2, shape).astype(np.float32)
+    dark = rng.normal(10, 1, shape).astype(np.float32)
+    return cube, bias, dark
 
 
 def _worker(rank, world, port, n_total, shape, out_dir):
@@ -47,50 +69,66 @@ def _worker(rank, world, port, n_total, shape, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from astrophotography_amd import parallel
-    rng = np.random.default_rng(42)                                  # same data on every rank
-    cube = rng.normal(500, 20, (n_total,) + shape).astype(np.float32)
-    hits = rng.random(cube.shape) < 0.03
-    cube[hits] += 3000
-    bias = rng.normal(100, 2, shape).astype(np.float32)
-    dark = rng.normal(10, 1, shape).astype(np.float32)
+    cube, bias, dark = _data(n_total, shape)
     lo, hi = parallel.shard_frames(n_total, world, rank)
     calib = dict(bias=torch.from_numpy(bias), dark=torch.from_numpy(dark), nflat=None, exp_ratio=0.4)
-    mean, mom = parallel.stack_nshard(torch.from_numpy(cube[lo:hi]), calib, sigma=3.0, maxiters=5, n_stripes=3,
-                                      local_moments=_oracle_local_moments, finalize=_cpu_finalize, return_moments=True)
-    # the mean-only exchange all-reduces just the (sum, count) prefix of the moments: same mean
-    mean2 = parallel.stack_nshard(torch.from_numpy(cube[lo:hi]), calib, sigma=3.0, maxiters=5, n_stripes=4,
-                                  local_moments=_oracle_local_moments, finalize=_cpu_finalize)
-    assert torch.equal(mean, mean2)
-    np.save(os.path.join(out_dir, f'mean{rank}.npy'), mean.numpy())
-    np.save(os.path.join(out_dir, f'mom{rank}.npy'), mom.numpy())
+    mine = torch.from_numpy(cube[lo:hi])
+    kw = dict(sigma=3.0, maxiters=5, local_moments=_oracle_local_moments, finalize=_cpu_finalize)
+    (mean, std), parts = parallel.stack_nshard(mine, calib, n_stripes=3, exchange='f64', want_std=True, return_moments=True, **kw)
+    mean_b = parallel.stack_nshard(mine, calib, n_stripes=4, exchange='f64', **kw)          # mean-only exchange: same mean
+    assert torch.equal(mean, mean_b)
+    mean32 = parallel.stack_nshard(mine, calib, n_stripes=2, exchange='f32', **kw)
+    with pytest.raises(ValueError):
+        parallel.stack_nshard(mine, calib, exchange='f32', want_std=True, **kw)
+    cnt = torch.cat([p['count'] for p in parts], 0)
+    np.savez(os.path.join(out_dir, f'r{rank}.npz'), mean=mean.numpy(), std=std.numpy(), mean32=mean32.numpy(), count=cnt.numpy())
+
+    # row-shard: every rank reduces all frames of its own rows (stand-in for the device call), then the image is gathered
+    H = shape[0]
+    r0, r1 = parallel.row_block(H, world, rank)
+    from oracle import apref
+    cal = apref.calibrate(cube[:, r0:r1], bias[r0:r1], dark[r0:r1], None, 0.4)
+    block = torch.from_numpy(apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean',))['mean'].astype(np.float32))
+    full = parallel.gather_rows(block, H)
+    np.save(os.path.join(out_dir, f'rows{rank}.npy'), full.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_nshard_allreduce_world2(tmp_path):
+def test_nshard_and_rowshard_world2(tmp_path):
     from oracle import apref
-    world, n_total, shape = 2, 24, (10, 16)
+    from astrophotography_amd import parallel
+    world, n_total, shape = 2, 24, (11, 16)                          # 11 rows: ragged row blocks (6 + 5) and stripes
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, shape, str(tmp_path)), nprocs=world, join=True)
-    means = [np.load(tmp_path / f'mean{r}.npy') for r in range(world)]
-    moms = [np.load(tmp_path / f'mom{r}.npy') for r in range(world)]
-    assert np.array_equal(means[0], means[1]) and np.array_equal(moms[0], moms[1])     # every rank holds the result
-    # expected: hierarchical clipping = sigma-clip each rank's frames, add the moments (SURVEY 8(e) option ii)
-    rng = np.random.default_rng(42)
-    cube = rng.normal(500, 20, (n_total,) + shape).astype(np.float32)
-    hits = rng.random(cube.shape) < 0.03
-    cube[hits] += 3000
-    bias = rng.normal(100, 2, shape).astype(np.float32)
-    dark = rng.normal(10, 1, shape).astype(np.float32)
+    res = [np.load(tmp_path / f'r{r}.npz') for r in range(world)]
+    for k in ('mean', 'std', 'mean32', 'count'):
+        assert np.array_equal(res[0][k], res[1][k]), k                # every rank holds the result
+    # expected: hierarchical clipping = sigma-clip each rank's frames, add the float64 moments (SURVEY 8(e) option ii)
+    cube, bias, dark = _data(n_total, shape)
     cal = apref.calibrate(cube, bias, dark, None, 0.4)
     tot = np.zeros(shape, np.float64)
-    cnt = np.zeros(shape, np.float64)
+    tot2 = np.zeros(shape, np.float64)
+    cnt = np.zeros(shape, np.int64)
     for r in range(world):
-        lo, hi = (0, 12) if r == 0 else (12, 24)
+        lo, hi = parallel.shard_frames(n_total, world, r)
         rr = apref.stack_sigclip(cal[lo:hi], sigma=3.0, maxiters=5, want=('keep', 'count'))
-        tot += np.where(rr['keep'], cal[lo:hi].astype(np.float64), 0).sum(0)
+        kept = np.where(rr['keep'], cal[lo:hi].astype(np.float64), 0)
+        tot += kept.sum(0)
+        tot2 += (kept * kept).sum(0)
         cnt += rr['count']
-    assert np.array_equal(moms[0][1], cnt.astype(np.float32))                           # planes: sum, count, sumsq
-    np.testing.assert_allclose(means[0], tot / cnt, rtol=3e-7)
-    assert cnt.min() >= 16 and cnt.max() == 24 and (cnt < 24).any()                     # outliers were clipped
+    assert np.array_equal(res[0]['count'], cnt)
+    mean64 = tot / cnt
+    # float64 exchange: the float64 combine rounded ONCE - bit-equal to the float32 rounding of the float64 mean
+    assert np.array_equal(res[0]['mean'], mean64.astype(np.float32))
+    std64 = np.sqrt(np.maximum(tot2 / cnt - mean64 * mean64, 0))
+    np.testing.assert_allclose(res[0]['std'], std64, rtol=1e-6)
+    assert 20 < np.median(res[0]['std']) < 40                         # sigma 30 on a 50000 ADU level survives the combine
+    # float32 exchange: per-rank rounding of the sums - close, not exact
+    np.testing.assert_allclose(res[0]['mean32'], mean64, rtol=3e-7)
+    assert cnt.min() >= 16 and cnt.max() == 24 and (cnt < 24).any()   # outliers were clipped
+    # row-shard + gather = the exact full-stack result on every rank
+    full_ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean',))['mean'].astype(np.float32)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f'rows{r}.npy'), full_ref)

@@ -31,8 +31,11 @@ def test_default_workload_line():
     rf = d['roofline']
     assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert rf['algorithmic_bytes'] == 4 * 16 * 256 * 512 + 16 * 256 * 512 and rf['avg_launch_ms'] > 0
+    assert rf['kernel'] == 'stack_sigclip_kernel<16, float, true, false, true>'       # reported by the library's dispatch
+    assert d['rccl_world_size'] == 1 and len(d['per_rank_ms']) == 1
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
+    assert cb['numpy']['single_process']['value'] > 0 and cb['numpy']['single_process']['cores'] == 1 and cb['numpy']['cpu']
     assert abs(d['value'] - 16 * 256 * 512 / 1e6 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
 
 
@@ -41,5 +44,15 @@ def test_other_workloads_run():
     assert d['dtype'] == 'u16' and 'median' in d['metric'] and 'cpu_baseline' not in d
     d = _run('--workload', 'c5', '--frames', '4', '--no-cpu-baseline')
     assert 'resample' in d['metric']
-    d = _run('--frames', '16', '--force-collective', '--no-cpu-baseline', '--stripes', '3')
+    for ex in ('f64', 'f32'):
+        d = _run('--frames', '16', '--force-collective', '--no-cpu-baseline', '--stripes', '3', '--exchange', ex)
+        assert d['n_gpus'] == 1 and d['value'] > 0 and d['exchange_bytes_per_pixel'] == (12 if ex == 'f64' else 8)
+    d = _run('--frames', '16', '--parallelism', 'rowshard', '--no-cpu-baseline')
     assert d['n_gpus'] == 1 and d['value'] > 0
+
+
+def test_gpus_flag_must_match_the_world():
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--no-cpu-baseline']
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()

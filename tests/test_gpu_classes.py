@@ -269,12 +269,24 @@ def test_nshard_collective_path_on_one_gpu():
         nflat, _ = ops.flat_normalize(masters['flat'])
         frames = synth.make_frames(N, masters, nflat, config_id=3)
         calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
-        direct = ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'moments'))
-        mean, mom = parallel.stack_nshard(frames, calib, n_stripes=5, force_collective=True, return_moments=True)
+        direct = ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'std', 'count', 'moments'))
+        direct64 = ops.stack_sigclip(frames, calib=calib, outputs=('moments_f64',))['moments_f64']
+        for exchange in ('f64', 'f32'):
+            mean, parts = parallel.stack_nshard(frames, calib, n_stripes=5, force_collective=True, return_moments=True,
+                                                exchange=exchange)
+            torch.cuda.synchronize()
+            if exchange == 'f32':
+                assert torch.equal(torch.cat([p['sum'] for p in parts], 0), direct['moments'][0])
+                assert torch.equal(torch.cat([p['count'] for p in parts], 0), direct['moments'][1])
+            else:
+                assert torch.equal(torch.cat([p['sum'] for p in parts], 0), direct64['sum'])
+                assert torch.equal(torch.cat([p['count'] for p in parts], 0), direct['count'])
+            # mean from the moments (sum / count) vs the kernel's float64 mean c + S/n: within 1 ulp
+            assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'moments-finalised mean ' + exchange)
+        mean, std = parallel.stack_nshard(frames, calib, n_stripes=3, force_collective=True, want_std=True)
         torch.cuda.synchronize()
-        assert torch.equal(mom, direct['moments'])
-        # mean from float32 moments (sum / count) vs the kernel's float64 mean: within 1 ulp
-        assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'moments-finalised mean')
+        assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'mean with std')
+        assert float(((std - direct['std']).abs() / direct['std']).max()) < 1e-5
         # row-sharded exact path: two half images reduce to the same pixels
         top = parallel.stack_rowshard(frames[:, :48], dict(calib, bias=calib['bias'][:48], dark=calib['dark'][:48], nflat=nflat[:48]))
         assert torch.equal(top['mean'], direct['mean'][:48])

@@ -220,8 +220,18 @@ def test_stack_properties_large(ops):
     const = torch.full((N, 64, 64), 123.25, device='cuda')
     rc = ops.stack_sigclip(const, outputs=('mean', 'std', 'count'))
     assert torch.all(rc['mean'] == 123.25) and torch.all(rc['std'] == 0) and torch.all(rc['count'] == N)
-    mean, std = ops.moments_finalize(ops.stack_sigclip(cube, outputs=('moments',))['moments'])
+    mean = ops.moments_finalize(ops.stack_sigclip(cube, outputs=('moments',))['moments'])
     assert float((mean - r1['mean']).abs().max()) < 1e-3
+    with pytest.raises(ValueError):                       # float32 sums about zero cannot give a std (cancellation)
+        ops.moments_finalize(ops.stack_sigclip(cube, outputs=('moments',))['moments'], want_std=True)
+    # the float64 layout: mean is the kernel's float64 mean rounded once (bit-equal), std within 2 ulp of the two-pass plane
+    rs = ops.stack_sigclip(cube, outputs=('mean', 'std', 'count'))
+    m64 = ops.stack_sigclip(cube, outputs=('moments_f64',))['moments_f64']
+    assert torch.equal(m64['count'], rs['count'])
+    (mean2, std2), (mean64, std64) = ops.moments_finalize(m64, want_f64=True)
+    assert_ulp(host(mean2), host(rs['mean']), 1, 'mean from float64 moments')
+    assert float(((std2 - rs['std']).abs() / rs['std']).max()) < 1e-5
+    assert torch.equal(mean64.float(), mean2)
 
 
 # ---- A3 / A4 ---------------------------------------------------------------------------------------------

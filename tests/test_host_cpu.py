@@ -23,7 +23,7 @@ def test_capi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, 'binding missing for ' + name
     assert set(_lib.SIGNATURES) == declared
-    assert lib.apgpu_version() == 100
+    assert lib.apgpu_version() == 110
     assert lib.apgpu_last_error() is not None
     # argument validation happens before any device work
     assert lib.apgpu_calibrate(None, 0, None, None, None, None, None, 0, None, 1, 1, None) == _lib.E_INVAL
@@ -38,9 +38,9 @@ def test_stack_args_struct_matches_header():
     from astrophotography_amd._lib import StackArgs
     hdr = open(os.path.join(ROOT, 'include', 'apgpu.h')).read()
     body = hdr[hdr.index('typedef struct apgpu_stack_args {'):hdr.index('} apgpu_stack_args;')]
-    fields = re.findall(r'^\s+(?:const\s+)?[a-z0-9_]+\s*\*?\s*\*?([a-z_]+);', body, re.M)
+    fields = re.findall(r'^\s+(?:const\s+)?[a-z0-9_]+\s*\*?\s*\*?([a-z_0-9]+);', body, re.M)
     assert fields == [f[0] for f in StackArgs._fields_]
-    assert C.sizeof(StackArgs) == 152
+    assert C.sizeof(StackArgs) == 176
 
 
 def test_fitsio_reads_and_rewrites_astropy_files(tmp_path):

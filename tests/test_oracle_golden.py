@@ -230,3 +230,20 @@ def test_g9_bayer_stamps(golden_dir):
     for k, c in enumerate(chans):
         assert np.array_equal(planes[k], g[c + '_black']), c
         assert planes[k].sum() == g[c + '_black_stats'][4]
+
+
+def test_numpy_baseline_restatement_matches_the_oracle():
+    """oracle/numpy_ref.py (the NumPy CPU baseline bench.py times) computes what the pinned C oracle computes."""
+    from oracle import apref, numpy_ref
+    rng = np.random.default_rng(3)
+    raw, bias, dark, nflat = numpy_ref.synth_block(16, 6, 40, 9)
+    raw[3, 2, 5] = np.nan
+    nflat[1, 1] = 0.0
+    cal = np.stack([numpy_ref.calibrate_numpy(raw[f], bias, dark, nflat, 0.4) for f in range(raw.shape[0])])
+    assert np.array_equal(cal, apref.calibrate(raw, bias, dark, nflat, 0.4), equal_nan=True)
+    mean, cnt = numpy_ref.sigclip_numpy(cal, 3.0, 5)
+    ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean', 'count'))
+    assert np.array_equal(cnt, ref['count'])
+    np.testing.assert_allclose(mean, ref['mean'], rtol=1e-13)
+    m2, c2 = numpy_ref.calibrate_stack_numpy(raw, bias, dark, nflat, 0.4)
+    assert np.array_equal(c2, cnt) and np.array_equal(m2, mean)
