@@ -9,7 +9,7 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libapgpu.so')
 
-APGPU_F32, APGPU_U16 = 0, 1
+APGPU_F32, APGPU_U16, APGPU_F64 = 0, 1, 2
 OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
 CENTER = {'median': 0, 'mean': 1}
 DEV = {'std': 0, 'mad_std': 1}
@@ -45,6 +45,10 @@ SIGNATURES = {
     'apgpu_flat_normalize_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_calibrate': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'apgpu_flat_normalize_f64_ws_bytes': (C.c_size_t, [C.c_int64]),
+    'apgpu_flat_normalize_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_calibrate_mixed': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
     'apgpu_stack_sigclip': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     'apgpu_stack_median': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     'apgpu_stack_kernel_name': (C.c_int, [C.POINTER(StackArgs), C.c_int, C.c_char_p, C.c_size_t]),
@@ -64,9 +68,13 @@ SIGNATURES = {
     'apgpu_mask_add_rects_u8': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'apgpu_fix_badpix_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    'apgpu_fix_badpix_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     'apgpu_imarith': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_imarith_f64': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_decode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_encode_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_fits_encode_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_bayer_split_u16': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'apgpu_resample_affine_f32': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,

@@ -6,9 +6,12 @@ delta_pix, norm_flat, fixcosmic)`` (:406-509) - and adds what the reference list
 calibration of images in memory", :3): slab entry points that keep the masters resident in HBM and
 calibrate (and optionally stack) N frames per kernel launch.
 
-Arithmetic (ApCalibrate.py:439-464), all float32, each operation rounded separately:
-    x = raw - bias;  D = dark - bias if dark_still_biased else dark;  x = x - float32(exp_ratio) * D
+Arithmetic (ApCalibrate.py:439-464), each operation rounded separately:
+    x = raw - bias;  D = dark - bias if dark_still_biased else dark;  x = x - exp_ratio * D
     y = where(nflat != 0, x / nflat, x)   with nflat = flat / nanmean(flat)   (:166-190)
+in float32 when every array is float32 / uint16, and with NumPy's per-operation promotion to float64 as soon as a
+float64 array takes part: _read_fits converts only non-float FITS data to float32 (:301-305), and the masters
+ApMasterCal writes are float64 (scripts/ap_combine_darks.py:437) - the calibrated file is then BITPIX -64.
 """
 import time
 from datetime import datetime
@@ -61,16 +64,17 @@ class ApCalibrate:
     # -------------------------------------------------------------------------------------------
     @staticmethod
     def _to_f32(t):
+        """ApCalibrate._read_fits (:301-305): floating-point data stays as stored, everything else becomes float32."""
         import torch
-        if t.dtype == torch.float32:
+        if t.dtype in (torch.float32, torch.float64):
             return t
         if t.dtype == torch.uint16:                       # exact widening
             return (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32)
         return t.to(torch.float32)
 
     def _read_master(self, path):
-        """Master frame -> float32 device tensor (+ header); payload decoded on the device (fitsio.read_device).
-        PEDESTAL handling as _read_fits (core/ApCalibrate.py:318-326): a non-zero pedestal is added."""
+        """Master frame -> float32 / float64 device tensor (+ header); payload decoded on the device
+        (fitsio.read_device).  PEDESTAL handling as _read_fits (core/ApCalibrate.py:318-326): a non-zero pedestal is added."""
         import torch
         from .. import ops
         path = _common.check_file_exists(self._logger, path)
@@ -81,9 +85,6 @@ class ApCalibrate:
             raise SystemExit(1)
         if data is None or data.dim() != 2:
             raise RuntimeError(f'{path}: expected a 2-D primary image, found NAXIS={hdr["NAXIS"]}.')
-        if data.dtype == torch.float64:
-            # ccdproc writes float64 masters; the reference would then calibrate in float64
-            self._logger.warning(f'{Path(path).name} is float64; the device path calibrates in float32.')
         data = self._to_f32(data).contiguous()
         if 'PEDESTAL' in hdr and float(hdr['PEDESTAL']) != 0:
             self._logger.debug(f'Removing a PEDESTAL value of {float(hdr["PEDESTAL"])} ADU.')
@@ -91,24 +92,19 @@ class ApCalibrate:
         return data, hdr
 
     def _find_exptime_ratio(self, img_hdr, dark_hdr):
-        """EXPOSURE, then EXPTIME (ApCalibrate.py:128-164)."""
-        img_exp = dark_exp = None
-        for kw in ['EXPOSURE', 'EXPTIME']:
-            if img_exp is None and kw in img_hdr:
-                img_exp = float(img_hdr[kw])
-            if dark_exp is None and kw in dark_hdr:
-                dark_exp = float(dark_hdr[kw])
-        msg = None
-        if img_exp is None and dark_exp is None:
-            msg = 'Could not determine exposure time for both image and dark.'
-        elif img_exp is None:
-            msg = 'Could not determine exposure time for image (dark exposure found).'
-        elif dark_exp is None:
-            msg = 'Could not determine exposure time for dark (img exposure found).'
+        """Image / dark exposure-time ratio; EXPOSURE wins over EXPTIME (ApCalibrate.py:128-164, same messages)."""
+        def exposure(hdr):
+            return next((float(hdr[kw]) for kw in ('EXPOSURE', 'EXPTIME') if kw in hdr), None)
+
+        times = (exposure(img_hdr), exposure(dark_hdr))
+        problems = {(True, True): 'Could not determine exposure time for both image and dark.',
+                    (True, False): 'Could not determine exposure time for image (dark exposure found).',
+                    (False, True): 'Could not determine exposure time for dark (img exposure found).'}
+        msg = problems.get((times[0] is None, times[1] is None))
         if msg is not None:
             self._logger.error(msg)
             raise RuntimeError(msg)
-        exp_ratio = img_exp / dark_exp
+        exp_ratio = times[0] / times[1]
         self._logger.info(f'Image to dark exposure time ratio: {exp_ratio:.3f}')
         return exp_ratio
 
@@ -124,7 +120,7 @@ class ApCalibrate:
         return out_flat
 
     def _read_raw(self, raw_image):
-        """Raw light frame -> (device tensor uint16|float32, header, pedestal to add on the device)."""
+        """Raw light frame -> (device tensor uint16|float32|float64, header, pedestal to add on the device)."""
         import torch
         raw_image = _common.check_file_exists(self._logger, raw_image)
         t, hdr = fitsio.read_device(str(raw_image))
@@ -134,9 +130,7 @@ class ApCalibrate:
         if t is None or t.dim() != 2:
             raise RuntimeError(f'{raw_image}: expected a 2-D primary image, found NAXIS={hdr["NAXIS"]}.')
         pedestal = float(hdr['PEDESTAL']) if 'PEDESTAL' in hdr else 0.0
-        if t.dtype not in (torch.uint16, torch.float32):
-            if t.dtype == torch.float64:
-                self._logger.warning(f'{raw_image.name} is float64; the device path calibrates in float32.')
+        if t.dtype not in (torch.uint16, torch.float32, torch.float64):
             t = t.to(torch.float32)                          # ApCalibrate.py:304-307 for integers
         if tuple(t.shape) != tuple(self._bias_data.shape):
             raise RuntimeError(f'{raw_image.name} has shape {tuple(t.shape)}, the masters have {tuple(self._bias_data.shape)}.')
@@ -234,14 +228,20 @@ class ApCalibrate:
             hdrs.append(hdr)
             ratios.append(self._find_exptime_ratio(hdr, self._dark_hdr))
             peds.append(ped)
-        if len({t.dtype for t in tensors}) != 1:            # mixed uint16 / float32 inputs: widen exactly
+        kinds = {t.dtype for t in tensors}
+        if len(kinds) != 1:
+            if torch.float64 in kinds:
+                raise TypeError('raw frames mix float64 with other types: their results have different dtypes, calibrate '
+                                'them one at a time')
+            # mixed uint16 / float32 inputs: widen exactly (uint16 becomes float32 at read time anyway)
             tensors = [t if t.dtype == torch.float32
                        else (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32) for t in tensors]
         slab = torch.stack(tensors, 0)
         return slab, hdrs, ratios, (peds if any(p != 0 for p in peds) else None)
 
     def calibrate_slab(self, slab, exp_ratio, pedestal=None):
-        """raw[N,H,W] (uint16|float32 device tensor) -> calibrated float32 [N,H,W] in one launch."""
+        """raw[N,H,W] (uint16|float32|float64 device tensor) -> calibrated [N,H,W] in one launch (float32, or float64 if
+        the frames or any master are float64)."""
         from .. import ops
         return ops.calibrate(slab, self._bias_data, self._dark_data, self._norm_flat, exp_ratio, pedestal=pedestal,
                              dark_still_biased=self._dark_still_biased)
@@ -251,7 +251,12 @@ class ApCalibrate:
         from .. import ops
         if len(raw_images) != len(cal_images):
             raise ValueError('raw_images and cal_images differ in length')
-        slab, hdrs, ratios, peds = self.load_slab(raw_images)
+        try:
+            slab, hdrs, ratios, peds = self.load_slab(raw_images)
+        except TypeError:                                   # float64 and other raw types mixed: one frame at a time
+            for src, dst in zip(raw_images, cal_images):
+                self.calibrate(src, dst, delta_pix, None, False)
+            return
         cal = self.calibrate_slab(slab, ratios, peds)
         for i, (src, dst) in enumerate(zip(raw_images, cal_images)):
             odict = self._base_keywords()

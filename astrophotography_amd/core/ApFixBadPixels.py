@@ -30,7 +30,7 @@ class ApFixBadPixels:
 
     # -- array level -----------------------------------------------------------------------------
     def fix_bad_pixels_tensor(self, data, badpixmask, deltapix=1):
-        """Device form: float32 tensor [H,W] + mask tensor -> (fixed tensor, int64[3] stats tensor)."""
+        """Device form: float32 / float64 tensor [H,W] + mask tensor -> (fixed tensor, int64[3] stats tensor)."""
         from .. import ops
         return ops.fix_badpix(data, badpixmask, int(deltapix), self._min_valid)
 
@@ -53,14 +53,21 @@ class ApFixBadPixels:
             self._logger.warning('Pixel medians may suffer from casting truncation because'
                                  f' the input data is not a floating point datatype ({data.dtype}).')
         t0 = time.perf_counter()
-        d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).cuda()
-        m = torch.from_numpy(np.ascontiguousarray(badpixmask != ApFixBadPixels.MASK_GOOD).view(np.uint8)).cuda()
+        # medians in the input's own floating type (np.median): float32 stays float32, float64 stays float64; any
+        # other dtype is widened to float64 (exact for integers below 2^53) and only the repaired pixels are written
+        # back, so good pixels keep their bits (the reference works on data.copy(), :334)
+        work_dt = np.float32 if data.dtype == np.float32 else np.float64
+        d = torch.from_numpy(np.ascontiguousarray(data, dtype=work_dt)).cuda()
+        bad = np.ascontiguousarray(badpixmask != ApFixBadPixels.MASK_GOOD)
+        m = torch.from_numpy(bad.view(np.uint8)).cuda()
         out, st = ops.fix_badpix(d, m, deltapix, self._min_valid)
         nbad, nfixed, nnotfix = (int(x) for x in st.cpu().numpy())
         newdata = out.cpu().numpy()
-        if data.dtype != np.float32:
-            # the reference assigns float medians into an array of the input dtype (C truncation)
-            newdata = newdata.astype(data.dtype) if is_float else np.trunc(newdata).astype(data.dtype)
+        if data.dtype != work_dt:
+            fixed = newdata
+            newdata = data.copy()
+            # the reference assigns float medians into an array of the input dtype (C truncation for integers)
+            newdata[bad] = fixed[bad].astype(data.dtype) if is_float else np.trunc(fixed[bad]).astype(data.dtype)
         run_time = time.perf_counter() - t0
         npix = data.size
         pctbad = 100.0 * nbad / npix

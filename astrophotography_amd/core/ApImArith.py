@@ -44,22 +44,25 @@ class ApImArith:
         from .._lib import ApGpuError
         operation = self._sanitize_operation(operation)
         data1 = np.ascontiguousarray(data1)
-        if data1.dtype == np.float32:
+        if data1.dtype in (np.float32, np.float64):
             a = torch.from_numpy(data1).cuda()
         elif data1.dtype == np.uint16:
             a = ops.to_device_u16(data1)
         else:
-            raise TypeError(f'ApImArith supports float32 and uint16 images on the GPU, not {data1.dtype}')
+            raise TypeError(f'ApImArith supports float32, float64 and uint16 images on the GPU, not {data1.dtype}')
         if isinstance(data2, np.ndarray):
             if data1.shape != data2.shape:
                 raise RuntimeError('Error, the dimension of the second data array does not match the first.'
                                    f' First image shape: {data1.shape}, second image shape: {data2.shape}')
             if data2.dtype != data1.dtype:
-                if data1.dtype == np.float32:
-                    data2 = data2.astype(np.float32)         # numpy casts the operand to the out dtype
+                if data1.dtype.kind == 'f':
+                    # numpy computes in the promoted type and stores in data1's dtype (out=zeros_like(data1)):
+                    # a float64 operand is passed as it is, anything else widens exactly to data1's dtype
+                    if data2.dtype != np.float64:
+                        data2 = data2.astype(data1.dtype if data2.dtype.itemsize <= 2 or data1.dtype == np.float64 else np.float64)
                 else:
                     raise TypeError(f'Cannot cast {data2.dtype} operand to {data1.dtype} (same_kind)')
-            b = torch.from_numpy(np.ascontiguousarray(data2)).cuda() if data1.dtype == np.float32 else ops.to_device_u16(data2)
+            b = torch.from_numpy(np.ascontiguousarray(data2)).cuda() if data1.dtype.kind == 'f' else ops.to_device_u16(data2)
         else:
             b = float(data2)
         try:

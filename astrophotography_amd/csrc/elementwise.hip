@@ -157,16 +157,20 @@ __global__ __launch_bounds__(kBlock) void calibrate_kernel(const RawT *__restric
 constexpr int kPiece = 8192;
 constexpr int kLeaf = 128;
 
-__device__ __forceinline__ float nan0(float x, int &nans)
+// The same kernels serve float32 and float64 flats (a ccdproc-written master flat is float64 and the reference then
+// normalises it in float64, core/ApCalibrate.py:301-305, 181-188; golden G11): T is the array's own type.
+template <typename T>
+__device__ __forceinline__ T nan0(T x, int &nans)
 {
-    if (x != x) { nans++; return 0.f; }
+    if (x != x) { nans++; return (T)0; }
     return x;
 }
 
-__device__ float leaf_sum(const float *a, int n, int &nans)
+template <typename T>
+__device__ T leaf_sum(const T *a, int n, int &nans)
 {
     // numpy pairwise_sum for 8 <= n <= 128
-    float r[8];
+    T r[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) r[k] = nan0(a[k], nans);
     int i = 8;
@@ -174,17 +178,18 @@ __device__ float leaf_sum(const float *a, int n, int &nans)
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = r[k] + nan0(a[i + k], nans);
     }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < n; i++) res = res + nan0(a[i], nans);
     return res;
 }
 
-__device__ float pairwise_generic(const float *a, int n, int &nans)
+template <typename T>
+__device__ T pairwise_generic(const T *a, int n, int &nans)
 {
     // iterative form of numpy's recursion for the ragged last piece (n < 8192): explicit stack
     struct Item { int off, len; };
     Item stack[32];
-    float vals[32];
+    T vals[32];
     int state[32];
     int sp = 0, vp = 0;
     stack[sp] = {0, n}; state[sp] = 0; sp++;
@@ -193,7 +198,7 @@ __device__ float pairwise_generic(const float *a, int n, int &nans)
         Item it = stack[sp - 1];
         int stt = state[sp - 1];
         if (it.len < 8) {
-            float res = 0.f;
+            T res = (T)0;
             for (int i = 0; i < it.len; i++) res = res + nan0(a[it.off + i], nans);
             vals[vp++] = res; sp--;
         } else if (it.len <= kLeaf) {
@@ -206,8 +211,8 @@ __device__ float pairwise_generic(const float *a, int n, int &nans)
             stack[sp] = {it.off, n2}; state[sp] = 0; sp++;
         } else {
             // both children evaluated: left was pushed last so it was evaluated first
-            float right = vals[--vp];
-            float left = vals[--vp];
+            T right = vals[--vp];
+            T left = vals[--vp];
             vals[vp++] = left + right;
             sp--;
         }
@@ -215,8 +220,9 @@ __device__ float pairwise_generic(const float *a, int n, int &nans)
     return vals[0];
 }
 
-__global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const float *__restrict__ flat, int64_t n,
-                                                                float *__restrict__ piece_sums,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const T *__restrict__ flat, int64_t n,
+                                                                T *__restrict__ piece_sums,
                                                                 unsigned long long *__restrict__ nan_count)
 {
     const int64_t npieces_full = n / kPiece;
@@ -226,11 +232,11 @@ __global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const float *__
     for (int64_t piece = (int64_t)blockIdx.x * waves_per_block + wave; piece < npieces_full;
          piece += (int64_t)gridDim.x * waves_per_block) {
         int nans = 0;
-        float s = leaf_sum(flat + piece * kPiece + lane * kLeaf, kLeaf, nans);
+        T s = leaf_sum(flat + piece * kPiece + lane * kLeaf, kLeaf, nans);
         // numpy's recursion on 8192 = 64 leaves halves evenly: pair neighbours, then pairs of pairs ...
 #pragma unroll
         for (int d = 1; d < kWave; d <<= 1) {
-            const float other = __shfl_xor(s, d);
+            const T other = __shfl_xor(s, d);
             // the lower lane of each pair holds the left operand
             s = (lane & d) ? other + s : s + other;
         }
@@ -244,19 +250,20 @@ __global__ __launch_bounds__(kBlock) void flat_piece_sums_kernel(const float *__
     }
 }
 
-__global__ __launch_bounds__(kBlock) void flat_norm_kernel(const float *__restrict__ flat, int64_t n,
-                                                          const float *__restrict__ piece_sums,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void flat_norm_kernel(const T *__restrict__ flat, int64_t n,
+                                                          const T *__restrict__ piece_sums,
                                                           const unsigned long long *__restrict__ nan_count,
-                                                          float *__restrict__ norm_out)
+                                                          T *__restrict__ norm_out)
 {
     // One workgroup.  The piece sums are accumulated sequentially (numpy's order) by lane 0, but all lanes fetch
     // them - and the ragged last piece - into LDS first: a lone lane walking global memory pays a full miss
     // latency per element.
     if (blockIdx.x != 0) return;
     constexpr int kStage = 2048;
-    __shared__ float stage[kPiece > kStage ? kPiece : kStage];
+    __shared__ T stage[kPiece > kStage ? kPiece : kStage];
     const int64_t npieces_full = n / kPiece;
-    float res = 0.f;
+    T res = (T)0;
     for (int64_t i0 = 0; i0 < npieces_full; i0 += kStage) {
         const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
         for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(kBlock) void flat_norm_kernel(const float *__restri
         if (threadIdx.x == 0) {
             int t = 0;
             for (; t + 8 <= cnt; t += 8) {                  // 8 LDS reads in flight, then the 8 ordered adds
-                float x[8];
+                T x[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) x[k] = stage[t + k];
 #pragma unroll
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void flat_norm_kernel(const float *__restri
     if (rem > 0) res = res + pairwise_generic(stage, rem, nans);
     const unsigned long long bad = *nan_count + (unsigned long long)nans;
     const double cnt = (double)(n - (int64_t)bad);
-    norm_out[0] = (float)((double)res / cnt);          // numpy 1.26: float32 / int -> float64 -> float32
+    norm_out[0] = (T)((double)res / cnt);              // numpy 1.26: float32 / int -> float64 -> float32; float64 / int -> float64
 }
 
 __global__ __launch_bounds__(kBlock) void divide_by_scalar_kernel(const float *__restrict__ in,
@@ -299,6 +306,64 @@ __global__ __launch_bounds__(kBlock) void divide_by_scalar_kernel(const float *_
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         out[i] = __fdiv_rn(in[i], s);
+}
+
+__global__ __launch_bounds__(kBlock) void divide_by_scalar_f64_kernel(const double *__restrict__ in,
+                                                                     const double *__restrict__ scalar,
+                                                                     double *__restrict__ out, int64_t n)
+{
+    const double s = scalar[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i] / s;   // IEEE (no fast-math)
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2 with float64 inputs (golden G11): NumPy promotes per operation - the result of an operation is float64 if
+// either operand ARRAY is float64, else float32; the python float exp_ratio takes the type of the dark it multiplies
+// (core/ApCalibrate.py:301-305 keeps float64 FITS data as it is, :439-464 the expressions).  Every operation is
+// evaluated in float64 and rounded to float32 where NumPy's result type is float32: for + - * / of float32 operands
+// this is exactly the float32 operation (53 >= 2*24 + 2 significand bits: double rounding is innocuous).
+// ------------------------------------------------------------------------------------------------
+struct MixedTypes {
+    int raw, bias, dark, nflat;            // APGPU_F32 / APGPU_U16 (raw only) / APGPU_F64
+    int t1, t2, t3, t4;                    // 1 = the operation's NumPy result type is float64
+};
+
+__device__ __forceinline__ double load_as_f64(const void *a, int dt, int64_t i)
+{
+    if (dt == APGPU_F64) return static_cast<const double *>(a)[i];
+    if (dt == APGPU_U16) return (double)static_cast<const uint16_t *>(a)[i];
+    return (double)static_cast<const float *>(a)[i];
+}
+
+__device__ __forceinline__ double round_as(double x, int is64) { return is64 ? x : (double)(float)x; }
+
+__global__ __launch_bounds__(kBlock) void calibrate_mixed_kernel(const void *__restrict__ raw, const void *__restrict__ bias,
+                                                                const void *__restrict__ dark, const void *__restrict__ nflat,
+                                                                const double *__restrict__ exp_ratio,
+                                                                const double *__restrict__ pedestal, int still_biased,
+                                                                void *__restrict__ out, int64_t N, int64_t P, MixedTypes ty)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int r64 = ty.raw == APGPU_F64;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const double b = load_as_f64(bias, ty.bias, p), d = load_as_f64(dark, ty.dark, p);
+        const double D = still_biased ? round_as(d - b, ty.t2) : d;          // ApCalibrate.py:440-445
+        const bool has_flat = nflat != nullptr;
+        const double nf = has_flat ? load_as_f64(nflat, ty.nflat, p) : 1.0;
+        for (int64_t f = 0; f < N; f++) {
+            double r = load_as_f64(raw, ty.raw, f * P + p);
+            const double ped = pedestal ? pedestal[f] : 0.0;
+            if (ped != 0.0) r = round_as(r + round_as(ped, r64), r64);       // :318-326, in the raw array's own type
+            const double e = round_as(exp_ratio[f], ty.t2);                  // weak python scalar
+            const double x = round_as(r - b, ty.t1);                         // :439
+            const double ds = round_as(e * D, ty.t2);                        // :450
+            double y = round_as(x - ds, ty.t3);                              // :451
+            if (has_flat && nf != 0.0) y = round_as(y / nf, ty.t4);          // :462-464 (NaN != 0 -> divide -> NaN)
+            if (ty.t4) static_cast<double *>(out)[f * P + p] = y;
+            else static_cast<float *>(out)[f * P + p] = (float)y;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -378,6 +443,26 @@ __global__ __launch_bounds__(kBlock) void imarith_f32_kernel(const float *__rest
     }
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         out[i] = arith<OP>(a[i], b ? b[i] : scalar);
+}
+
+// float64 images, and float32 (op) float64 pairs: np.add(data1, data2, out=result) computes in float64 as soon as one
+// operand array is float64 and stores in data1's dtype (core/ApImArith.py:321-333, same_kind casting).
+template <int OP>
+__global__ __launch_bounds__(kBlock) void imarith_f64_kernel(const void *__restrict__ a, int a64, const void *__restrict__ b, int b64,
+                                                            double scalar, void *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double x = a64 ? static_cast<const double *>(a)[i] : (double)static_cast<const float *>(a)[i];
+        const double y = b ? (b64 ? static_cast<const double *>(b)[i] : (double)static_cast<const float *>(b)[i]) : scalar;
+        double r;
+        if constexpr (OP == APGPU_OP_ADD) r = x + y;
+        else if constexpr (OP == APGPU_OP_SUB) r = x - y;
+        else if constexpr (OP == APGPU_OP_MUL) r = x * y;
+        else r = x / y;
+        if (a64) static_cast<double *>(out)[i] = r;
+        else static_cast<float *>(out)[i] = (float)r;
+    }
 }
 
 template <int OP>
@@ -462,6 +547,14 @@ __global__ __launch_bounds__(kBlock) void fits_swap32_kernel(const unsigned *__r
     for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = bswap32(in[i]);
 }
 
+// BITPIX -64 / 64: 8-byte swap (decode and encode are the same operation)
+__global__ __launch_bounds__(kBlock) void fits_swap64_kernel(const unsigned long long *__restrict__ in,
+                                                            unsigned long long *__restrict__ out, int64_t n)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = __builtin_bswap64(in[i]);
+}
+
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -488,35 +581,87 @@ extern "C" int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias
     return check_launch("calibrate");
 }
 
+extern "C" int apgpu_calibrate_mixed(const void *raw, int raw_dtype, const void *bias, int bias_dtype, const void *dark,
+                                     int dark_dtype, const void *nflat, int nflat_dtype, const double *exp_ratio,
+                                     const double *pedestal, int dark_still_biased, void *out, int out_dtype,
+                                     int64_t n_frames, int64_t n_pixels, void *stream)
+{
+    if (!raw || !bias || !dark || !exp_ratio || !out) return fail(APGPU_EINVAL, "calibrate_mixed: NULL pointer argument");
+    if (n_frames <= 0 || n_pixels <= 0) return fail(APGPU_EINVAL, "calibrate_mixed: n_frames = %lld, n_pixels = %lld", (long long)n_frames, (long long)n_pixels);
+    auto okm = [](int d) { return d == APGPU_F32 || d == APGPU_F64; };
+    if (!(raw_dtype == APGPU_F32 || raw_dtype == APGPU_U16 || raw_dtype == APGPU_F64) || !okm(bias_dtype) || !okm(dark_dtype) ||
+        (nflat && !okm(nflat_dtype)) || !okm(out_dtype))
+        return fail(APGPU_EINVAL, "calibrate_mixed: bad dtype tag");
+    MixedTypes ty;
+    ty.raw = raw_dtype; ty.bias = bias_dtype; ty.dark = dark_dtype; ty.nflat = nflat ? nflat_dtype : APGPU_F32;
+    const int r64 = raw_dtype == APGPU_F64, b64 = bias_dtype == APGPU_F64, d64 = dark_dtype == APGPU_F64;
+    ty.t1 = r64 || b64;
+    ty.t2 = dark_still_biased ? (d64 || b64) : d64;
+    ty.t3 = ty.t1 || ty.t2;
+    ty.t4 = nflat ? (ty.t3 || nflat_dtype == APGPU_F64) : ty.t3;
+    if ((out_dtype == APGPU_F64) != (ty.t4 != 0))
+        return fail(APGPU_EINVAL, "calibrate_mixed: NumPy's result type for these inputs is %s, out_dtype says otherwise",
+                    ty.t4 ? "float64" : "float32");
+    hipLaunchKernelGGL(calibrate_mixed_kernel, dim3(grid_for(n_pixels)), dim3(kBlock), 0, as_stream(stream), raw, bias, dark, nflat,
+                       exp_ratio, pedestal, dark_still_biased, out, n_frames, n_pixels, ty);
+    return check_launch("calibrate_mixed");
+}
+
 extern "C" size_t apgpu_flat_normalize_ws_bytes(int64_t n_pixels)
 {
     if (n_pixels < 0) return 0;
     return 16 + sizeof(float) * (size_t)(n_pixels / kPiece + 1);
 }
 
+template <typename T>
+static int flat_normalize_impl(const T *flat, T *nflat, T *norm_out, int64_t n_pixels, void *ws, size_t ws_bytes, void *stream);
+
+extern "C" size_t apgpu_flat_normalize_f64_ws_bytes(int64_t n_pixels)
+{
+    if (n_pixels < 0) return 0;
+    return 16 + sizeof(double) * (size_t)(n_pixels / kPiece + 1);
+}
+
+extern "C" int apgpu_flat_normalize_f64(const double *flat, double *nflat, double *norm_out, int64_t n_pixels, void *ws,
+                                        size_t ws_bytes, void *stream)
+{
+    if (ws_bytes < apgpu_flat_normalize_f64_ws_bytes(n_pixels))
+        return fail(APGPU_EWORKSPACE, "flat_normalize_f64: workspace %zu < %zu bytes", ws_bytes, apgpu_flat_normalize_f64_ws_bytes(n_pixels));
+    return flat_normalize_impl<double>(flat, nflat, norm_out, n_pixels, ws, ws_bytes, stream);
+}
+
 extern "C" int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *norm_out, int64_t n_pixels, void *ws,
                                         size_t ws_bytes, void *stream)
 {
-    if (!flat || !norm_out || !ws) return fail(APGPU_EINVAL, "flat_normalize: NULL pointer argument");
-    if (n_pixels <= 0) return fail(APGPU_EINVAL, "flat_normalize: n_pixels = %lld", (long long)n_pixels);
     if (ws_bytes < apgpu_flat_normalize_ws_bytes(n_pixels))
         return fail(APGPU_EWORKSPACE, "flat_normalize: workspace %zu < %zu bytes", ws_bytes, apgpu_flat_normalize_ws_bytes(n_pixels));
+    return flat_normalize_impl<float>(flat, nflat, norm_out, n_pixels, ws, ws_bytes, stream);
+}
+
+template <typename T>
+static int flat_normalize_impl(const T *flat, T *nflat, T *norm_out, int64_t n_pixels, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!flat || !norm_out || !ws) return fail(APGPU_EINVAL, "flat_normalize: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "flat_normalize: n_pixels = %lld", (long long)n_pixels);
     if (!aligned16(flat) || (nflat && !aligned16(nflat)) || !aligned16(ws)) return fail(APGPU_EINVAL, "flat_normalize: buffers must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     unsigned long long *nan_count = static_cast<unsigned long long *>(ws);
-    float *piece_sums = reinterpret_cast<float *>(static_cast<char *>(ws) + 16);
+    T *piece_sums = reinterpret_cast<T *>(static_cast<char *>(ws) + 16);
     if (hipMemsetAsync(nan_count, 0, 16, st) != hipSuccess) return fail(APGPU_ELAUNCH, "flat_normalize: memset failed");
     const int64_t npieces = n_pixels / kPiece;
     if (npieces > 0) {
         const unsigned grid = grid_for(npieces * kWave);
-        hipLaunchKernelGGL(flat_piece_sums_kernel, dim3(grid), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count);
+        hipLaunchKernelGGL(flat_piece_sums_kernel<T>, dim3(grid), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count);
         if (int rc = check_launch("flat_piece_sums")) return rc;
     }
-    hipLaunchKernelGGL(flat_norm_kernel, dim3(1), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count, norm_out);
+    hipLaunchKernelGGL(flat_norm_kernel<T>, dim3(1), dim3(kBlock), 0, st, flat, n_pixels, piece_sums, nan_count, norm_out);
     if (int rc = check_launch("flat_norm")) return rc;
     if (nflat) {
-        hipLaunchKernelGGL(divide_by_scalar_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, flat, norm_out, nflat,
-                           n_pixels);
+        if constexpr (sizeof(T) == 8)
+            hipLaunchKernelGGL(divide_by_scalar_f64_kernel, dim3(grid_for(n_pixels)), dim3(kBlock), 0, st, flat, norm_out, nflat, n_pixels);
+        else
+            hipLaunchKernelGGL(divide_by_scalar_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, flat, norm_out, nflat,
+                               n_pixels);
         if (int rc = check_launch("flat_divide")) return rc;
     }
     return APGPU_OK;
@@ -548,6 +693,28 @@ extern "C" int apgpu_mask_add_rects_u8(uint8_t *mask, int64_t height, int64_t wi
         if (int rc = check_launch("mask_add_rects")) return rc;
     }
     return APGPU_OK;
+}
+
+extern "C" int apgpu_imarith_f64(const void *a, int a_dtype, const void *b, int b_dtype, double scalar, int op, void *out,
+                                 int64_t n_pixels, void *stream)
+{
+    if (!a || !out) return fail(APGPU_EINVAL, "imarith_f64: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "imarith_f64: n_pixels = %lld", (long long)n_pixels);
+    if (op < APGPU_OP_ADD || op > APGPU_OP_DIV) return fail(APGPU_EINVAL, "imarith_f64: bad operation %d", op);
+    auto okd = [](int d) { return d == APGPU_F32 || d == APGPU_F64; };
+    if (!okd(a_dtype) || (b && !okd(b_dtype))) return fail(APGPU_EINVAL, "imarith_f64: bad dtype tag");
+    if (a_dtype == APGPU_F32 && !(b && b_dtype == APGPU_F64))
+        return fail(APGPU_EINVAL, "imarith_f64: nothing is float64 here - use apgpu_imarith");
+    hipStream_t st = as_stream(stream);
+    const unsigned grid = grid_for(n_pixels);
+    const int a64 = a_dtype == APGPU_F64, b64 = b_dtype == APGPU_F64;
+    switch (op) {
+    case APGPU_OP_ADD: hipLaunchKernelGGL(imarith_f64_kernel<APGPU_OP_ADD>, dim3(grid), dim3(kBlock), 0, st, a, a64, b, b64, scalar, out, n_pixels); break;
+    case APGPU_OP_SUB: hipLaunchKernelGGL(imarith_f64_kernel<APGPU_OP_SUB>, dim3(grid), dim3(kBlock), 0, st, a, a64, b, b64, scalar, out, n_pixels); break;
+    case APGPU_OP_MUL: hipLaunchKernelGGL(imarith_f64_kernel<APGPU_OP_MUL>, dim3(grid), dim3(kBlock), 0, st, a, a64, b, b64, scalar, out, n_pixels); break;
+    default: hipLaunchKernelGGL(imarith_f64_kernel<APGPU_OP_DIV>, dim3(grid), dim3(kBlock), 0, st, a, a64, b, b64, scalar, out, n_pixels); break;
+    }
+    return check_launch("imarith_f64");
 }
 
 extern "C" int apgpu_imarith(const void *a, const void *b, double scalar, int op, int dtype, void *out, int64_t n_pixels,
@@ -618,6 +785,9 @@ extern "C" int apgpu_fits_decode(const void *payload, int bitpix, int unsigned16
     } else if (bitpix == -32 || bitpix == 32) {
         hipLaunchKernelGGL(fits_swap32_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, st, (const unsigned *)payload,
                            (unsigned *)out, n_pixels);
+    } else if (bitpix == -64 || bitpix == 64) {
+        hipLaunchKernelGGL(fits_swap64_kernel, dim3(grid_for(n_pixels)), dim3(kBlock), 0, st, (const unsigned long long *)payload,
+                           (unsigned long long *)out, n_pixels);
     } else {
         return fail(APGPU_EUNSUPPORTED, "fits_decode: BITPIX %d is decoded on the host", bitpix);
     }
@@ -632,4 +802,14 @@ extern "C" int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n
     hipLaunchKernelGGL(fits_swap32_kernel, dim3(grid_for(n_pixels / 4 + 1)), dim3(kBlock), 0, as_stream(stream),
                        (const unsigned *)data, (unsigned *)payload, n_pixels);
     return check_launch("fits_encode");
+}
+
+extern "C" int apgpu_fits_encode_f64(const double *data, void *payload, int64_t n_pixels, void *stream)
+{
+    if (!data || !payload) return fail(APGPU_EINVAL, "fits_encode_f64: NULL pointer argument");
+    if (n_pixels <= 0) return fail(APGPU_EINVAL, "fits_encode_f64: n_pixels = %lld", (long long)n_pixels);
+    if (!aligned16(data) || !aligned16(payload)) return fail(APGPU_EINVAL, "fits_encode_f64: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(fits_swap64_kernel, dim3(grid_for(n_pixels)), dim3(kBlock), 0, as_stream(stream),
+                       (const unsigned long long *)data, (unsigned long long *)payload, n_pixels);
+    return check_launch("fits_encode_f64");
 }

@@ -16,33 +16,57 @@ using namespace apgpu;
 constexpr int kMaxDelta = 3;
 constexpr int kMaxWin = (2 * kMaxDelta + 1) * (2 * kMaxDelta + 1);
 
-// Median of the good neighbours of pixel p, or the pixel's own value if fewer than min_valid exist.
-__device__ float repair_pixel(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W, int delta,
-                              int min_valid, int64_t p, float own, unsigned &nfix)
+// Median of the good neighbours of pixel p, or the pixel's own value if fewer than min_valid exist - the general
+// form: any deltapix (the reference has no limit, core/ApFixBadPixels.py:292), float32 or float64 images (a float64
+// calibration feeds float64 data, golden G11).  No window array: the two middle order statistics are found by rank
+// counting - a good value x is the k-th smallest iff #(values < x) <= k < #(values <= x) - i.e. (window size)^2 reads
+// from L2 per bad pixel; bad pixels are few (~0.02 %), and the fast paths below serve float32 with deltapix <= 3.
+template <typename T>
+__device__ T repair_pixel(const T *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W, int delta,
+                          int min_valid, int64_t p, T own, unsigned &nfix)
 {
     const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
     const int rmin = max(0, r - delta), rmax = min(H, r + delta + 1);
     const int cmin = max(0, c - delta), cmax = min(W, c + delta + 1);
-    float good[kMaxWin];
     int ng = 0;
     bool has_nan = false;
     for (int rr = rmin; rr < rmax; rr++)
         for (int cc = cmin; cc < cmax; cc++) {
             const int64_t q = (int64_t)rr * W + cc;
             if (mask[q] == 0) {
-                const float x = data[q];
+                const T x = data[q];
                 has_nan = has_nan || (x != x);
-                int k = ng++;                       // insertion into the sorted prefix
-                while (k > 0 && good[k - 1] > x) { good[k] = good[k - 1]; k--; }
-                good[k] = x;
+                ng++;
             }
         }
     if (ng < min_valid) return own;
     nfix++;
-    if (has_nan) return __builtin_nanf("");         // np.median propagates NaN
-    if (ng & 1) return good[ng / 2];
-    const float t = good[ng / 2 - 1] + good[ng / 2];
-    return (float)((double)t / 2.0);
+    if (has_nan) return (T)__builtin_nan("");       // np.median propagates NaN
+    const int k1 = (ng - 1) >> 1, k2 = ng >> 1;
+    T m1 = (T)0, m2 = (T)0;
+    for (int rr = rmin; rr < rmax; rr++)
+        for (int cc = cmin; cc < cmax; cc++) {
+            const int64_t q = (int64_t)rr * W + cc;
+            if (mask[q] != 0) continue;
+            const T x = data[q];
+            int lt = 0, le = 0;
+            for (int r2 = rmin; r2 < rmax; r2++)
+                for (int c2 = cmin; c2 < cmax; c2++) {
+                    const int64_t q2 = (int64_t)r2 * W + c2;
+                    if (mask[q2] != 0) continue;
+                    const T y = data[q2];
+                    lt += (y < x) ? 1 : 0;
+                    le += (y <= x) ? 1 : 0;
+                }
+            if (lt <= k1 && k1 < le) m1 = x;
+            if (lt <= k2 && k2 < le) m2 = x;
+        }
+    if (ng & 1) return m2;
+    if constexpr (sizeof(T) == 8) return (m1 + m2) / 2.0;   // np.mean of the two middle float64 values
+    else {
+        const float t = m1 + m2;                    // float32: np.mean = float32 sum, then / 2
+        return (float)((double)t / 2.0);
+    }
 }
 
 // Register-resident repair for a compile-time window: the (2D+1)^2 neighbourhood is gathered into a
@@ -87,12 +111,12 @@ __device__ __forceinline__ float repair_window(const float *__restrict__ data, c
     return has_nan ? __builtin_nanf("") : med;      // np.median propagates NaN
 }
 
-template <int D>
-__device__ __forceinline__ float repair_any(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
-                                            int delta, int min_valid, int64_t p, float own, unsigned &nfix)
+template <typename T, int D>
+__device__ __forceinline__ T repair_any(const T *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
+                                        int delta, int min_valid, int64_t p, T own, unsigned &nfix)
 {
-    if constexpr (D > 0) return repair_window<D>(data, mask, H, W, min_valid, p, own, nfix);
-    else return repair_pixel(data, mask, H, W, delta, min_valid, p, own, nfix);
+    if constexpr (D > 0 && sizeof(T) == 4) return repair_window<D>(data, mask, H, W, min_valid, p, own, nfix);
+    else return repair_pixel<T>(data, mask, H, W, delta, min_valid, p, own, nfix);
 }
 
 // A block streams tiles of kTile pixels (16-byte loads/stores, 4-byte mask loads) and appends the
@@ -102,9 +126,12 @@ __device__ __forceinline__ float repair_any(const float *__restrict__ data, cons
 constexpr int kPxPerLane = 16;
 constexpr int kTile = 256 * kPxPerLane;
 
-template <int D>
-__global__ __launch_bounds__(256) void fix_badpix_kernel(const float *__restrict__ data, const uint8_t *__restrict__ mask,
-                                                        int H, int W, int delta, int min_valid, float *__restrict__ out,
+// VEC: float32 image with 16-byte aligned data/out and a 4-byte aligned mask (float4 / uchar4 accesses); otherwise
+// (float64 images, or a frame cut out of a slab whose pixel count is not a multiple of 4) the same tile is streamed with
+// coalesced scalar accesses.
+template <typename T, int D, bool VEC>
+__global__ __launch_bounds__(256) void fix_badpix_kernel(const T *__restrict__ data, const uint8_t *__restrict__ mask,
+                                                        int H, int W, int delta, int min_valid, T *__restrict__ out,
                                                         unsigned long long *__restrict__ stats)
 {
     __shared__ int s_n;
@@ -117,35 +144,46 @@ __global__ __launch_bounds__(256) void fix_badpix_kernel(const float *__restrict
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         const int64_t base = tile * kTile;
+        if constexpr (VEC) {
 #pragma unroll
-        for (int q = 0; q < kPxPerLane / 4; q++) {
-            const int64_t g = base / 4 + q * 256 + threadIdx.x;
-            if (g < groups) {
-                const float4 v = reinterpret_cast<const float4 *>(data)[g];
-                const uchar4 m = reinterpret_cast<const uchar4 *>(mask)[g];
-                reinterpret_cast<float4 *>(out)[g] = v;
-                if (m.x | m.y | m.z | m.w) {
-                    const int off = (int)(g * 4 - base);
-                    if (m.x) s_list[atomicAdd(&s_n, 1)] = off;
-                    if (m.y) s_list[atomicAdd(&s_n, 1)] = off + 1;
-                    if (m.z) s_list[atomicAdd(&s_n, 1)] = off + 2;
-                    if (m.w) s_list[atomicAdd(&s_n, 1)] = off + 3;
+            for (int q = 0; q < kPxPerLane / 4; q++) {
+                const int64_t g = base / 4 + q * 256 + threadIdx.x;
+                if (g < groups) {
+                    const float4 v = reinterpret_cast<const float4 *>(data)[g];
+                    const uchar4 m = reinterpret_cast<const uchar4 *>(mask)[g];
+                    reinterpret_cast<float4 *>(out)[g] = v;
+                    if (m.x | m.y | m.z | m.w) {
+                        const int off = (int)(g * 4 - base);
+                        if (m.x) s_list[atomicAdd(&s_n, 1)] = off;
+                        if (m.y) s_list[atomicAdd(&s_n, 1)] = off + 1;
+                        if (m.z) s_list[atomicAdd(&s_n, 1)] = off + 2;
+                        if (m.w) s_list[atomicAdd(&s_n, 1)] = off + 3;
+                    }
                 }
             }
-        }
-        // the up-to-3 pixels past the last whole group belong to the last tile
-        if (tile == ntiles - 1 && threadIdx.x < (int)(P - groups * 4)) {
-            const int64_t pp = groups * 4 + threadIdx.x;
-            out[pp] = data[pp];
-            if (mask[pp] != 0) s_list[atomicAdd(&s_n, 1)] = (int)(pp - base);
+            // the up-to-3 pixels past the last whole group belong to the last tile
+            if (tile == ntiles - 1 && threadIdx.x < (int)(P - groups * 4)) {
+                const int64_t pp = groups * 4 + threadIdx.x;
+                out[pp] = data[pp];
+                if (mask[pp] != 0) s_list[atomicAdd(&s_n, 1)] = (int)(pp - base);
+            }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < kPxPerLane; q++) {
+                const int64_t pp = base + q * 256 + threadIdx.x;
+                if (pp < P) {
+                    out[pp] = data[pp];
+                    if (mask[pp] != 0) s_list[atomicAdd(&s_n, 1)] = (int)(pp - base);
+                }
+            }
         }
         __syncthreads();
         const int n = s_n;
         for (int i = threadIdx.x; i < n; i += 256) {
             const int64_t pp = base + s_list[i];
             nbad++;
-            const float own = data[pp];
-            const float val = repair_any<D>(data, mask, H, W, delta, min_valid, pp, own, nfix);
+            const T own = data[pp];
+            const T val = repair_any<T, D>(data, mask, H, W, delta, min_valid, pp, own, nfix);
             out[pp] = val;
         }
         __syncthreads();
@@ -168,33 +206,60 @@ __global__ void fix_badpix_finish_kernel(unsigned long long *stats)
 
 }  // namespace
 
-extern "C" int apgpu_fix_badpix_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width, int32_t deltapix,
-                                    int32_t min_valid, float *out, int64_t *stats_out, void *stream)
+template <typename T>
+static int fix_badpix_impl(const T *data, const uint8_t *mask, int64_t height, int64_t width, int32_t deltapix,
+                           int32_t min_valid, T *out, int64_t *stats_out, void *stream)
 {
     if (!data || !mask || !out || !stats_out) return fail(APGPU_EINVAL, "fix_badpix: NULL pointer argument");
     if (out == data) return fail(APGPU_EINVAL, "fix_badpix: out may not alias data");
     if (height <= 0 || width <= 0 || height > 0x7fffffff || width > 0x7fffffff) return fail(APGPU_EINVAL, "fix_badpix: bad shape");
-    if (deltapix < 0 || deltapix > kMaxDelta) return fail(APGPU_EUNSUPPORTED, "fix_badpix: deltapix %d outside 0..%d", deltapix, kMaxDelta);
+    if (deltapix < 0) return fail(APGPU_EINVAL, "fix_badpix: deltapix %d < 0", deltapix);
     if (min_valid < 1) return fail(APGPU_EINVAL, "fix_badpix: min_valid must be >= 1");
+    if ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & (sizeof(T) - 1))
+        return fail(APGPU_EINVAL, "fix_badpix: data/out must be aligned to their element size");
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(stats_out, 0, 3 * sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "fix_badpix: memset failed");
     const int64_t P = height * width;
-    if ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 15 || reinterpret_cast<uintptr_t>(mask) & 3)
-        return fail(APGPU_EINVAL, "fix_badpix: data/out must be 16-byte and mask 4-byte aligned");
     int64_t grid = (P + kTile - 1) / kTile;
     if (grid > kNumCU * 8) grid = kNumCU * 8;
     unsigned long long *st_dev = reinterpret_cast<unsigned long long *>(stats_out);
-#define APGPU_FIX_LAUNCH(D)                                                                                               \
-    hipLaunchKernelGGL(fix_badpix_kernel<D>, dim3((unsigned)grid), dim3(256), 0, st, data, mask, (int)height, (int)width, \
+#define APGPU_FIX_LAUNCH(TT, D, V)                                                                                         \
+    hipLaunchKernelGGL((fix_badpix_kernel<TT, D, V>), dim3((unsigned)grid), dim3(256), 0, st, data, mask, (int)height, (int)width, \
                        deltapix, min_valid, out, st_dev)
-    switch (deltapix) {
-    case 1: APGPU_FIX_LAUNCH(1); break;
-    case 2: APGPU_FIX_LAUNCH(2); break;
-    case 3: APGPU_FIX_LAUNCH(3); break;
-    default: APGPU_FIX_LAUNCH(0); break;
+    if constexpr (sizeof(T) == 4) {
+        const bool vec = !(((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 15) || (reinterpret_cast<uintptr_t>(mask) & 3));
+        if (vec) {
+            switch (deltapix) {
+            case 1: APGPU_FIX_LAUNCH(float, 1, true); break;
+            case 2: APGPU_FIX_LAUNCH(float, 2, true); break;
+            case 3: APGPU_FIX_LAUNCH(float, 3, true); break;
+            default: APGPU_FIX_LAUNCH(float, 0, true); break;
+            }
+        } else {
+            switch (deltapix) {
+            case 1: APGPU_FIX_LAUNCH(float, 1, false); break;
+            case 2: APGPU_FIX_LAUNCH(float, 2, false); break;
+            case 3: APGPU_FIX_LAUNCH(float, 3, false); break;
+            default: APGPU_FIX_LAUNCH(float, 0, false); break;
+            }
+        }
+    } else {
+        APGPU_FIX_LAUNCH(double, 0, false);
     }
 #undef APGPU_FIX_LAUNCH
     if (int rc = check_launch("fix_badpix")) return rc;
     hipLaunchKernelGGL(fix_badpix_finish_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(stats_out));
     return check_launch("fix_badpix_finish");
+}
+
+extern "C" int apgpu_fix_badpix_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width, int32_t deltapix,
+                                    int32_t min_valid, float *out, int64_t *stats_out, void *stream)
+{
+    return fix_badpix_impl<float>(data, mask, height, width, deltapix, min_valid, out, stats_out, stream);
+}
+
+extern "C" int apgpu_fix_badpix_f64(const double *data, const uint8_t *mask, int64_t height, int64_t width, int32_t deltapix,
+                                    int32_t min_valid, double *out, int64_t *stats_out, void *stream)
+{
+    return fix_badpix_impl<double>(data, mask, height, width, deltapix, min_valid, out, stats_out, stream);
 }

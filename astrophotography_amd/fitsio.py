@@ -96,24 +96,64 @@ def _format_value(value):
     return ("'%-8s'" % s).ljust(20)
 
 
+def _ascii(text):
+    """Header text is 7-bit ASCII: anything else becomes '?' (what astropy does when it reads such a card)."""
+    return ''.join(ch if ' ' <= ch <= '~' else '?' for ch in text)
+
+
+def _long_string_cards(head, value, comment):
+    """A string that does not fit one card, in the CONTINUE convention astropy writes (and reads): the pieces end in
+    '&', the following cards are `CONTINUE  'piece&'`, the comment rides on the last cards."""
+    esc = str(value).replace("'", "''")
+    pieces = []
+    while esc:
+        n = 67
+        if len(esc) > n and esc[:n].endswith("'") and (len(esc[:n]) - len(esc[:n].rstrip("'"))) % 2 == 1:
+            n -= 1                                          # never split an escaped quote pair
+        pieces.append(esc[:n])
+        esc = esc[n:]
+    cards = []
+    for i, pc in enumerate(pieces):
+        last = i == len(pieces) - 1
+        h = head if i == 0 else 'CONTINUE  '
+        cards.append("%s'%s%s'" % (h, pc, '' if last else '&'))
+    if comment:
+        if len(cards[-1]) + 3 + len(comment) <= 80:
+            cards[-1] += ' / ' + comment
+        else:
+            cards[-1] = cards[-1][:-1] + "&'" if len(cards[-1]) < 80 else cards[-1]
+            if not cards[-1].endswith("&'"):                # full last piece: move its final character to a new card
+                body = cards[-1][:-1]
+                cards[-1] = body[:-1] + "&'"
+                cards.append("CONTINUE  '%s&'" % body[-1])
+            text = comment
+            while text:
+                chunk, text = text[:62], text[62:]
+                cards.append("CONTINUE  '%s' / %s" % ('&' if text else '', chunk))
+    return ''.join(c.ljust(80) for c in cards)
+
+
 def _format_card(card):
     if card.raw is not None:
         return card.raw
     key = card.key.upper()
     if key in _COMMENTARY:
-        text = '' if card.value is None else str(card.value)
+        text = '' if card.value is None else _ascii(str(card.value))
         return ('%-8s%s' % (key, text))[:80].ljust(80)
     if len(key) > 8:
         head = 'HIERARCH %s = ' % key
     else:
         head = '%-8s= ' % key
-    body = _format_value(card.value)
+    value = _ascii(card.value) if isinstance(card.value, str) else card.value
+    comment = _ascii(card.comment) if card.comment else ''
+    body = _format_value(value)
     img = head + body
-    if card.comment:
-        img += ' / ' + card.comment
+    if isinstance(value, str) and len(img) > 80:
+        return _long_string_cards(head, value, comment)     # e.g. DATAFILE = a full path (ApFindBadPixels.py:154)
+    if comment:
+        img += ' / ' + comment
     if len(img) > 80:
-        # keep the value intact, truncate the comment (strings longer than the card are cut)
-        img = img[:80]
+        img = img[:80]                                      # the value is intact; only the comment is cut
     return img.ljust(80)
 
 
@@ -188,12 +228,21 @@ class Header:
     # -- (de)serialisation -----------------------------------------------------------------------
     @classmethod
     def fromstring(cls, text):
+        text = _ascii(text)                                 # a stray non-ASCII byte (e.g. a degree sign) reads as '?'
         cards = []
         for i in range(0, len(text), 80):
             img = text[i:i + 80]
             key = img[:8].rstrip().upper()
             if key == 'END':
                 break
+            if key == 'CONTINUE' and cards and isinstance(cards[-1].value, str) and cards[-1].value.endswith('&') \
+                    and cards[-1].key not in _COMMENTARY:
+                val, com = _parse_value(img[8:])            # long string (CONTINUE convention): glue the pieces
+                prev = cards[-1]
+                prev.value = prev.value[:-1] + (val if isinstance(val, str) else '')
+                prev.comment = (prev.comment + ' ' + com).strip() if com else prev.comment
+                prev.raw = (prev.raw or '') + img
+                continue
             if key in _COMMENTARY:
                 if img.strip() == '':
                     continue
@@ -246,7 +295,9 @@ def _structural(hdr, data):
     had_extend = any(c.key == 'EXTEND' for c in hdr.cards)
     if had_extend:
         head.append(Card('EXTEND', True, ''))
-    rest = [c for c in rest if c.key not in ('BSCALE', 'BZERO')] if bzero is not None or dt.kind == 'f' else rest
+    # the scaling keywords describe the SOURCE file's storage; the data written here are physical values, so they
+    # always go and only the unsigned-integer convention puts its own pair back (astropy does the same)
+    rest = [c for c in rest if c.key not in ('BSCALE', 'BZERO')]
     if bzero is not None:
         head += [Card('BSCALE', 1, ''), Card('BZERO', bzero, '')]
     return Header(head + rest)
@@ -424,7 +475,7 @@ def read_device(path, device='cuda'):
     unsigned16 = bitpix == 16 and bscale == 1 and bzero == 32768
     plain = bscale == 1 and bzero == 0
     hdr._tail = raw[pos + ((nbytes + BLOCK - 1) // BLOCK) * BLOCK:].tobytes()
-    if count == 0 or naxis != 2 or not (unsigned16 or (plain and bitpix in (16, -32))):
+    if count == 0 or naxis != 2 or not (unsigned16 or (plain and bitpix in (16, -32, -64))):
         data, hdr2 = read(path)
         if data is None:
             return None, hdr2
@@ -436,7 +487,7 @@ def read_device(path, device='cuda'):
     if raw.size < pos + nbytes:
         raise OSError('%s: data unit is truncated.' % path)
     payload = torch.from_numpy(raw[pos:pos + nbytes].copy()).to(device)
-    out = torch.empty(shape, dtype=torch.uint16 if unsigned16 else torch.float32, device=device)
+    out = torch.empty(shape, dtype=torch.uint16 if unsigned16 else (torch.float64 if bitpix == -64 else torch.float32), device=device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _lib.check(_lib.load().apgpu_fits_decode(C.c_void_p(payload.data_ptr()), bitpix, int(unsigned16),
                                             C.c_void_p(out.data_ptr()), count, stream))
@@ -445,22 +496,24 @@ def read_device(path, device='cuda'):
 
 
 def write_device(path, tensor, header=None, overwrite=True):
-    """float32 device tensor -> BITPIX -32 primary HDU (big-endian conversion on the device)."""
+    """float32 / float64 device tensor -> BITPIX -32 / -64 primary HDU (big-endian conversion on the device)."""
     import ctypes as C
     import torch
     from . import _lib
     if os.path.exists(path) and not overwrite:
         raise OSError("File '%s' already exists." % path)
-    if tensor.dtype != torch.float32 or not tensor.is_cuda:
+    if tensor.dtype not in (torch.float32, torch.float64) or not tensor.is_cuda:
         return write(path, tensor.cpu().numpy() if tensor.dtype != torch.uint16
                      else tensor.view(torch.int16).cpu().numpy().view(np.uint16), header, overwrite)
     tensor = tensor.contiguous()
-    payload = torch.empty(tensor.numel() * 4, dtype=torch.uint8, device=tensor.device)
+    f64 = tensor.dtype == torch.float64
+    payload = torch.empty(tensor.numel() * (8 if f64 else 4), dtype=torch.uint8, device=tensor.device)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(_lib.load().apgpu_fits_encode_f32(C.c_void_p(tensor.data_ptr()), C.c_void_p(payload.data_ptr()),
-                                                tensor.numel(), stream))
+    enc = _lib.load().apgpu_fits_encode_f64 if f64 else _lib.load().apgpu_fits_encode_f32
+    _lib.check(enc(C.c_void_p(tensor.data_ptr()), C.c_void_p(payload.data_ptr()), tensor.numel(), stream))
     data_bytes = payload.cpu().numpy().tobytes()
-    hdr = _structural(header if header is not None else Header(), _ShapeOnly(tuple(tensor.shape), np.dtype(np.float32)))
+    hdr = _structural(header if header is not None else Header(),
+                      _ShapeOnly(tuple(tensor.shape), np.dtype(np.float64 if f64 else np.float32)))
     pad = (-len(data_bytes)) % BLOCK
     tail = getattr(header, '_tail', b'') if header is not None else b''
     tmp = str(path) + '.tmp%d' % os.getpid()

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import APGPU_F32, APGPU_U16, StackArgs, check
+from ._lib import APGPU_F32, APGPU_F64, APGPU_U16, StackArgs, check
 
 
 def _stream():
@@ -64,11 +64,32 @@ def _per_frame(x, n, device):
 
 
 # ---------------------------------------------------------------------------------------------------
+def _dtype_tag(t, what, allow_u16=False):
+    if t.dtype == torch.float32:
+        return APGPU_F32
+    if t.dtype == torch.float64:
+        return APGPU_F64
+    if allow_u16 and t.dtype in (torch.uint16, torch.int16):
+        return APGPU_U16
+    raise TypeError('%s must be float32 or float64%s, got %s' % (what, ' or uint16' if allow_u16 else '', t.dtype))
+
+
 def flat_normalize(flat):
-    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190): returns (nflat, norm[1] device tensor)."""
+    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190): returns (nflat, norm[1] device tensor), both in the
+    flat's own dtype - float32, or float64 for a float64 master (the reference keeps float FITS data as stored,
+    ApCalibrate.py:301-305)."""
     _need_cuda(flat)
-    flat = _f32c(flat, 'flat')
     lib = _lib.load()
+    if flat.dtype == torch.float64:
+        flat = flat.contiguous()
+        n = flat.numel()
+        ws_bytes = lib.apgpu_flat_normalize_f64_ws_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=flat.device)
+        nflat = torch.empty_like(flat)
+        norm = torch.empty(1, dtype=torch.float64, device=flat.device)
+        check(lib.apgpu_flat_normalize_f64(_ptr(flat), _ptr(nflat), _ptr(norm), n, _ptr(ws), ws_bytes, _stream()))
+        return nflat, norm
+    flat = _f32c(flat, 'flat')
     n = flat.numel()
     ws_bytes = lib.apgpu_flat_normalize_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=flat.device)
@@ -83,6 +104,8 @@ def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biase
     _need_cuda(raw, bias, dark, nflat)
     lib = _lib.load()
     raw = raw.contiguous()
+    if any(t is not None and t.dtype == torch.float64 for t in (raw, bias, dark, nflat)):
+        return _calibrate_mixed(raw, bias, dark, nflat, exp_ratio, pedestal, dark_still_biased, out)
     dt = _raw_dtype(raw)
     single = raw.dim() == 2
     N = 1 if single else raw.shape[0]
@@ -97,6 +120,45 @@ def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biase
         out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
     check(lib.apgpu_calibrate(_ptr(raw), dt, _ptr(bias), _ptr(dark), _ptr(nflat), _ptr(e), _ptr(ped),
                               int(bool(dark_still_biased)), _ptr(out), N, P, _stream()))
+    return out
+
+
+def _per_frame_f64(x, n, device):
+    if x is None:
+        return None
+    if torch.is_tensor(x):
+        t = x.to(device=device, dtype=torch.float64).reshape(-1)
+        return (t.expand(n) if t.numel() == 1 and n > 1 else t).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)))).to(device)
+
+
+def _calibrate_mixed(raw, bias, dark, nflat, exp_ratio, pedestal, dark_still_biased, out):
+    """A2 with float64 inputs (apgpu_calibrate_mixed): NumPy's per-operation promotion; the result is float64 if any
+    participating array is float64."""
+    lib = _lib.load()
+    single = raw.dim() == 2
+    N = 1 if single else raw.shape[0]
+    P = raw.numel() // N
+    rt = _dtype_tag(raw, 'raw', allow_u16=True)
+    bias, dark = bias.contiguous(), dark.contiguous()
+    nflat = None if nflat is None else nflat.contiguous()
+    bt, dk = _dtype_tag(bias, 'bias'), _dtype_tag(dark, 'dark')
+    nt = _dtype_tag(nflat, 'nflat') if nflat is not None else APGPU_F32
+    for nm, t in (('bias', bias), ('dark', dark), ('nflat', nflat)):
+        if t is not None and t.numel() != P:
+            raise RuntimeError('%s has %d pixels, frames have %d' % (nm, t.numel(), P))
+    r64, b64, d64 = rt == APGPU_F64, bt == APGPU_F64, dk == APGPU_F64
+    t3 = (r64 or b64) or ((d64 or b64) if dark_still_biased else d64)
+    t4 = (t3 or nt == APGPU_F64) if nflat is not None else t3
+    odt = torch.float64 if t4 else torch.float32
+    e = _per_frame_f64(exp_ratio, N, raw.device)
+    ped = _per_frame_f64(pedestal, N, raw.device)
+    if out is None:
+        out = torch.empty(raw.shape, dtype=odt, device=raw.device)
+    elif out.dtype != odt or out.shape != raw.shape or not out.is_contiguous():
+        raise TypeError('out must be a contiguous %s tensor of the raw shape' % odt)
+    check(lib.apgpu_calibrate_mixed(_ptr(raw), rt, _ptr(bias), bt, _ptr(dark), dk, _ptr(nflat), nt, _ptr(e), _ptr(ped),
+                                    int(bool(dark_still_biased)), _ptr(out), APGPU_F64 if t4 else APGPU_F32, N, P, _stream()))
     return out
 
 
@@ -370,9 +432,11 @@ def mask_add_rects(mask, rects, value=2):
 def fix_badpix(data, mask, deltapix=1, min_valid=4):
     """A5 ApFixBadPixels.fix_bad_pixels (ApFixBadPixels.py:292-445).
 
-    Returns (out float32, stats int64[3] device tensor = nbad, nfixed, nremaining)."""
+    float32 or float64 images (medians in the image's own type, as np.median); any deltapix >= 0.
+    Returns (out, stats int64[3] device tensor = nbad, nfixed, nremaining)."""
     _need_cuda(data, mask)
-    data = _f32c(data, 'data')
+    f64 = data.dtype == torch.float64
+    data = data.contiguous() if f64 else _f32c(data, 'data')
     if data.dim() != 2:
         raise ValueError('data must be 2-D')
     if tuple(mask.shape) != tuple(data.shape):
@@ -381,8 +445,8 @@ def fix_badpix(data, mask, deltapix=1, min_valid=4):
     m8 = (mask != 0).to(torch.uint8).contiguous() if mask.dtype != torch.uint8 else mask.contiguous()
     out = torch.empty_like(data)
     stats = torch.empty(3, dtype=torch.int64, device=data.device)
-    check(_lib.load().apgpu_fix_badpix_f32(_ptr(data), _ptr(m8), data.shape[0], data.shape[1], int(deltapix),
-                                           int(min_valid), _ptr(out), _ptr(stats), _stream()))
+    fn = _lib.load().apgpu_fix_badpix_f64 if f64 else _lib.load().apgpu_fix_badpix_f32
+    check(fn(_ptr(data), _ptr(m8), data.shape[0], data.shape[1], int(deltapix), int(min_valid), _ptr(out), _ptr(stats), _stream()))
     return out, stats
 
 
@@ -390,9 +454,23 @@ def imarith(a, op, b):
     """A8 ApImArith op block (ApImArith.py:320-333): a (op) b, b a tensor or a python float."""
     _need_cuda(a)
     a = a.contiguous()
+    opi = _lib.OPS[op]
+    b_is_t = torch.is_tensor(b)
+    if a.dtype == torch.float64 or (b_is_t and b.dtype == torch.float64 and a.dtype == torch.float32):
+        # float64 somewhere: computed in float64, stored in a's dtype (numpy, out=zeros_like(data1))
+        out = torch.empty_like(a)
+        adt = _dtype_tag(a, 'a')
+        if b_is_t:
+            _need_cuda(b)
+            if b.shape != a.shape:
+                raise RuntimeError('Error, the dimension of the second data array does not match the first.')
+            b = b.contiguous()
+            check(_lib.load().apgpu_imarith_f64(_ptr(a), adt, _ptr(b), _dtype_tag(b, 'b'), 0.0, opi, _ptr(out), a.numel(), _stream()))
+        else:
+            check(_lib.load().apgpu_imarith_f64(_ptr(a), adt, None, APGPU_F64, float(b), opi, _ptr(out), a.numel(), _stream()))
+        return out
     dt = _raw_dtype(a)
     out = torch.empty_like(a)
-    opi = _lib.OPS[op]
     if torch.is_tensor(b):
         _need_cuda(b)
         if b.shape != a.shape:

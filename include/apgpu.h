@@ -41,6 +41,7 @@ extern "C" {
 /* element types of pixel data */
 #define APGPU_F32 0
 #define APGPU_U16 1
+#define APGPU_F64 2                 /* float64 masters / frames (apgpu_calibrate_mixed, *_f64 entry points) */
 
 /* ApImArith._allowed_ops (core/ApImArith.py:34) */
 #define APGPU_OP_ADD 0
@@ -68,6 +69,11 @@ int apgpu_version(void);
 size_t apgpu_flat_normalize_ws_bytes(int64_t n_pixels);
 int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *norm_out, int64_t n_pixels,
                              void *ws, size_t ws_bytes, void *stream);
+/* The same for a float64 flat (a master written by ccdproc is float64 and _read_fits keeps float data as it is,
+ * core/ApCalibrate.py:301-305): float64 pairwise sum in the same 8192-element pieces, float64 division. */
+size_t apgpu_flat_normalize_f64_ws_bytes(int64_t n_pixels);
+int apgpu_flat_normalize_f64(const double *flat, double *nflat, double *norm_out, int64_t n_pixels,
+                             void *ws, size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A2  ApCalibrate.calibrate arithmetic block (core/ApCalibrate.py:439-464) incl. the read-time
@@ -81,6 +87,17 @@ int apgpu_flat_normalize_f32(const float *flat, float *nflat, float *norm_out, i
 int apgpu_calibrate(const void *raw, int raw_dtype, const float *bias, const float *dark,
                     const float *nflat, const float *exp_ratio, const float *pedestal,
                     int dark_still_biased, float *out, int64_t n_frames, int64_t n_pixels, void *stream);
+
+/* A2 with float64 inputs: any mix of raw APGPU_U16 / APGPU_F32 / APGPU_F64 and masters APGPU_F32 / APGPU_F64, evaluated with
+ * NumPy's per-operation type promotion exactly as the reference's expressions do (core/ApCalibrate.py:301-305: only
+ * non-float FITS data is converted to float32; scripts/ap_combine_darks.py:437: ApMasterCal writes float64 masters):
+ *   x = raw - bias in T1 = f64 if raw or bias is f64;  D = dark - bias in T2 = f64 if dark or bias is f64 (or D = dark,
+ *   T2 = dark's type);  ds = T2(exp_ratio) * D;  y = x - ds in T3 = T1 | T2;  out = y / nflat in T4 = T3 | nflat's type.
+ * exp_ratio[N] and pedestal[N] (may be NULL) are float64 device arrays (python floats; the pedestal is added in the raw
+ * frame's own type).  out_dtype must be T4 (APGPU_F64 if any participating array is float64, else APGPU_F32). */
+int apgpu_calibrate_mixed(const void *raw, int raw_dtype, const void *bias, int bias_dtype, const void *dark, int dark_dtype,
+                          const void *nflat, int nflat_dtype, const double *exp_ratio, const double *pedestal,
+                          int dark_still_biased, void *out, int out_dtype, int64_t n_frames, int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A6/A7 + the fused north-star kernel: per-pixel sigma-clipped reduction along N of a slab
@@ -201,10 +218,14 @@ int apgpu_mask_add_rects_u8(uint8_t *mask, int64_t height, int64_t width, const 
  *     becomes the median of the good pixels of the ORIGINAL image inside the (2*deltapix+1)^2 window
  *     clipped to the image, if at least min_valid of them exist; otherwise it is left unchanged.
  *     out may not alias data.  stats_out[3] (device int64) = { nbad, nfixed, nremaining }.
- *     deltapix <= 3.
+ *     Any deltapix >= 0 (register-resident sorting networks for 1..3, rank counting beyond); any alignment of
+ *     data/out (a frame cut out of a slab).  _f64: the same on a float64 image, medians in float64 - what the
+ *     reference computes after a float64 calibration (np.median in the input's dtype).
  * ------------------------------------------------------------------------------------------- */
 int apgpu_fix_badpix_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width,
                          int32_t deltapix, int32_t min_valid, float *out, int64_t *stats_out, void *stream);
+int apgpu_fix_badpix_f64(const double *data, const uint8_t *mask, int64_t height, int64_t width,
+                         int32_t deltapix, int32_t min_valid, double *out, int64_t *stats_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A8  ApImArith.process_files op block (core/ApImArith.py:320-333): out = a (op) b, with b an image
@@ -214,6 +235,11 @@ int apgpu_fix_badpix_f32(const float *data, const uint8_t *mask, int64_t height,
  * ------------------------------------------------------------------------------------------- */
 int apgpu_imarith(const void *a, const void *b, double scalar, int op, int dtype, void *out,
                   int64_t n_pixels, void *stream);
+/* The float64 cases of the same block: a float64 image (op) image / scalar, and float32 (op) float64 image pairs -
+ * NumPy computes in float64 as soon as one operand ARRAY is float64 and stores in the dtype of `a`
+ * (np.add(data1, data2, out=zeros_like(data1)), same_kind casting).  a_dtype / b_dtype: APGPU_F32 | APGPU_F64. */
+int apgpu_imarith_f64(const void *a, int a_dtype, const void *b, int b_dtype, double scalar, int op, void *out,
+                      int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A9  RawConv split geometry (core/RawConv.py:111-128, 163-190): planes[k] = where(colour == k,
@@ -229,11 +255,13 @@ int apgpu_bayer_split_u16(const uint16_t *raw, int64_t height, int64_t width, co
  *     (device copy of the raw bytes).
  *     decode: BITPIX 16 with unsigned16 != 0 (BSCALE 1, BZERO 32768) -> uint16[n];
  *             BITPIX 16 with unsigned16 == 0 -> float32[n] (integers are converted to float32 at read
- *             time, core/ApCalibrate.py:304-307); BITPIX -32 -> float32[n]; BITPIX 32 -> int32[n].
- *     encode: float32[n] -> big-endian BITPIX -32 payload.
+ *             time, core/ApCalibrate.py:304-307); BITPIX -32 -> float32[n]; BITPIX 32 -> int32[n];
+ *             BITPIX -64 -> float64[n]; BITPIX 64 -> int64[n].
+ *     encode: float32[n] -> big-endian BITPIX -32 payload; float64[n] -> BITPIX -64 payload.
  * ------------------------------------------------------------------------------------------- */
 int apgpu_fits_decode(const void *payload, int bitpix, int unsigned16, void *out, int64_t n_pixels, void *stream);
 int apgpu_fits_encode_f32(const float *data, void *payload, int64_t n_pixels, void *stream);
+int apgpu_fits_encode_f64(const double *data, void *payload, int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F3  Affine Lanczos-3 resample of registered frames - the step the reference hands to SWarp

@@ -182,6 +182,90 @@ int apref_calibrate(const void *raw, int raw_dtype, const float *bias, const flo
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* A1/A2 with float64 inputs (golden group G11).  ApCalibrate._read_fits converts only NON-float  */
+/* data to float32 (ref: core/ApCalibrate.py:301-305) and ApMasterCal writes float64 masters      */
+/* (ref: scripts/ap_combine_darks.py:437), so the reference's NumPy expressions promote per       */
+/* operation: result type = float64 if either operand array is float64, else float32; the python  */
+/* float exp_ratio is a weak scalar (takes the type of the dark array it multiplies).             */
+/*   T_raw: u16 -> float32 at read; PEDESTAL is added in T_raw (in-place +=, :318-326)            */
+/*   x  = raw - bias               in T1 = promote(T_raw, T_bias)             (:439)              */
+/*   D  = dark - bias | dark       in T2 = promote(T_dark, T_bias) | T_dark   (:440-445)          */
+/*   ds = e * D                    in T2                                      (:450)              */
+/*   y  = x - ds                   in T3 = promote(T1, T2)                    (:451)              */
+/*   out= where(nf != 0, y / nf, y) in T4 = promote(T3, T_flat)               (:462-464)          */
+/* Each operation is evaluated in double and, where NumPy's result type is float32, rounded to    */
+/* float32: for + - * / of float32 operands this double rounding is exact (53 >= 2*24 + 2,        */
+/* Figueroa 1995), so the float32-only case reproduces apref_calibrate bit for bit (tested).      */
+/* dtype tags: 0 float32, 1 uint16 (raw only), 2 float64.  out is float64 if out_f64 else float32;*/
+/* out_f64 must equal "T4 is float64" (returns -3 otherwise).                                     */
+/* ------------------------------------------------------------------------------------------- */
+static inline double rnd_to(double x, int is64)
+{
+    if (is64) return x;
+    volatile float f = (float)x;
+    return (double)f;
+}
+
+static inline double load_px(const void *a, int dt, long i)
+{
+    if (dt == 0) return (double)((const float *)a)[i];
+    if (dt == 1) return (double)((const uint16_t *)a)[i];
+    return ((const double *)a)[i];
+}
+
+int apref_calibrate_mixed(const void *raw, int raw_dt, const void *bias, int bias_dt, const void *dark, int dark_dt,
+                          const void *nflat, int nflat_dt, const double *e, const double *pedestal,
+                          int dark_still_biased, void *out, int out_f64, long N, long P)
+{
+    const int r64 = raw_dt == 2, b64 = bias_dt == 2, d64 = dark_dt == 2, n64 = nflat_dt == 2;
+    const int t1 = r64 || b64;
+    const int t2 = dark_still_biased ? (d64 || b64) : d64;
+    const int t3 = t1 || t2;
+    const int t4 = nflat ? (t3 || n64) : t3;
+    if ((out_f64 != 0) != (t4 != 0)) return -3;
+#pragma omp parallel for schedule(static)
+    for (long f = 0; f < N; f++) {
+        const double ped = pedestal ? pedestal[f] : 0.0;
+        const double ef = rnd_to(e[f], t2);                    /* weak python scalar: cast to the array's type */
+        for (long p = 0; p < P; p++) {
+            double r = load_px(raw, raw_dt, f * P + p);
+            if (ped != 0.0) r = rnd_to(r + rnd_to(ped, r64), r64);
+            const double b = load_px(bias, bias_dt, p), d = load_px(dark, dark_dt, p);
+            const double x = rnd_to(r - b, t1);
+            const double D = dark_still_biased ? rnd_to(d - b, t2) : d;
+            const double ds = rnd_to(ef * D, t2);
+            double y = rnd_to(x - ds, t3);
+            if (nflat) {
+                const double nf = load_px(nflat, nflat_dt, p);
+                if (nf != 0.0) y = rnd_to(y / nf, t4);           /* NaN != 0 is true -> NaN */
+            }
+            if (out_f64) ((double *)out)[f * P + p] = y;
+            else ((float *)out)[f * P + p] = (float)y;
+        }
+    }
+    return 0;
+}
+
+/* _generate_flat for a float64 flat: np.nanmean(float64) = float64 pairwise sum in 8192-element pieces (NaN -> 0) / count;
+ * nflat = flat / norm in float64 (pinned by golden G11 s*_nanmean and f*_nflat). */
+int apref_flat_normalize_f64(const double *flat, long n, double *nflat, double *norm_out)
+{
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (!tmp) return -1;
+    long cnt = 0;
+    for (long i = 0; i < n; i++) {
+        if (isnan(flat[i])) tmp[i] = 0.; else { tmp[i] = flat[i]; cnt++; }
+    }
+    double tot = npsum_f64(tmp, n);
+    free(tmp);
+    double norm = tot / (double)cnt;
+    if (norm_out) *norm_out = norm;
+    if (nflat)
+        for (long i = 0; i < n; i++) nflat[i] = flat[i] / norm;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* Exact selection helpers                                                                       */
 /* ------------------------------------------------------------------------------------------- */
 /* astropy: src/wirth_select.c  kth_smallest / wirth_median (in-place, permutes the buffer).     */
@@ -624,6 +708,49 @@ int apref_fix_badpix_f32(const float *data, const uint8_t *mask, long H, long W,
                 else {
                     qsort(good, (size_t)ng, sizeof(float), cmp_float);
                     out[r * W + c] = median_sorted_f32(good, ng);
+                }
+                nfix++;
+            }
+        }
+    free(good);
+    if (stats) { stats[0] = nbad; stats[1] = nfix; stats[2] = nbad - nfix; }
+    return 0;
+}
+
+/* A5 on a float64 image (what fix_bad_pixels sees after a float64 calibration): the same window logic, np.median in
+ * float64 (even count: (a + b) / 2 in float64).  Pinned by golden G11 (cases with use_mask). */
+static int cmp_double_nan_last(const void *a, const void *b)
+{
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+int apref_fix_badpix_f64(const double *data, const uint8_t *mask, long H, long W, int deltapix,
+                         int min_valid, double *out, int64_t *stats)
+{
+    memcpy(out, data, sizeof(double) * (size_t)(H * W));
+    int64_t nbad = 0, nfix = 0;
+    int wmax = (2 * deltapix + 1) * (2 * deltapix + 1);
+    double *good = (double *)malloc(sizeof(double) * (size_t)wmax);
+    for (long r = 0; r < H; r++)
+        for (long c = 0; c < W; c++) {
+            if (!mask[r * W + c]) continue;
+            nbad++;
+            long rmin = r - deltapix < 0 ? 0 : r - deltapix;
+            long rmax = r + deltapix + 1 > H ? H : r + deltapix + 1;
+            long cmin = c - deltapix < 0 ? 0 : c - deltapix;
+            long cmax = c + deltapix + 1 > W ? W : c + deltapix + 1;
+            int ng = 0;
+            for (long rr = rmin; rr < rmax; rr++)
+                for (long cc = cmin; cc < cmax; cc++)
+                    if (!mask[rr * W + cc]) good[ng++] = data[rr * W + cc];
+            if (ng >= min_valid) {
+                int has_nan = 0;
+                for (int i = 0; i < ng; i++) if (isnan(good[i])) has_nan = 1;
+                if (has_nan) out[r * W + c] = NAN;
+                else {
+                    qsort(good, (size_t)ng, sizeof(double), cmp_double_nan_last);
+                    out[r * W + c] = (ng & 1) ? good[ng / 2] : (good[ng / 2 - 1] + good[ng / 2]) / 2.0;
                 }
                 nfix++;
             }

@@ -59,7 +59,15 @@ def pairwise_sum_f32(a):
 
 
 def flat_normalize(flat):
-    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190) -> (nflat f32, norm f32)."""
+    """A1 ApCalibrate._generate_flat (ApCalibrate.py:166-190) -> (nflat, norm) in the flat's own dtype
+    (float32, or float64 for a float64 master)."""
+    if np.asarray(flat).dtype == np.float64:
+        flat = _c(flat, np.float64)
+        nflat = np.empty_like(flat)
+        norm = C.c_double()
+        rc = lib().apref_flat_normalize_f64(_p(flat), C.c_long(flat.size), _p(nflat), C.byref(norm))
+        assert rc == 0
+        return nflat, np.float64(norm.value)
     flat = _c(flat, np.float32)
     nflat = np.empty_like(flat)
     norm = C.c_float()
@@ -96,6 +104,33 @@ def calibrate(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biase
     rc = lib().apref_calibrate(_p(raw), C.c_int(dt), _p(bias), _p(dark), _p(nflat), _p(e), _p(ped),
                                C.c_int(int(bool(dark_still_biased))), _p(out), C.c_long(N), C.c_long(P))
     assert rc == 0
+    return out[0] if single else out
+
+
+_DT = {np.dtype(np.float32): 0, np.dtype(np.uint16): 1, np.dtype(np.float64): 2}
+
+
+def calibrate_mixed(raw, bias, dark, nflat, exp_ratio, pedestal=None, dark_still_biased=False):
+    """A2 with NumPy's per-operation type promotion for float64 inputs (ApCalibrate.py:301-305, 439-464; golden G11):
+    raw u16|f32|f64, masters f32|f64 in any mix -> float32 if nothing is float64, else float64."""
+    raw = np.ascontiguousarray(raw)
+    single = raw.ndim == 2
+    if single:
+        raw = raw[None]
+    N, P = raw.shape[0], raw[0].size
+    arrs = [np.ascontiguousarray(a) if a is not None else None for a in (bias, dark, nflat)]
+    dts = [_DT[a.dtype] if a is not None else 0 for a in arrs]
+    r64, b64, d64, n64 = raw.dtype == np.float64, dts[0] == 2, dts[1] == 2, dts[2] == 2
+    t1 = r64 or b64
+    t2 = (d64 or b64) if dark_still_biased else d64
+    t4 = (t1 or t2 or n64) if nflat is not None else (t1 or t2)
+    e = np.ascontiguousarray(np.broadcast_to(np.asarray(exp_ratio, np.float64), (N,)))
+    ped = None if pedestal is None else np.ascontiguousarray(np.broadcast_to(np.asarray(pedestal, np.float64), (N,)))
+    out = np.empty(raw.shape, np.float64 if t4 else np.float32)
+    rc = lib().apref_calibrate_mixed(_p(raw), C.c_int(_DT[raw.dtype]), _p(arrs[0]), C.c_int(dts[0]), _p(arrs[1]), C.c_int(dts[1]),
+                                     _p(arrs[2]), C.c_int(dts[2]), _p(e), _p(ped), C.c_int(int(bool(dark_still_biased))),
+                                     _p(out), C.c_int(int(t4)), C.c_long(N), C.c_long(P))
+    assert rc == 0, rc
     return out[0] if single else out
 
 
@@ -213,12 +248,14 @@ def mask_add_rects(mask, rects, value=2):
 
 
 def fix_badpix(data, mask, deltapix=1, min_valid=4):
-    """A5 ApFixBadPixels.fix_bad_pixels (ApFixBadPixels.py:292-445) -> (out f32, dict(nbad,nfix,nrem))."""
-    d = _c(data, np.float32)
+    """A5 ApFixBadPixels.fix_bad_pixels (ApFixBadPixels.py:292-445) -> (out, dict(nbad,nfix,nrem)); float64 images are
+    repaired in float64, everything else in float32."""
+    f64 = np.asarray(data).dtype == np.float64
+    d = _c(data, np.float64 if f64 else np.float32)
     m = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
     out = np.empty_like(d)
     st = np.zeros(3, np.int64)
-    rc = lib().apref_fix_badpix_f32(_p(d), _p(m), C.c_long(d.shape[0]), C.c_long(d.shape[1]),
+    rc = (lib().apref_fix_badpix_f64 if f64 else lib().apref_fix_badpix_f32)(_p(d), _p(m), C.c_long(d.shape[0]), C.c_long(d.shape[1]),
                                     C.c_int(int(deltapix)), C.c_int(int(min_valid)), _p(out), _p(st))
     assert rc == 0
     return out, dict(nbad=int(st[0]), nfix=int(st[1]), nrem=int(st[2]))

@@ -81,12 +81,17 @@ def synth_block(n_frames, rows, width, seed):
 
 
 def _work(args):
-    n_frames, rows, width, seed, reps = args
+    """Reduces synthetic blocks of `rows` rows until `seconds` have passed: (blocks done, compute seconds)."""
+    n_frames, rows, width, seed, seconds = args
     raw, bias, dark, nflat = synth_block(n_frames, rows, width, seed)
     t0 = time.perf_counter()
-    for _ in range(reps):
+    n = 0
+    while True:
         calibrate_stack_numpy(raw, bias, dark, nflat, 0.4)
-    return time.perf_counter() - t0
+        n += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return n, time.perf_counter() - t0
 
 
 def cpu_model():
@@ -101,28 +106,26 @@ def cpu_model():
 
 def time_numpy(n_frames=64, width=4096, seconds=10.0, workers=0):
     """Mpixels/s (input frame pixels) of the NumPy path: single process, and `workers` processes (0 = os.cpu_count())
-    each reducing its own row block.  Bounded: about `seconds` per leg."""
-    pilot_rows = 4
-    _work((n_frames, pilot_rows, width, 0, 1))              # warm
-    t = _work((n_frames, pilot_rows, width, 1, 1))
-    rate = n_frames * pilot_rows * width / t
-    rows = int(max(pilot_rows, min(256, seconds * rate / (n_frames * width))))
-    t1 = _work((n_frames, rows, width, 2, 1))
-    single = n_frames * rows * width / 1e6 / t1
+    each reducing its own row blocks.  Bounded: every leg stops after `seconds` (+ at most one block)."""
+    rows = 8
+    _work((n_frames, 2, width, 0, 0.0))                     # warm
+    n1, t1 = _work((n_frames, rows, width, 2, seconds))
+    single = n1 * n_frames * rows * width / 1e6 / t1
     workers = workers or os.cpu_count() or 1
-    res = dict(single=dict(value=single, unit='Mpixels/s', cores=1, rows=rows, seconds=t1), cpu=cpu_model(),
+    res = dict(single=dict(value=single, unit='Mpixels/s', cores=1, rows_per_block=rows, blocks=n1, seconds=t1), cpu=cpu_model(),
                numpy=np.__version__)
     if workers > 1:
-        rows_w = 16                                         # per worker: ~0.15 GB of NumPy temporaries at 64 x 16 x 4096
-        reps = int(max(1, min(50, 0.7 * seconds * single * 1e6 / (n_frames * rows_w * width))))
+        rows_w = 2                                          # small blocks: with every core busy a block takes much longer
         ctx = mp.get_context('fork')
         t0 = time.perf_counter()
         with ctx.Pool(workers) as pool:
-            ts = pool.map(_work, [(n_frames, rows_w, width, 10 + w, reps) for w in range(workers)], chunksize=1)
+            out = pool.map(_work, [(n_frames, rows_w, width, 10 + w, seconds) for w in range(workers)], chunksize=1)
         wall = time.perf_counter() - t0
-        # throughput of the compute phase: every worker's blocks over the slowest worker's compute time
-        res['multi'] = dict(value=workers * reps * n_frames * rows_w * width / 1e6 / max(ts), unit='Mpixels/s', cores=workers,
-                            rows_per_worker=rows_w, reps=reps, seconds=max(ts), wall_seconds_incl_synthesis=wall)
+        # aggregate throughput of the compute phase: all blocks done over the slowest worker's compute time
+        blocks = sum(n for n, _ in out)
+        tmax = max(t for _, t in out)
+        res['multi'] = dict(value=blocks * n_frames * rows_w * width / 1e6 / tmax, unit='Mpixels/s', cores=workers,
+                            rows_per_block=rows_w, blocks=blocks, seconds=tmax, wall_seconds_incl_synthesis=wall)
     return res
 
 

@@ -90,7 +90,8 @@ if 'SQ_INSTS_VALU' in avg and avg.get('SQ_WAVES'):
         if k in avg:
             res[k.lower().replace('sq_insts_', '') + '_insts_per_wave'] = avg[k] / avg['SQ_WAVES']
 if 'GRBM_GUI_ACTIVE' in avg and durs:
-    res['gpu_clock_ghz_during_kernel'] = avg['GRBM_GUI_ACTIVE'] / (sum(durs) / len(durs))
+    # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs of the chip
+    res["gpu_clock_ghz_during_kernel"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / (sum(durs) / len(durs))
 if 'SQ_WAVE_CYCLES' in avg and avg.get('SQ_BUSY_CYCLES'):
     res['sq_wave_cycles_over_busy_cycles'] = avg['SQ_WAVE_CYCLES'] / avg['SQ_BUSY_CYCLES']
 json.dump(res, open(os.path.join(out, 'summary_%s.json' % tag), 'w'), indent=1)

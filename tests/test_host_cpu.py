@@ -115,14 +115,54 @@ def test_fitsio_image_extensions(tmp_path):
 def test_fitsio_scaled_integers(tmp_path):
     from astrophotography_amd import fitsio
     h = fitsio.Header()
-    h['BSCALE'] = 2.0
-    h['BZERO'] = 10.0
-    # write raw int16 then patch scaling keywords in by hand (writer drops them for floats only)
+    h['XSCALE'] = 2.0
+    h['XZERO'] = 10.0
+    # a scaled int16 file: written plain, then the two placeholder cards are renamed in the file image
     data = np.array([[1, -2], [300, 4]], np.int16)
     fitsio.write(str(tmp_path / 's.fits'), data, h)
+    raw = (tmp_path / 's.fits').read_bytes().replace(b'XSCALE  =', b'BSCALE  =').replace(b'XZERO   =', b'BZERO   =')
+    (tmp_path / 's.fits').write_bytes(raw)
     d, hh = fitsio.read(str(tmp_path / 's.fits'))
     assert hh['BSCALE'] == 2.0
     assert d.dtype == np.float32 and np.array_equal(d, data.astype(np.float32) * 2 + 10)
+    # the scaling keywords describe the source file's storage: physical values written back must not inherit them
+    fitsio.write(str(tmp_path / 't.fits'), d, hh)
+    d2, h2 = fitsio.read(str(tmp_path / 't.fits'))
+    assert 'BSCALE' not in h2 and 'BZERO' not in h2 and np.array_equal(d2, d)
+    # int16 data with a header read from a uint16 file: BZERO = 32768 must not survive (it would shift the data)
+    u, hu = fitsio.read(os.path.join(GOLDEN, 'g1_c0_raw.fits'))
+    assert hu['BZERO'] == 32768
+    i16 = (u[:4, :4].astype(np.int32) - 1000).astype(np.int16)
+    fitsio.write(str(tmp_path / 'i.fits'), i16, hu)
+    d3, h3 = fitsio.read(str(tmp_path / 'i.fits'))
+    assert d3.dtype == np.int16 and np.array_equal(d3, i16) and 'BZERO' not in h3
+
+
+def test_fitsio_long_strings_and_non_ascii(tmp_path):
+    """CONTINUE long-string cards (a full path in DATAFILE, core/ApFindBadPixels.py:154) and non-ASCII header bytes."""
+    from astrophotography_amd import fitsio
+    h = fitsio.Header()
+    path = '/data/observatory/' + 'sub/' * 25 + "master_dark_it's-300s.fits"
+    h['DATAFILE'] = (path, 'Name of the dark the mask was made from')
+    h['NOTE'] = ('25\u00b0C', 'sensor \u00b0')
+    fitsio.write(str(tmp_path / 'l.fits'), np.zeros((2, 2), np.uint8), h)
+    raw = (tmp_path / 'l.fits').read_bytes()
+    assert len(raw) % 2880 == 0 and b"CONTINUE  '" in raw and raw[:2880 * 2].decode('ascii')      # pure ASCII, whole blocks
+    for i in range(0, raw.index(b'END' + b' ' * 77), 80):
+        card = raw[i:i + 80].decode('ascii')
+        if card.startswith(('DATAFILE', 'CONTINUE')):
+            assert card.rstrip().count("'") % 2 == 0                                            # every quote is closed
+    _, h2 = fitsio.read(str(tmp_path / 'l.fits'))
+    assert h2['DATAFILE'] == path and h2.comment('DATAFILE').startswith('Name of the dark')
+    assert h2['NOTE'] == '25?C'
+    # a stray non-ASCII byte in a file from capture software reads as '?' and the file can be rewritten
+    patched = raw.replace(b'25?C', b'25\xb0C')
+    (tmp_path / 'n.fits').write_bytes(patched)
+    d3, h3 = fitsio.read(str(tmp_path / 'n.fits'))
+    assert h3['NOTE'] == '25?C'
+    h3['NEWKEY'] = 1
+    fitsio.write(str(tmp_path / 'n2.fits'), d3, h3)
+    assert fitsio.read(str(tmp_path / 'n2.fits'))[1]['NOTE'] == '25?C'
 
 
 def test_user_badpix_yaml_semantics(tmp_path):

@@ -247,3 +247,43 @@ def test_numpy_baseline_restatement_matches_the_oracle():
     np.testing.assert_allclose(mean, ref['mean'], rtol=1e-13)
     m2, c2 = numpy_ref.calibrate_stack_numpy(raw, bias, dark, nflat, 0.4)
     assert np.array_equal(c2, cnt) and np.array_equal(m2, mean)
+
+
+def _g11_case(g, ci):
+    m = json.loads(str(g[f'f{ci}_meta']))
+    raw = g['raw_' + m['raw']]
+    bias, dark = g[m['bias']], g[m['dark']]
+    flat = g[m['flat']] if m['flat'] else None
+    return m, raw, bias, dark, flat
+
+
+def test_g11_calibrate_float64(golden_dir):
+    """float64 masters / raw frames: NumPy's per-operation promotion, float64 flat normalisation and bad-pixel repair."""
+    from oracle import apref
+    g = load(golden_dir, 'g11_calibrate_f64.npz')
+    for j in range(int(g['nsums'])):
+        a = g[f's{j}_a']
+        assert apref.lib().apref_pairwise_sum_f64(a.ctypes.data_as(__import__('ctypes').c_void_p), __import__('ctypes').c_long(a.size)) \
+            == float(g[f's{j}_sum']), j
+        b = a.copy()
+        b[::97] = np.nan
+        _, norm = apref.flat_normalize(b)
+        assert norm == float(g[f's{j}_nanmean']), j
+    for ci in range(int(g['ncases'])):
+        m, raw, bias, dark, flat = _g11_case(g, ci)
+        nflat = None
+        if flat is not None:
+            nflat, _ = apref.flat_normalize(flat)
+            assert nflat.dtype == g[f'f{ci}_nflat'].dtype and np.array_equal(nflat, g[f'f{ci}_nflat'], equal_nan=True), ci
+        out = apref.calibrate_mixed(raw, bias, dark, nflat, m['img_exp'] / m['dark_exp'], m['pedestal'], m['dark_still_biased'])
+        if m['use_mask']:
+            out, st = apref.fix_badpix(out, g['mask'], m['deltapix'])
+        ref = g[f'f{ci}_out']
+        assert out.dtype == ref.dtype == np.float64 and m['bitpix'] == -64, ci
+        assert np.array_equal(out, ref, equal_nan=True), (ci, m)
+    # with nothing float64 the mixed routine is the float32 routine
+    g1 = load(golden_dir, 'g1_calibrate.npz')
+    raw, bias, dark, flat = g1['raw_f32_64x64'], g1['bias_64x64'], g1['dark_64x64'], g1['flat_64x64']
+    nf, _ = apref.flat_normalize(flat)
+    a = apref.calibrate_mixed(raw, bias, dark, nf, 0.4, -100.0, True)
+    assert a.dtype == np.float32 and np.array_equal(a, apref.calibrate(raw, bias, dark, nf, 0.4, -100.0, True), equal_nan=True)
