@@ -6,10 +6,11 @@ sigma_clip_dev_func=mad_std, mem_limit=5e8)`` (:394-420).  Here the files are re
 slab in HBM and reduced by ONE launch of the stack kernel configured the same way (one clipping pass,
 median centre, 1.4826*MAD deviation, 5 sigma): no 500 MB tiling and no re-reading of every file per tile.
 
-Deviations from the reference, on purpose: the master is written as float32 (BITPIX -32, primary HDU
-only) - ccdproc writes float64 plus MASK/UNCERT extensions - because the device calibration path
-consumes float32 masters; ccdproc itself is not available to pin the arithmetic (parity unpinned,
-see DESIGN.md).
+The product has ccdproc's CCDData layout (ap_combine_darks.py:437 ``master.write``): a float64 primary HDU holding
+the kernel's float64 mean (``mean_f64``: never narrowed to float32 on the way), a MASK extension (pixels with every
+input rejected) and an UNCERT extension (float64 std of the survivors / sqrt(their number)).  ApCalibrate then
+calibrates with these float64 masters in float64, as the reference does.  ccdproc itself is not available in the build
+container to pin the arithmetic (parity unpinned).
 """
 import fnmatch
 import os
@@ -157,14 +158,15 @@ class ApMasterCal:
         else:
             slab = torch.from_numpy(np.stack([a.astype(np.float32) for a in arrs], 0)).cuda()
         res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
-                                outputs=('mean', 'count', 'std'))
+                                outputs=('mean_f64', 'count', 'std_f64'))
         # ccdproc's CCDData product (ap_combine_darks.py:411-439): float64 primary, MASK = pixels with every
-        # input rejected, UNCERT = std of the surviving values / sqrt(their number)
-        master = res['mean'].cpu().numpy().astype(np.float64)
+        # input rejected, UNCERT = std of the surviving values / sqrt(their number) - all in float64
+        master = res['mean_f64'].cpu().numpy()
         count = res['count'].cpu().numpy()
         all_masked = (count == 0).astype(np.uint8)
         with np.errstate(divide='ignore', invalid='ignore'):
-            uncert = res['std'].cpu().numpy().astype(np.float64) / np.sqrt(count.astype(np.float64))
+            uncert = res['std_f64'].cpu().numpy() / np.sqrt(count.astype(np.float64))
+        res['mean'] = res['mean_f64']
         hdr = hdrs[0].copy()
         for k in ('BSCALE', 'BZERO', 'UT', 'TIME-OBS', 'SWOWNER', 'SWCREATE', 'SBSTDVER'):
             if k in hdr:

@@ -129,7 +129,7 @@ def _per_frame_f64(x, n, device):
     if torch.is_tensor(x):
         t = x.to(device=device, dtype=torch.float64).reshape(-1)
         return (t.expand(n) if t.numel() == 1 and n > 1 else t).contiguous()
-    return torch.from_numpy(np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)))).to(device)
+    return torch.from_numpy(np.array(np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)))).to(device)
 
 
 def _calibrate_mixed(raw, bias, dark, nflat, exp_ratio, pedestal, dark_still_biased, out):

@@ -189,12 +189,15 @@ def test_apmastercal_and_apstack(tmp_path):
     m, h = fitsio.read(str(d / 'master_dark.fits'))
     ref = apref.combine_ccdproc(cube.astype(np.float64), 5.0, 5.0)
     assert m.dtype == np.float64 and h['BITPIX'] == -64           # CCDData product: float64 primary + MASK + UNCERT
-    assert_ulp(m.astype(np.float32), ref['mean'].astype(np.float32), 1, 'master dark vs ccdproc-style oracle')
+    # the float64 mean is written as it is (not narrowed to float32 on the device): float64 agreement with the oracle,
+    # and the values are NOT all float32-representable
+    np.testing.assert_allclose(m, ref['mean'], rtol=1e-14)
+    assert (m != m.astype(np.float32)).any()
     mask, mh = fitsio.read_extension(str(d / 'master_dark.fits'), 'MASK')
     unc, uh = fitsio.read_extension(str(d / 'master_dark.fits'), 'UNCERT')
     assert mask.dtype == np.uint8 and mask.shape == shape and not mask.any()
     assert uh['UTYPE'] == 'StdDevUncertainty' and unc.dtype == np.float64
-    np.testing.assert_allclose(unc, ref['std'] / np.sqrt(ref['count']), rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(unc, ref['std'] / np.sqrt(ref['count']), rtol=1e-12, atol=1e-300)
     assert h['IMAGETYP'] == 'MASTER DARK' and h['NCOMBINE'] == N and h['IFILE011'] == 'dark11.fits' and h['BUNIT'] == 'adu'
     # second construction ignores the master it just wrote
     assert len(ap.ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL')._values('file')) == N
