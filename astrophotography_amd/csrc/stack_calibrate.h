@@ -92,7 +92,11 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
 // Each lane of a packed operation is an ordinary IEEE float32 operation, so results do not change.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP>
+// RANGE_GUARD = false: the quotient-range test is left to the caller, who reads it off the ends of the SORTED column
+// (range_ok_sorted) instead of tracking max |q| and min |q| through the loop (one v_max3 + one v_min3 per frame pair).
+// (Hoisting e * D for a stack with one exposure ratio was built and measured: no fewer VALU instructions after the
+// compiler's own scheduling and 2 % slower with the extra workgroup vote - not kept.)
+template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
                                                bool dodiv, float (&v)[NP])
 {
@@ -114,8 +118,8 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 const v2f ped = {fs.ped[f], fs.ped[f + 1]};
                 x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
             }                                                // which changes nothing but the sign of a -0.0 input
-            const v2f e2 = {fs.e[f], fs.e[f + 1]};
             x = x - b2;                                      // :439
+            const v2f e2 = {fs.e[f], fs.e[f + 1]};
             const v2f ds = e2 * D2;                          // :450
             x = x - ds;                                      // :451
             const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
@@ -126,10 +130,12 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
             v[f] = q.x;
             v[f + 1] = q.y;
             acc = __builtin_elementwise_fma(q, zero2, acc);  // NaN iff some value is not finite
-            mx = fmaxf(fmaxf(mx, fabsf(q.x)), fabsf(q.y));
-            mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
+            if constexpr (RANGE_GUARD) {
+                mx = fmaxf(fmaxf(mx, fabsf(q.x)), fabsf(q.y));
+                mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
+            }
         }
-        const bool range_ok = !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
+        const bool range_ok = !RANGE_GUARD || !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
         return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
     } else {
         float x = to_f32(raw[0]);
@@ -145,58 +151,44 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
     }
 }
 
-// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
-// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
-// FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
-// wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
-__device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
-                                           float (&v)[NP])
+// The quotient-range condition of the reciprocal division (all |q| in (2^-50, 2^50), see calibrate_fast), read off a column
+// that is already sorted ascending and finite: max |q| sits at an end; min |q| too unless the signs are mixed - then (and
+// only then, wave-wide) the magnitudes are scanned.
+template <int NP>
+__device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv)
+{
+    const float lo = v[0], hi = v[NP - 1];
+    const bool big_ok = fmaxf(fabsf(lo), fabsf(hi)) < 0x1p50f;
+    const bool one_sign = lo > 0x1p-50f || hi < -0x1p-50f;    // then min |q| = |lo| or |hi| and it is above 2^-50
+    bool small_ok = one_sign;
+    if (wave_any(dodiv && !one_sign)) {
+        float mn = __builtin_inff();
+        if constexpr (NP >= 2) {
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) mn = fminf(fminf(mn, fabsf(v[i])), fabsf(v[i + 1]));
+        } else {
+            mn = fabsf(v[0]);
+        }
+        small_ok = mn > 0x1p-50f;
+    }
+    return !dodiv || (big_ok && small_ok);
+}
+
+// Per-lane context of a column load: what the exact fallback and the deferred range check need.
+struct ColumnCtx {
+    float b, D, nf;
+    bool dodiv, skip;
+    bool range_pending;     // wave-uniform: the fast path ran without range guards; verify with range_ok_sorted after the sort
+};
+
+// The exact column: IEEE division, one frame at a time (re-read from memory: no second raw[] column in flight), non-finite
+// values (sigma clip) or NaNs (plain median), padding slots and masked pixels become +inf sentinels.  Returns the number of
+// valid values.  RAWREG: take the raw values from `raw` (already in registers, !CALIB) instead of re-reading them.
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int NRAW>
+__device__ __forceinline__ int load_column_exact(const StackParams &prm, const FrameScalars<NP> &fs, int64_t p, const ColumnCtx &cx,
+                                                 const RawT (&raw)[NRAW], float (&v)[NP])
 {
     const int N = prm.N;
-    const int64_t p = base + lane;
-    constexpr bool HALVES = CALIB && NP >= 112;           // 112 / 128 slots: two half columns (register budget: 2 waves/SIMD)
-    RawT raw[HALVES ? 1 : NP];
-    if constexpr (!HALVES) load_raw<NP, RawT, FULL>(prm, base, lane, raw);
-    float b = 0.f, D = 0.f, nf = 1.f;
-    bool dodiv = false;
-    if constexpr (CALIB) {
-        b = prm.bias[p];
-        const float d = prm.dark[p];
-        D = prm.still_biased ? d - b : d;                    // ApCalibrate.py:440-445
-        if (prm.nflat) {
-            nf = prm.nflat[p];
-            dodiv = (nf != 0.f);                             // ApCalibrate.py:462 (NaN != 0 is True)
-        }
-    }
-    const bool skip = prm.pixmask && prm.pixmask[p];
-    if constexpr (CALIB) {
-        bool good;
-        if constexpr (HALVES) {
-            constexpr int HN = NP / 2;
-            RawT half[HN];
-            load_raw<NP, RawT, FULL, 0, HN>(prm, base, lane, half);
-            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN>(fs, half, b, D, nf, dodiv, v)
-                                : calibrate_fast<NP, RawT, false, 0, HN>(fs, half, b, D, nf, dodiv, v);
-            load_raw<NP, RawT, FULL, HN, HN>(prm, base, lane, half);
-            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN>(fs, half, b, D, nf, dodiv, v)
-                                            : calibrate_fast<NP, RawT, false, HN, HN>(fs, half, b, D, nf, dodiv, v);
-            good = good && good2;
-        } else {
-            if (prm.pedestal) good = calibrate_fast<NP, RawT, true>(fs, raw, b, D, nf, dodiv, v);
-            else good = calibrate_fast<NP, RawT, false>(fs, raw, b, D, nf, dodiv, v);
-        }
-        if (__all(good && !skip)) {
-            if constexpr (FULL) return NP;
-            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
-            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
-#pragma unroll
-            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
-            return N;
-        }
-        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
-        // redo the column exactly (IEEE division), one frame at a time - no second raw[] column in flight
-    }
     int n = 0;
     const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
     int nleft = N;
@@ -208,23 +200,105 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             x = to_f32(*fp);
             if (FULL || f + 1 < nleft) fp += prm.stride;
         } else {
-            x = to_f32(raw[f]);
+            x = to_f32(raw[f < NRAW ? f : 0]);
         }
         if constexpr (CALIB) {
             const float e = fs.e[f];
             const float ped = fs.ped[f];
             if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
-            x = x - b;                                       // :439
-            const float ds = e * D;                          // :450
+            x = x - cx.b;                                    // :439
+            const float ds = e * cx.D;                       // :450
             x = x - ds;                                      // :451
-            if (dodiv) x = __fdiv_rn(x, nf);                 // :463
+            if (cx.dodiv) x = __fdiv_rn(x, cx.nf);           // :463
         }
         bool ok;
         if constexpr (FINITE_ONLY) ok = fabsf(x) < __builtin_inff();
         else ok = (x == x);
-        ok = ok && (FULL || f < N) && !skip;
+        ok = ok && (FULL || f < N) && !cx.skip;
         n += ok ? 1 : 0;
         v[f] = ok ? x : __builtin_inff();
+    }
+    return n;
+}
+
+// Loads the lane's column, applies the fused calibration, maps non-finite values (sigma clip) or
+// NaNs (plain median) to the +inf sentinel and returns the number of valid values.
+// FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
+// wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes), and the range guards of the
+// reciprocal division are deferred to the sorted column (cx.range_pending, see load_sorted_column).
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+__device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
+                                           float (&v)[NP], ColumnCtx &cx)
+{
+    const int N = prm.N;
+    const int64_t p = base + lane;
+    constexpr bool HALVES = CALIB && NP >= 112;           // 112 / 128 slots: two half columns (register budget: 2 waves/SIMD)
+    constexpr bool GUARD = !FULL;                         // padded columns end in +inf after the lift: guard inside the loop
+    RawT raw[HALVES ? 1 : NP];
+    if constexpr (!HALVES) load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+    cx.b = 0.f; cx.D = 0.f; cx.nf = 1.f;
+    cx.dodiv = false;
+    cx.range_pending = false;
+    if constexpr (CALIB) {
+        cx.b = prm.bias[p];
+        const float d = prm.dark[p];
+        cx.D = prm.still_biased ? d - cx.b : d;              // ApCalibrate.py:440-445
+        if (prm.nflat) {
+            cx.nf = prm.nflat[p];
+            cx.dodiv = (cx.nf != 0.f);                       // ApCalibrate.py:462 (NaN != 0 is True)
+        }
+    }
+    cx.skip = prm.pixmask && prm.pixmask[p];
+    if constexpr (CALIB) {
+        const float b = cx.b, D = cx.D, nf = cx.nf;
+        const bool dodiv = cx.dodiv;
+        bool good;
+        if constexpr (HALVES) {
+            constexpr int HN = NP / 2;
+            RawT half[HN];
+            load_raw<NP, RawT, FULL, 0, HN>(prm, base, lane, half);
+            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD>(fs, half, b, D, nf, dodiv, v)
+                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD>(fs, half, b, D, nf, dodiv, v);
+            load_raw<NP, RawT, FULL, HN, HN>(prm, base, lane, half);
+            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD>(fs, half, b, D, nf, dodiv, v)
+                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD>(fs, half, b, D, nf, dodiv, v);
+            good = good && good2;
+        } else {
+            if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD>(fs, raw, b, D, nf, dodiv, v);
+            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD>(fs, raw, b, D, nf, dodiv, v);
+        }
+        if (wave_all(good && !cx.skip)) {
+            if constexpr (FULL) {
+                cx.range_pending = !GUARD;
+                return NP;
+            }
+            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
+            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
+#pragma unroll
+            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+            return N;
+        }
+        // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
+        // redo the column exactly
+    }
+    return load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, p, cx, raw, v);
+}
+
+// Column loaded AND sorted ascending (sentinels last).  When the fast calibration deferred its range guards, they are
+// evaluated on the sorted column; a failing lane sends the wave through the exact path and a second sort (rare).
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+__device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
+                                                  int lane, float (&v)[NP])
+{
+    ColumnCtx cx;
+    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base, lane, v, cx);
+    sort_column<NP>(v);
+    if constexpr (CALIB && FULL) {
+        if (cx.range_pending && !wave_all(range_ok_sorted<NP>(v, cx.dodiv))) {
+            RawT none[1] = {};
+            n = load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base + lane, cx, none, v);
+            sort_column<NP>(v);
+        }
     }
     return n;
 }

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
     if (p >= prm.P) return;
 
     float v[NP];
-    APGPU_MARK("load_calibrate");
-    const int n = load_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
+    APGPU_MARK("load_calibrate_sort");
+    const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
     if constexpr (EXTRA) reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
     else reduce_and_store<NP>(prm, v, n, p);
 }
@@ -61,8 +61,7 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     if constexpr (CALIB || !FULL) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
-    const int n = load_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);
-    sort_column<NP>(v);
+    const int n = load_sorted_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);
     const float m1 = pick_at<NP>(v, (n - 1) >> 1);
     const float m2 = pick_at<NP>(v, n >> 1);
     const double med = ((double)m1 + (double)m2) / 2.0;
@@ -173,8 +172,7 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
             float v[NP];
             StackParams q = prm;
             asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
-            const int n = load_column<NP, uint16_t, CALIB, false, FULL>(q, fs, base, lane, v);
-            sort_column<NP>(v);
+            const int n = load_sorted_column<NP, uint16_t, CALIB, false, FULL>(q, fs, base, lane, v);
             const float m1 = pick_at<NP>(v, (n - 1) >> 1);
             const float m2 = pick_at<NP>(v, n >> 1);
             const double med = ((double)m1 + (double)m2) / 2.0;
@@ -209,13 +207,15 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
     if constexpr (CALIB) {
         // non-decreasing map: finite masters and a positive (or unused) flat
         const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
-        const bool good = calibrate_fast<NP, float, false>(fs, rawf, b, D, nf, dv, v);
+        // FULL columns come out sorted (non-decreasing map of a sorted raw column), so their range guards are read off the ends
+        bool good = calibrate_fast<NP, float, false, 0, NP, !FULL>(fs, rawf, b, D, nf, dv, v);
+        if constexpr (FULL) good = good && (!increasing || range_ok_sorted<NP>(v, dv));
         fast = fast && good && increasing;
     } else {
 #pragma unroll
         for (int f = 0; f < NP; f++) v[f] = rawf[f];
     }
-    if (__all(fast)) {
+    if (wave_all(fast)) {
         if constexpr (!FULL) {
 #pragma unroll
             for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
@@ -237,7 +237,7 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
         }
         sort_column<NP>(v);
     }
-    reduce_and_store<NP, true>(prm, v, n, p);
+    reduce_and_store<NP>(prm, v, n, p);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs
             float v[NP];
             StackParams q = prm;
             asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
-            const int n = load_column<NP, uint16_t, CALIB, true, FULL>(q, fs, base, lane, v);
+            const int n = load_sorted_column<NP, uint16_t, CALIB, true, FULL>(q, fs, base, lane, v);
             reduce_and_store<NP>(prm, v, n, p);
         }
         return;
@@ -393,7 +393,11 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         }
     }
 
+#ifdef APGPU_VARIANT_FORCE_RICH                             // tools/variant_lib.sh experiment: LDS-resident column for every output set
+    const bool rich = !median_only;
+#else
     const bool rich = !median_only && (prm.median || prm.std || prm.mean64 || prm.std64 || prm.dev == APGPU_DEV_MAD_STD);
+#endif
     const bool full = prm.N == NP;
     const int block = rich ? rich_block<NP>() : 256;
     const int64_t grid = (prm.P + block - 1) / block;

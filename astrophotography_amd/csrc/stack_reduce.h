@@ -43,8 +43,9 @@ __device__ __forceinline__ T park_in_vgpr(T x)
 // CSEs the 64 conversions out of the clipping loop and keeps 64 doubles (128 VGPRs) live.
 __device__ __forceinline__ double widen(float x)
 {
-    asm volatile("" : "+v"(x));
-    return (double)x;
+    double d;
+    asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(x));     // the conversion itself is the barrier: no extra v_mov
+    return d;
 }
 
 // Trim rejected values from the low end: element I, then (only if some lane still has its cut
@@ -61,7 +62,7 @@ __device__ __forceinline__ void trim_low(const float (&v)[NP], ClipState &st, bo
             st.Q = fma(-d, d, st.Q);
             st.a = I + 1;
         }
-        if (__any(active && (st.a > I))) trim_low<I + 1, NP>(v, st, active);
+        if (wave_any(active && (st.a > I))) trim_low<I + 1, NP>(v, st, active);
     }
 }
 
@@ -69,7 +70,7 @@ template <int I, int NP>
 __device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
 {
     if constexpr (I >= 0) {
-        if (__any(active && (I < st.b))) {                  // padding slots above every lane's range: just step down
+        if (wave_any(active && (I < st.b))) {               // padding slots above every lane's range: just step down
             const double xd = widen(v[I]);
             const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
             if (rej) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, b
                 st.b = I;
             }
         }
-        if (__any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
+        if (wave_any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
     }
 }
 
@@ -87,7 +88,7 @@ template <int I, int NP>
 __device__ __forceinline__ void readmit_low(const float (&v)[NP], ClipState &st, int &a_new)
 {
     if constexpr (I < NP) {
-        if (__any(I < st.a)) {
+        if (wave_any(I < st.a)) {
             const double xd = widen(v[I]);
             const bool keep = (I < st.a) && !below(st, xd) && !above(st, xd);
             if (keep) {
@@ -105,7 +106,7 @@ template <int I, int NP>
 __device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new)
 {
     if constexpr (I >= 0) {
-        if (__any(I >= st.b)) {
+        if (wave_any(I >= st.b)) {
             const double xd = widen(v[I]);
             const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
             if (keep) {
@@ -164,7 +165,7 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
     double dl_prev = __builtin_inf();
     constexpr int CH = NP >= 4 ? 4 : NP;                    // windows per trip: 2*CH LDS reads in flight
     for (int L0 = 0; L0 < NP; L0 += CH) {
-        if (!__any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
+        if (!wave_any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
             dl_prev = __builtin_inf();
             continue;
         }
@@ -213,7 +214,7 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
 
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP, bool PRESORTED = false>
+template <int NP>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
     // everything the loop and the epilogue need from the kernel arguments, parked before the sort
@@ -225,18 +226,16 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
     const int maxiters = park_in_vgpr(prm.maxiters);
     const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
-    APGPU_MARK("sort");
-    if constexpr (!PRESORTED) sort_column<NP>(v);           // PRESORTED: ascending, sentinels last (uint16 pair kernel)
-    APGPU_MARK("moments");
+    APGPU_MARK("moments");                                   // v: sorted ascending, sentinels last (load_sorted_column)
 
-    // pivot: the lower median of the finite values
-    float cf, cf2;
-    pick_middle<NP>(v, (n - 1) >> 1, (n - 1) >> 1, cf, cf2);
-    cf = n > 0 ? cf : 0.f;
+    // the two middle values of the finite range: the lower one is the pivot, and together they are the first pass's median
+    float m1, m2;
+    pick_middle<NP>(v, (n - 1) >> 1, n >> 1, m1, m2);
+    const float cf = n > 0 ? m1 : 0.f;
     const double c = (double)cf;
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
-    if (__all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
+    if (wave_all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             const double d = (double)v[i] - c;
@@ -271,12 +270,10 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     bool active = n > 0;
     int it = 0;
 
-    while (__any(active)) {
+    while (wave_any(active)) {
         const int a0 = st.a, b0 = st.b;
-        float m1 = 0.f, m2 = 0.f;
-        if (use_median) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
-        const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
         if (active) {
+            const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
             st.nn = (double)(st.b - st.a);
             st.cen = use_median ? med : c + st.S / st.nn;
             st.wscale = st.nn;
@@ -290,20 +287,40 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         it++;
         const bool changed = (st.a != a0) || (st.b != b0);
         active = active && changed && (maxiters < 0 || it < maxiters);
+        // the middle pair for the next pass (the first pass uses the pair picked for the pivot)
+        if (use_median && wave_any(active)) pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, m1, m2);
     }
 
     APGPU_MARK("readmit_output");
     // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by
-    // an earlier, tighter pass that lie inside the final bounds are re-admitted.
-    if (__any(st.a > 0)) {
-        int a_new = st.a;
-        readmit_low<0, NP>(v, st, a_new);
-        st.a = a_new;
+    // an earlier, tighter pass that lie inside the final bounds are re-admitted.  The column is sorted, so nothing
+    // can come back on a side whose innermost trimmed value (v[a-1] / v[b]) is still outside; for the usual few
+    // trimmed values that one element is picked with a 4-way select and the walk over the trimmed slots is skipped.
+    if (wave_any(st.a > 0)) {
+        bool walk = st.a > 0;
+        if constexpr (NP >= 8) if (wave_all(st.a <= 4)) {
+            const double xd = widen(pick_rel<0, 4, NP>(v, (st.a - 1) & 3));
+            walk = st.a > 0 && (st.a >= st.b || !below(st, xd));
+        }
+        if (wave_any(walk)) {
+            int a_new = st.a;
+            readmit_low<0, NP>(v, st, a_new);
+            st.a = a_new;
+        }
     }
-    if (__any(st.b < n)) {
-        int b_new = st.b;
-        readmit_high<NP - 1, NP>(v, st, n, b_new);
-        st.b = b_new;
+    if (wave_any(st.b < n)) {
+        bool walk = st.b < n;
+        if constexpr (NP >= 8) {
+            if (wave_all(n == NP && st.b >= NP - 4)) {
+                const double xd = widen(pick_rel<NP - 4, 4, NP>(v, st.b & 3));     // NP is a multiple of 4: (b - (NP - 4)) & 3
+                walk = st.b < n && (st.a >= st.b || !above(st, xd));
+            }
+        }
+        if (wave_any(walk)) {
+            int b_new = st.b;
+            readmit_high<NP - 1, NP>(v, st, n, b_new);
+            st.b = b_new;
+        }
     }
     const int a = st.a, b = st.b;
     const double S = st.S, Q = st.Q;
@@ -329,9 +346,8 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     const bool use_mad = prm.dev == APGPU_DEV_MAD_STD;
     const double sl2 = prm.sl2, su2 = prm.su2;
     const int maxiters = prm.maxiters;
-    sort_column<NP>(v);
 #pragma unroll
-    for (int i = 0; i < NP; i++) col[i * B] = v[i];
+    for (int i = 0; i < NP; i++) col[i * B] = v[i];          // v: sorted ascending, sentinels last (load_sorted_column)
 
     // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
     const float cf = n > 0 ? col_read<NP>(col, (n - 1) >> 1) : 0.f;
@@ -358,7 +374,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     bool active = n > 0;
     int it = 0;
 
-    while (__any(active)) {
+    while (wave_any(active)) {
         const int a0 = st.a, b0 = st.b;
         const float m1 = col_read<NP>(col, (st.a + st.b - 1) >> 1);
         const float m2 = col_read<NP>(col, (st.a + st.b) >> 1);
@@ -390,7 +406,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
                 st.Q = fma(-d, d, st.Q);
                 st.a++;
             }
-            if (!__any(rej)) break;
+            if (!wave_any(rej)) break;
         }
         for (;;) {
             const double xd = (double)col_read<NP>(col, st.b - 1);
@@ -401,7 +417,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
                 st.Q = fma(-d, d, st.Q);
                 st.b--;
             }
-            if (!__any(rej)) break;
+            if (!wave_any(rej)) break;
         }
         it++;
         const bool changed = (st.a != a0) || (st.b != b0);
@@ -411,9 +427,9 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     // astropy applies the FINAL bounds to all values (sigma_clipping.py:356-358): values trimmed by an
     // earlier, tighter pass that lie inside the final bounds are re-admitted (ascending, then descending,
     // like the lean kernel's chains).
-    if (__any(st.a > 0)) {
+    if (wave_any(st.a > 0)) {
         int a_new = st.a;
-        for (int i = 0; __any(i < st.a); i++) {
+        for (int i = 0; wave_any(i < st.a); i++) {
             const double xd = (double)col_read<NP>(col, i);
             const bool keep = (i < st.a) && !below(st, xd) && !above(st, xd);
             if (keep) {
@@ -425,9 +441,9 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         }
         st.a = a_new;
     }
-    if (__any(st.b < n)) {
+    if (wave_any(st.b < n)) {
         int b_new = st.b;
-        for (int i = NP - 1; __any(i >= st.b); i--) {
+        for (int i = NP - 1; wave_any(i >= st.b); i--) {
             const double xd = (double)col_read<NP>(col, i);
             const bool keep = (i >= st.b) && (i < n) && !below(st, xd) && !above(st, xd);
             if (keep) {
@@ -454,7 +470,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         constexpr int CH = NP >= 8 ? 8 : NP;                  // LDS reads in flight per trip
         double s1 = 0.0;
         for (int i0 = 0; i0 < NP; i0 += CH) {
-            if (!__any(i0 + CH > a && i0 < b)) continue;
+            if (!wave_any(i0 + CH > a && i0 < b)) continue;
             float x[CH];
 #pragma unroll
             for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
@@ -467,7 +483,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         const double m1 = s1 / nf;
         double q1 = 0.0;
         for (int i0 = 0; i0 < NP; i0 += CH) {
-            if (!__any(i0 + CH > a && i0 < b)) continue;
+            if (!wave_any(i0 + CH > a && i0 < b)) continue;
             float x[CH];
 #pragma unroll
             for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);

@@ -17,6 +17,11 @@ using namespace apgpu;
 #define APGPU_MARK(name) asm volatile("; APGPU_SECTION " name)
 #endif
 
+// Wave-wide votes as one compare into an SGPR pair + a scalar test.  HIP's __any / __all go through an int (v_cndmask 0/1 +
+// v_cmp_ne) before the ballot: two extra VALU instructions per vote, and the clip loop votes ~12 times per pass.
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0; }
+
 // -------------------------------------------------------------------------------------------------
 // Batcher odd-even merge sorting network, generated at compile time.  For NP that is not a power of two the
 // network of the next power of two is pruned to its first NP wires: the missing inputs are +inf, which never
@@ -149,7 +154,7 @@ __device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2
     } else {
         constexpr int WLO = NP / 2 - 4;
         const bool inside = (i1 >= WLO) && (i2 < WLO + 8);
-        if (__all(inside)) {
+        if (wave_all(inside)) {
             m1 = pick_rel<WLO, 8, NP>(v, i1 - WLO);
             m2 = pick_rel<WLO, 8, NP>(v, i2 - WLO);
         } else {
@@ -158,7 +163,7 @@ __device__ __forceinline__ void pick_middle(const float (&v)[NP], int i1, int i2
             int k = (__builtin_amdgcn_readfirstlane(i1) - 2) >> 2;
             k = k < 0 ? 0 : (k > NP / 4 - 2 ? NP / 4 - 2 : k);
             const bool inside_k = (i1 >= 4 * k) && (i2 < 4 * k + 8);
-            if (__all(inside_k)) {
+            if (wave_all(inside_k)) {
                 pick_window<0, NP>(v, k, i1, i2, m1, m2);
             } else {
                 m1 = pick_at<NP>(v, i1);

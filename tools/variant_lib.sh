@@ -1,17 +1,27 @@
 #!/bin/bash
-# Development aid: links a variant of libapgpu.so in which ONE translation unit is rebuilt with extra -D flags.
-#   bash tools/variant_lib.sh <tag> <source.hip> [-DFLAG ...]   -> build_variants/libapgpu_<tag>.so
-# Use it with  APGPU_LIBRARY=<path> python tools/bench_kernels.py ...  (the loader honours APGPU_LIBRARY).
+# Development aid: builds a VARIANT of libapgpu.so for same-box A/B measurements.
+#   tools/variant_lib.sh <name> "<extra hipcc flags>" <translation unit> [<translation unit> ...]
+# recompiles the named csrc/*.hip files with the extra flags (e.g. -DAPGPU_VARIANT_X) into build_variants/<name>/ and links
+# them with the production objects of every other unit -> build_variants/<name>/libapgpu.so.  Select it at run time with
+# APGPU_LIBRARY=build_variants/<name>/libapgpu.so (astrophotography_amd/_lib.py).  Never used by tests or the bench.
 set -e
-TAG=$1; SRC=$2; shift; shift
-REPO=$(cd "$(dirname "$0")/.." && pwd)
-CS=$REPO/astrophotography_amd/csrc
-OUT=$REPO/build_variants
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; FLAGS=$2; shift 2
+OUT=$ROOT/build_variants/$NAME
 mkdir -p $OUT
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I$CS -I$REPO/include "$@" -c $CS/$SRC -o $OUT/${SRC%.hip}_$TAG.o
+CS=$ROOT/astrophotography_amd/csrc
 OBJS=""
 for o in $CS/_obj/*.o; do
-  if [ "$(basename $o)" != "${SRC%.hip}.o" ]; then OBJS="$OBJS $o"; fi
+  b=$(basename $o .o); skip=0
+  for tu in "$@"; do [ "$b" = "$(basename $tu .hip)" ] && skip=1; done
+  [ $skip = 0 ] && OBJS="$OBJS $o"
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libapgpu_$TAG.so $OBJS $OUT/${SRC%.hip}_$TAG.o
-echo $OUT/libapgpu_$TAG.so
+for tu in "$@"; do
+  b=$(basename $tu .hip)
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+    -I$ROOT/include -I$CS $FLAGS -c $CS/$b.hip -o $OUT/$b.o &
+done
+wait
+for tu in "$@"; do OBJS="$OBJS $OUT/$(basename $tu .hip).o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libapgpu.so $OBJS
+echo built $OUT/libapgpu.so
