@@ -13,7 +13,7 @@ APGPU_F32, APGPU_U16, APGPU_F64 = 0, 1, 2
 OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
 CENTER = {'median': 0, 'mean': 1}
 DEV = {'std': 0, 'mad_std': 1}
-MAX_STACK = 128
+MAX_STACK = 512
 
 E_INVAL, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4
 

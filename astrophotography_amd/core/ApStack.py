@@ -33,8 +33,22 @@ class ApStack:
         'mean': plain mean (a clip with an infinite bound, one pass); 'median': np.nanmedian along N.
         calib: None or ApCalibrate.masters() + exp_ratio (+ pedestal) for the fused path."""
         from .. import ops
+        from .._lib import MAX_STACK
         if method not in METHODS:
             raise ValueError(f'Error, stacking method {method} is not one of the allowed methods: {METHODS}')
+        if frames.shape[0] > MAX_STACK and method != 'median':
+            # beyond what one launch reduces exactly (512 frames): chunks, float64 moments added (ops.stack_sigclip_chunked)
+            want = set(outputs) - {'mean', 'count', 'std'}
+            if want:
+                raise ValueError(f'stacks of more than {MAX_STACK} frames provide mean / count / std only, not {sorted(want)}')
+            if method == 'mean':
+                clip = dict(sigma=1e30, maxiters=1, cenfunc='mean', stdfunc='std')
+            else:
+                self._logger.warning(f'{frames.shape[0]} frames exceed the {MAX_STACK} one launch clips exactly: clipping in chunks '
+                                     '(every chunk against its own statistics), moments combined in float64.')
+                clip = dict(sigma=self.sigma, sigma_lower=self.sigma_lower, sigma_upper=self.sigma_upper, maxiters=self.maxiters,
+                            cenfunc=self.cenfunc, stdfunc=self.stdfunc)
+            return ops.stack_sigclip_chunked(frames, want_std='std' in outputs, calib=calib, pixmask=pixmask, **clip)
         if method == 'median':
             return {'median': ops.stack_median(frames, calib=calib, pixmask=pixmask)}
         if method == 'mean':

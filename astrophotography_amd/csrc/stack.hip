@@ -5,6 +5,10 @@
 
 #include <cstdlib>
 
+namespace apgpu_stack {
+int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe);   // stack_big.hip
+}
+
 namespace {
 using namespace apgpu;
 using namespace apgpu_stack;
@@ -47,7 +51,7 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     if (args->n_pixels <= 0) return fail(APGPU_EINVAL, "stack: n_pixels = %lld", (long long)args->n_pixels);
     if (args->n_frames < 1) return fail(APGPU_EINVAL, "stack: n_frames = %d", args->n_frames);
     if (args->n_frames > APGPU_MAX_STACK)
-        return fail(APGPU_EUNSUPPORTED, "stack: n_frames = %d exceeds APGPU_MAX_STACK = %d (shard the frames or "
+        return fail(APGPU_EUNSUPPORTED, "stack: n_frames = %d exceeds APGPU_MAX_STACK = %d (shard the frames over GPUs or "
                     "combine partial moments)", args->n_frames, APGPU_MAX_STACK);
     if (args->dtype != APGPU_F32 && args->dtype != APGPU_U16) return fail(APGPU_EINVAL, "stack: bad dtype %d", args->dtype);
     if (args->frame_stride != 0 && args->frame_stride < args->n_pixels)
@@ -101,6 +105,8 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     if (const char *e = getenv("APGPU_DEBUG_MAXITERS")) prm.maxiters = atoi(e);
 #endif
     hipStream_t st = as_stream(stream);
+    if (prm.N > 128)                                        // the column does not fit the registers: LDS-resident path
+        return launch_big(prm, args->dtype == APGPU_U16, calib, median_only, st, describe);
     if (args->dtype == APGPU_F32)
         return calib ? launch_np<float, true>(prm, median_only, st, describe) : launch_np<float, false>(prm, median_only, st, describe);
     return calib ? launch_np<uint16_t, true>(prm, median_only, st, describe) : launch_np<uint16_t, false>(prm, median_only, st, describe);

@@ -1,0 +1,192 @@
+// stack_big.hip - stacks of 129 .. 512 frames (APGPU_MAX_STACK): exact sigma-clipped statistics / median of a column that
+// no longer fits the registers.  Same semantics and outputs as the register kernels (stack_kernels.h):
+//   astropy.stats.sigma_clipped_stats(cube, axis=0)   astropy/stats/sigma_clipping.py:298-383, 924-937
+//   ccdproc.combine(median / mad_std, one pass)       reference call site scripts/ap_combine_darks.py:394-420
+//   np.nanmedian(cube, axis=0)
+// ccdproc and astropy take any N (ap_combine_darks.py:411-420 combines whatever the directory holds).
+//
+// One wavefront per workgroup, one pixel per lane; the lane's column lives in LDS as [slot][lane] (bank = lane: every
+// access is conflict-free, nothing is shared between lanes), 64 KB for 256 slots, 128 KB for 512 (one or two
+// workgroups per CU).  The column is sorted by register-sized pieces:
+//   1. every 128-frame chunk is loaded, calibrated and sorted in registers by the ordinary 128-slot path
+//      (load_sorted_column: same fused calibration, guards and compile-time Batcher network) and parked in LDS;
+//   2. sorted runs are merged pairwise with the bitonic scheme: one streaming pass of compare-exchanges
+//      (col[i], col[len-1-i]) leaves the lower and the upper half as bitonic sequences; halves longer than 128 get one
+//      streaming half-cleaner pass per level; every 128-element bitonic piece is then sorted in registers by the
+//      7-layer bitonic merge network (448 compare-exchanges, static indices).  LDS traffic per 256-merge: 2 x 256
+//      element reads + writes instead of 4 per compare-exchange.
+//   3. the clipping passes run on the LDS column with run-time cursors (reduce_and_store_rich, the rich kernels' code).
+// HBM traffic is the algorithmic minimum (every frame row read once, coalesced, 256 B per wavefront and frame).
+#include "stack_kernels.h"
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+// 7-layer bitonic merge network of 128 wires (sorts any bitonic sequence ascending), generated at compile time.
+struct BitonicNet128 {
+    CE ce[448];
+};
+
+constexpr BitonicNet128 make_bitonic128()
+{
+    BitonicNet128 net{};
+    int c = 0;
+    for (int k = 64; k >= 1; k /= 2)
+        for (int i = 0; i < 128; i++)
+            if ((i & k) == 0) {
+                net.ce[c].a = (unsigned char)i;
+                net.ce[c].b = (unsigned char)(i + k);
+                c++;
+            }
+    return net;
+}
+
+template <int BASE, int... I>
+__device__ __forceinline__ void bitonic_chunk(float (&v)[128], std::integer_sequence<int, I...>)
+{
+    constexpr BitonicNet128 net = make_bitonic128();
+    (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int BASE>
+__device__ __forceinline__ void bitonic_from(float (&v)[128])
+{
+    if constexpr (BASE < 448) {
+        bitonic_chunk<BASE>(v, std::make_integer_sequence<int, 64>{});
+        bitonic_from<BASE + 64>(v);
+    }
+}
+
+constexpr int kBigLanes = 64;
+
+// (col[lo + i], col[lo + j(i)]) <- (min, max) for i in [0, half): j = len - 1 - i (MIRROR: first layer of the merge of two
+// sorted runs) or j = i + half (half-cleaner of a bitonic sequence).  8 pairs in flight per trip.
+template <bool MIRROR>
+__device__ __forceinline__ void lds_exchange_pass(float *col, int lo, int len)
+{
+    const int half = len / 2;
+    for (int i0 = 0; i0 < half; i0 += 8) {
+        float x[8], y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = lo + i0 + k;
+            const int j = MIRROR ? lo + len - 1 - (i0 + k) : i + half;
+            x[k] = col[i * kBigLanes];
+            y[k] = col[j * kBigLanes];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = lo + i0 + k;
+            const int j = MIRROR ? lo + len - 1 - (i0 + k) : i + half;
+            cmpx(x[k], y[k]);
+            col[i * kBigLanes] = x[k];
+            col[j * kBigLanes] = y[k];
+        }
+    }
+}
+
+// Sorts the bitonic sequence col[lo .. lo + len) ascending (len = 128 * 2^k).
+__device__ __forceinline__ void lds_bitonic_sort(float *col, int lo, int len)
+{
+    for (int span = len; span > 128; span /= 2)
+        for (int s0 = lo; s0 < lo + len; s0 += span) lds_exchange_pass<false>(col, s0, span);
+#pragma unroll 1
+    for (int s0 = lo; s0 < lo + len; s0 += 128) {
+        float v[128];
+#pragma unroll
+        for (int i = 0; i < 128; i++) v[i] = col[(s0 + i) * kBigLanes];
+        bitonic_from<0>(v);
+#pragma unroll
+        for (int i = 0; i < 128; i++) col[(s0 + i) * kBigLanes] = v[i];
+    }
+}
+
+template <int NP, typename RawT, bool CALIB, bool MEDIAN>
+__global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm)
+{
+    extern __shared__ float col_all[];                      // [NP][64]
+    __shared__ FrameScalars<128> fs;
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kBigLanes;
+    const int64_t p = base + lane;
+    const bool live = p < prm.P;                            // dead lanes of the last workgroup still stage and vote
+    float *const col = col_all + lane;
+    int n = 0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NP; c0 += 128) {
+        StackParams q = prm;                                // the chunk as a stack of its own
+        q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)c0 * prm.stride;
+        q.N = prm.N - c0 < 128 ? prm.N - c0 : 128;
+        if (prm.exp_ratio) q.exp_ratio = prm.exp_ratio + c0;
+        if (prm.pedestal) q.pedestal = prm.pedestal + c0;
+        float v[128];
+        int nc = 0;
+        if (q.N > 0) {
+            __syncthreads();                                // the previous chunk is done with the staged scalars
+            stage_frame_scalars<128>(q, fs);
+            if (live) nc = load_sorted_column<128, RawT, CALIB, !MEDIAN, false>(q, fs, base, lane, v);
+        }
+        if (!(q.N > 0 && live)) {
+#pragma unroll
+            for (int i = 0; i < 128; i++) v[i] = __builtin_inff();
+        }
+#pragma unroll
+        for (int i = 0; i < 128; i++) col[(c0 + i) * kBigLanes] = v[i];
+        n += nc;
+    }
+    // merge the sorted 128-runs: 2 -> 256, (2 x 256) -> 512
+    for (int len = 256; len <= NP; len *= 2)
+        for (int lo = 0; lo < NP; lo += len) {
+            lds_exchange_pass<true>(col, lo, len);
+            lds_bitonic_sort(col, lo, len / 2);
+            lds_bitonic_sort(col, lo + len / 2, len / 2);
+        }
+    if (!live) return;
+    if constexpr (MEDIAN) {
+        const float m1 = col_read<NP, kBigLanes>(col, (n - 1) >> 1);
+        const float m2 = col_read<NP, kBigLanes>(col, n >> 1);
+        const double med = ((double)m1 + (double)m2) / 2.0;
+        if (prm.median) prm.median[p] = n > 0 ? (float)med : __builtin_nanf("");
+        if (prm.count) prm.count[p] = n;
+    } else {
+        float dummy[1] = {0.f};
+        reduce_and_store_rich<NP, kBigLanes, false, 1>(prm, dummy, n, p, col);
+    }
+}
+
+template <int NP, typename RawT, bool CALIB, bool MEDIAN>
+static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe)
+{
+    if (describe) {
+        snprintf(describe, 256, "stack_big_kernel<%d, %s, %s, %s>", NP, sizeof(RawT) == 2 ? "unsigned short" : "float",
+                 CALIB ? "true" : "false", MEDIAN ? "true" : "false");
+        return APGPU_OK;
+    }
+    const int64_t grid = (prm.P + kBigLanes - 1) / kBigLanes;
+    if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    const size_t lds = (size_t)NP * kBigLanes * sizeof(float);
+    auto kern = stack_big_kernel<NP, RawT, CALIB, MEDIAN>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (big): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBigLanes), lds, st, prm);
+    return check_launch("stack kernel (129..512 frames)");
+}
+
+template <typename RawT, bool CALIB>
+static int launch_big_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe)
+{
+    if (prm.N <= 256)
+        return median_only ? launch_big_one<256, RawT, CALIB, true>(prm, st, describe) : launch_big_one<256, RawT, CALIB, false>(prm, st, describe);
+    return median_only ? launch_big_one<512, RawT, CALIB, true>(prm, st, describe) : launch_big_one<512, RawT, CALIB, false>(prm, st, describe);
+}
+
+int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
+{
+    if (u16) return calib ? launch_big_np<uint16_t, true>(prm, median_only, st, describe) : launch_big_np<uint16_t, false>(prm, median_only, st, describe);
+    return calib ? launch_big_np<float, true>(prm, median_only, st, describe) : launch_big_np<float, false>(prm, median_only, st, describe);
+}
+
+}  // namespace apgpu_stack

@@ -140,11 +140,12 @@ struct ColumnLds<NP, true> {
     __device__ __forceinline__ float *lane_ptr(int lane) { return &x[0][lane]; }
 };
 
-template <int NP>
+// Element i of the lane's column; B = lanes per LDS row (the workgroup size of the kernel that parked the column).
+template <int NP, int B = rich_block<NP>()>
 __device__ __forceinline__ float col_read(const float *col, int i)
 {
     i = i < 0 ? 0 : (i > NP - 1 ? NP - 1 : i);
-    return col[i * rich_block<NP>()];
+    return col[i * B];
 }
 
 // astropy.stats.mad_std of the survivors x[a .. b): 1.482602218505602 * median(|x - med|)
@@ -153,7 +154,7 @@ __device__ __forceinline__ float col_read(const float *col, int i)
 // statistic of the deviations is  min over L of max(|x_L - med|, |x_(L+j) - med|)  (|x - med| is convex
 // along the sorted column, so a window's largest deviation sits at one of its ends).  Windows leaving
 // [a, b) get an infinite deviation.  Every value is the exact float64 |x - med| the reference sorts.
-template <int NP>
+template <int NP, int B = rich_block<NP>()>
 __device__ __forceinline__ double mad_std_window(const float *col, bool active, int a, int b, double med)
 {
     const int n = b - a;
@@ -172,8 +173,8 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
         float xl[CH], xr[CH];
 #pragma unroll
         for (int j = 0; j < CH; j++) {
-            xl[j] = col_read<NP>(col, L0 + j);
-            xr[j] = col_read<NP>(col, L0 + j + k1);
+            xl[j] = col_read<NP, B>(col, L0 + j);
+            xr[j] = col_read<NP, B>(col, L0 + j + k1);
         }
 #pragma unroll
         for (int j = 0; j < CH; j++) {
@@ -193,7 +194,8 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
 //   float32 layout  [3][P]: sum, count, sum of squares - the first two are all a mean needs, so an exchange that does
 //                           not want std all-reduces a contiguous [2][P] prefix (8 bytes per pixel);
 //   float64 layout: double sum[P], double sumsq[P], int32 count[P] - the combine of SURVEY 8(e) "f64 sum + i32 count":
-//                           ranks add float64 sums, so the combined mean is the float64 mean rounded once.
+//                           ranks add float64 sums, so the combined mean is the float64 mean rounded once
+//                           (layout value 2: add to what the buffer holds - the chunks of a stack beyond APGPU_MAX_STACK).
 __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t Pn, int64_t p, int cnt, double c, double S, double Q)
 {
     const double nf = (double)cnt;
@@ -201,9 +203,11 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
     const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
     if (f64_layout) {
         double *d = static_cast<double *>(out);
-        d[p] = sum;
-        d[Pn + p] = sq;
-        reinterpret_cast<int32_t *>(d + 2 * Pn)[p] = cnt;
+        int32_t *k = reinterpret_cast<int32_t *>(d + 2 * Pn);
+        const bool acc = f64_layout == 2;                   // accumulate onto the moments of earlier chunks of the stack
+        d[p] = acc ? d[p] + sum : sum;
+        d[Pn + p] = acc ? d[Pn + p] + sq : sq;
+        k[p] = acc ? k[p] + cnt : cnt;
     } else {
         float *f = static_cast<float *>(out);
         f[p] = (float)sum;
@@ -337,28 +341,45 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
 // Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and
 // std output planes, (c) the sorted column in LDS (see above).  Arithmetic on S / Q is performed in the
 // same order as in the lean kernel, so both produce identical mean / count / moments.
-template <int NP>
-__device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
+// FROM_REGS = false: the sorted column is already in LDS (the big-stack kernel, stack_big.h: N > 128 does not fit the
+// registers); v is then a dummy and the moments pass reads LDS as well.
+template <int NP, int B = rich_block<NP>(), bool FROM_REGS = true, int NV = NP>
+__device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, float (&v)[NV], const int n, const int64_t p,
                                                       float *const col)
 {
-    constexpr int B = rich_block<NP>();
     const bool use_median = prm.center == APGPU_CENTER_MEDIAN;
     const bool use_mad = prm.dev == APGPU_DEV_MAD_STD;
     const double sl2 = prm.sl2, su2 = prm.su2;
     const int maxiters = prm.maxiters;
+    if constexpr (FROM_REGS) {
 #pragma unroll
-    for (int i = 0; i < NP; i++) col[i * B] = v[i];          // v: sorted ascending, sentinels last (load_sorted_column)
+        for (int i = 0; i < NP; i++) col[i * B] = v[i];      // v: sorted ascending, sentinels last (load_sorted_column)
+    }
 
     // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
-    const float cf = n > 0 ? col_read<NP>(col, (n - 1) >> 1) : 0.f;
+    const float cf = n > 0 ? col_read<NP, B>(col, (n - 1) >> 1) : 0.f;
     const double c = (double)cf;
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (FROM_REGS) {
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
-        const float x = (i < n) ? v[i] : cf;
-        const double d = (double)x - c;
-        Sa[i & 3] += d;
-        Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        for (int i = 0; i < NP; i++) {
+            const float x = (i < n) ? v[i] : cf;
+            const double d = (double)x - c;
+            Sa[i & 3] += d;
+            Qa[i & 3] = fma(d, d, Qa[i & 3]);
+        }
+    } else {
+        for (int i0 = 0; i0 < NP; i0 += 8) {                  // same association as above: element i feeds chain i & 3
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = col[(i0 + j) * B];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double d = (double)((i0 + j < n) ? x[j] : cf) - c;
+                Sa[j & 3] += d;
+                Qa[j & 3] = fma(d, d, Qa[j & 3]);
+            }
+        }
     }
     ClipState st;
     st.S = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
@@ -376,11 +397,11 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
 
     while (wave_any(active)) {
         const int a0 = st.a, b0 = st.b;
-        const float m1 = col_read<NP>(col, (st.a + st.b - 1) >> 1);
-        const float m2 = col_read<NP>(col, (st.a + st.b) >> 1);
+        const float m1 = col_read<NP, B>(col, (st.a + st.b - 1) >> 1);
+        const float m2 = col_read<NP, B>(col, (st.a + st.b) >> 1);
         const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
         double mad = 0.0;
-        if (use_mad) mad = mad_std_window<NP>(col, active, st.a, st.b, med);
+        if (use_mad) mad = mad_std_window<NP, B>(col, active, st.a, st.b, med);
         if (active) {
             st.nn = (double)(st.b - st.a);
             st.cen = use_median ? med : c + st.S / st.nn;
@@ -398,7 +419,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         }
         // trim from the low end, then from the high end: every lane walks its own cursor
         for (;;) {
-            const double xd = (double)col_read<NP>(col, st.a);
+            const double xd = (double)col_read<NP, B>(col, st.a);
             const bool rej = active && (st.a < st.b) && below(st, xd);
             if (rej) {
                 const double d = xd - st.c;
@@ -409,7 +430,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
             if (!wave_any(rej)) break;
         }
         for (;;) {
-            const double xd = (double)col_read<NP>(col, st.b - 1);
+            const double xd = (double)col_read<NP, B>(col, st.b - 1);
             const bool rej = active && (st.a < st.b) && above(st, xd);
             if (rej) {
                 const double d = xd - st.c;
@@ -430,7 +451,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     if (wave_any(st.a > 0)) {
         int a_new = st.a;
         for (int i = 0; wave_any(i < st.a); i++) {
-            const double xd = (double)col_read<NP>(col, i);
+            const double xd = (double)col_read<NP, B>(col, i);
             const bool keep = (i < st.a) && !below(st, xd) && !above(st, xd);
             if (keep) {
                 const double d = xd - st.c;
@@ -443,8 +464,8 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     }
     if (wave_any(st.b < n)) {
         int b_new = st.b;
-        for (int i = NP - 1; wave_any(i >= st.b); i--) {
-            const double xd = (double)col_read<NP>(col, i);
+        for (int i = (prm.N < NP ? prm.N : NP) - 1; wave_any(i >= st.b); i--) {   // slots >= N are padding for every lane
+            const double xd = (double)col_read<NP, B>(col, i);
             const bool keep = (i >= st.b) && (i < n) && !below(st, xd) && !above(st, xd);
             if (keep) {
                 const double d = xd - st.c;
@@ -473,7 +494,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
             if (!wave_any(i0 + CH > a && i0 < b)) continue;
             float x[CH];
 #pragma unroll
-            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP, B>(col, i0 + j);
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 const bool in = (i0 + j >= a && i0 + j < b);
@@ -486,7 +507,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
             if (!wave_any(i0 + CH > a && i0 < b)) continue;
             float x[CH];
 #pragma unroll
-            for (int j = 0; j < CH; j++) x[j] = col_read<NP>(col, i0 + j);
+            for (int j = 0; j < CH; j++) x[j] = col_read<NP, B>(col, i0 + j);
 #pragma unroll
             for (int j = 0; j < CH; j++) {
                 const bool in = (i0 + j >= a && i0 + j < b);
@@ -500,8 +521,8 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         if (prm.std64) prm.std64[p] = sd;
     }
     if (prm.median) {
-        const float m1 = col_read<NP>(col, (a + b - 1) >> 1);
-        const float m2 = col_read<NP>(col, (a + b) >> 1);
+        const float m1 = col_read<NP, B>(col, (a + b - 1) >> 1);
+        const float m2 = col_read<NP, B>(col, (a + b) >> 1);
         prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
     }
     if (prm.moments) store_moments(prm.moments, prm.moments64, prm.P, p, cnt, c, S, Q);

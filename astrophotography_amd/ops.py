@@ -245,6 +245,54 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
     return res
 
 
+def stack_sigclip_chunked(frames, chunk=None, want_std=False, **clip):
+    """A stack of MORE than APGPU_MAX_STACK (512) frames on one GPU: the frames are reduced in chunks of at most `chunk`
+    (default: the largest equal split not above 512), every chunk clipped against its own statistics, and the float64
+    moments of the chunks accumulate in one buffer (apgpu_stack_args.moments_f64 = 2) - the single-GPU form of the
+    N-shard combine (parallel.stack_nshard).  Exact for an unclipped mean; for a clipped stack the semantics are
+    hierarchical (SURVEY 8(e) option ii), NOT the full-N clip.  clip: sigma, maxiters, cenfunc, stdfunc, calib, pixmask.
+    Returns dict(mean, count[, std])."""
+    _need_cuda(frames)
+    lib = _lib.load()
+    N = frames.shape[0]
+    if chunk is None:
+        parts = -(-N // _lib.MAX_STACK)
+        chunk = -(-N // parts)
+    chunk = int(min(chunk, _lib.MAX_STACK))
+    shp = tuple(frames.shape[1:])
+    mom = alloc_moments_f64(shp, frames.device)
+    calib = clip.pop('calib', None)
+    pixmask = clip.pop('pixmask', None)
+    for k, lo in enumerate(range(0, N, chunk)):
+        hi = min(N, lo + chunk)
+        c = None
+        if calib is not None:
+            c = dict(calib)
+            for key in ('exp_ratio', 'pedestal'):
+                v = c.get(key)
+                if v is not None and not np.isscalar(v):
+                    c[key] = v[lo:hi]
+        keep = []
+        a, n, P, _, dev = _stack_args(frames[lo:hi], c, pixmask, keep)
+        a.center = _lib.CENTER[clip.get('cenfunc', 'median')]
+        a.dev = _lib.DEV[clip.get('stdfunc', 'std')]
+        mi = clip.get('maxiters', 5)
+        a.maxiters = -1 if mi is None else int(mi)
+        sg = clip.get('sigma', 3.0)
+        a.sigma_lower = float(clip.get('sigma_lower') or sg)
+        a.sigma_upper = float(clip.get('sigma_upper') or sg)
+        a.moments = mom['buffer'].data_ptr()
+        a.moments_f64 = 1 if k == 0 else 2
+        check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
+    out = moments_finalize(mom, want_std=want_std)
+    res = dict(count=mom['count'])
+    if want_std:
+        res['mean'], res['std'] = out
+    else:
+        res['mean'] = out
+    return res
+
+
 def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std'):
     """Name of the kernel variant the library dispatches for such a stack call (apgpu_stack_kernel_name): what the
     bench line and the profiles call the dominant kernel.  Needs no device."""

@@ -55,8 +55,8 @@ extern "C" {
 #define APGPU_DEV_STD       0
 #define APGPU_DEV_MAD_STD   1
 
-/* largest N one stack call reduces (the per-pixel column lives in registers) */
-#define APGPU_MAX_STACK 128
+/* largest N one stack call reduces: up to 128 frames the per-pixel column lives in registers, 129 .. 512 in LDS */
+#define APGPU_MAX_STACK 512
 
 const char *apgpu_last_error(void);
 int apgpu_version(void);
@@ -117,7 +117,10 @@ int apgpu_calibrate_mixed(const void *raw, int raw_dtype, const void *bias, int 
  *                         the contiguous [2][P] prefix, 8 bytes per pixel; the float32 sums round per rank);
  *       moments_f64 != 0: double sum[P], double sumsq[P], int32 count[P] laid out back to back in `moments`
  *                         (20 P bytes, 8-byte aligned): ranks add float64 sums and int32 counts, the combined
- *                         mean is the float64 combine rounded once to float32 (12 bytes per pixel mean-only).
+ *                         mean is the float64 combine rounded once to float32 (12 bytes per pixel mean-only);
+ *       moments_f64 == 2: the same layout, but the call ADDS its moments to what the buffer already holds: a stack
+ *                         of more than APGPU_MAX_STACK frames is reduced chunk by chunk into one buffer (hierarchical
+ *                         clipping: every chunk is clipped against its own statistics).
  * ------------------------------------------------------------------------------------------- */
 typedef struct apgpu_stack_args {
     const void *frames;          /* [N][P] APGPU_F32 or APGPU_U16 */

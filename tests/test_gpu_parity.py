@@ -130,7 +130,7 @@ def test_stack_sigclip_golden(ops):
     assert_ulp(host(r['median']), g['u16_median'].astype(np.float32), 1, 'u16 median')
 
 
-@pytest.mark.parametrize('N', [1, 2, 3, 5, 8, 13, 16, 20, 32, 33, 64, 65, 100, 128])
+@pytest.mark.parametrize('N', [1, 2, 3, 5, 8, 13, 16, 20, 32, 33, 64, 65, 100, 128, 129, 200, 256, 257, 384, 512])
 def test_stack_sigclip_vs_oracle(ops, apref, N):
     rng = np.random.default_rng(100 + N)
     shape = (37, 53)
@@ -152,6 +152,60 @@ def test_stack_sigclip_vs_oracle(ops, apref, N):
         kept = np.where(ref['keep'], cube.astype(np.float64), 0.0)
         np.testing.assert_allclose(mom[0], kept.sum(0), rtol=3e-7, atol=1e-30)
         np.testing.assert_allclose(mom[2], (kept * kept).sum(0), rtol=3e-7, atol=1e-30)
+
+
+def test_big_stacks_other_paths(ops, apref):
+    """129 .. 512 frames (LDS-resident column): fused calibration, uint16 frames, mad_std, plain median, pixel mask, float64
+    planes and moments - against the oracle; more than 512 frames are refused by the kernel and chunked by ApStack."""
+    rng = np.random.default_rng(77)
+    for N, dt in ((130, np.float32), (256, np.uint16), (300, np.float32)):
+        shape = (9, 70)                                      # 630 pixels: a partly filled last workgroup
+        bias, dark, flat = synth_masters(rng, shape)
+        flat[0, 0] = 0.0
+        flat[0, 1] = np.nan
+        raw = synth_cube(rng, N, shape, dtype=dt)
+        if dt == np.float32:
+            raw = raw + bias + 0.4 * dark
+            raw[5, 3, 4] = np.inf
+        nflat, _ = apref.flat_normalize(flat)
+        e = rng.uniform(0.3, 0.5, N)
+        ped = np.where(rng.random(N) < 0.3, -50.0, 0.0)
+        pm = (rng.random(shape) < 0.05).astype(np.uint8)
+        cal = apref.calibrate(raw, bias, dark, nflat, e, ped, True)
+        calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=e, pedestal=ped, dark_still_biased=True)
+        d = dev(raw, ops)
+        for kw in (dict(sigma=3.0, maxiters=5), dict(sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std'),
+                   dict(sigma=2.5, maxiters=None, cenfunc='mean')):
+            ref = apref.stack_sigclip(cal, pixmask=pm, **kw)
+            r = ops.stack_sigclip(d, calib=calib, pixmask=dev(pm, ops), outputs=('mean', 'median', 'std', 'count', 'mean_f64', 'moments_f64'), **kw)
+            what = f'big N={N} {dt.__name__} {kw}'
+            assert np.array_equal(host(r['count']), ref['count']), what
+            assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, 'mean ' + what)
+            assert_ulp(host(r['median']), ref['median'].astype(np.float32), 1, 'median ' + what)
+            assert_ulp(host(r['std']), ref['std'].astype(np.float32), 2, 'std ' + what)
+            np.testing.assert_allclose(host(r['mean_f64']), ref['mean'], rtol=1e-13, equal_nan=True)
+            assert np.array_equal(host(r['moments_f64']['count']), ref['count']), what
+        med = ops.stack_median(d, calib=calib)
+        assert_ulp(host(med), apref.stack_median(cal).astype(np.float32), 1, f'big median N={N}')
+    with pytest.raises(Exception):
+        ops.stack_sigclip(torch.zeros((513, 4, 64), device='cuda'))
+    # beyond 512 frames: ApStack reduces chunk by chunk; an unclipped mean is exact, the clipped mean is hierarchical
+    import astrophotography_amd as ap
+    cube = synth_cube(rng, 600, (6, 64))
+    d = dev(cube, ops)
+    st = ap.ApStack('CRITICAL')
+    r = st.stack(d, method='mean', outputs=('mean', 'count'))
+    np.testing.assert_allclose(host(r['mean']), cube.astype(np.float64).mean(0), rtol=1.2e-7)
+    assert int(r['count'].min()) == 600
+    r = st.stack(d, method='sigclip', outputs=('mean', 'count', 'std'))
+    tot = np.zeros((6, 64))
+    cnt = np.zeros((6, 64), np.int64)
+    for lo in (0, 300):
+        rr = apref.stack_sigclip(cube[lo:lo + 300], sigma=3.0, maxiters=5, want=('keep', 'count'))
+        tot += np.where(rr['keep'], cube[lo:lo + 300].astype(np.float64), 0).sum(0)
+        cnt += rr['count']
+    assert np.array_equal(host(r['count']), cnt)
+    assert_ulp(host(r['mean']), (tot / cnt).astype(np.float32), 1, 'chunked clip = oracle per chunk, moments added')
 
 
 def test_stack_u16_and_pixmask(ops, apref):
