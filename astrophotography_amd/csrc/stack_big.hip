@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackPara
         if (q.N > 0) {
             __syncthreads();                                // the previous chunk is done with the staged scalars
             stage_frame_scalars<128>(q, fs);
-            if (live) nc = load_sorted_column<128, RawT, CALIB, !MEDIAN, false>(q, fs, base, lane, v);
+            if (live) nc = load_sorted_column<128, RawT, CALIB, !MEDIAN, false, 0>(q, fs, base, lane, v);   // a chunk may hold 1..128 frames
         }
         if (!(q.N > 0 && live)) {
 #pragma unroll

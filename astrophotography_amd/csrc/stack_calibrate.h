@@ -25,6 +25,24 @@ struct StackParams {
     double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
 };
 
+// The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a
+// stack that runs with NP slots has more than prev_slots(NP) frames, so only the slots from there on can be padding.
+// Padded stacks of 112 / 128 slots keep the older scheme (every slot loaded and calibrated, padding lifted to +inf with
+// one v_max per slot): the per-slot scalar tests cost them ~50 VGPRs, i.e. the second wavefront per SIMD.
+constexpr int prev_slots(int np);
+constexpr int padded_minn(int np, bool full) { return (full || np >= 112) ? np : prev_slots(np); }
+
+constexpr int prev_slots(int np)
+{
+    constexpr int counts[] = {1, 4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128};
+    int prev = 0;
+    for (int c : counts) {
+        if (c >= np) break;
+        prev = c;
+    }
+    return prev;
+}
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
 
@@ -66,7 +84,8 @@ __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, Fram
 
 // F0 / CNT: the slots F0 .. F0+CNT-1 of the column (large slot counts are loaded and calibrated in two halves so that
 // only half of the raw values sit in registers next to v[]); F0 > 0 is a real frame for every N that selects this NP.
-template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP>
+// MINN: slots below MINN are real frames for every N this instantiation serves (prev_slots; 0 = no such knowledge).
+template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP, int MINN = 0>
 __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[CNT])
 {
     // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
@@ -77,8 +96,10 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
     if constexpr (!FULL) asm volatile("" : "+s"(nframes));
 #pragma unroll
     for (int f = 0; f < CNT; f++) {
-        raw[f] = fb[lane];
-        if (FULL || F0 + f + 1 < nframes) fb += prm.stride;  // padded slots re-read the last frame (cache hit)
+        constexpr bool SKIP = !FULL && MINN < NP;           // padding slots are not loaded (wave-uniform test); without
+        if (!SKIP || F0 + f < MINN || F0 + f < nframes) raw[f] = fb[lane];      // SKIP they re-read the last frame (cache hit)
+        else raw[f] = RawT(0);
+        if (FULL || (SKIP && F0 + f + 1 < MINN) || F0 + f + 1 < nframes) fb += prm.stride;
         // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
         if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
@@ -96,9 +117,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // (range_ok_sorted) instead of tracking max |q| and min |q| through the loop (one v_max3 + one v_min3 per frame pair).
 // (Hoisting e * D for a stack with one exposure ratio was built and measured: no fewer VALU instructions after the
 // compiler's own scheduling and 2 % slower with the extra workgroup vote - not kept.)
-template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true>
+// nframes / MINN (padded stacks): groups of 8 slots that are entirely padding (>= nframes, wave-uniform) are skipped;
+// every padding slot ends as the +inf sentinel.  FULL stacks pass nframes = NP, MINN = NP: nothing of this remains.
+template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
-                                               bool dodiv, float (&v)[NP])
+                                               bool dodiv, float (&v)[NP], int nframes = NP)
 {
     // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
     // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
@@ -113,6 +136,7 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
 #pragma unroll
         for (int g = 0; g < CNT; g += 2) {
             const int f = F0 + g;
+            if ((f & ~7) >= MINN && (f & ~7) >= nframes) continue;      // a whole 8-slot group of padding (scalar test)
             v2f x = {to_f32(raw[g]), to_f32(raw[g + 1])};
             if constexpr (HAS_PED) {
                 const v2f ped = {fs.ped[f], fs.ped[f + 1]};
@@ -135,6 +159,11 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 mn = fminf(fminf(mn, fabsf(q.x)), fabsf(q.y));
             }
         }
+        if constexpr (MINN < NP) {
+#pragma unroll
+            for (int g = 0; g < CNT; g++)
+                if (F0 + g >= MINN && F0 + g >= nframes) v[F0 + g] = __builtin_inff();   // scalar test per slot, one v_mov per pad
+        }
         const bool range_ok = !RANGE_GUARD || !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
         return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
     } else {
@@ -154,15 +183,30 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
 // The quotient-range condition of the reciprocal division (all |q| in (2^-50, 2^50), see calibrate_fast), read off a column
 // that is already sorted ascending and finite: max |q| sits at an end; min |q| too unless the signs are mixed - then (and
 // only then, wave-wide) the magnitudes are scanned.
-template <int NP>
-__device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv)
+// v[idx] for a WAVE-UNIFORM idx in [LO, NP): scalar compare-and-branch chain, one v_mov executed.
+template <int LO, int NP>
+__device__ __forceinline__ float uniform_pick(const float (&v)[NP], int idx)
 {
-    const float lo = v[0], hi = v[NP - 1];
+    if constexpr (LO >= NP - 1) return v[NP - 1];
+    else {
+        if (idx <= LO) return v[LO];
+        return uniform_pick<LO + 1, NP>(v, idx);
+    }
+}
+
+// nvalid (wave-uniform): the column's finite values occupy v[0 .. nvalid), +inf sentinels follow; MINN <= nvalid.
+template <int NP, int MINN = NP>
+__device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv, int nvalid = NP)
+{
+    const float lo = v[0];
+    float hi;
+    if constexpr (MINN >= NP) hi = v[NP - 1];
+    else hi = uniform_pick<(MINN > 0 ? MINN - 1 : 0), NP>(v, __builtin_amdgcn_readfirstlane(nvalid) - 1);
     const bool big_ok = fmaxf(fabsf(lo), fabsf(hi)) < 0x1p50f;
     const bool one_sign = lo > 0x1p-50f || hi < -0x1p-50f;    // then min |q| = |lo| or |hi| and it is above 2^-50
     bool small_ok = one_sign;
     if (wave_any(dodiv && !one_sign)) {
-        float mn = __builtin_inff();
+        float mn = __builtin_inff();                        // (+inf sentinels of padding slots do not disturb a minimum)
         if constexpr (NP >= 2) {
 #pragma unroll
             for (int i = 0; i < NP; i += 2) mn = fminf(fminf(mn, fabsf(v[i])), fabsf(v[i + 1]));
@@ -226,16 +270,18 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
 // FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
 // wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes), and the range guards of the
 // reciprocal division are deferred to the sorted column (cx.range_pending, see load_sorted_column).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL)>
 __device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
                                            float (&v)[NP], ColumnCtx &cx)
 {
     const int N = prm.N;
     const int64_t p = base + lane;
     constexpr bool HALVES = CALIB && NP >= 112;           // 112 / 128 slots: two half columns (register budget: 2 waves/SIMD)
-    constexpr bool GUARD = !FULL;                         // padded columns end in +inf after the lift: guard inside the loop
+    // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
+    // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
+    constexpr bool GUARD = NP >= 112;
     RawT raw[HALVES ? 1 : NP];
-    if constexpr (!HALVES) load_raw<NP, RawT, FULL>(prm, base, lane, raw);
+    if constexpr (!HALVES) load_raw<NP, RawT, FULL, 0, NP, MINN>(prm, base, lane, raw);
     cx.b = 0.f; cx.D = 0.f; cx.nf = 1.f;
     cx.dodiv = false;
     cx.range_pending = false;
@@ -256,27 +302,26 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
         if constexpr (HALVES) {
             constexpr int HN = NP / 2;
             RawT half[HN];
-            load_raw<NP, RawT, FULL, 0, HN>(prm, base, lane, half);
-            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD>(fs, half, b, D, nf, dodiv, v)
-                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD>(fs, half, b, D, nf, dodiv, v);
-            load_raw<NP, RawT, FULL, HN, HN>(prm, base, lane, half);
-            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD>(fs, half, b, D, nf, dodiv, v)
-                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD>(fs, half, b, D, nf, dodiv, v);
+            load_raw<NP, RawT, FULL, 0, HN, MINN>(prm, base, lane, half);
+            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N)
+                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N);
+            load_raw<NP, RawT, FULL, HN, HN, MINN>(prm, base, lane, half);
+            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N)
+                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N);
             good = good && good2;
         } else {
-            if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD>(fs, raw, b, D, nf, dodiv, v);
-            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD>(fs, raw, b, D, nf, dodiv, v);
+            if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N);
+            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N);
         }
         if (wave_all(good && !cx.skip)) {
-            if constexpr (FULL) {
-                cx.range_pending = !GUARD;
-                return NP;
-            }
-            // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
-            // one v_max against the staged pad vector (no NP wave-wide (f < N) masks)
+            cx.range_pending = !GUARD;
+            if constexpr (!FULL && MINN >= NP) {
+                // padding slots hold a calibrated copy of the last frame: lift them to the +inf sentinel with
+                // one v_max against the staged pad vector (with MINN < NP calibrate_fast wrote the sentinels itself)
 #pragma unroll
-            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
-            return N;
+                for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+            }
+            return FULL ? NP : N;
         }
         // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
         // redo the column exactly
@@ -286,15 +331,15 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 
 // Column loaded AND sorted ascending (sentinels last).  When the fast calibration deferred its range guards, they are
 // evaluated on the sorted column; a failing lane sends the wave through the exact path and a second sort (rare).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL>
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL)>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
                                                   int lane, float (&v)[NP])
 {
     ColumnCtx cx;
-    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base, lane, v, cx);
+    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN>(prm, fs, base, lane, v, cx);
     sort_column<NP>(v);
-    if constexpr (CALIB && FULL) {
-        if (cx.range_pending && !wave_all(range_ok_sorted<NP>(v, cx.dodiv))) {
+    if constexpr (CALIB) {
+        if (cx.range_pending && !wave_all(range_ok_sorted<NP, MINN>(v, cx.dodiv, n))) {
             RawT none[1] = {};
             n = load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base + lane, cx, none, v);
             sort_column<NP>(v);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
     APGPU_MARK("load_calibrate_sort");
     const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
     if constexpr (EXTRA) reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
-    else reduce_and_store<NP>(prm, v, n, p);
+    else reduce_and_store<NP, padded_minn(NP, FULL)>(prm, v, n, p);
 }
 
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.

@@ -66,21 +66,27 @@ __device__ __forceinline__ void trim_low(const float (&v)[NP], ClipState &st, bo
     }
 }
 
-template <int I, int NP>
-__device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active)
+// ns (wave-uniform, = N) / MINN: slots >= ns are padding for every lane; levels I >= MINN test that with a scalar compare
+// and step down without touching the VALU (one call site per level: a second one would double the inlined chain).
+template <int I, int NP, int MINN = NP>
+__device__ __forceinline__ void trim_high(const float (&v)[NP], ClipState &st, bool active, int ns = NP)
 {
     if constexpr (I >= 0) {
-        if (wave_any(active && (I < st.b))) {               // padding slots above every lane's range: just step down
-            const double xd = widen(v[I]);
-            const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
-            if (rej) {
-                const double d = xd - st.c;
-                st.S -= d;
-                st.Q = fma(-d, d, st.Q);
-                st.b = I;
+        bool down = true;
+        if (I < MINN || I < ns) {
+            if (wave_any(active && (I < st.b))) {           // slots above every lane's range: just step down
+                const double xd = widen(v[I]);
+                const bool rej = active && (I >= st.a) && (I < st.b) && above(st, xd);
+                if (rej) {
+                    const double d = xd - st.c;
+                    st.S -= d;
+                    st.Q = fma(-d, d, st.Q);
+                    st.b = I;
+                }
             }
+            down = wave_any(active && (st.b <= I));
         }
-        if (wave_any(active && (st.b <= I))) trim_high<I - 1, NP>(v, st, active);
+        if (down) trim_high<I - 1, NP, MINN>(v, st, active, ns);
     }
 }
 
@@ -102,21 +108,25 @@ __device__ __forceinline__ void readmit_low(const float (&v)[NP], ClipState &st,
     }
 }
 
-template <int I, int NP>
-__device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new)
+template <int I, int NP, int MINN = NP>
+__device__ __forceinline__ void readmit_high(const float (&v)[NP], ClipState &st, int n, int &b_new, int ns = NP)
 {
     if constexpr (I >= 0) {
-        if (wave_any(I >= st.b)) {
-            const double xd = widen(v[I]);
-            const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
-            if (keep) {
-                const double d = xd - st.c;
-                st.S += d;
-                st.Q = fma(d, d, st.Q);
-                b_new = b_new > I + 1 ? b_new : I + 1;
+        bool down = true;
+        if (I < MINN || I < ns) {
+            down = wave_any(I >= st.b);
+            if (down) {
+                const double xd = widen(v[I]);
+                const bool keep = (I >= st.b) && (I < n) && !below(st, xd) && !above(st, xd);
+                if (keep) {
+                    const double d = xd - st.c;
+                    st.S += d;
+                    st.Q = fma(d, d, st.Q);
+                    b_new = b_new > I + 1 ? b_new : I + 1;
+                }
             }
-            readmit_high<I - 1, NP>(v, st, n, b_new);
         }
+        if (down) readmit_high<I - 1, NP, MINN>(v, st, n, b_new, ns);
     }
 }
 
@@ -218,9 +228,10 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
 
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP>
+template <int NP, int MINN = NP>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
+    const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
     // everything the loop and the epilogue need from the kernel arguments, parked before the sort
     float *const out_mean = park_in_vgpr(prm.mean);
     int32_t *const out_count = park_in_vgpr(prm.count);
@@ -239,9 +250,10 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const double c = (double)cf;
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
-    if (wave_all(n == NP)) {               // the usual case: no padding, no rejected value in the whole wave
+    if (wave_all(n == ns)) {               // the usual case: no rejected value in the whole wave (padding: scalar skips)
 #pragma unroll
         for (int i = 0; i < NP; i++) {
+            if (i >= MINN && i >= ns) continue;
             const double d = (double)v[i] - c;
             Sa[i & 3] += d;
             Qa[i & 3] = fma(d, d, Qa[i & 3]);
@@ -287,7 +299,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
             st.Thi = su2 * V;
         }
         trim_low<0, NP>(v, st, active);
-        trim_high<NP - 1, NP>(v, st, active);
+        trim_high<NP - 1, NP, MINN>(v, st, active, ns);
         it++;
         const bool changed = (st.a != a0) || (st.b != b0);
         active = active && changed && (maxiters < 0 || it < maxiters);
@@ -322,7 +334,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         }
         if (wave_any(walk)) {
             int b_new = st.b;
-            readmit_high<NP - 1, NP>(v, st, n, b_new);
+            readmit_high<NP - 1, NP, MINN>(v, st, n, b_new, ns);
             st.b = b_new;
         }
     }
