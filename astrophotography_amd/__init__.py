@@ -18,6 +18,7 @@ _LAZY = {
     'ApResample': ('.core.ApResample', 'ApResample'),
     'ApImageDifference': ('.core.ApCalcReadNoise', 'ApImageDifference'),
     'ApCalcReadNoise': ('.core.ApCalcReadNoise', 'ApCalcReadNoise'),
+    'ApMeasureBackground': ('.core.ApMeasureBackground', 'ApMeasureBackground'),
 }
 
 __all__ = sorted(_LAZY) + ['__version__']

@@ -71,6 +71,13 @@ SIGNATURES = {
     'apgpu_fix_badpix_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     'apgpu_imarith': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    'apgpu_source_mask_ws_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
+    'apgpu_source_mask_u8': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]),
+    'apgpu_box_clipped_stats_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double,
+                                              C.c_int32, C.c_void_p, C.c_void_p]),
+    'apgpu_spline_zoom_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p]),
     'apgpu_imarith_f64': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_decode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_encode_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

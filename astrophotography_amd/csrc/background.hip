@@ -1,0 +1,400 @@
+// background.hip - F4 (first half): the sky-background mesh of ApMeasureBackground (core/ApMeasureBackground.py:142-175,
+// 382-415) on gfx950.  The reference delegates everything to photutils (absent from the build container: parity
+// unpinned; the definitions below restate photutils' published algorithms and are what oracle/background_ref.py computes):
+//   source mask     detect_threshold(nsigma=2, SigmaClip(3, maxiters=10)) -> detect_sources(npixels=5, 8-connectivity)
+//                   -> make_source_mask(size=13)                                   (:154-157)
+//   mesh            Background2D(box_size, mask, exclude_percentile, SigmaClip(sigma), MedianBackground)   (:404-410)
+//   full image      BkgZoomInterpolator = scipy.ndimage.zoom(mesh, box_size, order=3, mode='reflect', grid_mode=True)
+// Kernels here do the per-pixel work: 8-connected component labelling with a minimum-area filter (lock-free union-find),
+// square binary dilation, per-box sigma-clipped median / std (one workgroup per box, exact radix-select medians) and the
+// cubic B-spline evaluation of the mesh over every pixel.  The mesh-sized steps between them (ny x nx numbers: filling
+// excluded boxes, the 3 x 3 median filter, the spline prefilter) are host logic in core/ApMeasureBackground.py.
+#include "common.h"
+
+namespace {
+using namespace apgpu;
+
+constexpr int kBlock = 256;
+
+inline unsigned grid1d(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kNumCU * 16) g = kNumCU * 16;
+    return (unsigned)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Connected components (8-connectivity) by lock-free union-find on the label array: label[p] = p for
+// foreground pixels, every pixel is united with its W / NW / N / NE foreground neighbours (the other four
+// directions are covered from the neighbour's side), then every pixel looks up its root.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int *L, int i)
+{
+    int r = L[i];
+    while (r != i) {
+        i = r;
+        r = L[i];
+    }
+    return i;
+}
+
+__device__ __forceinline__ void uf_union(int *L, int a, int b)
+{
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&L[b], a);               // hang the larger root under the smaller one
+        if (old == b) return;
+        b = old;                                            // somebody moved b meanwhile: retry from there
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ccl_init_kernel(const uint8_t *__restrict__ fg, int *__restrict__ L, int *__restrict__ size, int64_t P)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        L[p] = fg[p] ? (int)p : -1;
+        size[p] = 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ccl_union_kernel(const uint8_t *__restrict__ fg, int *__restrict__ L, int H, int W)
+{
+    const int64_t P = (int64_t)H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        if (!fg[p]) continue;
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        if (c > 0 && fg[p - 1]) uf_union(L, (int)p, (int)p - 1);
+        if (r > 0) {
+            if (fg[p - W]) uf_union(L, (int)p, (int)(p - W));
+            if (c > 0 && fg[p - W - 1]) uf_union(L, (int)p, (int)(p - W - 1));
+            if (c < W - 1 && fg[p - W + 1]) uf_union(L, (int)p, (int)(p - W + 1));
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ccl_count_kernel(int *__restrict__ L, int *__restrict__ size, int64_t P)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        if (L[p] < 0) continue;
+        const int root = uf_find(L, (int)p);
+        L[p] = root;                                        // flatten (roots keep L[root] == root)
+        atomicAdd(&size[root], 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ccl_filter_kernel(const int *__restrict__ L, const int *__restrict__ size, int min_pixels,
+                                                           uint8_t *__restrict__ out, unsigned long long *__restrict__ nsrc, int64_t P)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const int l = L[p];
+        const bool keep = l >= 0 && size[l >= 0 ? uf_find(L, l) : 0] >= min_pixels;
+        out[p] = keep ? 1 : 0;
+        if (keep && l == (int)p && nsrc) atomicAdd(nsrc, 1ull);        // one count per surviving component (its root pixel)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Binary dilation with a size x size square footprint (scipy.ndimage.binary_dilation, border_value 0), separable:
+// a pixel is set if any pixel within +-size/2 along the row (pass 1) / column (pass 2) is set.
+// ------------------------------------------------------------------------------------------------
+template <bool ROWS>
+__global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W, int half)
+{
+    const int64_t P = (int64_t)H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        uint8_t any = 0;
+        if (ROWS) {
+            const int c0 = max(0, c - half), c1 = min(W - 1, c + half);
+            for (int cc = c0; cc <= c1; cc++) any |= in[(int64_t)r * W + cc];
+        } else {
+            const int r0 = max(0, r - half), r1 = min(H - 1, r + half);
+            for (int rr = r0; rr <= r1; rr++) any |= in[(int64_t)rr * W + c];
+        }
+        out[p] = any ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-box sigma-clipped statistics: one workgroup per mesh box.  astropy's SigmaClip(sigma, maxiters, median / std)
+// along the box: every pass computes the median (exact, 4-pass 8-bit radix select on order-preserving keys) and the
+// standard deviation of the current survivors and keeps lo <= x <= hi; clipping only ever shrinks the interval, so the
+// survivors of pass k are exactly the unmasked finite values inside the running [lo, hi] - no compaction, every pass
+// re-reads the box (<= 270 KB, L2-resident).  Pixels outside the image (edge_method 'pad'), masked or non-finite
+// pixels count as masked.  Output per box (float64): median, std of the final survivors, number of survivors,
+// number of masked pixels before clipping.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f32_key(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_f32(unsigned k)
+{
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+struct BoxView {
+    const float *data;
+    const uint8_t *mask;
+    int H, W, r0, c0, bh, bw;
+};
+
+// value of box element e (row-major inside the box) or NaN if masked / outside / non-finite
+__device__ __forceinline__ float box_value(const BoxView &b, int e)
+{
+    const int rr = b.r0 + e / b.bw, cc = b.c0 + e % b.bw;
+    if (rr >= b.H || cc >= b.W) return __builtin_nanf("");
+    const int64_t p = (int64_t)rr * b.W + cc;
+    if (b.mask && b.mask[p]) return __builtin_nanf("");
+    const float x = b.data[p];
+    return (fabsf(x) < __builtin_inff()) ? x : __builtin_nanf("");
+}
+
+__device__ double block_sum(double v, double *scratch)
+{
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_down(v, d);
+    __syncthreads();
+    if ((threadIdx.x % kWave) == 0) scratch[threadIdx.x / kWave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < kBlock / kWave; w++) t += scratch[w];    // every thread forms the same ordered sum
+    return t;
+}
+
+// k-th smallest (0-based) survivor key; survivors = values with lo <= x <= hi.
+__device__ unsigned box_select(const BoxView &b, int npix, float lo, float hi, int k, unsigned *hist)
+{
+    unsigned prefix = 0, pmask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int t = threadIdx.x; t < 256; t += kBlock) hist[t] = 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < npix; e += kBlock) {
+            const float x = box_value(b, e);
+            if (x >= lo && x <= hi) {                       // false for NaN
+                const unsigned key = f32_key(x);
+                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        // every thread walks the 256 bins (LDS broadcast reads) and finds the digit holding rank k
+        int digit = 0;
+        unsigned cum = 0;
+        for (int d = 0; d < 256; d++) {
+            const unsigned h = hist[d];
+            if (cum + h > (unsigned)k) {
+                digit = d;
+                break;
+            }
+            cum += h;
+        }
+        k -= (int)cum;
+        prefix |= (unsigned)digit << shift;
+        pmask |= 255u << shift;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(kBlock) void box_stats_kernel(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
+                                                          int bh, int bw, int nx, double sigma, int maxiters,
+                                                          double *__restrict__ out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ double scratch[kBlock / kWave];
+    BoxView b;
+    b.data = data; b.mask = mask; b.H = H; b.W = W; b.bh = bh; b.bw = bw;
+    const int box = blockIdx.x;
+    b.r0 = (box / nx) * bh;
+    b.c0 = (box % nx) * bw;
+    const int npix = bh * bw;
+    // Working set of the clipping passes: values inside the running intersection [lo_run, hi_run] of all bounds so far
+    // (astropy packs its buffer the same way).  The FINAL survivors are the values inside the LAST computed bounds
+    // [lo_last, hi_last] applied to all data (astropy sigma_clipping.py:356-358: a value clipped by an earlier, tighter
+    // pass can come back).  Bounds are float64 in astropy and applied to float32 data: lo <= (double)x <= hi is the
+    // same set as ceil32(lo) <= x <= floor32(hi).
+    float lo_run = -__builtin_inff(), hi_run = __builtin_inff(), lo_last = -__builtin_inff(), hi_last = __builtin_inff();
+    double med = __builtin_nan(""), sd = __builtin_nan("");
+    int n = 0, n_prev = -1, n_unmasked = -1;
+    for (int pass = 0;; pass++) {
+        const bool final_pass = pass >= maxiters || n_prev == -2;
+        const float lo = final_pass ? lo_last : lo_run, hi = final_pass ? hi_last : hi_run;
+        double cnt = 0.0, sum = 0.0;
+        for (int e = threadIdx.x; e < npix; e += kBlock) {
+            const float x = box_value(b, e);
+            if (x >= lo && x <= hi) {
+                cnt += 1.0;
+                sum += (double)x;
+            }
+        }
+        n = (int)block_sum(cnt, scratch);
+        const double total = block_sum(sum, scratch);
+        if (n_unmasked < 0) n_unmasked = n;
+        if (n == 0) {
+            med = sd = __builtin_nan("");
+            break;
+        }
+        if (!final_pass && n == n_prev) {                   // the last bounds removed nothing: converged, evaluate the survivors
+            n_prev = -2;
+            continue;
+        }
+        const double mean = total / (double)n;
+        double ss = 0.0;
+        for (int e = threadIdx.x; e < npix; e += kBlock) {
+            const float x = box_value(b, e);
+            if (x >= lo && x <= hi) {
+                const double d = mean - (double)x;
+                ss += d * d;
+            }
+        }
+        sd = sqrt(block_sum(ss, scratch) / (double)n);
+        const float m1 = key_f32(box_select(b, npix, lo, hi, (n - 1) >> 1, hist));
+        const float m2 = (n & 1) ? m1 : key_f32(box_select(b, npix, lo, hi, n >> 1, hist));
+        med = ((double)m1 + (double)m2) / 2.0;
+        if (final_pass) break;
+        const double lo64 = med - sigma * sd, hi64 = med + sigma * sd;
+        float lof = (float)lo64, hif = (float)hi64;
+        if ((double)lof < lo64) lof = nextafterf(lof, __builtin_inff());
+        if ((double)hif > hi64) hif = nextafterf(hif, -__builtin_inff());
+        lo_last = lof;
+        hi_last = hif;
+        lo_run = fmaxf(lo_run, lof);
+        hi_run = fminf(hi_run, hif);
+        n_prev = n;
+    }
+    if (threadIdx.x == 0) {
+        out[4 * box + 0] = med;
+        out[4 * box + 1] = sd;
+        out[4 * box + 2] = (double)n;
+        out[4 * box + 3] = (double)(npix - (n_unmasked < 0 ? 0 : n_unmasked));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scipy.ndimage.zoom(mesh, (zy, zx), order=3, mode='reflect', grid_mode=True) evaluated at every output pixel from the
+// prefiltered cubic B-spline coefficients coef[ny][nx] (float64; the prefilter of the ny x nx mesh is host logic):
+// input coordinate y = (i + 0.5) * ny / Hz - 0.5 (Hz = the zoomed height ny * zy), folded into [-0.5, ny - 0.5] by
+// half-sample reflection; taps floor(y) - 1 .. + 2, tap indices folded the same way.  Output clipped to [vmin, vmax]
+// (BkgZoomInterpolator(clip=True)) and cropped to H x W.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n)
+{
+    if (n == 1) return 0;
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+__device__ __forceinline__ void bspline3(double t, double (&w)[4])
+{
+    const double t2 = t * t, t3 = t2 * t, u = 1.0 - t;
+    w[0] = u * u * u / 6.0;
+    w[1] = (3.0 * t3 - 6.0 * t2 + 4.0) / 6.0;
+    w[2] = (-3.0 * t3 + 3.0 * t2 + 3.0 * t + 1.0) / 6.0;
+    w[3] = t3 / 6.0;
+}
+
+__global__ __launch_bounds__(kBlock) void spline_zoom_kernel(const double *__restrict__ coef, int ny, int nx, int zy, int zx, int H, int W,
+                                                            double vmin, double vmax, double *__restrict__ out)
+{
+    const int64_t P = (int64_t)H * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const int i = (int)(p / W), j = (int)(p - (int64_t)i * W);
+        const double y = ((double)i + 0.5) / (double)zy - 0.5, x = ((double)j + 0.5) / (double)zx - 0.5;
+        const double fy = floor(y), fx = floor(x);
+        double wy[4], wx[4];
+        bspline3(y - fy, wy);
+        bspline3(x - fx, wx);
+        const int iy = (int)fy - 1, ix = (int)fx - 1;
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const double *row = coef + (int64_t)reflect_idx(iy + a, ny) * nx;
+            double r = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) r += wx[q] * row[reflect_idx(ix + q, nx)];
+            acc += wy[a] * r;
+        }
+        out[p] = fmin(fmax(acc, vmin), vmax);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t apgpu_source_mask_ws_bytes(int64_t height, int64_t width)
+{
+    if (height <= 0 || width <= 0) return 0;
+    return (size_t)(height * width) * (2 * sizeof(int32_t) + 2) + 64;
+}
+
+extern "C" int apgpu_source_mask_u8(const uint8_t *above, int64_t height, int64_t width, int32_t min_pixels, int32_t dilate_size,
+                                    uint8_t *mask_out, int64_t *nsources_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!above || !mask_out || !ws) return fail(APGPU_EINVAL, "source_mask: NULL pointer argument");
+    if (height <= 0 || width <= 0 || height * width > 0x7fffffffLL) return fail(APGPU_EINVAL, "source_mask: bad shape");
+    if (min_pixels < 1) return fail(APGPU_EINVAL, "source_mask: min_pixels must be >= 1");
+    if (dilate_size < 1 || (dilate_size & 1) == 0) return fail(APGPU_EINVAL, "source_mask: dilate_size must be odd and >= 1");
+    if (ws_bytes < apgpu_source_mask_ws_bytes(height, width)) return fail(APGPU_EWORKSPACE, "source_mask: workspace too small");
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(APGPU_EINVAL, "source_mask: workspace must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const int64_t P = height * width;
+    int *L = static_cast<int *>(ws);
+    int *size = L + P;
+    uint8_t *tmp1 = reinterpret_cast<uint8_t *>(size + P);
+    uint8_t *tmp2 = tmp1 + P;
+    const unsigned g = grid1d(P);
+    if (nsources_out && hipMemsetAsync(nsources_out, 0, sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "source_mask: memset failed");
+    hipLaunchKernelGGL(ccl_init_kernel, dim3(g), dim3(kBlock), 0, st, above, L, size, P);
+    hipLaunchKernelGGL(ccl_union_kernel, dim3(g), dim3(kBlock), 0, st, above, L, (int)height, (int)width);
+    hipLaunchKernelGGL(ccl_count_kernel, dim3(g), dim3(kBlock), 0, st, L, size, P);
+    hipLaunchKernelGGL(ccl_filter_kernel, dim3(g), dim3(kBlock), 0, st, L, size, min_pixels, tmp1,
+                       reinterpret_cast<unsigned long long *>(nsources_out), P);
+    if (int rc = check_launch("source_mask (components)")) return rc;
+    const int half = dilate_size / 2;
+    hipLaunchKernelGGL(dilate_kernel<true>, dim3(g), dim3(kBlock), 0, st, tmp1, tmp2, (int)height, (int)width, half);
+    hipLaunchKernelGGL(dilate_kernel<false>, dim3(g), dim3(kBlock), 0, st, tmp2, mask_out, (int)height, (int)width, half);
+    return check_launch("source_mask (dilation)");
+}
+
+extern "C" int apgpu_box_clipped_stats_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width, int32_t box_height,
+                                           int32_t box_width, double sigma, int32_t maxiters, double *stats_out, void *stream)
+{
+    if (!data || !stats_out) return fail(APGPU_EINVAL, "box_clipped_stats: NULL pointer argument");
+    if (height <= 0 || width <= 0 || height > 0x7fffffff || width > 0x7fffffff) return fail(APGPU_EINVAL, "box_clipped_stats: bad shape");
+    if (box_height < 1 || box_width < 1 || (int64_t)box_height * box_width > (1 << 24))
+        return fail(APGPU_EINVAL, "box_clipped_stats: bad box size %d x %d", box_height, box_width);
+    if (!(sigma >= 0.0) || maxiters < 0) return fail(APGPU_EINVAL, "box_clipped_stats: bad clip parameters");
+    const int ny = (int)((height + box_height - 1) / box_height), nx = (int)((width + box_width - 1) / box_width);
+    hipLaunchKernelGGL(box_stats_kernel, dim3((unsigned)(ny * nx)), dim3(kBlock), 0, as_stream(stream), data, mask, (int)height, (int)width,
+                       box_height, box_width, nx, sigma, maxiters, stats_out);
+    return check_launch("box_clipped_stats");
+}
+
+extern "C" int apgpu_spline_zoom_f64(const double *coef, int32_t ny, int32_t nx, int32_t zoom_y, int32_t zoom_x, int64_t height,
+                                     int64_t width, double vmin, double vmax, double *out, void *stream)
+{
+    if (!coef || !out) return fail(APGPU_EINVAL, "spline_zoom: NULL pointer argument");
+    if (ny < 1 || nx < 1 || zoom_y < 1 || zoom_x < 1) return fail(APGPU_EINVAL, "spline_zoom: bad mesh / zoom");
+    if (height <= 0 || width <= 0 || height > (int64_t)ny * zoom_y || width > (int64_t)nx * zoom_x)
+        return fail(APGPU_EINVAL, "spline_zoom: output %lld x %lld exceeds the zoomed mesh", (long long)height, (long long)width);
+    hipLaunchKernelGGL(spline_zoom_kernel, dim3(grid1d(height * width)), dim3(kBlock), 0, as_stream(stream), coef, ny, nx, zoom_y, zoom_x,
+                       (int)height, (int)width, vmin, vmax, out);
+    return check_launch("spline_zoom");
+}

@@ -669,3 +669,57 @@ def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDI
         r = stack_sigclip(res, sigma=sigma, maxiters=maxiters, outputs=('mean', 'count'))
         return dict(image=r['mean'], count=r['count'])
     raise ValueError("combine must be one of MEDIAN, AVERAGE, WEIGHTED, SUM, CLIPPED")
+
+
+# ---------------------------------------------------------------------------------------------------
+# F4: sky-background mesh (core/ApMeasureBackground.py:142-175, 382-415; photutils restated, parity unpinned)
+# ---------------------------------------------------------------------------------------------------
+def source_mask(above, min_pixels=5, dilate_size=13):
+    """detect_sources(npixels=min_pixels, 8-connectivity) + make_source_mask(size=dilate_size) on a uint8 map of the pixels
+    above the detection threshold.  Returns (mask uint8 [H,W], nsources int64[1] device tensor)."""
+    _need_cuda(above)
+    if above.dtype != torch.uint8 or above.dim() != 2:
+        raise TypeError('above must be a 2-D uint8 tensor')
+    above = above.contiguous()
+    lib = _lib.load()
+    H, W = above.shape
+    ws_bytes = lib.apgpu_source_mask_ws_bytes(H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=above.device)
+    out = torch.empty_like(above)
+    nsrc = torch.empty(1, dtype=torch.int64, device=above.device)
+    check(lib.apgpu_source_mask_u8(_ptr(above), H, W, int(min_pixels), int(dilate_size), _ptr(out), _ptr(nsrc), _ptr(ws), ws_bytes,
+                                   _stream()))
+    return out, nsrc
+
+
+def box_clipped_stats(data, mask, box_height, box_width, sigma=3.0, maxiters=5):
+    """Background2D's per-box SigmaClip(sigma, maxiters) + median / std: float64 device tensor [ny, nx, 4] =
+    median, std, survivors, pixels masked before clipping (boxes sticking out of the image are padded with masked pixels)."""
+    _need_cuda(data, mask)
+    data = _f32c(data, 'data')
+    if data.dim() != 2:
+        raise ValueError('data must be 2-D')
+    if mask is not None:
+        if mask.dtype != torch.uint8 or tuple(mask.shape) != tuple(data.shape):
+            raise TypeError('mask must be uint8 with the image shape')
+        mask = mask.contiguous()
+    H, W = data.shape
+    ny, nx = -(-H // int(box_height)), -(-W // int(box_width))
+    out = torch.empty((ny, nx, 4), dtype=torch.float64, device=data.device)
+    check(_lib.load().apgpu_box_clipped_stats_f32(_ptr(data), _ptr(mask), H, W, int(box_height), int(box_width), float(sigma),
+                                                  int(maxiters), _ptr(out), _stream()))
+    return out
+
+
+def spline_zoom(coef, zoom_y, zoom_x, height, width, vmin, vmax):
+    """scipy.ndimage.zoom(mesh, (zoom_y, zoom_x), order=3, mode='reflect', grid_mode=True)[:height, :width] from prefiltered
+    B-spline coefficients coef [ny, nx] (float64 device tensor), clipped to [vmin, vmax]; float64 [height, width]."""
+    _need_cuda(coef)
+    if coef.dtype != torch.float64 or coef.dim() != 2:
+        raise TypeError('coef must be a 2-D float64 tensor')
+    coef = coef.contiguous()
+    ny, nx = coef.shape
+    out = torch.empty((int(height), int(width)), dtype=torch.float64, device=coef.device)
+    check(_lib.load().apgpu_spline_zoom_f64(_ptr(coef), ny, nx, int(zoom_y), int(zoom_x), int(height), int(width), float(vmin),
+                                            float(vmax), _ptr(out), _stream()))
+    return out

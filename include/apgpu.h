@@ -291,6 +291,32 @@ int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_i
                               const float *lut, int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out,
                               int64_t w_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * F4  Sky-background mesh of ApMeasureBackground (core/ApMeasureBackground.py:142-175, 382-415).  The reference calls
+ *     photutils (detect_threshold / detect_sources / make_source_mask, Background2D with MedianBackground + SigmaClip,
+ *     BkgZoomInterpolator); photutils is not in the build container, so these entry points implement its published
+ *     algorithms as restated in oracle/background_ref.py (parity with photutils itself is unpinned).
+ *
+ *     apgpu_source_mask_u8: `above` [H][W] uint8 (non-zero = pixel above the detection threshold, e.g. from
+ *       apgpu_threshold_mask_f32) -> 8-connected components, components with fewer than min_pixels pixels dropped
+ *       (detect_sources(npixels)), the rest dilated with a dilate_size x dilate_size square
+ *       (SegmentationImage.make_source_mask(size)); mask_out [H][W] uint8 0/1; nsources_out[0] (device int64, may be
+ *       NULL) = surviving components.
+ *     apgpu_box_clipped_stats_f32: the image is cut into box_height x box_width boxes (the last row / column of boxes
+ *       may stick out of the image: those pixels count as masked, Background2D's edge_method 'pad'); per box astropy's
+ *       SigmaClip(sigma, maxiters, median / std) over the unmasked finite pixels; stats_out[ny][nx][4] (device float64)
+ *       = { median, std, count of the final survivors, pixels masked before clipping }.
+ *     apgpu_spline_zoom_f64: scipy.ndimage.zoom(mesh, (zoom_y, zoom_x), order=3, mode='reflect', grid_mode=True)[:H, :W]
+ *       from the prefiltered cubic B-spline coefficients coef[ny][nx] (device float64), clipped to [vmin, vmax].
+ * ------------------------------------------------------------------------------------------- */
+size_t apgpu_source_mask_ws_bytes(int64_t height, int64_t width);
+int apgpu_source_mask_u8(const uint8_t *above, int64_t height, int64_t width, int32_t min_pixels, int32_t dilate_size,
+                         uint8_t *mask_out, int64_t *nsources_out, void *ws, size_t ws_bytes, void *stream);
+int apgpu_box_clipped_stats_f32(const float *data, const uint8_t *mask, int64_t height, int64_t width, int32_t box_height,
+                                int32_t box_width, double sigma, int32_t maxiters, double *stats_out, void *stream);
+int apgpu_spline_zoom_f64(const double *coef, int32_t ny, int32_t nx, int32_t zoom_y, int32_t zoom_x, int64_t height,
+                          int64_t width, double vmin, double vmax, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,7 +98,7 @@ def test_random_stack_configs(ops, apref, seed):
 def test_too_many_frames_is_refused(ops):
     from astrophotography_amd._lib import ApGpuError
     with pytest.raises(ApGpuError):
-        ops.stack_sigclip(torch.zeros((129, 2, 8), device='cuda'))
+        ops.stack_sigclip(torch.zeros((513, 2, 8), device='cuda'))
 
 
 @pytest.mark.parametrize('seed', range(12))

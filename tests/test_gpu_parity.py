@@ -404,7 +404,7 @@ def test_bayer_split_reference_stamps(ops):
 def test_errors_are_loud(ops):
     from astrophotography_amd._lib import ApGpuError
     with pytest.raises(ApGpuError):
-        ops.stack_sigclip(torch.zeros((129, 4, 4), device='cuda'))
+        ops.stack_sigclip(torch.zeros((513, 4, 4), device='cuda'))              # beyond APGPU_MAX_STACK
     with pytest.raises(ValueError):
         ops.stack_sigclip(torch.zeros((4, 4, 4)))
 
