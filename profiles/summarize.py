@@ -61,8 +61,9 @@ with open(os.path.join(out, 'dominant_kernel_dispatches.csv'), 'w', newline='') 
 if durs:
     res['dominant_kernel_trace'] = {'dispatches': len(durs), 'avg_ns': sum(durs) / len(durs), 'min_ns': min(durs),
                                     'max_ns': max(durs), 'rocprof_resources': regs,
-                                    'note': 'rocprofv3 prints VGPR_Count = allocated VGPRs / 2 on gfx950 (allocation granule 8 '
-                                            'reported in units of 4): 76 here = 152 registers in the code object metadata'}
+                                    'note': 'rocprofv3 prints VGPR_Count = allocated VGPRs / 2 on gfx950 (the allocation granule of 8 '
+                                            'registers reported in units of 4): VGPR_Count 80 = 160 allocated = the 153 registers of the '
+                                            'code object metadata (profiles/<tag>/kernel_resources.csv) rounded up to the granule'}
 
 counters = {}
 with open(os.path.join(out, 'pmc_dominant_kernel.csv'), 'w', newline='') as fh:
