@@ -19,6 +19,7 @@ _LAZY = {
     'ApImageDifference': ('.core.ApCalcReadNoise', 'ApImageDifference'),
     'ApCalcReadNoise': ('.core.ApCalcReadNoise', 'ApCalcReadNoise'),
     'ApMeasureBackground': ('.core.ApMeasureBackground', 'ApMeasureBackground'),
+    'ApFixCosmicRays': ('.core.ApFixCosmicRays', 'ApFixCosmicRays'),
 }
 
 __all__ = sorted(_LAZY) + ['__version__']

@@ -78,6 +78,12 @@ SIGNATURES = {
                                               C.c_int32, C.c_void_p, C.c_void_p]),
     'apgpu_spline_zoom_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_double,
                                         C.c_double, C.c_void_p, C.c_void_p]),
+    'apgpu_lacosmic_ws_bytes': (C.c_size_t, [C.c_int64, C.c_int64]),
+    'apgpu_sepmedfilt_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'apgpu_lacosmic_satmask': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    'apgpu_lacosmic_iterate': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_imarith_f64': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_decode': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_fits_encode_f32': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -42,6 +42,7 @@ class ApCalibrate:
         self._master_dark = Path(master_dark_file)
         self._dark_still_biased = bool(dark_still_biased) if dark_still_biased is not None else False
         self._bpix = None
+        self._crfix = None
         self._bias_data, self._bias_hdr = self._read_master(self._master_bias)
         self._dark_data, self._dark_hdr = self._read_master(self._master_dark)
         if self._bias_data.shape != self._dark_data.shape:
@@ -108,6 +109,19 @@ class ApCalibrate:
         self._logger.info(f'Image to dark exposure time ratio: {exp_ratio:.3f}')
         return exp_ratio
 
+    def _get_gain(self, hdr):
+        """Gain in e/ADU from GAIN, then EGAIN (the later keyword wins, as in the reference's loop); 1.0 if neither is there
+        (ApCalibrate.py:192-208)."""
+        gain = None
+        for kw in ['GAIN', 'EGAIN']:
+            if kw in hdr:
+                gain = float(hdr[kw])
+                self._logger.debug(f'Read gain value of {gain:.3f} e/ADU from {kw} keyword.')
+        if gain is None:
+            gain = 1.0
+            self._logger.warning(f'Could not find gain value in header. Assuming gain={gain:.3f} e/ADU.')
+        return gain
+
     def _generate_flat(self, flat_data, flat_method):
         from .. import ops
         if flat_method != ApCalibrate.MEAN_FULL:
@@ -170,11 +184,6 @@ class ApCalibrate:
     def calibrate(self, raw_image, cal_image, delta_pix, norm_flat, fixcosmic):
         from .. import ops
         perf_time_start = time.perf_counter()
-        if fixcosmic:
-            msg = ('Cosmic ray removal (ApFixCosmicRays -> ccdproc.cosmicray_lacosmic) is outside the scope of the '
-                   'MI355X calibrate/stack path; run with fixcosmic=False.')
-            self._logger.error(msg)
-            raise RuntimeError(msg)
         raw_image = Path(raw_image)
         raw, raw_hdr, pedestal = self._read_raw(raw_image)
         if self._dark_still_biased:
@@ -205,6 +214,18 @@ class ApCalibrate:
             odict['BPIXNFIX'] = (nfixed, 'Number of bad pixels corrected')
         else:
             self._logger.info('No bad pixel correction applied.')
+        if fixcosmic:                                           # ApCalibrate.py:490-497
+            self._logger.info('Correcting cosmic rays...')
+            gain = self._get_gain(raw_hdr)
+            if self._crfix is None:
+                from .ApFixCosmicRays import ApFixCosmicRays
+                self._crfix = ApFixCosmicRays(self._loglevel)
+            img_clean, crmask, _ = self._crfix.process_tensor(img_bdf, gain)
+            numbad = int(crmask.sum())
+            self._logger.info(f'{numbad} pixels in image identified as affected by cosmic rays.')
+            odict['CR_CLEAN'] = (True, 'Has cosmic ray removal been performed?')
+            odict['CR_NPIX'] = (numbad, 'Number of pixels modified by lacosmic.')
+            img_bdf = img_clean
         run_time_secs = time.perf_counter() - perf_time_start
         self._logger.info(f'Writing calibrated image to {cal_image}')
         self._write_corrected_image(raw_image, cal_image, img_bdf, odict)

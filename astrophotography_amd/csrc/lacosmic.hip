@@ -1,0 +1,316 @@
+// lacosmic.hip - F4 (second half): L.A.Cosmic cosmic-ray rejection, the step ApFixCosmicRays hands to
+// ccdproc.cosmicray_lacosmic -> astroscrappy.detect_cosmics (core/ApFixCosmicRays.py:267-295: sigclip 4.5, sigfrac 0.3,
+// objlim 5, readnoise 12 e-, niter 6, fsmode 'convolve' with a 3.5-pixel Gaussian, sepmed, cleantype 'meanmask').
+// astroscrappy / ccdproc are absent from the build container: PARITY UNPINNED.  The kernels implement van Dokkum's (2001)
+// algorithm in the structure of astroscrappy's detect_cosmics as restated in oracle/lacosmic_ref.py (float32 planes):
+//   per iteration:  s  = rebin(clip0(laplace(subsample2(clean))))            Laplacian of the 2x subsampled image
+//                   m5 = sepmed7(clean); noise = sqrt(max(m5, 1e-5) + rn^2); s /= 2 noise; sp = s - sepmed7(s)
+//                   f  = conv(clean, psf 7x7); f = max((f - sepmed9(f)) / noise, 0.01)   fine-structure image
+//                   cr = good & (sp > sigclip) & (sp / f > objlim); grown twice by 3x3 with sp > sigclip, sp > sigfrac*sigclip
+//                   clean[cr] = mean of the non-CR, unmasked pixels of the 5x5 neighbourhood (background level if none)
+//   "sepmedK" = median of K along rows, then of K along columns, border pixels copied (astroscrappy's separable filters).
+// Everything is one pass over the image per step (HBM / L2 streaming); the 1-D medians sort 5 / 7 / 9 values in registers
+// with the compile-time networks of the stack kernels.
+#include "common.h"
+#include "stack_sort.h"
+
+namespace {
+using namespace apgpu;
+
+constexpr int kBlock = 256;
+
+inline unsigned grid1d(int64_t n)
+{
+    int64_t g = (n + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > kNumCU * 16) g = kNumCU * 16;
+    return (unsigned)g;
+}
+
+#define APGPU_FOR_PIXELS(p, P) \
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, _stride = (int64_t)gridDim.x * blockDim.x; p < (P); p += _stride)
+
+// 1-D median of K (odd) along rows (ALONG_X) or columns; pixels closer than K/2 to the border are copied.
+template <int K, bool ALONG_X>
+__global__ __launch_bounds__(kBlock) void median1d_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W)
+{
+    constexpr int NP = K <= 8 ? 8 : 16;
+    constexpr int HALF = K / 2;
+    const int64_t P = (int64_t)H * W;
+    APGPU_FOR_PIXELS(p, P) {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        const int pos = ALONG_X ? c : r, len = ALONG_X ? W : H;
+        if (pos < HALF || pos >= len - HALF) {
+            out[p] = in[p];
+            continue;
+        }
+        float v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            if (k < K) v[k] = in[ALONG_X ? p + (k - HALF) : p + (int64_t)(k - HALF) * W];
+            else v[k] = __builtin_inff();
+        }
+        apgpu_stack::sort_column<NP>(v);
+        out[p] = v[HALF];
+    }
+}
+
+// Laplacian of the 2x2-subsampled image, negative values clipped, block-averaged back (kernel 0 -1 0 / -1 4 -1 / 0 -1 0;
+// a neighbour outside the image is dropped).  For pixel v with neighbours u, d, l, r the four sub-pixels give
+// 2v - u - l, 2v - u - r, 2v - d - l, 2v - d - r (a missing neighbour leaves its own term out: e.g. 3v - l ... see oracle).
+__global__ __launch_bounds__(kBlock) void laplace_kernel(const float *__restrict__ a, float *__restrict__ s, int H, int W)
+{
+    const int64_t P = (int64_t)H * W;
+    APGPU_FOR_PIXELS(p, P) {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        const float v = a[p];
+        const bool hu = r > 0, hd = r < H - 1, hl = c > 0, hr = c < W - 1;
+        const float u = hu ? a[p - W] : 0.f, d = hd ? a[p + W] : 0.f, l = hl ? a[p - 1] : 0.f, rr = hr ? a[p + 1] : 0.f;
+        // sub-pixel (top-left): neighbours up (pixel above, or outside), left (pixel to the left, or outside), right and down are v itself
+        const float tl = 4.f * v - u - l - v - v;
+        const float tr = 4.f * v - u - rr - v - v;
+        const float bl = 4.f * v - d - l - v - v;
+        const float br = 4.f * v - d - rr - v - v;
+        s[p] = (fmaxf(tl, 0.f) + fmaxf(tr, 0.f) + fmaxf(bl, 0.f) + fmaxf(br, 0.f)) * 0.25f;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void noise_sigmap_kernel(const float *__restrict__ m5, float *__restrict__ s, float *__restrict__ noise,
+                                                             float rn2, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) {
+        const float m = fmaxf(m5[p], 0.00001f);
+        const float n = sqrtf(m + rn2);
+        noise[p] = n;
+        s[p] = s[p] / (2.0f * n);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void subtract_kernel(float *__restrict__ a, const float *__restrict__ b, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) a[p] = a[p] - b[p];
+}
+
+// f = sum_k psf[k] * clean[shifted]  (7 x 7, zero outside the image), accumulated in row-major kernel order
+__global__ __launch_bounds__(kBlock) void convolve7_kernel(const float *__restrict__ a, const float *__restrict__ psf, float *__restrict__ f,
+                                                          int H, int W)
+{
+    __shared__ float k[49];
+    if (threadIdx.x < 49) k[threadIdx.x] = psf[threadIdx.x];
+    __syncthreads();
+    const int64_t P = (int64_t)H * W;
+    APGPU_FOR_PIXELS(p, P) {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = -3; dy <= 3; dy++) {
+            const int rr = r + dy;
+            if (rr < 0 || rr >= H) continue;
+#pragma unroll
+            for (int dx = -3; dx <= 3; dx++) {
+                const int cc = c + dx;
+                if (cc < 0 || cc >= W) continue;
+                acc = acc + k[(dy + 3) * 7 + (dx + 3)] * a[(int64_t)rr * W + cc];
+            }
+        }
+        f[p] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fine_kernel(float *__restrict__ f, const float *__restrict__ m7, const float *__restrict__ noise, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) f[p] = fmaxf((f[p] - m7[p]) / noise[p], 0.01f);
+}
+
+__global__ __launch_bounds__(kBlock) void select_kernel(const float *__restrict__ sp, const float *__restrict__ f, const uint8_t *__restrict__ mask,
+                                                       float sigclip, float objlim, uint8_t *__restrict__ cr, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) {
+        const float x = sp[p];
+        cr[p] = (!(mask && mask[p]) && x > sigclip && (x / f[p]) > objlim) ? 1 : 0;
+    }
+}
+
+// out = dilate(in) [& !mask] [& sp > thr].  SHAPE 3: 3x3 square; SHAPE 5: 5x5 without its corners.  Zero outside the image.
+template <int SHAPE>
+__global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restrict__ in, const float *__restrict__ sp, const uint8_t *__restrict__ mask,
+                                                       float thr, uint8_t *__restrict__ out, int H, int W)
+{
+    constexpr int R = SHAPE / 2;
+    const int64_t P = (int64_t)H * W;
+    APGPU_FOR_PIXELS(p, P) {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        bool any = false;
+#pragma unroll
+        for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+            for (int dx = -R; dx <= R; dx++) {
+                if (SHAPE == 5 && (dy == -2 || dy == 2) && (dx == -2 || dx == 2)) continue;
+                const int rr = r + dy, cc = c + dx;
+                if (rr >= 0 && rr < H && cc >= 0 && cc < W) any = any || in[(int64_t)rr * W + cc] != 0;
+            }
+        if (mask && mask[p]) any = false;
+        if (sp && !(sp[p] > thr)) any = false;
+        out[p] = any ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void merge_count_kernel(const uint8_t *__restrict__ cr, uint8_t *__restrict__ crmask,
+                                                            unsigned long long *__restrict__ ncr, int64_t P)
+{
+    unsigned n = 0;
+    APGPU_FOR_PIXELS(p, P) {
+        if (cr[p]) {
+            n++;
+            crmask[p] = 1;
+        }
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) n += __shfl_down(n, d);
+    if ((threadIdx.x % kWave) == 0 && n) atomicAdd(ncr, (unsigned long long)n);
+}
+
+// cleantype 'meanmask': every CR pixel at least 2 pixels from the border becomes the mean of the pixels of its 5x5
+// neighbourhood that are neither CR nor masked (the background level if there is none).  Only CR pixels are written and
+// only non-CR pixels are read: in place.
+__global__ __launch_bounds__(kBlock) void clean_meanmask_kernel(float *__restrict__ a, const uint8_t *__restrict__ crmask,
+                                                               const uint8_t *__restrict__ mask, float background, int H, int W)
+{
+    const int64_t P = (int64_t)H * W;
+    APGPU_FOR_PIXELS(p, P) {
+        if (!crmask[p]) continue;
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        if (r < 2 || r >= H - 2 || c < 2 || c >= W - 2) continue;
+        float sum = 0.f;
+        int n = 0;
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+            for (int dx = -2; dx <= 2; dx++) {
+                const int64_t q = p + (int64_t)dy * W + dx;
+                if (!crmask[q] && !(mask && mask[q])) {
+                    sum = sum + a[q];
+                    n++;
+                }
+            }
+        a[p] = n > 0 ? sum / (float)n : background;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void saturated_kernel(const float *__restrict__ a, const float *__restrict__ m5, float satlevel,
+                                                          uint8_t *__restrict__ sat, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) sat[p] = (a[p] >= satlevel && m5[p] > satlevel / 10.0f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void or_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint8_t *__restrict__ out, int64_t P)
+{
+    APGPU_FOR_PIXELS(p, P) out[p] = (a[p] || (b && b[p])) ? 1 : 0;
+}
+
+template <int K>
+void sepmed(const float *in, float *out, float *tmp, int H, int W, hipStream_t st)
+{
+    const unsigned g = grid1d((int64_t)H * W);
+    hipLaunchKernelGGL((median1d_kernel<K, true>), dim3(g), dim3(kBlock), 0, st, in, tmp, H, W);
+    hipLaunchKernelGGL((median1d_kernel<K, false>), dim3(g), dim3(kBlock), 0, st, tmp, out, H, W);
+}
+
+struct Work {
+    float *s, *noise, *f, *t1, *t2;
+    uint8_t *u1, *u2;
+};
+
+Work carve(void *ws, int64_t P)
+{
+    Work w;
+    float *fp = static_cast<float *>(ws);
+    const int64_t Pa = (P + 3) & ~(int64_t)3;
+    w.s = fp; w.noise = fp + Pa; w.f = fp + 2 * Pa; w.t1 = fp + 3 * Pa; w.t2 = fp + 4 * Pa;
+    w.u1 = reinterpret_cast<uint8_t *>(fp + 5 * Pa);
+    w.u2 = w.u1 + Pa;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t apgpu_lacosmic_ws_bytes(int64_t height, int64_t width)
+{
+    if (height <= 0 || width <= 0) return 0;
+    const int64_t Pa = (height * width + 3) & ~(int64_t)3;
+    return (size_t)Pa * (5 * sizeof(float) + 2) + 64;
+}
+
+extern "C" int apgpu_sepmedfilt_f32(const float *data, int64_t height, int64_t width, int32_t size, float *out, void *ws, size_t ws_bytes,
+                                    void *stream)
+{
+    if (!data || !out || !ws) return fail(APGPU_EINVAL, "sepmedfilt: NULL pointer argument");
+    if (height <= 0 || width <= 0 || height > 0x7fffffff || width > 0x7fffffff) return fail(APGPU_EINVAL, "sepmedfilt: bad shape");
+    if (ws_bytes < (size_t)(height * width) * sizeof(float)) return fail(APGPU_EWORKSPACE, "sepmedfilt: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float *tmp = static_cast<float *>(ws);
+    switch (size) {
+    case 5: sepmed<5>(data, out, tmp, (int)height, (int)width, st); break;
+    case 7: sepmed<7>(data, out, tmp, (int)height, (int)width, st); break;
+    case 9: sepmed<9>(data, out, tmp, (int)height, (int)width, st); break;
+    default: return fail(APGPU_EUNSUPPORTED, "sepmedfilt: size %d (5, 7 or 9)", size);
+    }
+    return check_launch("sepmedfilt");
+}
+
+extern "C" int apgpu_lacosmic_satmask(const float *data, const uint8_t *inmask, int64_t height, int64_t width, float satlevel,
+                                      uint8_t *mask_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!data || !mask_out || !ws) return fail(APGPU_EINVAL, "lacosmic_satmask: NULL pointer argument");
+    if (height <= 0 || width <= 0 || height > 0x7fffffff || width > 0x7fffffff) return fail(APGPU_EINVAL, "lacosmic_satmask: bad shape");
+    if (ws_bytes < apgpu_lacosmic_ws_bytes(height, width)) return fail(APGPU_EWORKSPACE, "lacosmic_satmask: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int H = (int)height, W = (int)width;
+    const int64_t P = height * width;
+    Work w = carve(ws, P);
+    const unsigned g = grid1d(P);
+    sepmed<7>(data, w.t1, w.t2, H, W, st);                                                  // large-scale structure
+    hipLaunchKernelGGL(saturated_kernel, dim3(g), dim3(kBlock), 0, st, data, w.t1, satlevel, w.u1, P);
+    hipLaunchKernelGGL(dilate_kernel<5>, dim3(g), dim3(kBlock), 0, st, w.u1, (const float *)nullptr, (const uint8_t *)nullptr, 0.f, w.u2, H, W);
+    hipLaunchKernelGGL(dilate_kernel<5>, dim3(g), dim3(kBlock), 0, st, w.u2, (const float *)nullptr, (const uint8_t *)nullptr, 0.f, w.u1, H, W);
+    if (inmask) {
+        hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, inmask, (const float *)nullptr, (const uint8_t *)nullptr, 0.f, w.u2, H, W);
+        hipLaunchKernelGGL(or_kernel, dim3(g), dim3(kBlock), 0, st, w.u1, w.u2, mask_out, P);
+    } else {
+        hipLaunchKernelGGL(or_kernel, dim3(g), dim3(kBlock), 0, st, w.u1, (const uint8_t *)nullptr, mask_out, P);
+    }
+    return check_launch("lacosmic_satmask");
+}
+
+extern "C" int apgpu_lacosmic_iterate(float *clean, const uint8_t *mask, uint8_t *crmask, int64_t height, int64_t width, float sigclip,
+                                      float sigfrac, float objlim, float readnoise, const float *psfk, float background_level,
+                                      int64_t *ncr_out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!clean || !crmask || !ncr_out || !ws) return fail(APGPU_EINVAL, "lacosmic_iterate: NULL pointer argument");
+    if (height < 5 || width < 5 || height > 0x7fffffff || width > 0x7fffffff) return fail(APGPU_EINVAL, "lacosmic_iterate: bad shape");
+    if (ws_bytes < apgpu_lacosmic_ws_bytes(height, width)) return fail(APGPU_EWORKSPACE, "lacosmic_iterate: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const int H = (int)height, W = (int)width;
+    const int64_t P = height * width;
+    Work w = carve(ws, P);
+    const unsigned g = grid1d(P);
+    if (hipMemsetAsync(ncr_out, 0, sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "lacosmic_iterate: memset failed");
+    hipLaunchKernelGGL(laplace_kernel, dim3(g), dim3(kBlock), 0, st, clean, w.s, H, W);
+    sepmed<7>(clean, w.t1, w.t2, H, W, st);                                                 // m5
+    hipLaunchKernelGGL(noise_sigmap_kernel, dim3(g), dim3(kBlock), 0, st, w.t1, w.s, w.noise, readnoise * readnoise, P);
+    sepmed<7>(w.s, w.t1, w.t2, H, W, st);
+    hipLaunchKernelGGL(subtract_kernel, dim3(g), dim3(kBlock), 0, st, w.s, w.t1, P);        // sp = s - sepmed7(s)
+    if (psfk) {
+        hipLaunchKernelGGL(convolve7_kernel, dim3(g), dim3(kBlock), 0, st, clean, psfk, w.f, H, W);
+    } else {
+        sepmed<5>(clean, w.f, w.t2, H, W, st);                                              // fsmode 'median'
+    }
+    sepmed<9>(w.f, w.t1, w.t2, H, W, st);
+    hipLaunchKernelGGL(fine_kernel, dim3(g), dim3(kBlock), 0, st, w.f, w.t1, w.noise, P);
+    hipLaunchKernelGGL(select_kernel, dim3(g), dim3(kBlock), 0, st, w.s, w.f, mask, sigclip, objlim, w.u1, P);
+    hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, w.u1, w.s, mask, sigclip, w.u2, H, W);
+    hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, w.u2, w.s, mask, sigfrac * sigclip, w.u1, H, W);
+    hipLaunchKernelGGL(merge_count_kernel, dim3(g), dim3(kBlock), 0, st, w.u1, crmask, reinterpret_cast<unsigned long long *>(ncr_out), P);
+    hipLaunchKernelGGL(clean_meanmask_kernel, dim3(g), dim3(kBlock), 0, st, clean, crmask, mask, background_level, H, W);
+    return check_launch("lacosmic_iterate");
+}

@@ -723,3 +723,58 @@ def spline_zoom(coef, zoom_y, zoom_x, height, width, vmin, vmax):
     check(_lib.load().apgpu_spline_zoom_f64(_ptr(coef), ny, nx, int(zoom_y), int(zoom_x), int(height), int(width), float(vmin),
                                             float(vmax), _ptr(out), _stream()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# F4: L.A.Cosmic (core/ApFixCosmicRays.py:267-295 -> ccdproc -> astroscrappy; restated, parity unpinned)
+# ---------------------------------------------------------------------------------------------------
+def sepmedfilt(data, size):
+    """astroscrappy's separable median filter: median of `size` (5, 7, 9) along rows, then along columns, borders copied."""
+    _need_cuda(data)
+    data = _f32c(data, 'data')
+    out = torch.empty_like(data)
+    ws = torch.empty(data.numel() * 4, dtype=torch.uint8, device=data.device)
+    check(_lib.load().apgpu_sepmedfilt_f32(_ptr(data), data.shape[0], data.shape[1], int(size), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def gauss_psf_kernel(fwhm, size=7, device='cuda'):
+    """astroscrappy's gausskernel(psffwhm, kernsize): normalised float32 Gaussian, [size, size] device tensor."""
+    x = np.tile(np.arange(size) - size // 2, (size, 1)).astype(np.float64)
+    y = x.T.copy()
+    sigma2 = fwhm * fwhm / 2.35482 / 2.35482
+    k = np.exp(-0.5 * (x * x + y * y) / sigma2).astype(np.float32)
+    return torch.from_numpy((k / k.sum()).astype(np.float32)).to(device)
+
+
+def lacosmic(data_electrons, inmask=None, sigclip=4.5, sigfrac=0.3, objlim=5.0, readnoise=12.0, satlevel=65535.0, niter=6,
+             psffwhm=3.5, fsmode='convolve'):
+    """astroscrappy.detect_cosmics on a float32 image in electrons (device tensor): returns (cleaned float32 tensor,
+    crmask uint8 tensor, iterations run).  Non-finite pixels must have been zeroed and put into inmask by the caller.
+    One host read of the per-iteration cosmic-ray count decides whether to go on (astroscrappy stops at 0)."""
+    _need_cuda(data_electrons, inmask)
+    lib = _lib.load()
+    clean = _f32c(data_electrons, 'data').clone()
+    H, W = clean.shape
+    if inmask is not None and (inmask.dtype != torch.uint8 or tuple(inmask.shape) != (H, W)):
+        raise TypeError('inmask must be uint8 with the image shape')
+    ws_bytes = lib.apgpu_lacosmic_ws_bytes(H, W)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=clean.device)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=clean.device)
+    check(lib.apgpu_lacosmic_satmask(_ptr(clean), _ptr(inmask.contiguous()) if inmask is not None else None, H, W, float(satlevel),
+                                     _ptr(mask), _ptr(ws), ws_bytes, _stream()))
+    # background level for cosmic rays without a good neighbour: np.median of the unmasked pixels (A3 kernels, no clipping)
+    masked = torch.where(mask != 0, torch.full_like(clean, float('nan')), clean)
+    bkg = float(sigclip_global(masked, sigma=1e30, maxiters=1)[1].item())
+    if bkg != bkg:
+        bkg = 0.0
+    psfk = gauss_psf_kernel(psffwhm, 7, clean.device) if fsmode == 'convolve' else None
+    crmask = torch.zeros((H, W), dtype=torch.uint8, device=clean.device)
+    ncr = torch.zeros(1, dtype=torch.int64, device=clean.device)
+    it = 0
+    for it in range(1, int(niter) + 1):
+        check(lib.apgpu_lacosmic_iterate(_ptr(clean), _ptr(mask), _ptr(crmask), H, W, float(sigclip), float(sigfrac), float(objlim),
+                                         float(readnoise), _ptr(psfk), bkg, _ptr(ncr), _ptr(ws), ws_bytes, _stream()))
+        if int(ncr.item()) == 0:
+            break
+    return clean, crmask, it

@@ -2,7 +2,7 @@
 """ap_calibrate - bias/dark/flat (and bad pixel) calibration of one raw frame on the GPU.
 
 Same positional arguments and flags as the reference script (scripts/ap_calibrate.py:40-122);
-``--fixcosmic`` is accepted but rejected at run time (L.A.Cosmic is outside this build).
+``--fixcosmic`` runs L.A.Cosmic (ApFixCosmicRays, csrc/lacosmic.hip) after the bad-pixel repair, as in the reference.
 """
 import argparse
 import logging
@@ -24,7 +24,7 @@ def command_line_opts(argv):
                         help='Also write the normalised flat field to this file.')
     parser.add_argument('--deltapix', default=p_delta, type=int, metavar='NPIX',
                         help=f'Half-size of the box good neighbours are drawn from. Default: {p_delta}')
-    parser.add_argument('--fixcosmic', default=False, action='store_true', help='Cosmic ray removal (not available).')
+    parser.add_argument('--fixcosmic', default=False, action='store_true', help='If specified, cosmic rays will be removed with the L.A.Cosmic algorithm after bad pixel correction.')
     parser.add_argument('--dark_still_biased', default=False, action='store_true',
                         help='The master dark has NOT had the bias subtracted yet.')
     parser.add_argument('-l', '--loglevel', default='INFO', help='Logging message level. Default: INFO')

@@ -317,6 +317,31 @@ int apgpu_box_clipped_stats_f32(const float *data, const uint8_t *mask, int64_t 
 int apgpu_spline_zoom_f64(const double *coef, int32_t ny, int32_t nx, int32_t zoom_y, int32_t zoom_x, int64_t height,
                           int64_t width, double vmin, double vmax, double *out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * F4  L.A.Cosmic, the step ApFixCosmicRays.process hands to ccdproc.cosmicray_lacosmic -> astroscrappy.detect_cosmics
+ *     (core/ApFixCosmicRays.py:267-295).  Neither package is in the build container: the entry points implement the
+ *     algorithm as restated in oracle/lacosmic_ref.py (parity with astroscrappy itself is unpinned).  Images are float32 in
+ *     ELECTRONS (the caller multiplies by the gain, as ccdproc does with gain_apply = True).
+ *     apgpu_sepmedfilt_f32: median of `size` (5, 7 or 9) along rows, then along columns, borders copied (astroscrappy's
+ *       separable median filters); ws >= 4 * H * W bytes.
+ *     apgpu_lacosmic_satmask: astroscrappy's update_mask - cores of saturated stars (data >= satlevel where the 7-median
+ *       exceeds satlevel / 10) dilated twice with the 5 x 5 kernel, OR inmask (may be NULL) grown by one pixel.
+ *     apgpu_lacosmic_iterate: ONE detect_cosmics iteration, in place on clean / crmask: Laplacian of the 2x subsampled
+ *       image, noise model sqrt(max(sepmed7, 1e-5) + readnoise^2), fine-structure image from the 7 x 7 kernel psfk (device,
+ *       49 floats; NULL = fsmode 'median'), sp > sigclip and sp / f > objlim, two 3 x 3 growth steps (sp > sigclip, then
+ *       sp > sigfrac * sigclip), 'meanmask' cleaning over 5 x 5 with background_level where no good neighbour exists;
+ *       ncr_out[0] (device int64) = cosmic-ray pixels found in this iteration (the caller stops at 0).
+ *     ws >= apgpu_lacosmic_ws_bytes(H, W) for the last two.
+ * ------------------------------------------------------------------------------------------- */
+size_t apgpu_lacosmic_ws_bytes(int64_t height, int64_t width);
+int apgpu_sepmedfilt_f32(const float *data, int64_t height, int64_t width, int32_t size, float *out, void *ws, size_t ws_bytes,
+                         void *stream);
+int apgpu_lacosmic_satmask(const float *data, const uint8_t *inmask, int64_t height, int64_t width, float satlevel,
+                           uint8_t *mask_out, void *ws, size_t ws_bytes, void *stream);
+int apgpu_lacosmic_iterate(float *clean, const uint8_t *mask, uint8_t *crmask, int64_t height, int64_t width, float sigclip,
+                           float sigfrac, float objlim, float readnoise, const float *psfk, float background_level,
+                           int64_t *ncr_out, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+"""F4 (second half): L.A.Cosmic on the GPU against oracle/lacosmic_ref.py - a restatement of astroscrappy's detect_cosmics
+as ccdproc.cosmicray_lacosmic runs it for ApFixCosmicRays.  ccdproc / astroscrappy are absent from the build container:
+parity with the reference's own output is UNPINNED; these tests pin the kernels to the restatement, bit for bit."""
+import numpy as np
+import pytest
+
+from tests.util import assert_biteq
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from astrophotography_amd import ops as _ops
+    return _ops
+
+
+def _field(rng, H, W, ncr=40):
+    """Sky + stars (PSF sigma 1.5) + a saturated star + cosmic rays (single pixels, short tracks)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = rng.normal(400.0, 8.0, (H, W))
+    for _ in range(25):
+        cy, cx, amp = rng.uniform(5, H - 5), rng.uniform(5, W - 5), rng.uniform(200, 8000)
+        img += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 1.5 ** 2))
+    img += 400000.0 * np.exp(-((xx - W * 0.3) ** 2 + (yy - H * 0.6) ** 2) / (2 * 2.0 ** 2))     # saturates
+    img = np.minimum(img, 65535.0)
+    truth = np.zeros((H, W), bool)
+    for _ in range(ncr):
+        r, c = rng.integers(3, H - 3), rng.integers(3, W - 3)
+        n = rng.integers(1, 4)
+        for k in range(n):
+            rr, cc = min(H - 1, r + k), min(W - 1, c + (k if rng.random() < 0.5 else 0))
+            img[rr, cc] += rng.uniform(500, 6000)
+            truth[rr, cc] = True
+    return img.astype(np.float32), truth
+
+
+def test_sepmedfilt_vs_oracle(ops):
+    from oracle import lacosmic_ref as L
+    rng = np.random.default_rng(61)
+    for shape in ((40, 57), (9, 9), (6, 30), (30, 4)):
+        a = rng.normal(100, 20, shape).astype(np.float32)
+        for size in (5, 7, 9):
+            assert_biteq(ops.sepmedfilt(torch.from_numpy(a).cuda(), size).cpu().numpy(), L.sepmedfilt(a, size), f'sepmed{size} {shape}')
+
+
+def test_detect_cosmics_vs_oracle(ops):
+    from oracle import lacosmic_ref as L
+    rng = np.random.default_rng(62)
+    for (H, W, gain, fsmode) in ((120, 150, 1.3, 'convolve'), (90, 64, 1.0, 'median')):
+        img, truth = _field(rng, H, W)
+        ref_clean, ref_mask = L.detect_cosmics(img, gain=gain, satlevel=gain * 65535, fsmode=fsmode)
+        e = (torch.from_numpy(img).cuda() * np.float32(gain))
+        clean, crmask, niter = ops.lacosmic(e, satlevel=gain * 65535, fsmode=fsmode)
+        assert np.array_equal(crmask.cpu().numpy().astype(bool), ref_mask), (H, W, fsmode)
+        assert_biteq(clean.cpu().numpy(), ref_clean, f'cleaned image {H}x{W} {fsmode}')
+        # it finds the planted cosmic rays (outside the saturated star's mask) and leaves the stars alone
+        found = ref_mask & truth
+        assert found.sum() >= 0.8 * truth.sum() and ref_mask.sum() <= truth.sum() * 4.0 + 20
+
+
+def test_apfixcosmicrays_and_calibrate_fixcosmic(ops, tmp_path):
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio
+    from astrophotography_amd.scripts import ap_fix_cosmic_rays
+    from oracle import apref, lacosmic_ref as L
+    rng = np.random.default_rng(63)
+    H, W = 100, 128
+    img, truth = _field(rng, H, W)
+    gain = 1.46
+    fx = ap.ApFixCosmicRays('CRITICAL')
+    clean, kw = fx.process(img, gain)
+    ref_clean, ref_mask = L.detect_cosmics(img, gain=gain, satlevel=gain * 65535)
+    ref_adu = ref_clean / np.float32(gain)
+    assert clean.dtype == np.float32
+    assert_biteq(clean, ref_adu, 'ApFixCosmicRays.process (ADU)')
+    assert kw['CR_CLEAN'][0] is True and kw['CR_NPIX'][0] == int(ref_mask.sum()) == int(fx.get_crmask().sum())
+    assert np.array_equal(fx.get_crdiff() != 0, img != ref_adu)
+    # file front-end with the reference's flags; EGAIN keyword; mask + difference images
+    h = fitsio.Header()
+    h['EGAIN'] = gain
+    fitsio.write(str(tmp_path / 'in.fits'), img, h)
+    assert ap_fix_cosmic_rays.main([str(tmp_path / 'in.fits'), str(tmp_path / 'out.fits'), '--crmaskim', str(tmp_path / 'm.fits'),
+                                    '--crdiffim', str(tmp_path / 'd.fits'), '-l', 'CRITICAL']) == 0
+    out, ho = fitsio.read(str(tmp_path / 'out.fits'))
+    assert_biteq(out, ref_adu, 'ap_fix_cosmic_rays output')
+    assert ho['CR_CLEAN'] is True and ho['CR_NPIX'] == int(ref_mask.sum()) and ho['CREATOR'] == 'ApFixCosmicRays'
+    m, _ = fitsio.read(str(tmp_path / 'm.fits'))
+    assert m.dtype == np.uint8 and np.array_equal(m.astype(bool), ref_mask)
+    # ApCalibrate.calibrate(..., fixcosmic=True): calibrate_all.sh's own command line (:406-411)
+    bias = rng.normal(1000, 3, (H, W)).astype(np.float32)
+    dark = rng.normal(20, 2, (H, W)).astype(np.float32)
+    flat = rng.normal(30000, 200, (H, W)).astype(np.float32)
+    raw = np.clip(np.rint(img + bias + 0.4 * dark), 0, 65535).astype(np.uint16)
+    fitsio.write(str(tmp_path / 'bias.fits'), bias)
+    hd = fitsio.Header(); hd['EXPTIME'] = 300.0
+    fitsio.write(str(tmp_path / 'dark.fits'), dark, hd)
+    fitsio.write(str(tmp_path / 'flat.fits'), flat)
+    hr = fitsio.Header(); hr['EXPTIME'] = 120.0; hr['EGAIN'] = gain
+    fitsio.write(str(tmp_path / 'raw.fits'), raw, hr)
+    cal = ap.ApCalibrate(str(tmp_path / 'bias.fits'), str(tmp_path / 'dark.fits'), str(tmp_path / 'flat.fits'), None, 'CRITICAL',
+                         dark_still_biased=False)
+    cal.calibrate(str(tmp_path / 'raw.fits'), str(tmp_path / 'cal.fits'), 2, None, True)
+    got, hc = fitsio.read(str(tmp_path / 'cal.fits'))
+    nflat, _ = apref.flat_normalize(flat)
+    calref = apref.calibrate(raw, bias, dark, nflat, 120.0 / 300.0)
+    cref, mref = L.detect_cosmics(calref, gain=gain, satlevel=gain * 65535)
+    assert_biteq(got, cref / np.float32(gain), 'calibrate with fixcosmic')
+    assert hc['CR_CLEAN'] is True and hc['CR_NPIX'] == int(mref.sum()) and hc['FLATCORR'] is True

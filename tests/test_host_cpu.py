@@ -249,7 +249,10 @@ def test_scripts_keep_the_reference_flags():
     b = ap_measure_background.command_line_opts(['cal.fits', 'bg.fits'])
     assert (b.nbg_cols, b.nbg_rows, b.min_bgwidth, b.min_bgheight, b.bg_filter_width, b.bg_badbox_pctile, b.bg_sigmaclip, b.srclist) == \
         (16, 16, 48, 48, 3, 25.0, 3.0, None)
-    for mod in (ap_calibrate, ap_find_badpix, ap_imarith, ap_fix_badpix, ap_combine_darks, ap_measure_background):
+    from astrophotography_amd.scripts import ap_fix_cosmic_rays
+    cr = ap_fix_cosmic_rays.command_line_opts(['in.fits', 'out.fits', '--crmaskim', 'm.fits'])
+    assert (cr.input, cr.output, cr.crmaskim, cr.crdiffim) == ('in.fits', 'out.fits', 'm.fits', None)
+    for mod in (ap_calibrate, ap_find_badpix, ap_imarith, ap_fix_badpix, ap_combine_darks, ap_measure_background, ap_fix_cosmic_rays):
         with pytest.raises(SystemExit) as e:
             mod.command_line_opts(['--help'])
         assert e.value.code == 0
