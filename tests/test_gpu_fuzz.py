@@ -141,3 +141,39 @@ def test_random_image_kernels(ops, apref, seed):
     for op in ('ADD', 'SUB', 'MUL', 'DIV'):
         with np.errstate(all='ignore'):
             assert np.array_equal(ops.imarith(_dev(img, ops), op, _dev(bias, ops)).cpu().numpy(), apref.imarith(img, op, bias), equal_nan=True)
+
+
+@pytest.mark.parametrize('N', [8, 64, 72, 128])
+def test_fused_division_guards_on_the_sorted_column(ops, apref, N):
+    """The reciprocal division's range guards are read off the ends of the sorted column (full AND padded slot counts):
+    columns with quotients below 2^-50 or above 2^50, mixed signs, exact zeros and non-finite values must send their wave
+    through the exact IEEE path and still match the oracle."""
+    rng = np.random.default_rng(900 + N)
+    H, W = 8, 192                                            # 6 wavefronts per row group
+    bias = rng.normal(100, 2, (H, W)).astype(np.float32)
+    dark = rng.normal(10, 1, (H, W)).astype(np.float32)
+    nflat = rng.normal(1.0, 0.02, (H, W)).astype(np.float32)
+    raw = (rng.normal(600, 20, (N, H, W)) + bias + 0.4 * dark).astype(np.float32)
+    e = np.float32(0.4)
+    base = (bias + e * dark).astype(np.float32)
+    raw[:, 0, 5] = base[0, 5] + np.float32(1e-20)           # quotients ~1e-20 < 2^-50: all one sign
+    raw[: N // 2, 1, 70] -= np.float32(1200)                # mixed signs, ordinary magnitudes
+    raw[:, 2, 130] = base[2, 130]                           # exact zeros
+    raw[3 % N, 2, 130] += np.float32(5)
+    raw[:, 3, 10] *= np.float32(1e20)
+    nflat[3, 10] = np.float32(1e-25)                        # quotient ~1e47 > 2^50 (and the divisor below 2^-40)
+    raw[1 % N, 4, 20] = np.inf
+    raw[2 % N, 4, 21] = np.nan
+    nflat[5, 100] = np.float32(-1.5)                        # negative flat: the order of the column reverses
+    nflat[6, 7] = 0.0                                       # no division at all
+    cal = apref.calibrate(raw, bias, dark, nflat, float(e))
+    ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5)
+    d = torch.from_numpy(raw).cuda()
+    calib = dict(bias=torch.from_numpy(bias).cuda(), dark=torch.from_numpy(dark).cuda(), nflat=torch.from_numpy(nflat).cuda(),
+                 exp_ratio=float(e))
+    r = ops.stack_sigclip(d, calib=calib, outputs=('mean', 'count'))
+    assert np.array_equal(r['count'].cpu().numpy(), ref['count'])
+    with np.errstate(over='ignore'):
+        assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, f'guards N={N}')
+    med = ops.stack_median(d, calib=calib)
+    assert_ulp(med.cpu().numpy(), apref.stack_median(cal).astype(np.float32), 1, f'median guards N={N}')
