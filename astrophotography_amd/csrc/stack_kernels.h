@@ -32,7 +32,9 @@ namespace apgpu_stack {
 
 using namespace apgpu;
 
-template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL>
+// EXTRA: the rich kernels (sorted column parked in LDS: mad_std, float64 planes).  PLUS (lean only): median and std planes
+// straight from the register-resident column - the same kernel as the benchmarked one with a longer epilogue.
+template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
 __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
     APGPU_MARK("load_calibrate_sort");
     const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
     if constexpr (EXTRA) reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
-    else reduce_and_store<NP, padded_minn(NP, FULL)>(prm, v, n, p);
+    else reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p);
 }
 
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
@@ -395,8 +397,14 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
 
 #ifdef APGPU_VARIANT_FORCE_RICH                             // tools/variant_lib.sh experiment: LDS-resident column for every output set
     const bool rich = !median_only;
+    const bool plus = false;
 #else
-    const bool rich = !median_only && (prm.median || prm.std || prm.mean64 || prm.std64 || prm.dev == APGPU_DEV_MAD_STD);
+    // median / std planes come from the lean kernel's longer epilogue (PLUS) for slot counts whose column leaves room in the
+    // registers; mad_std, the float64 planes and the largest slot counts take the LDS-resident (rich) kernel
+    const bool wants_planes = !median_only && (prm.median || prm.std);
+    const bool needs_lds = !median_only && (prm.mean64 || prm.std64 || prm.dev == APGPU_DEV_MAD_STD);
+    const bool plus = wants_planes && !needs_lds && NP <= 96;
+    const bool rich = needs_lds || (wants_planes && !plus);
 #endif
     const bool full = prm.N == NP;
     const int block = rich ? rich_block<NP>() : 256;
@@ -404,7 +412,8 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (describe) {
         if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
-        else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
+        else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
+        else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
         return APGPU_OK;
     }
     const dim3 g((unsigned)grid), b(block);
@@ -414,6 +423,11 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     } else if (rich) {
         if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, prm);
         else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, prm);
+    } else if (plus) {
+        if constexpr (NP <= 96) {
+            if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true, true>), g, b, 0, st, prm);
+            else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false, true>), g, b, 0, st, prm);
+        }
     } else if (full) {
         hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), g, b, 0, st, prm);
     } else {

@@ -228,7 +228,7 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
 
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP, int MINN = NP>
+template <int NP, int MINN = NP, bool PLUS = false>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
 {
     const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
@@ -348,6 +348,40 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     if (out_mean) out_mean[p] = cnt > 0 ? (float)(c + ms) : (float)nan;
     if (out_count) out_count[p] = cnt;
     if (out_moments) store_moments(out_moments, mom64, Pn, p, cnt, c, S, Q);
+    if constexpr (PLUS) {
+        // median and std planes of the final survivors v[a .. b), same definitions as the rich kernel (nanmedian: mean of the
+        // two middle values; nanstd: two passes - a column of identical survivors gives exactly 0, which the running S / Q,
+        // updated by subtraction, cannot guarantee)
+        if (prm.median) {
+            float m1, m2;
+            pick_middle<NP>(v, (a + b - 1) >> 1, (a + b) >> 1, m1, m2);
+            prm.median[p] = cnt > 0 ? (float)(((double)m1 + (double)m2) / 2.0) : (float)nan;
+        }
+        if (prm.std) {
+            // one wave-uniform test per slot even for full stacks: the scalar branches keep the two passes as 64 short blocks
+            // (as one straight-line block the register allocator keeps every converted value alive: 256 VGPRs + scratch)
+            int nslots = ns;
+            asm volatile("" : "+s"(nslots));
+            double s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                if (i >= nslots) continue;
+                const bool in = (i >= a) && (i < b);
+                s1 += widen(in ? v[i] : cf) - c;             // a rejected slot contributes exactly 0
+            }
+            const double mm = s1 / nf;
+            double q1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                if (i >= nslots) continue;
+                const bool in = (i >= a) && (i < b);
+                const double dd = (widen(v[i]) - c) - mm;
+                const double d = in ? dd : 0.0;
+                q1 = fma(d, d, q1);
+            }
+            prm.std[p] = cnt > 0 ? (float)sqrt(q1 > 0.0 ? q1 / nf : 0.0) : (float)nan;
+        }
+    }
 }
 
 // Rich reduction: the lean algorithm with (a) mad_std as an alternative deviation, (b) the median and

@@ -47,8 +47,8 @@ def test_apcalibrate_files_golden(tmp_path):
     assert 'BZERO' not in hdr and 'BSCALE' not in hdr
     assert hdr.history()[-1].startswith('Processed by ApCalibrate ')
     assert_biteq(fitsio.read(str(nf))[0], g['nflat_64x64'], 'normalised flat file')
-    with pytest.raises(RuntimeError):
-        cal.calibrate(src('raw'), str(out), 2, None, True)           # cosmic rays: out of scope, loud
+    cal.calibrate(src('raw'), str(out), 2, None, True)               # --fixcosmic: L.A.Cosmic after the repair (test_gpu_lacosmic.py)
+    assert fitsio.read(str(out))[1]['CR_CLEAN'] is True
     with pytest.raises(RuntimeError):
         ap.ApCalibrate(src('bias'), str(tmp_path / 'missing.fits'), None, None, 'CRITICAL')
 
