@@ -22,6 +22,13 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _aligned16(t):
+    """A contiguous tensor whose storage starts on a 16-byte boundary (the vectorised kernels require it): a frame cut out
+    of a slab with an odd pixel count is copied once."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -451,7 +458,7 @@ def threshold_mask(data, lothresh=0.0, hithresh=0.0, thresholds=None):
     Returns (mask uint8, nbad int64[1] device tensor)."""
     _need_cuda(data, thresholds)
     lib = _lib.load()
-    data = _f32c(data, 'data')
+    data = _aligned16(_f32c(data, 'data'))
     mask = torch.empty(data.shape, dtype=torch.uint8, device=data.device)
     nbad = torch.empty(1, dtype=torch.int64, device=data.device)
     if thresholds is not None and (thresholds.dtype != torch.float64 or thresholds.numel() < 2):
@@ -518,6 +525,7 @@ def imarith(a, op, b):
             check(_lib.load().apgpu_imarith_f64(_ptr(a), adt, None, APGPU_F64, float(b), opi, _ptr(out), a.numel(), _stream()))
         return out
     dt = _raw_dtype(a)
+    a = _aligned16(a)
     out = torch.empty_like(a)
     if torch.is_tensor(b):
         _need_cuda(b)
@@ -525,7 +533,7 @@ def imarith(a, op, b):
             raise RuntimeError('Error, the dimension of the second data array does not match the first.')
         if _raw_dtype(b) != dt:
             raise TypeError('operands must have the same dtype')
-        b = b.contiguous()
+        b = _aligned16(b)
         check(_lib.load().apgpu_imarith(_ptr(a), _ptr(b), 0.0, opi, dt, _ptr(out), a.numel(), _stream()))
     else:
         check(_lib.load().apgpu_imarith(_ptr(a), None, float(b), opi, dt, _ptr(out), a.numel(), _stream()))

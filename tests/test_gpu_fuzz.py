@@ -177,3 +177,23 @@ def test_fused_division_guards_on_the_sorted_column(ops, apref, N):
         assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, f'guards N={N}')
     med = ops.stack_median(d, calib=calib)
     assert_ulp(med.cpu().numpy(), apref.stack_median(cal).astype(np.float32), 1, f'median guards N={N}')
+
+
+def test_frames_cut_out_of_an_odd_sized_slab(ops, apref):
+    """ApCalibrate.calibrate_files hands cal[i] of an [N, H, W] slab to the per-frame kernels; with H * W % 4 != 0 every
+    frame after the first starts off a 16-byte boundary (image arithmetic, threshold mask, bad-pixel repair)."""
+    rng = np.random.default_rng(17)
+    H, W = 37, 53
+    slab = torch.from_numpy(rng.normal(500, 20, (3, H, W)).astype(np.float32)).cuda()
+    other = torch.from_numpy(rng.normal(5, 1, (3, H, W)).astype(np.float32)).cuda()
+    mask = (rng.random((H, W)) < 0.03).astype(np.uint8)
+    for i in range(3):
+        assert (slab[i].data_ptr() % 16 != 0) == (i * H * W * 4 % 16 != 0)
+        out = ops.imarith(slab[i], 'SUB', other[i])
+        assert np.array_equal(out.cpu().numpy(), slab[i].cpu().numpy() - other[i].cpu().numpy())
+        m, nbad = ops.threshold_mask(slab[i], 480.0, 520.0)
+        ref = ((slab[i].cpu().numpy() < np.float32(480)) | (slab[i].cpu().numpy() > np.float32(520)))
+        assert np.array_equal(m.cpu().numpy().astype(bool), ref) and int(nbad.item()) == int(ref.sum())
+        fixed, st = ops.fix_badpix(slab[i], torch.from_numpy(mask).cuda(), 2)
+        rf, _ = apref.fix_badpix(slab[i].cpu().numpy(), mask, 2)
+        assert np.array_equal(fixed.cpu().numpy(), rf, equal_nan=True)
