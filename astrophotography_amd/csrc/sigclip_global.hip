@@ -12,8 +12,8 @@
 // tree, so the tree is reproduced exactly (bit-exact statistics -> bit-exact bad-pixel mask):
 //     np.sum      = sequential float32 fold of 8192-element pieces, each piece a pairwise tree over
 //                   128-element leaves with 8 strided accumulators  (numpy loops_utils.h.src)
-//     np.median   = exact order statistic (radix select on order-preserving keys, 4 x 8-bit passes);
-//                   even count -> float32(a + b) / 2
+//     np.median   = exact order statistic (radix select on order-preserving keys, 11-bit digits: 3 levels for
+//                   float32, 6 for float64); even count -> float32(a + b) / 2
 //     np.var      = mean = sum / float32(n); float32 sum of (x - mean)^2; float32(float64(sum) / n)
 //     bounds      = float64 (np.float32 * python float promotes to float64 under numpy 1.26), demoted
 //                   to float32 when compared with the float32 array
@@ -22,8 +22,9 @@
 //
 // Everything runs on the stream without host synchronisation: the iteration count is a launch-time
 // constant and a device-side `done` flag turns the remaining iterations into no-ops.
-// Traffic: ~9 reads + 1 write of the surviving values per iteration (67 MB at 4096^2 - resident in the
-// 256 MB Infinity Cache after the first pass).
+// Traffic per iteration (float32): 3 fused statistics reads (each one select level, the first two also one of numpy's
+// sums), the tile count and the compaction (1 read + 1 write) - 5 reads + 1 write of the surviving values, 67 MB at
+// 4096^2 and resident in the 256 MB Infinity Cache after the first pass; 9 launches (round 1: 10 reads, 20 launches).
 #include "common.h"
 
 namespace {
@@ -34,33 +35,39 @@ constexpr int kTile = 2048;            // elements per compaction tile (8 per th
 constexpr int kPiece = 8192;           // numpy reduction buffer
 constexpr int kLeaf = 128;             // numpy PW_BLOCKSIZE
 constexpr int kMaxItersCap = 32;
+constexpr int kDigit = 11;             // radix-select digit: float32 keys in 3 levels (11 + 11 + 10 bits), float64 in 6
+constexpr int kBins = 1 << kDigit;
+constexpr int kScanBlock = 512;        // workgroup of the fused statistics passes (8 wavefronts, one 8192-element piece each)
+constexpr unsigned kSkip = 0xffffffffu;
 
 // T = float : float32 data, numpy float32 statistics (float32 darks / flats)
 // T = double: float64 data and statistics - what numpy computes for INTEGER images (np.median/np.var of
 //             a uint16 array run in float64; the host widens integer images exactly) and for float64 data.
-struct GState {
+struct IterState {
     long long m;                // survivors in the current buffer
-    long long m_next;
-    long long k;                // rank searched by the radix select
-    unsigned long long cnt_less;
-    unsigned long long prefix;          // key prefix found so far
-    unsigned long long max_less_key;    // order-preserving key of max{x < v_hi}
-    unsigned long long min_key, max_key;    // extremes of the survivors (final pass)
-    int done;                   // set when an iteration removed nothing
+    int cur;                    // index (0/1) of the buffer holding them
+    int done;                   // set when an iteration removed nothing: its statistics are final
     int iter;                   // iterations executed
-    int cur;                    // index (0/1) of the buffer holding the survivors
     int pad;
+};
+
+struct GState {
+    IterState it[2];            // it[i & 1] is read by iteration i and written by iteration i - 1's tile scan
+    long long k;                // rank searched by the radix select (relative to the current prefix)
+    unsigned long long prefix;          // key prefix found so far
+    unsigned long long max_below;       // largest key below every key that shares the prefix (last level)
+    unsigned long long min_key, max_key;    // extremes of the survivors
     double tot;                 // np.sum of the survivors          (holds a float32 value when T = float)
     double s2;                  // np.sum((x - mean)^2)
     double med, sd;
     double lo, hi;
-    unsigned hist[256];
+    unsigned hist[kBins];
 };
 
 template <typename T> struct KeyOf;
 template <> struct KeyOf<float> {
     using type = unsigned;
-    static constexpr int passes = 4;
+    static constexpr int bits = 32;
     __device__ static unsigned to(float x)
     {
         const unsigned b = __float_as_uint(x);
@@ -75,7 +82,7 @@ template <> struct KeyOf<float> {
 };
 template <> struct KeyOf<double> {
     using type = unsigned long long;
-    static constexpr int passes = 8;
+    static constexpr int bits = 64;
     __device__ static unsigned long long to(double x)
     {
         const unsigned long long b = (unsigned long long)__double_as_longlong(x);
@@ -87,12 +94,22 @@ template <> struct KeyOf<double> {
         return __longlong_as_double((long long)b);
     }
 };
+template <typename T> constexpr int key_levels() { return (KeyOf<T>::bits + kDigit - 1) / kDigit; }
+// level l looks at key bits [shift, shift + width)
+template <typename T> __host__ __device__ constexpr int level_shift(int l)
+{
+    return KeyOf<T>::bits - kDigit * (l + 1) > 0 ? KeyOf<T>::bits - kDigit * (l + 1) : 0;
+}
+template <typename T> __host__ __device__ constexpr int level_width(int l)
+{
+    return l < key_levels<T>() - 1 ? kDigit : KeyOf<T>::bits - kDigit * (key_levels<T>() - 1);
+}
 
 template <typename T> __device__ __forceinline__ bool is_finite(T x) { return fabs((double)x) < __builtin_inf(); }
 
 // ---- order-preserving compaction: tile counts -> scan -> scatter -------------------------------
 // mode 0: keep finite values of `data` (length n, host-known); mode 1: keep lo <= x <= hi of the
-// current survivors (length st->m).
+// current survivors (iteration state `slot`).
 template <int MODE, typename T>
 __device__ __forceinline__ bool keep_pred(T x, T lof, T hif)
 {
@@ -102,23 +119,36 @@ __device__ __forceinline__ bool keep_pred(T x, T lof, T hif)
 
 template <int MODE, typename T>
 __global__ __launch_bounds__(kBlock) void tile_count_kernel(const T *__restrict__ src0, const T *__restrict__ src1,
-                                                           long long n_static, const GState *__restrict__ st,
+                                                           long long n_static, const GState *__restrict__ st, int slot,
                                                            unsigned *__restrict__ tile_counts)
 {
-    if (MODE == 1 && st->done) return;
-    const T *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
-    const long long m = (MODE == 0) ? n_static : st->m;
+    const IterState s = st->it[slot];
+    if (MODE == 1 && s.done) return;
+    const T *src = (MODE == 0) ? src0 : (s.cur ? src1 : src0);
+    const long long m = (MODE == 0) ? n_static : s.m;
     // float32: the float64 bounds are demoted to float32 for the comparison, as numpy 1.26 does
     const T lof = (T)st->lo, hif = (T)st->hi;
     const long long ntiles = (m + kTile - 1) / kTile;
     __shared__ unsigned wsum[kBlock / kWave];
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T x[V]; };
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = tile * kTile + (long long)threadIdx.x * 8;
         unsigned c = 0;
+        if (aligned && base + 8 <= m) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const long long i = base + j;
-            if (i < m) c += keep_pred<MODE, T>(src[i], lof, hif) ? 1u : 0u;
+            for (int j = 0; j < 8 / V; j++) {
+                const Vec v = reinterpret_cast<const Vec *>(src + base)[j];
+#pragma unroll
+                for (int q = 0; q < V; q++) c += keep_pred<MODE, T>(v.x[q], lof, hif) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const long long i = base + j;
+                if (i < m) c += keep_pred<MODE, T>(src[i], lof, hif) ? 1u : 0u;
+            }
         }
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) c += __shfl_down(c, d);
@@ -129,13 +159,21 @@ __global__ __launch_bounds__(kBlock) void tile_count_kernel(const T *__restrict_
     }
 }
 
+// Exclusive scan of the tile counts; publishes the NEXT iteration's state (slot ^ 1) - there is no separate commit
+// kernel - and resets the per-iteration extremes.  Runs (as a copy) even when the iteration is a no-op, so that the
+// state a later iteration or the final pass reads is always current.
 template <int MODE>
-__global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GState *__restrict__ st,
+__global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GState *__restrict__ st, int slot,
                                                         const unsigned *__restrict__ tile_counts,
                                                         unsigned long long *__restrict__ tile_offsets)
 {
-    if (MODE == 1 && st->done) return;
-    const long long m = (MODE == 0) ? n_static : st->m;
+    const IterState s = st->it[slot];
+    IterState *next = MODE == 0 ? &st->it[0] : &st->it[slot ^ 1];
+    if (MODE == 1 && s.done) {
+        if (threadIdx.x == 0) *next = s;
+        return;
+    }
+    const long long m = (MODE == 0) ? n_static : s.m;
     const long long ntiles = (m + kTile - 1) / kTile;
     const long long per = (ntiles + 1023) / 1024;
     const long long t0 = (long long)threadIdx.x * per;
@@ -157,34 +195,69 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
         tile_offsets[t] = run;
         run += tile_counts[t];
     }
-    if (threadIdx.x == 1023) st->m_next = (long long)sums[1023];
+    if (threadIdx.x == 1023) {
+        const long long m_next = (long long)sums[1023];
+        IterState nx;
+        nx.pad = 0;
+        if (MODE == 0) {
+            nx.m = m_next; nx.cur = 0; nx.done = 0; nx.iter = 0;
+            st->lo = __builtin_nan("");
+            st->hi = __builtin_nan("");
+        } else if (m_next == s.m) {             // nothing removed: survivors stay in buffer `cur`, statistics are final
+            nx.m = s.m; nx.cur = s.cur; nx.done = 1; nx.iter = s.iter + 1;
+        } else {
+            nx.m = m_next; nx.cur = s.cur ^ 1; nx.done = 0; nx.iter = s.iter + 1;
+            st->min_key = ~0ull;                // extremes are gathered again by the next first-level pass
+            st->max_key = 0;
+        }
+        if (MODE == 0) { st->min_key = ~0ull; st->max_key = 0; }
+        *next = nx;
+    }
 }
 
 template <int MODE, typename T>
 __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(const T *__restrict__ src0, const T *__restrict__ src1,
                                                              T *__restrict__ dst0, T *__restrict__ dst1,
-                                                             long long n_static, const GState *__restrict__ st,
+                                                             long long n_static, const GState *__restrict__ st, int slot,
                                                              const unsigned long long *__restrict__ tile_offsets)
 {
-    if (MODE == 1 && st->done) return;
-    const T *src = (MODE == 0) ? src0 : (st->cur ? src1 : src0);
-    T *dst = (MODE == 0) ? dst0 : (st->cur ? dst0 : dst1);
-    const long long m = (MODE == 0) ? n_static : st->m;
+    const IterState s = st->it[slot];
+    if (MODE == 1 && (s.done || st->it[slot ^ 1].done)) return;     // nothing to remove: no copy
+    const T *src = (MODE == 0) ? src0 : (s.cur ? src1 : src0);
+    T *dst = (MODE == 0) ? dst0 : (s.cur ? dst0 : dst1);
+    const long long m = (MODE == 0) ? n_static : s.m;
     const T lof = (T)st->lo, hif = (T)st->hi;
     const long long ntiles = (m + kTile - 1) / kTile;
     __shared__ unsigned wsum[kBlock / kWave];
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T x[V]; };
+    const bool aligned = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long base = tile * kTile + (long long)threadIdx.x * 8;
         T x[8];
         bool kp[8];
         unsigned c = 0;
+        if (aligned && base + 8 <= m) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const long long i = base + j;
-            x[j] = i < m ? src[i] : (T)0;
-            kp[j] = (i < m) && keep_pred<MODE, T>(x[j], lof, hif);
-            c += kp[j] ? 1u : 0u;
+            for (int j = 0; j < 8 / V; j++) {
+                const Vec v = reinterpret_cast<const Vec *>(src + base)[j];
+#pragma unroll
+                for (int q = 0; q < V; q++) x[j * V + q] = v.x[q];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                kp[j] = keep_pred<MODE, T>(x[j], lof, hif);
+                c += kp[j] ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const long long i = base + j;
+                x[j] = i < m ? src[i] : (T)0;
+                kp[j] = (i < m) && keep_pred<MODE, T>(x[j], lof, hif);
+                c += kp[j] ? 1u : 0u;
+            }
         }
         // exclusive scan of c over the block: wave inclusive scan + wave totals
         unsigned inc = c;
@@ -198,216 +271,24 @@ __global__ __launch_bounds__(kBlock) void tile_scatter_kernel(const T *__restric
         unsigned woff = 0;
         for (int w = 0; w < wave; w++) woff += wsum[w];
         unsigned long long pos = tile_offsets[tile] + woff + (inc - c);
+        if (c == 8 && (pos % V) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (kp[j]) dst[pos++] = x[j];
+            for (int j = 0; j < 8 / V; j++) {
+                Vec v;
+#pragma unroll
+                for (int q = 0; q < V; q++) v.x[q] = x[j * V + q];
+                reinterpret_cast<Vec *>(dst + pos)[j] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (kp[j]) dst[pos++] = x[j];
+        }
         __syncthreads();
     }
 }
 
-// commit a compaction: MODE 0 initialises the state, MODE 1 closes a clipping iteration
-template <int MODE>
-__global__ void commit_kernel(GState *st)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (MODE == 0) {
-        st->m = st->m_next;
-        st->cur = 0;
-        st->done = 0;
-        st->iter = 0;
-        st->lo = __builtin_nan("");
-        st->hi = __builtin_nan("");
-        for (int i = 0; i < 256; i++) st->hist[i] = 0;
-    } else {
-        if (st->done) return;
-        st->iter += 1;
-        if (st->m_next == st->m) st->done = 1;      // nothing removed: survivors stay in buffer `cur`
-        else { st->m = st->m_next; st->cur ^= 1; }
-    }
-}
-
-// ---- exact median: radix select ------------------------------------------------------------------
-__global__ void select_begin_kernel(GState *st, int final_pass)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!final_pass && st->done) return;
-    st->k = st->m / 2;              // upper median rank (0-based); odd m: the median itself
-    st->prefix = 0;
-    st->cnt_less = 0;
-    st->max_less_key = 0;
-    st->min_key = ~0ull;
-    st->max_key = 0;
-}
-
-// Visits src[0 .. m) with 16-byte loads where the pointer allows it (grid-stride over vectors, scalar tail).
-template <typename T, typename F>
-__device__ __forceinline__ void for_each_value(const T *__restrict__ src, long long m, F f)
-{
-    constexpr int V = 16 / sizeof(T);
-    struct alignas(16) Vec { T x[V]; };
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nthreads = (long long)gridDim.x * blockDim.x;
-    long long done = 0;
-    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const long long nvec = m / V;
-        constexpr int U = 4;                                // 4 x 16 bytes in flight per lane: these scans run with few,
-        long long i = tid;                                  // fat workgroups and are latency-bound otherwise
-        for (; i + (U - 1) * nthreads < nvec; i += U * nthreads) {
-            Vec v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) v[u] = reinterpret_cast<const Vec *>(src)[i + u * nthreads];
-#pragma unroll
-            for (int u = 0; u < U; u++)
-#pragma unroll
-                for (int k = 0; k < V; k++) f(v[u].x[k]);
-        }
-        for (; i < nvec; i += nthreads) {
-            const Vec v = reinterpret_cast<const Vec *>(src)[i];
-#pragma unroll
-            for (int k = 0; k < V; k++) f(v.x[k]);
-        }
-        done = nvec * V;
-    }
-    for (long long i = done + tid; i < m; i += nthreads) f(src[i]);
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void hist_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
-                                                     GState *__restrict__ st, int pass, int final_pass)
-{
-    using K = KeyOf<T>;
-    if (!final_pass && st->done) return;
-    const T *src = st->cur ? b1 : b0;
-    const long long m = st->m;
-    const int shift = 8 * (K::passes - 1 - pass);
-    const typename K::type prefix = (typename K::type)st->prefix;
-    __shared__ unsigned h[256];
-    h[threadIdx.x] = 0;
-    __syncthreads();
-    for_each_value<T>(src, m, [&](T x) {
-        const typename K::type key = K::to(x);
-        const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
-        const unsigned d = (unsigned)(key >> shift) & 0xffu;
-        // A dark frame's values share their leading digits: nearly every lane of a wave hits the same bin and
-        // the LDS atomics serialise.  Up to 4 rounds of "leader adds the population count of its digit",
-        // then plain atomics for whatever is left (the spread-out low digits).
-        unsigned long long todo = __ballot(match);
-        for (int round = 0; round < 4 && todo; round++) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const unsigned dl = (unsigned)__shfl((int)d, leader);
-            const unsigned long long same = __ballot(match && d == dl) & todo;
-            if ((int)(threadIdx.x % kWave) == leader) atomicAdd(&h[dl], (unsigned)__popcll(same));
-            todo &= ~same;
-        }
-        if ((todo >> (threadIdx.x % kWave)) & 1ull) atomicAdd(&h[d], 1u);
-    });
-    __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&st->hist[threadIdx.x], h[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void select_digit_kernel(GState *st, int final_pass)
-{
-    // one lane per bin: exclusive prefix over the 256 counts in LDS, the lane whose interval holds rank k wins
-    if (blockIdx.x != 0) return;
-    if (!final_pass && st->done) return;
-    __shared__ long long cum[257];
-    __shared__ int digit;
-    const int t = threadIdx.x;
-    const long long c = st->hist[t];
-    cum[t + 1] = c;
-    if (t == 0) { cum[0] = 0; digit = 255; }
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {                     // Hillis-Steele inclusive scan over cum[1..256]
-        const long long add = (t + 1 - d >= 1) ? cum[t + 1 - d] : 0;
-        __syncthreads();
-        cum[t + 1] += add;
-        __syncthreads();
-    }
-    const long long k = st->k;
-    if (k >= cum[t] && k < cum[t + 1]) digit = t;           // at most one lane (intervals are disjoint)
-    st->hist[t] = 0;
-    __syncthreads();
-    if (t == 0) {
-        const int d = digit;
-        st->k = k - cum[d];
-        st->prefix = (st->prefix << 8) | (unsigned long long)d;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void less_stats_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
-                                                           GState *__restrict__ st, int final_pass)
-{
-    using K = KeyOf<T>;
-    if (!final_pass && st->done) return;
-    const T *src = st->cur ? b1 : b0;
-    const long long m = st->m;
-    const unsigned long long vkey = st->prefix;
-    unsigned cnt = 0;
-    unsigned long long mx = 0, lo = ~0ull, hi = 0;
-    for_each_value<T>(src, m, [&](T x) {
-        const unsigned long long key = K::to(x);
-        if (key < vkey) { cnt++; mx = key > mx ? key : mx; }
-        lo = key < lo ? key : lo;
-        hi = key > hi ? key : hi;
-    });
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        cnt += __shfl_down(cnt, d);
-        const unsigned long long o = __shfl_down(mx, d);
-        mx = o > mx ? o : mx;
-        const unsigned long long l2 = __shfl_down(lo, d), h2 = __shfl_down(hi, d);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    // block-level combine in LDS: one set of global atomics per workgroup, not per wave
-    __shared__ unsigned s_cnt[kBlock / kWave];
-    __shared__ unsigned long long s_mx[kBlock / kWave], s_lo[kBlock / kWave], s_hi[kBlock / kWave];
-    const int wave = threadIdx.x / kWave;
-    if ((threadIdx.x % kWave) == 0) {
-        s_cnt[wave] = cnt;
-        s_mx[wave] = mx;
-        s_lo[wave] = lo;
-        s_hi[wave] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long c = 0;
-        for (int w = 0; w < kBlock / kWave; w++) {
-            c += s_cnt[w];
-            mx = s_mx[w] > mx ? s_mx[w] : mx;
-            lo = s_lo[w] < lo ? s_lo[w] : lo;
-            hi = s_hi[w] > hi ? s_hi[w] : hi;
-        }
-        if (c) {
-            atomicAdd(&st->cnt_less, c);
-            atomicMax(&st->max_less_key, mx);
-        }
-        if (final_pass && hi >= lo) {
-            atomicMin(&st->min_key, lo);
-            atomicMax(&st->max_key, hi);
-        }
-    }
-}
-
-template <typename T>
-__global__ void median_finish_kernel(GState *st, int final_pass)
-{
-    using K = KeyOf<T>;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!final_pass && st->done) return;
-    const long long m = st->m;
-    if (m <= 0) { st->med = __builtin_nan(""); return; }
-    const T vhi = K::from(st->prefix);
-    if (m & 1) { st->med = (double)vhi; return; }
-    const long long k2 = m / 2;
-    // rank k2-1 holds vhi again if fewer than k2 values are strictly below vhi
-    const T vlo = ((long long)st->cnt_less <= k2 - 1) ? vhi : K::from(st->max_less_key);
-    const T t = vlo + vhi;                                  // np.mean of the two middle values, in T
-    st->med = (double)(T)((double)t / 2.0);
-}
-
-// ---- numpy float32 pairwise sums --------------------------------------------------------------------
+// ---- numpy pairwise sums --------------------------------------------------------------------------
 template <int SQ, typename T>
 __device__ __forceinline__ T tr(T x, T mean)
 {
@@ -476,120 +357,331 @@ __device__ T one_leaf(const T *a, int n, T mean)
 }
 
 template <typename T>
-__device__ __forceinline__ T var_mean(const GState *st)
+__device__ __forceinline__ T var_mean(const GState *st, long long m)
 {
-    return (T)st->tot / (T)st->m;           // np.var: arrmean = true_divide(sum, n) in the array's dtype
+    return (T)st->tot / (T)m;               // np.var: arrmean = true_divide(sum, n) in the array's dtype
 }
 
-template <int SQ, typename T>
-__global__ __launch_bounds__(kBlock) void piece_sums_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
-                                                           const GState *__restrict__ st, T *__restrict__ piece_sums,
-                                                           int final_pass)
+// ---- fused statistics pass ---------------------------------------------------------------------------
+// One read of the survivors does one level of the radix select (exact median) and, on the first two levels, one of
+// numpy's two sums:
+//     level 0:  histogram of the top 11 key bits          + piece sums of x              (+ min / max key)
+//     level 1:  histogram of the next 11 bits (prefix)    + piece sums of (x - mean)^2
+//     level 2+: histogram of the next digit               (last level: + largest key below the prefix, for the lower
+//                                                           middle element of an even count)
+// so an iteration reads its data 3 (float32) or 6 (float64) times for the statistics instead of 7 or 11.
+// A wavefront owns an 8192-element piece and a lane one 128-element leaf of it (numpy's order); the lane's digits
+// are run-length coded before they go to the LDS histogram, because a dark frame's values share their leading
+// digits and 64 lanes adding to one bin serialise.
+// KIND: 0 first level, 1 middle, 2 last.
+template <typename T, int SUM, int KIND>
+__global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ b0, const T *__restrict__ b1,
+                                                         GState *__restrict__ st, T *__restrict__ piece_sums, int slot, int level)
 {
-    if (!final_pass && st->done) return;
-    const T *src = st->cur ? b1 : b0;
-    const long long m = st->m;
-    const T mean = SQ ? var_mean<T>(st) : (T)0;
+    using K = KeyOf<T>;
+    using KT = typename K::type;
+    const IterState s = st->it[slot];
+    if (s.done) return;
+    const T *src = s.cur ? b1 : b0;
+    const long long m = s.m;
+    const T mean = SUM == 2 ? var_mean<T>(st, m) : (T)0;
+    const int shift = level_shift<T>(level), width = level_width<T>(level);
+    const KT prefix = (KT)st->prefix;
+    const unsigned dmask = (1u << width) - 1u;
+    __shared__ unsigned h[kBins];
+    for (int t = threadIdx.x; t < kBins; t += kScanBlock) h[t] = 0;
+    __syncthreads();
     const long long npieces_full = m / kPiece;
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    const int wpb = kBlock / kWave;
+    constexpr int wpb = kScanBlock / kWave;
+    // Lane (g, k) = (lane / 8, lane % 8) owns numpy's accumulator k of the leaves 8g .. 8g+7 of the piece, one leaf per
+    // round: a load instruction then reads 8 runs of 32 (64) contiguous bytes and a cache line is used up within 4 (2)
+    // consecutive loads - a lane walking a whole leaf on its own would keep 64 lines per wavefront alive and thrash
+    // the 32 KB vector cache.
+    const int g = lane / 8, kacc = lane % 8;
+    unsigned cur_d = kSkip, cur_n = 0;
+    KT below = 0, kmin = ~(KT)0, kmax = 0;
     for (long long piece = (long long)blockIdx.x * wpb + wave; piece < npieces_full; piece += (long long)gridDim.x * wpb) {
-        T s = leaf_sum<SQ, T>(src + piece * kPiece + lane * kLeaf, kLeaf, mean);
+        const T *pbase = src + piece * kPiece + (long long)(8 * g) * kLeaf + kacc;
+        T sleaf[8];
 #pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const T other = __shfl_xor(s, d);
-            s = (lane & d) ? other + s : s + other;
+        for (int j = 0; j < 8; j++) {
+            const T *a = pbase + j * kLeaf;
+            T x[kLeaf / 8];
+#pragma unroll
+            for (int i = 0; i < kLeaf / 8; i++) x[i] = a[8 * i];
+            if constexpr (SUM != 0) {
+                T r = tr<SUM == 2, T>(x[0], mean);
+#pragma unroll
+                for (int i = 1; i < kLeaf / 8; i++) r = r + tr<SUM == 2, T>(x[i], mean);
+                r = r + __shfl_xor(r, 1);                       // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                sleaf[j] = r;
+            }
+#pragma unroll
+            for (int i = 0; i < kLeaf / 8; i++) {
+                const KT key = K::to(x[i]);
+                unsigned d;
+                if constexpr (KIND == 0) {
+                    d = (unsigned)(key >> shift);
+                    kmin = key < kmin ? key : kmin;
+                    kmax = key > kmax ? key : kmax;
+                } else {
+                    const KT top = key >> (shift + width);
+                    d = top == prefix ? ((unsigned)(key >> shift) & dmask) : kSkip;
+                    if constexpr (KIND == 2)
+                        if (top < prefix) below = key > below ? key : below;
+                }
+                if (d != cur_d) {
+                    if (cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
+                    cur_d = d;
+                    cur_n = 0;
+                }
+                cur_n++;
+            }
         }
-        if (lane == 0) piece_sums[piece] = s;
+        if constexpr (SUM != 0) {
+            // the balanced tree over the 64 leaves: leaves 8g .. 8g+7 in registers, then across the 8 lane groups
+            T sum = ((sleaf[0] + sleaf[1]) + (sleaf[2] + sleaf[3])) + ((sleaf[4] + sleaf[5]) + (sleaf[6] + sleaf[7]));
+            sum = sum + __shfl_xor(sum, 8);
+            sum = sum + __shfl_xor(sum, 16);
+            sum = sum + __shfl_xor(sum, 32);
+            if (lane == 0) piece_sums[piece] = sum;
+        }
+    }
+    if (cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
+    __syncthreads();
+    for (int t = threadIdx.x; t < kBins; t += kScanBlock)
+        if (h[t]) atomicAdd(&st->hist[t], h[t]);
+    if constexpr (KIND == 0 || KIND == 2) {
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            if constexpr (KIND == 0) {
+                const KT l2 = __shfl_down(kmin, d), h2 = __shfl_down(kmax, d);
+                kmin = l2 < kmin ? l2 : kmin;
+                kmax = h2 > kmax ? h2 : kmax;
+            } else {
+                const KT o = __shfl_down(below, d);
+                below = o > below ? o : below;
+            }
+        }
+        if (lane == 0) {
+            if constexpr (KIND == 0) {
+                if (kmax >= kmin) {
+                    atomicMin(&st->min_key, (unsigned long long)kmin);
+                    atomicMax(&st->max_key, (unsigned long long)kmax);
+                }
+            } else {
+                if (below) atomicMax(&st->max_below, (unsigned long long)below);
+            }
+        }
     }
 }
 
-template <int SQ, typename T>
-__global__ void fold_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
-                            const T *__restrict__ piece_sums, int final_pass)
+// Closes a statistics pass (one workgroup): the ragged last piece (its sums and its histogram share), the sequential
+// fold of the piece sums in numpy's order, the digit of the searched rank - and on the last level the median and, inside
+// a clipping iteration, the bounds.
+template <typename T, int SUM, int KIND>
+__global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
+                                                      const T *__restrict__ piece_sums, int slot, int level, int final_pass,
+                                                      double sigma_lower, double sigma_upper)
 {
-    // one workgroup: the piece sums are accumulated sequentially (numpy's order), but fetched by all
-    // lanes into LDS first - a lone lane walking global memory pays a full miss latency per piece
+    using K = KeyOf<T>;
+    using KT = typename K::type;
     if (blockIdx.x != 0) return;
-    if (!final_pass && st->done) return;
-    const T *src = st->cur ? b1 : b0;
-    const long long m = st->m;
-    const T mean = SQ ? var_mean<T>(st) : (T)0;
+    const IterState s = st->it[slot];
+    if (s.done) return;
+    const T *src = s.cur ? b1 : b0;
+    const long long m = s.m;
+    const T mean = SUM == 2 ? var_mean<T>(st, m) : (T)0;
+    const int shift = level_shift<T>(level), width = level_width<T>(level);
+    const KT prefix = (KT)st->prefix;
+    const unsigned dmask = (1u << width) - 1u;
     const long long npieces_full = m / kPiece;
+    const int rem = (int)(m - npieces_full * kPiece);
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+
+    __shared__ unsigned h[kBins];
+    __shared__ T ragged[kPiece];
+    __shared__ unsigned long long sh_below, sh_min, sh_max;
+    __shared__ long long sh_newk;
+    __shared__ int sh_digit, sh_dlow;
+    for (int t = threadIdx.x; t < kBins; t += kBlock) {
+        h[t] = st->hist[t];
+        st->hist[t] = 0;                            // ready for the next pass
+    }
+    for (int t = threadIdx.x; t < rem; t += kBlock) ragged[t] = src[npieces_full * kPiece + t];
+    if (threadIdx.x == 0) { sh_below = 0; sh_min = ~0ull; sh_max = 0; sh_digit = 0; sh_dlow = -1; sh_newk = 0; }
+    __syncthreads();
+    // the ragged piece's share of the histogram and of the extremes
+    {
+        unsigned long long below = 0, kmin = ~0ull, kmax = 0;
+        for (int t = threadIdx.x; t < rem; t += kBlock) {
+            const KT key = K::to(ragged[t]);
+            if constexpr (KIND == 0) {
+                atomicAdd(&h[(unsigned)(key >> shift)], 1u);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+            } else {
+                const KT top = key >> (shift + width);
+                if (top == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
+                if constexpr (KIND == 2)
+                    if (top < prefix) below = key > below ? key : below;
+            }
+        }
+        if constexpr (KIND == 0) {
+            if (kmax >= kmin) { atomicMin(&sh_min, kmin); atomicMax(&sh_max, kmax); }
+        } else if constexpr (KIND == 2) {
+            if (below) atomicMax(&sh_below, below);
+        }
+    }
+    __syncthreads();
+
+    // digit of the searched rank: wavefront 1 scans the histogram (32 bins per lane) while lane 0 of wavefront 0 folds
+    auto scan_digit = [&]() {
+        const long long k = KIND == 0 ? m / 2 : st->k;      // upper median rank (0-based); odd m: the median itself
+        unsigned long long c = 0;
+        constexpr int per = kBins / kWave;
+#pragma unroll 4
+        for (int j = 0; j < per; j++) c += h[lane * per + j];
+        unsigned long long inc = c;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        const unsigned long long exc = inc - c;
+        int dlow = -1;
+        const bool mine = (unsigned long long)k >= exc && (unsigned long long)k < inc;
+        int digit = -1;
+        if (mine) {
+            unsigned long long run = exc;
+            for (int j = 0; j < per; j++) {
+                const unsigned cnt = h[lane * per + j];
+                if ((unsigned long long)k < run + cnt) { digit = lane * per + j; sh_newk = k - (long long)run; break; }
+                if (cnt) dlow = lane * per + j;
+                run += cnt;
+            }
+            sh_digit = digit;
+        } else if ((unsigned long long)k >= inc) {
+            for (int j = per - 1; j >= 0; j--)
+                if (h[lane * per + j]) { dlow = lane * per + j; break; }
+        }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const int o = __shfl_down(dlow, d);
+            dlow = o > dlow ? o : dlow;
+        }
+        if (lane == 0) sh_dlow = dlow;                      // highest occupied bin below the digit (-1: none)
+    };
+
     constexpr int kStage = 2048;
     __shared__ T stage[kStage];
     T res = 0;
-    for (long long i0 = 0; i0 < npieces_full; i0 += kStage) {
-        const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
-        for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int t = 0;
-            for (; t + 8 <= cnt; t += 8) {                  // 8 LDS reads in flight, then the 8 ordered adds
-                T x[8];
+    bool scanned = false;
+    if constexpr (SUM != 0) {
+        for (long long i0 = 0; i0 < npieces_full; i0 += kStage) {
+            const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
+            for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int t = 0;
+                for (; t + 8 <= cnt; t += 8) {              // 8 LDS reads in flight, then the 8 ordered adds
+                    T x[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) x[k] = stage[t + k];
+                    for (int k = 0; k < 8; k++) x[k] = stage[t + k];
 #pragma unroll
-                for (int k = 0; k < 8; k++) res = res + x[k];
+                    for (int k = 0; k < 8; k++) res = res + x[k];
+                }
+                for (; t < cnt; t++) res = res + stage[t];
             }
-            for (; t < cnt; t++) res = res + stage[t];
-        }
-        __syncthreads();
-    }
-    const int rem = (int)(m - npieces_full * kPiece);
-    if (rem > 0) {
-        __shared__ LeafList ll;
-        __shared__ T leaf_vals[256];
-        if (threadIdx.x == 0) {
-            ll.n = 0;
-            enumerate_leaves(ll, 0, rem);
-        }
-        __syncthreads();
-        // the ragged piece goes through LDS as well: a leaf is up to 128 elements walked by one lane
-        __shared__ T ragged[kPiece];
-        for (int t = threadIdx.x; t < rem; t += blockDim.x) ragged[t] = src[npieces_full * kPiece + t];
-        __syncthreads();
-        const T *tail = ragged;
-        for (int l = threadIdx.x; l < ll.n; l += blockDim.x) leaf_vals[l] = one_leaf<SQ, T>(tail + ll.off[l], ll.len[l], mean);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int next = 0;
-            res = res + combine_leaves<T>(leaf_vals, next, rem);
+            if (wave == 1 && !scanned) scan_digit();
+            scanned = true;
+            __syncthreads();
         }
     }
+    if (!scanned && wave == 1) scan_digit();
+    if constexpr (SUM != 0) {
+        if (rem > 0) {
+            __shared__ LeafList ll;
+            __shared__ T leaf_vals[256];
+            if (threadIdx.x == 0) {
+                ll.n = 0;
+                enumerate_leaves(ll, 0, rem);
+            }
+            __syncthreads();
+            for (int l = threadIdx.x; l < ll.n; l += blockDim.x)
+                leaf_vals[l] = one_leaf<SUM == 2, T>(ragged + ll.off[l], ll.len[l], mean);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int next = 0;
+                res = res + combine_leaves<T>(leaf_vals, next, rem);
+            }
+        }
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
-    if (SQ) {
+    if constexpr (SUM == 1) st->tot = (double)res;
+    if constexpr (SUM == 2) {
         st->s2 = (double)res;
         const T var = (T)((double)res / (double)m);         // ret.dtype.type(ret / rcount)
         st->sd = (double)(T)sqrt((double)var);              // sqrt of a T value rounded to T (exact for float32 via float64)
-    } else {
-        st->tot = (double)res;
+    }
+    if constexpr (KIND == 0) {
+        st->max_below = 0;
+        if (sh_max >= sh_min) { atomicMin(&st->min_key, sh_min); atomicMax(&st->max_key, sh_max); }
+    }
+    const unsigned long long newprefix = KIND == 0 ? (unsigned long long)sh_digit
+                                                   : (((unsigned long long)prefix << width) | (unsigned long long)sh_digit);
+    st->prefix = newprefix;
+    st->k = sh_newk;
+    if constexpr (KIND == 2) {
+        if (m <= 0) {
+            st->med = __builtin_nan("");
+        } else {
+            const T vhi = K::from(newprefix);
+            if (m & 1) {
+                st->med = (double)vhi;
+            } else {
+                // rank m/2 - 1: the same key again if the searched rank is not the first of its bin; otherwise the highest
+                // occupied lower bin of this prefix, otherwise the largest key below the prefix
+                T vlo;
+                if (sh_newk >= 1) vlo = vhi;
+                else if (sh_dlow >= 0) vlo = K::from(((unsigned long long)prefix << width) | (unsigned long long)sh_dlow);
+                else {
+                    const unsigned long long gb = st->max_below, lb = sh_below;
+                    vlo = K::from(gb > lb ? gb : lb);
+                }
+                const T t = vlo + vhi;                      // np.mean of the two middle values, in T
+                st->med = (double)(T)((double)t / 2.0);
+            }
+        }
+        if (!final_pass) {
+            if (m <= 0) { st->lo = st->hi = __builtin_nan(""); }
+            else {
+                // SigmaClip._compute_bounds: float32 scalars * python float -> float64 (numpy 1.26)
+                st->lo = st->med - st->sd * sigma_lower;
+                st->hi = st->med + st->sd * sigma_upper;
+            }
+        }
     }
 }
 
-__global__ void bounds_kernel(GState *st, double sigma_lower, double sigma_upper)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->done) return;
-    if (st->m <= 0) { st->lo = st->hi = __builtin_nan(""); return; }
-    // SigmaClip._compute_bounds: float32 scalars * python float -> float64 (numpy 1.26)
-    st->lo = st->med - st->sd * sigma_lower;
-    st->hi = st->med + st->sd * sigma_upper;
-}
-
 template <typename T>
-__global__ void publish_kernel(const GState *st, double *out)
+__global__ void publish_kernel(const GState *st, int slot, double *out)
 {
     using K = KeyOf<T>;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const long long m = st->m;
+    const IterState s = st->it[slot];
+    const long long m = s.m;
     const double nan = __builtin_nan("");
     out[0] = m > 0 ? (double)(T)(st->tot / (double)m) : nan;        // np.mean: T(float64(sum) / n)
     out[1] = m > 0 ? st->med : nan;
     out[2] = m > 0 ? st->sd : nan;
     out[3] = st->lo;
     out[4] = st->hi;
-    out[5] = (double)st->iter;
+    out[5] = (double)s.iter;
     out[6] = (double)m;
     out[7] = m > 0 ? (double)K::from(st->min_key) : nan;
     out[8] = m > 0 ? (double)K::from(st->max_key) : nan;
@@ -620,7 +712,6 @@ template <typename T>
 int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, double sigma_upper, int maxiters, double *stats_out,
                        void *ws, size_t ws_bytes, void *stream)
 {
-    using K = KeyOf<T>;
     if (!data || !stats_out || !ws) return fail(APGPU_EINVAL, "sigclip_global: NULL pointer argument");
     if (n_pixels <= 0) return fail(APGPU_EINVAL, "sigclip_global: n_pixels = %lld", (long long)n_pixels);
     if (maxiters == 0) return fail(APGPU_EINVAL, "sigclip_global: maxiters must be >= 1 or < 0");
@@ -641,46 +732,48 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     const long long n = n_pixels;
     const long long ntiles = (n + kTile - 1) / kTile;
     const unsigned gtile = (unsigned)(ntiles < kNumCU * 8 ? ntiles : kNumCU * 8);
-    const unsigned gflat = (unsigned)((n + kBlock - 1) / kBlock < kNumCU * 8 ? (n + kBlock - 1) / kBlock : kNumCU * 8);
-    // histogram / rank scans end in global atomics per workgroup: fewer, fatter workgroups (16-byte loads)
-    const unsigned gscan = gflat < kNumCU * 2 ? gflat : kNumCU * 2;
-    const unsigned gpiece = (unsigned)((n / kPiece) / (kBlock / kWave) + 1 < kNumCU * 8 ? (n / kPiece) / (kBlock / kWave) + 1 : kNumCU * 8);
+    // statistics passes: one piece per wavefront, at most two workgroups per CU (each ends in up to 2048 global atomics)
+    constexpr int wpb = kScanBlock / kWave;
+    const long long wg_pieces = (n / kPiece + wpb - 1) / wpb;
+    const unsigned gpass = (unsigned)(wg_pieces < 1 ? 1 : (wg_pieces < kNumCU * 2 ? wg_pieces : kNumCU * 2));
+    constexpr int levels = key_levels<T>();
 
     if (hipMemsetAsync(st, 0, sizeof(GState), s) != hipSuccess) return fail(APGPU_ELAUNCH, "sigclip_global: memset failed");
     // finite values of data -> buffer 0
-    hipLaunchKernelGGL((tile_count_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, n, st, tcounts);
-    hipLaunchKernelGGL(tile_scan_kernel<0>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
-    hipLaunchKernelGGL((tile_scatter_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, toffs);
-    hipLaunchKernelGGL(commit_kernel<0>, dim3(1), dim3(64), 0, s, st);
+    hipLaunchKernelGGL((tile_count_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, n, st, 0, tcounts);
+    hipLaunchKernelGGL(tile_scan_kernel<0>, dim3(1), dim3(1024), 0, s, n, st, 0, tcounts, toffs);
+    hipLaunchKernelGGL((tile_scatter_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, 0, toffs);
     if (int rc = check_launch("sigclip_global: compact finite")) return rc;
 
-    auto stats_pass = [&](int final_pass) {
-        hipLaunchKernelGGL(select_begin_kernel, dim3(1), dim3(64), 0, s, st, final_pass);
-        for (int pass = 0; pass < K::passes; pass++) {
-            hipLaunchKernelGGL(hist_kernel<T>, dim3(gscan), dim3(kBlock), 0, s, b0, b1, st, pass, final_pass);
-            hipLaunchKernelGGL(select_digit_kernel, dim3(1), dim3(256), 0, s, st, final_pass);
+    auto stats_pass = [&](int slot, int final_pass) {
+        hipLaunchKernelGGL((pass_kernel<T, 1, 0>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 0);
+        hipLaunchKernelGGL((after_kernel<T, 1, 0>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 0, final_pass, sigma_lower,
+                           sigma_upper);
+        hipLaunchKernelGGL((pass_kernel<T, 2, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 1);
+        hipLaunchKernelGGL((after_kernel<T, 2, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 1, final_pass, sigma_lower,
+                           sigma_upper);
+        for (int level = 2; level < levels - 1; level++) {
+            hipLaunchKernelGGL((pass_kernel<T, 0, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, level);
+            hipLaunchKernelGGL((after_kernel<T, 0, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, level, final_pass,
+                               sigma_lower, sigma_upper);
         }
-        hipLaunchKernelGGL(less_stats_kernel<T>, dim3(gscan), dim3(kBlock), 0, s, b0, b1, st, final_pass);
-        hipLaunchKernelGGL(median_finish_kernel<T>, dim3(1), dim3(64), 0, s, st, final_pass);
-        hipLaunchKernelGGL((piece_sums_kernel<0, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL((fold_kernel<0, T>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL((piece_sums_kernel<1, T>), dim3(gpiece), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
-        hipLaunchKernelGGL((fold_kernel<1, T>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, final_pass);
+        hipLaunchKernelGGL((pass_kernel<T, 0, 2>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, levels - 1);
+        hipLaunchKernelGGL((after_kernel<T, 0, 2>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, levels - 1, final_pass,
+                           sigma_lower, sigma_upper);
     };
 
     for (int it = 0; it < iters; it++) {
-        stats_pass(0);
-        hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(64), 0, s, st, sigma_lower, sigma_upper);
-        hipLaunchKernelGGL((tile_count_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, tcounts);
-        hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), 0, s, n, st, tcounts, toffs);
-        hipLaunchKernelGGL((tile_scatter_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, toffs);
-        hipLaunchKernelGGL(commit_kernel<1>, dim3(1), dim3(64), 0, s, st);
+        const int slot = it & 1;
+        stats_pass(slot, 0);
+        hipLaunchKernelGGL((tile_count_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, slot, tcounts);
+        hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), 0, s, n, st, slot, tcounts, toffs);
+        hipLaunchKernelGGL((tile_scatter_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, slot, toffs);
         if (int rc = check_launch("sigclip_global: iteration")) return rc;
     }
-    // statistics of the survivors (the last iteration's statistics belong to the pre-clip set unless
-    // it removed nothing)
-    stats_pass(1);
-    hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, stats_out);
+    // statistics of the survivors: the last iteration's statistics belong to the pre-clip set unless it removed nothing
+    // (state `done`), in which case they are final already and these launches return at once
+    stats_pass(iters & 1, 1);
+    hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, iters & 1, stats_out);
     return check_launch("sigclip_global: publish");
 }
 

@@ -659,3 +659,40 @@ def test_stack_three_quarter_slot_sizes(ops, apref, N):
     assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, f'u16 N={N}')
     assert_ulp(host(ops.stack_median(dev(u16, ops), calib=calib)), apref.stack_median(calu).astype(np.float32),
                0 if N % 2 else 1, f'u16 median N={N}')
+
+
+def test_sigclip_global_median_neighbours(ops, apref):
+    """Even counts need the two middle order statistics; the radix select finds the upper one and takes the lower one from
+    (a) the same key, (b) a lower bin of the last digit, (c) a different prefix altogether.  Crafted float32 / float64 columns
+    for each case, at sizes with and without full 8192-element pieces, no clipping (sigma 1e300) and with clipping."""
+    rng = np.random.default_rng(2024)
+
+    def check(x, what):
+        for sigma, maxiters in ((1e300, 1), (3.0, 5)):
+            ref = apref.sigclip_global(x, sigma=sigma, maxiters=maxiters)
+            s = host(ops.sigclip_global(torch.from_numpy(x).cuda(), sigma=sigma, maxiters=maxiters))
+            got = [s[0], s[1], s[2]] if x.dtype == np.float64 else [np.float32(v) for v in s[:3]]
+            want = [ref['mean'], ref['median'], ref['std']] if x.dtype == np.float64 else [np.float32(ref[k]) for k in ('mean', 'median', 'std')]
+            assert got == want, (what, sigma, got, want)
+            assert int(s[6]) == ref['nkeep'] and int(s[5]) == ref['niter'], (what, sigma)
+
+    for dt, it, low_bits in ((np.float32, np.uint32, 10), (np.float64, np.uint64, 9)):
+        base = np.array([1.5], dt).view(it)[0]
+        aligned = it(int(base) >> low_bits << low_bits)            # smallest key of its last-digit group
+        for n in (2, 6, 1000, 8192, 8192 * 3, 8192 * 3 + 10, 40001 * 2):
+            half = n // 2
+            # (a) the middle pair is one repeated value
+            x = np.concatenate([rng.uniform(0.5, 1.0, half - 1), np.full(2, 1.25), rng.uniform(1.5, 2.0, n - half - 1)]).astype(dt)
+            check(rng.permutation(x), (dt.__name__, n, 'same key'))
+            # (b) lower neighbour a few ulps down, inside the same last-digit group
+            hi = np.array([int(aligned) + 7], it).view(dt)[0]
+            lo = np.array([int(aligned) + 2], it).view(dt)[0]
+            x = np.concatenate([rng.uniform(0.5, 1.0, half - 1), [lo, hi], rng.uniform(1.6, 2.0, n - half - 1)]).astype(dt)
+            check(rng.permutation(x), (dt.__name__, n, 'lower bin'))
+            # (c) the upper middle value is the first key of its group: the lower one lives under another prefix
+            hi = np.array([int(aligned)], it).view(dt)[0]
+            x = np.concatenate([rng.uniform(-1.0, 1.0, half), [hi], rng.uniform(1.6, 2.0, n - half - 1)]).astype(dt)
+            check(rng.permutation(x), (dt.__name__, n, 'other prefix'))
+            # negative / mixed-sign medians and constant data
+            check(rng.permutation(np.concatenate([rng.uniform(-3, -1, half), rng.uniform(-1, 4, n - half)]).astype(dt)), (dt.__name__, n, 'mixed'))
+            check(np.full(n, -2.75, dt), (dt.__name__, n, 'constant'))
