@@ -39,6 +39,7 @@ constexpr int kDigit = 11;             // radix-select digit: float32 keys in 3 
 constexpr int kBins = 1 << kDigit;
 constexpr int kScanBlock = 512;        // workgroup of the fused statistics passes (8 wavefronts, one 8192-element piece each)
 constexpr unsigned kSkip = 0xffffffffu;
+constexpr int kMaxPassGroups = kNumCU * 2;  // workgroups of a statistics pass
 
 // T = float : float32 data, numpy float32 statistics (float32 darks / flats)
 // T = double: float64 data and statistics - what numpy computes for INTEGER images (np.median/np.var of
@@ -55,13 +56,13 @@ struct GState {
     IterState it[2];            // it[i & 1] is read by iteration i and written by iteration i - 1's tile scan
     long long k;                // rank searched by the radix select (relative to the current prefix)
     unsigned long long prefix;          // key prefix found so far
-    unsigned long long max_below;       // largest key below every key that shares the prefix (last level)
     unsigned long long min_key, max_key;    // extremes of the survivors
     double tot;                 // np.sum of the survivors          (holds a float32 value when T = float)
     double s2;                  // np.sum((x - mean)^2)
     double med, sd;
     double lo, hi;
     unsigned hist[kBins];
+    unsigned long long wg_lo[kMaxPassGroups], wg_hi[kMaxPassGroups];   // per-workgroup extremes of a statistics pass
 };
 
 template <typename T> struct KeyOf;
@@ -180,16 +181,22 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
     const long long t1 = t0 + per < ntiles ? t0 + per : ntiles;
     unsigned long long local = 0;
     for (long long t = t0; t < t1; t++) local += tile_counts[t];
+    // inclusive scan over the 1024 partials: wavefront scan + 16 wavefront totals
+    __shared__ unsigned long long wtot[1024 / kWave];
     __shared__ unsigned long long sums[1024];
-    sums[threadIdx.x] = local;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int d = 1; d < 1024; d <<= 1) {
-        unsigned long long v = threadIdx.x >= d ? sums[threadIdx.x - d] : 0ull;
-        __syncthreads();
-        sums[threadIdx.x] += v;
-        __syncthreads();
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    unsigned long long inc = local;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
     }
+    if (lane == kWave - 1) wtot[wave] = inc;
+    __syncthreads();
+    unsigned long long woff = 0;
+    for (int w = 0; w < wave; w++) woff += wtot[w];
+    sums[threadIdx.x] = inc + woff;
+    __syncthreads();
     unsigned long long run = sums[threadIdx.x] - local;
     for (long long t = t0; t < t1; t++) {
         tile_offsets[t] = run;
@@ -207,10 +214,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
             nx.m = s.m; nx.cur = s.cur; nx.done = 1; nx.iter = s.iter + 1;
         } else {
             nx.m = m_next; nx.cur = s.cur ^ 1; nx.done = 0; nx.iter = s.iter + 1;
-            st->min_key = ~0ull;                // extremes are gathered again by the next first-level pass
-            st->max_key = 0;
         }
-        if (MODE == 0) { st->min_key = ~0ull; st->max_key = 0; }
         *next = nx;
     }
 }
@@ -294,66 +298,6 @@ __device__ __forceinline__ T tr(T x, T mean)
 {
     if constexpr (SQ) { const T d = x - mean; return d * d; }
     else return x;
-}
-
-template <int SQ, typename T>
-__device__ T leaf_sum(const T *a, int n, T mean)
-{
-    T r[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = tr<SQ, T>(a[k], mean);
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ, T>(a[i + k], mean);
-    }
-    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + tr<SQ, T>(a[i], mean);
-    return res;
-}
-
-// numpy's recursion for a ragged piece (n < 8192; depth <= 7), split in two walks so that the leaves -
-// which are independent - can be summed by different lanes: enumerate the leaves, sum them in parallel,
-// then combine the leaf sums in the recursion's order.
-struct LeafList {
-    int off[256], len[256];
-    int n;
-};
-
-__device__ void enumerate_leaves(LeafList &ll, int off, int n)
-{
-    if (n < 8 || n <= kLeaf) {
-        ll.off[ll.n] = off;
-        ll.len[ll.n] = n;
-        ll.n++;
-        return;
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    enumerate_leaves(ll, off, n2);
-    enumerate_leaves(ll, off + n2, n - n2);
-}
-
-template <typename T>
-__device__ T combine_leaves(const T *vals, int &next, int n)
-{
-    if (n < 8 || n <= kLeaf) return vals[next++];
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const T l = combine_leaves<T>(vals, next, n2);
-    const T r = combine_leaves<T>(vals, next, n - n2);
-    return l + r;
-}
-
-template <int SQ, typename T>
-__device__ T one_leaf(const T *a, int n, T mean)
-{
-    if (n < 8) {
-        T res = 0;
-        for (int i = 0; i < n; i++) res = res + tr<SQ, T>(a[i], mean);
-        return res;
-    }
-    return leaf_sum<SQ, T>(a, n, mean);
 }
 
 template <typename T>
@@ -455,6 +399,7 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
     for (int t = threadIdx.x; t < kBins; t += kScanBlock)
         if (h[t]) atomicAdd(&st->hist[t], h[t]);
     if constexpr (KIND == 0 || KIND == 2) {
+        // extremes: one slot per workgroup, reduced by after_kernel (thousands of atomics on one address serialise)
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) {
             if constexpr (KIND == 0) {
@@ -466,17 +411,48 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
                 below = o > below ? o : below;
             }
         }
+        __shared__ KT w_lo[wpb], w_hi[wpb];
         if (lane == 0) {
-            if constexpr (KIND == 0) {
-                if (kmax >= kmin) {
-                    atomicMin(&st->min_key, (unsigned long long)kmin);
-                    atomicMax(&st->max_key, (unsigned long long)kmax);
-                }
-            } else {
-                if (below) atomicMax(&st->max_below, (unsigned long long)below);
+            w_lo[wave] = kmin;
+            w_hi[wave] = KIND == 0 ? kmax : below;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            KT lo = w_lo[0], hi = w_hi[0];
+            for (int w = 1; w < wpb; w++) {
+                lo = w_lo[w] < lo ? w_lo[w] : lo;
+                hi = w_hi[w] > hi ? w_hi[w] : hi;
             }
+            // widened so that "nothing seen" stays ~0 / 0 for both key widths
+            st->wg_lo[blockIdx.x] = (KIND == 0 && hi >= lo) ? (unsigned long long)lo : ~0ull;
+            st->wg_hi[blockIdx.x] = (KIND == 2 || hi >= lo) ? (unsigned long long)hi : 0ull;
         }
     }
+}
+
+// LDS index of element i of the ragged piece: one pad word per 64 elements, so that lanes walking different leaves
+// (starts 64 .. 128 elements apart) do not all sit on one bank.
+__device__ __forceinline__ int ridx(int i) { return i + (i >> 6); }
+
+template <int SQ, typename T>
+__device__ T ragged_leaf(const T *rag, int off, int n, T mean)
+{
+    if (n < 8) {
+        T res = 0;
+        for (int i = 0; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
+        return res;
+    }
+    T r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = tr<SQ, T>(rag[ridx(off + k)], mean);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ, T>(rag[ridx(off + i + k)], mean);
+    }
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
+    return res;
 }
 
 // Closes a statistics pass (one workgroup): the ragged last piece (its sums and its histogram share), the sequential
@@ -485,7 +461,7 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
 template <typename T, int SUM, int KIND>
 __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
                                                       const T *__restrict__ piece_sums, int slot, int level, int final_pass,
-                                                      double sigma_lower, double sigma_upper)
+                                                      int ngroups, double sigma_lower, double sigma_upper)
 {
     using K = KeyOf<T>;
     using KT = typename K::type;
@@ -503,37 +479,48 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
 
     __shared__ unsigned h[kBins];
-    __shared__ T ragged[kPiece];
-    __shared__ unsigned long long sh_below, sh_min, sh_max;
+    __shared__ T ragged[kPiece + kPiece / 64];
+    __shared__ unsigned long long sh_lo, sh_hi;
     __shared__ long long sh_newk;
     __shared__ int sh_digit, sh_dlow;
     for (int t = threadIdx.x; t < kBins; t += kBlock) {
         h[t] = st->hist[t];
         st->hist[t] = 0;                            // ready for the next pass
     }
-    for (int t = threadIdx.x; t < rem; t += kBlock) ragged[t] = src[npieces_full * kPiece + t];
-    if (threadIdx.x == 0) { sh_below = 0; sh_min = ~0ull; sh_max = 0; sh_digit = 0; sh_dlow = -1; sh_newk = 0; }
+    for (int t = threadIdx.x; t < rem; t += kBlock) ragged[ridx(t)] = src[npieces_full * kPiece + t];
+    if (threadIdx.x == 0) { sh_lo = ~0ull; sh_hi = 0; sh_digit = 0; sh_dlow = -1; sh_newk = 0; }
     __syncthreads();
-    // the ragged piece's share of the histogram and of the extremes
-    {
-        unsigned long long below = 0, kmin = ~0ull, kmax = 0;
+    // the ragged piece's share of the histogram and of the extremes, and the workgroups' extremes
+    if constexpr (KIND == 0 || KIND == 2) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int t = threadIdx.x; t < ngroups; t += kBlock) {
+            const unsigned long long l = st->wg_lo[t], u = st->wg_hi[t];
+            lo = l < lo ? l : lo;
+            hi = u > hi ? u : hi;
+        }
         for (int t = threadIdx.x; t < rem; t += kBlock) {
-            const KT key = K::to(ragged[t]);
+            const KT key = K::to(ragged[ridx(t)]);
             if constexpr (KIND == 0) {
                 atomicAdd(&h[(unsigned)(key >> shift)], 1u);
-                kmin = key < kmin ? key : kmin;
-                kmax = key > kmax ? key : kmax;
+                lo = key < lo ? key : lo;
+                hi = key > hi ? key : hi;
             } else {
                 const KT top = key >> (shift + width);
                 if (top == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
-                if constexpr (KIND == 2)
-                    if (top < prefix) below = key > below ? key : below;
+                if (top < prefix) hi = key > hi ? key : hi;
             }
         }
-        if constexpr (KIND == 0) {
-            if (kmax >= kmin) { atomicMin(&sh_min, kmin); atomicMax(&sh_max, kmax); }
-        } else if constexpr (KIND == 2) {
-            if (below) atomicMax(&sh_below, below);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const unsigned long long l2 = __shfl_down(lo, d), h2 = __shfl_down(hi, d);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) { atomicMin(&sh_lo, lo); atomicMax(&sh_hi, hi); }
+    } else {
+        for (int t = threadIdx.x; t < rem; t += kBlock) {
+            const KT key = K::to(ragged[ridx(t)]);
+            if ((key >> (shift + width)) == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
         }
     }
     __syncthreads();
@@ -554,16 +541,14 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
         const unsigned long long exc = inc - c;
         int dlow = -1;
         const bool mine = (unsigned long long)k >= exc && (unsigned long long)k < inc;
-        int digit = -1;
         if (mine) {
             unsigned long long run = exc;
             for (int j = 0; j < per; j++) {
                 const unsigned cnt = h[lane * per + j];
-                if ((unsigned long long)k < run + cnt) { digit = lane * per + j; sh_newk = k - (long long)run; break; }
+                if ((unsigned long long)k < run + cnt) { sh_digit = lane * per + j; sh_newk = k - (long long)run; break; }
                 if (cnt) dlow = lane * per + j;
                 run += cnt;
             }
-            sh_digit = digit;
         } else if ((unsigned long long)k >= inc) {
             for (int j = per - 1; j >= 0; j--)
                 if (h[lane * per + j]) { dlow = lane * per + j; break; }
@@ -577,7 +562,8 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
     };
 
     constexpr int kStage = 2048;
-    __shared__ T stage[kStage];
+    constexpr int kBatch = 32;
+    __shared__ __attribute__((aligned(16))) T stage[kStage];
     T res = 0;
     bool scanned = false;
     if constexpr (SUM != 0) {
@@ -586,13 +572,26 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
             for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
             __syncthreads();
             if (threadIdx.x == 0) {
+                // the one serial chain of the algorithm (numpy adds the pieces in order): 32 values per batch in
+                // registers, the next batch's LDS reads issued before the current batch's dependent adds
+                T cur[kBatch], nxt[kBatch];
                 int t = 0;
-                for (; t + 8 <= cnt; t += 8) {              // 8 LDS reads in flight, then the 8 ordered adds
-                    T x[8];
+                if (cnt >= kBatch) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) x[k] = stage[t + k];
+                    for (int k = 0; k < kBatch; k++) cur[k] = stage[k];
+                    for (; t + kBatch <= cnt; t += kBatch) {
+                        const bool more = t + 2 * kBatch <= cnt;
+                        if (more) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) res = res + x[k];
+                            for (int k = 0; k < kBatch; k++) nxt[k] = stage[t + kBatch + k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < kBatch; k++) res = res + cur[k];
+                        if (more) {
+#pragma unroll
+                            for (int k = 0; k < kBatch; k++) cur[k] = nxt[k];
+                        }
+                    }
                 }
                 for (; t < cnt; t++) res = res + stage[t];
             }
@@ -604,20 +603,41 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
     if (!scanned && wave == 1) scan_digit();
     if constexpr (SUM != 0) {
         if (rem > 0) {
-            __shared__ LeafList ll;
-            __shared__ T leaf_vals[256];
-            if (threadIdx.x == 0) {
-                ll.n = 0;
-                enumerate_leaves(ll, 0, rem);
+            // numpy's recursion over the ragged piece, in parallel: every 64th element descends the split tree to its leaf
+            // (leaves are 64 .. 128 elements long, so each leaf is found by the thread at the first multiple of 64 inside
+            // it), the leaves are summed side by side, and the tree is folded level by level, deepest first; a node's value
+            // lives in the slot of the thread that owns its leftmost leaf.
+            __shared__ T vals[kPiece / 64];
+            const int t = threadIdx.x;
+            const int p = t * 64;
+            const bool valid = t < kPiece / 64 && p < rem;
+            int off = 0, n = rem;
+            int path_off[8], path_n[8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const bool internal = valid && n > kLeaf;
+                path_off[d] = off;
+                path_n[d] = internal ? n : 0;
+                if (internal) {
+                    int n2 = n / 2;
+                    n2 -= n2 % 8;
+                    if (p < off + n2) n = n2;
+                    else { off += n2; n -= n2; }
+                }
             }
+            const bool owner = valid && (off + 63) / 64 == t;
+            if (owner) vals[t] = ragged_leaf<SUM == 2, T>(ragged, off, n, mean);
             __syncthreads();
-            for (int l = threadIdx.x; l < ll.n; l += blockDim.x)
-                leaf_vals[l] = one_leaf<SUM == 2, T>(ragged + ll.off[l], ll.len[l], mean);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int next = 0;
-                res = res + combine_leaves<T>(leaf_vals, next, rem);
+#pragma unroll
+            for (int d = 7; d >= 0; d--) {
+                if (owner && path_n[d] > 0 && path_off[d] == off) {
+                    int n2 = path_n[d] / 2;
+                    n2 -= n2 % 8;
+                    vals[t] = vals[t] + vals[(path_off[d] + n2 + 63) / 64];
+                }
+                __syncthreads();
             }
+            if (threadIdx.x == 0) res = res + vals[0];
         }
     }
     __syncthreads();
@@ -629,8 +649,8 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
         st->sd = (double)(T)sqrt((double)var);              // sqrt of a T value rounded to T (exact for float32 via float64)
     }
     if constexpr (KIND == 0) {
-        st->max_below = 0;
-        if (sh_max >= sh_min) { atomicMin(&st->min_key, sh_min); atomicMax(&st->max_key, sh_max); }
+        st->min_key = sh_lo;
+        st->max_key = sh_hi;
     }
     const unsigned long long newprefix = KIND == 0 ? (unsigned long long)sh_digit
                                                    : (((unsigned long long)prefix << width) | (unsigned long long)sh_digit);
@@ -649,10 +669,7 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
                 T vlo;
                 if (sh_newk >= 1) vlo = vhi;
                 else if (sh_dlow >= 0) vlo = K::from(((unsigned long long)prefix << width) | (unsigned long long)sh_dlow);
-                else {
-                    const unsigned long long gb = st->max_below, lb = sh_below;
-                    vlo = K::from(gb > lb ? gb : lb);
-                }
+                else vlo = K::from(sh_hi);
                 const T t = vlo + vhi;                      // np.mean of the two middle values, in T
                 st->med = (double)(T)((double)t / 2.0);
             }
@@ -747,19 +764,19 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
 
     auto stats_pass = [&](int slot, int final_pass) {
         hipLaunchKernelGGL((pass_kernel<T, 1, 0>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 0);
-        hipLaunchKernelGGL((after_kernel<T, 1, 0>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 0, final_pass, sigma_lower,
-                           sigma_upper);
+        hipLaunchKernelGGL((after_kernel<T, 1, 0>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 0, final_pass, (int)gpass,
+                           sigma_lower, sigma_upper);
         hipLaunchKernelGGL((pass_kernel<T, 2, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 1);
-        hipLaunchKernelGGL((after_kernel<T, 2, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 1, final_pass, sigma_lower,
-                           sigma_upper);
+        hipLaunchKernelGGL((after_kernel<T, 2, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 1, final_pass, (int)gpass,
+                           sigma_lower, sigma_upper);
         for (int level = 2; level < levels - 1; level++) {
             hipLaunchKernelGGL((pass_kernel<T, 0, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, level);
             hipLaunchKernelGGL((after_kernel<T, 0, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, level, final_pass,
-                               sigma_lower, sigma_upper);
+                               (int)gpass, sigma_lower, sigma_upper);
         }
         hipLaunchKernelGGL((pass_kernel<T, 0, 2>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, levels - 1);
         hipLaunchKernelGGL((after_kernel<T, 0, 2>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, levels - 1, final_pass,
-                           sigma_lower, sigma_upper);
+                           (int)gpass, sigma_lower, sigma_upper);
     };
 
     for (int it = 0; it < iters; it++) {
