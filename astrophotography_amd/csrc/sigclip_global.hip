@@ -176,34 +176,49 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
     }
     const long long m = (MODE == 0) ? n_static : s.m;
     const long long ntiles = (m + kTile - 1) / kTile;
-    const long long per = (ntiles + 1023) / 1024;
-    const long long t0 = (long long)threadIdx.x * per;
-    const long long t1 = t0 + per < ntiles ? t0 + per : ntiles;
-    unsigned long long local = 0;
-    for (long long t = t0; t < t1; t++) local += tile_counts[t];
-    // inclusive scan over the 1024 partials: wavefront scan + 16 wavefront totals
+    // rounds of 4096 tiles: four consecutive counts per thread (one 16-byte load), wavefront scan, 16 wavefront totals
     __shared__ unsigned long long wtot[1024 / kWave];
-    __shared__ unsigned long long sums[1024];
+    __shared__ unsigned long long carry_s;
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    unsigned long long inc = local;
+    unsigned long long carry = 0;
+    for (long long base = 0; base < ntiles; base += 4096) {
+        const long long t0 = base + (long long)threadIdx.x * 4;
+        unsigned c[4] = {0, 0, 0, 0};
+        if (t0 + 4 <= ntiles) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(tile_counts + t0);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+        } else {
+            for (int j = 0; j < 4; j++)
+                if (t0 + j < ntiles) c[j] = tile_counts[t0 + j];
+        }
+        const unsigned long long local = (unsigned long long)c[0] + c[1] + c[2] + c[3];
+        unsigned long long inc = local;
 #pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const unsigned long long o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    if (lane == kWave - 1) wtot[wave] = inc;
-    __syncthreads();
-    unsigned long long woff = 0;
-    for (int w = 0; w < wave; w++) woff += wtot[w];
-    sums[threadIdx.x] = inc + woff;
-    __syncthreads();
-    unsigned long long run = sums[threadIdx.x] - local;
-    for (long long t = t0; t < t1; t++) {
-        tile_offsets[t] = run;
-        run += tile_counts[t];
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned long long o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == kWave - 1) wtot[wave] = inc;
+        __syncthreads();
+        unsigned long long woff = carry;
+        for (int w = 0; w < wave; w++) woff += wtot[w];
+        unsigned long long run = woff + inc - local;
+        if (t0 + 4 <= ntiles) {
+            ulonglong2 o0, o1;
+            o0.x = run; o0.y = run + c[0];
+            o1.x = o0.y + c[1]; o1.y = o1.x + c[2];
+            reinterpret_cast<ulonglong2 *>(tile_offsets + t0)[0] = o0;
+            reinterpret_cast<ulonglong2 *>(tile_offsets + t0)[1] = o1;
+        } else {
+            for (int j = 0; j < 4; j++)
+                if (t0 + j < ntiles) { tile_offsets[t0 + j] = run; run += c[j]; }
+        }
+        if (threadIdx.x == 1023) carry_s = woff + inc;
+        __syncthreads();
+        carry = carry_s;
     }
     if (threadIdx.x == 1023) {
-        const long long m_next = (long long)sums[1023];
+        const long long m_next = (long long)carry;
         IterState nx;
         nx.pad = 0;
         if (MODE == 0) {
@@ -347,54 +362,81 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
     KT below = 0, kmin = ~(KT)0, kmax = 0;
     for (long long piece = (long long)blockIdx.x * wpb + wave; piece < npieces_full; piece += (long long)gridDim.x * wpb) {
         const T *pbase = src + piece * kPiece + (long long)(8 * g) * kLeaf + kacc;
-        T sleaf[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const T *a = pbase + j * kLeaf;
-            T x[kLeaf / 8];
-#pragma unroll
-            for (int i = 0; i < kLeaf / 8; i++) x[i] = a[8 * i];
+        constexpr int E = kLeaf / 8;                            // values of one leaf per lane
+        // sum (numpy's leaf order) and bin one leaf's values
+        auto leaf = [&](const T(&x)[E]) -> T {
+            T r = 0;
             if constexpr (SUM != 0) {
-                T r = tr<SUM == 2, T>(x[0], mean);
+                r = tr<SUM == 2, T>(x[0], mean);
 #pragma unroll
-                for (int i = 1; i < kLeaf / 8; i++) r = r + tr<SUM == 2, T>(x[i], mean);
+                for (int i = 1; i < E; i++) r = r + tr<SUM == 2, T>(x[i], mean);
                 r = r + __shfl_xor(r, 1);                       // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
                 r = r + __shfl_xor(r, 2);
                 r = r + __shfl_xor(r, 4);
-                sleaf[j] = r;
             }
 #pragma unroll
-            for (int i = 0; i < kLeaf / 8; i++) {
+            for (int i = 0; i < E; i++) {
                 const KT key = K::to(x[i]);
-                unsigned d;
                 if constexpr (KIND == 0) {
-                    d = (unsigned)(key >> shift);
+                    // leading digits: nearly every value of a dark frame shares them - run-length coded per lane
+                    const unsigned d = (unsigned)(key >> shift);
                     kmin = key < kmin ? key : kmin;
                     kmax = key > kmax ? key : kmax;
+                    if (d != cur_d) {
+                        if (cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
+                        cur_d = d;
+                        cur_n = 0;
+                    }
+                    cur_n++;
                 } else {
+                    // lower digits are spread out: plain LDS atomics (a constant image serialises them, at about twice
+                    // the time of the pass)
                     const KT top = key >> (shift + width);
-                    d = top == prefix ? ((unsigned)(key >> shift) & dmask) : kSkip;
+                    if (top == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
                     if constexpr (KIND == 2)
                         if (top < prefix) below = key > below ? key : below;
                 }
-                if (d != cur_d) {
-                    if (cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
-                    cur_d = d;
-                    cur_n = 0;
+            }
+            return r;
+        };
+        // Leaves 8g .. 8g+7 in four rounds of two; the next leaf's loads are in flight while the current one is processed.
+        // The round loop is NOT unrolled: fully unrolled, the compiler hoists all 128 loads (256 VGPRs and scratch).
+        T xa[E], xb[E];
+#pragma unroll
+        for (int i = 0; i < E; i++) xa[i] = pbase[8 * i];
+        T q = 0, h0 = 0, sum = 0;
+#pragma unroll 1
+        for (int pp = 0; pp < 4; pp++) {
+            const T *a1 = pbase + (2 * pp + 1) * kLeaf;
+#pragma unroll
+            for (int i = 0; i < E; i++) xb[i] = a1[8 * i];
+            const T s0 = leaf(xa);
+            if (pp < 3) {
+#pragma unroll
+                for (int i = 0; i < E; i++) xa[i] = a1[kLeaf + 8 * i];
+            }
+            const T s1 = leaf(xb);
+            if constexpr (SUM != 0) {
+                // the balanced tree over the lane group's 8 leaves: ((p0 + p1) + (p2 + p3)), p = leaf pair
+                const T pr = s0 + s1;
+                if (pp & 1) {
+                    q = q + pr;
+                    if (pp == 1) h0 = q;
+                    else sum = h0 + q;
+                } else {
+                    q = pr;
                 }
-                cur_n++;
             }
         }
         if constexpr (SUM != 0) {
-            // the balanced tree over the 64 leaves: leaves 8g .. 8g+7 in registers, then across the 8 lane groups
-            T sum = ((sleaf[0] + sleaf[1]) + (sleaf[2] + sleaf[3])) + ((sleaf[4] + sleaf[5]) + (sleaf[6] + sleaf[7]));
+            // ... then across the 8 lane groups
             sum = sum + __shfl_xor(sum, 8);
             sum = sum + __shfl_xor(sum, 16);
             sum = sum + __shfl_xor(sum, 32);
             if (lane == 0) piece_sums[piece] = sum;
         }
     }
-    if (cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
+    if (KIND == 0 && cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
     __syncthreads();
     for (int t = threadIdx.x; t < kBins; t += kScanBlock)
         if (h[t]) atomicAdd(&st->hist[t], h[t]);
