@@ -105,6 +105,7 @@ class ApMeasureBackground:
         self._imdata = None
         self._imhdr = None
         self._bgdata = None
+        self._bgdata_dev = None
         self._logger = _common.make_logger(self._name, loglevel)
 
     # -- source mask (:142-175) ---------------------------------------------------------------------
@@ -205,7 +206,7 @@ class ApMeasureBackground:
             coef = torch.from_numpy(_bspline3_prefilter(mesh)).to(data_t.device)
             bg = ops.spline_zoom(coef, bh, bw, H, W, float(mesh.min()), float(mesh.max()))
         self._bgdata_dev = bg
-        self._bgdata = bg.cpu().numpy()
+        self._bgdata = None                     # host copy on demand (get_bgimage): 8 bytes per pixel over PCIe
         self._bgmedian = float(np.median(mesh))
         self._bgmedian_rms = float(np.median(rms))
         self._logger.info(f'Estimated median background level: {self._bgmedian:.3f}+/-{self._bgmedian_rms:.3f}')
@@ -219,10 +220,16 @@ class ApMeasureBackground:
         self.process_data(data, hdr, nbg_rows, nbg_cols, min_bgheight, min_bgwidth, bg_filter_width, bg_badbox_pctile, bg_sigmaclip)
 
     def get_bgimage(self):
+        if self._bgdata is None and self._bgdata_dev is not None:
+            self._bgdata = self._bgdata_dev.cpu().numpy()
         return self._bgdata
 
+    def get_bgimage_device(self):
+        """The background image as the float64 device tensor the zoom kernel wrote (no host copy)."""
+        return self._bgdata_dev
+
     def write_bgimage(self, output_bgfits):
-        if self._bgdata is None:
+        if self._bgdata_dev is None:
             raise RuntimeError('Error, you can not write a background image before generating one using process_data or process_files.')
         hdr = self._imhdr.copy() if self._imhdr is not None else fitsio.Header()
         _common.remove_pedestal_kw(self._logger, hdr)

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restric
 // Per-box sigma-clipped statistics: one workgroup per mesh box.  astropy's SigmaClip(sigma, maxiters, median / std)
 // along the box: every pass computes the median (exact, 4-pass 8-bit radix select on order-preserving keys) and the
 // standard deviation of the current survivors and keeps lo <= x <= hi; clipping only ever shrinks the interval, so the
-// survivors of pass k are exactly the unmasked finite values inside the running [lo, hi] - no compaction, every pass
-// re-reads the box (<= 270 KB, L2-resident).  Pixels outside the image (edge_method 'pad'), masked or non-finite
+// survivors of pass k are exactly the unmasked finite values inside the running [lo, hi] - no compaction: a box of up to
+// 32768 pixels is staged in LDS once (NaN = masked) and every pass walks the LDS copy; larger boxes re-read the image.  Pixels outside the image (edge_method 'pad'), masked or non-finite
 // pixels count as masked.  Output per box (float64): median, std of the final survivors, number of survivors,
 // number of masked pixels before clipping.
 // ------------------------------------------------------------------------------------------------
@@ -165,6 +165,7 @@ __device__ __forceinline__ float box_value(const BoxView &b, int e)
     return (fabsf(x) < __builtin_inff()) ? x : __builtin_nanf("");
 }
 
+template <int NT>
 __device__ double block_sum(double v, double *scratch)
 {
 #pragma unroll
@@ -173,77 +174,131 @@ __device__ double block_sum(double v, double *scratch)
     if ((threadIdx.x % kWave) == 0) scratch[threadIdx.x / kWave] = v;
     __syncthreads();
     double t = 0.0;
-    for (int w = 0; w < kBlock / kWave; w++) t += scratch[w];    // every thread forms the same ordered sum
+    for (int w = 0; w < NT / kWave; w++) t += scratch[w];       // every thread forms the same ordered sum
     return t;
 }
 
-// k-th smallest (0-based) survivor key; survivors = values with lo <= x <= hi.
-__device__ unsigned box_select(const BoxView &b, int npix, float lo, float hi, int k, unsigned *hist)
+constexpr int kBoxDigit = 11;               // radix-select digit: 11 + 11 + 10 bits of the order-preserving float32 key
+constexpr int kBoxBins = 1 << kBoxDigit;
+constexpr int kBoxLdsPixels = 32768;        // boxes up to this many pixels are staged in LDS (128 KB of the 160 KB)
+constexpr unsigned kNoDigit = 0xffffffffu;
+
+struct DigitPick {
+    int digit;          // bin that holds the searched rank
+    unsigned cum;       // values in the bins below it
+    int dlow;           // highest occupied bin below it (-1: none)
+};
+
+// Wavefront 0 finds the bin of rank k in hist[0 .. kBoxBins) (32 bins per lane + a wavefront scan) and publishes it.
+__device__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *shared_pick)
 {
-    unsigned prefix = 0, pmask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int t = threadIdx.x; t < 256; t += kBlock) hist[t] = 0;
-        __syncthreads();
-        for (int e = threadIdx.x; e < npix; e += kBlock) {
-            const float x = box_value(b, e);
-            if (x >= lo && x <= hi) {                       // false for NaN
-                const unsigned key = f32_key(x);
-                if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-            }
+    if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        constexpr int per = kBoxBins / kWave;
+        unsigned tot = 0;
+        for (int j = 0; j < per; j++) tot += hist[lane * per + j];
+        unsigned inc = tot;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
         }
-        __syncthreads();
-        // every thread walks the 256 bins (LDS broadcast reads) and finds the digit holding rank k
-        int digit = 0;
-        unsigned cum = 0;
-        for (int d = 0; d < 256; d++) {
-            const unsigned h = hist[d];
-            if (cum + h > (unsigned)k) {
-                digit = d;
-                break;
+        const unsigned exc = inc - tot;
+        int dlow = -1;
+        if (k >= exc && k < inc) {
+            unsigned run = exc;
+            for (int j = 0; j < per; j++) {
+                const unsigned c = hist[lane * per + j];
+                if (k < run + c) { shared_pick->digit = lane * per + j; shared_pick->cum = run; break; }
+                if (c) dlow = lane * per + j;
+                run += c;
             }
-            cum += h;
+        } else if (k >= inc) {
+            for (int j = per - 1; j >= 0; j--)
+                if (hist[lane * per + j]) { dlow = lane * per + j; break; }
         }
-        k -= (int)cum;
-        prefix |= (unsigned)digit << shift;
-        pmask |= 255u << shift;
-        __syncthreads();
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const int o = __shfl_down(dlow, d);
+            dlow = o > dlow ? o : dlow;
+        }
+        if (lane == 0) shared_pick->dlow = dlow;
     }
-    return prefix;
+    __syncthreads();
+    const DigitPick r = *shared_pick;
+    __syncthreads();
+    return r;
 }
 
-__global__ __launch_bounds__(kBlock) void box_stats_kernel(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
-                                                          int bh, int bw, int nx, double sigma, int maxiters,
-                                                          double *__restrict__ out)
+// NT threads per box: 256 for small boxes, 1024 for the 16 x 16 meshes of full frames (one workgroup per CU, 16 wavefronts).
+// RES: the box (<= kBoxLdsPixels pixels) is staged in LDS once, masked / outside / non-finite pixels as NaN; otherwise every
+// pass walks the image rows of the box (coalesced runs, L2 / Infinity Cache resident after the first pass).
+// Passes per clipping iteration: (a) count + sum, (b) sum of squared deviations + first select level, (c) second level,
+// (d) third level + the largest survivor below the found prefix - the lower middle element of an even count comes from the
+// last histogram or from (d)'s maximum, not from a second select.
+template <int NT, bool RES>
+__global__ __launch_bounds__(NT) void box_stats_kernel(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
+                                                      int bh, int bw, int nx, double sigma, int maxiters, double *__restrict__ out)
 {
-    __shared__ unsigned hist[256];
-    __shared__ double scratch[kBlock / kWave];
+    extern __shared__ float vals[];
+    __shared__ unsigned hist[kBoxBins];
+    __shared__ double scratch[NT / kWave];
+    __shared__ unsigned s_below[NT / kWave];
+    __shared__ DigitPick s_pick;
     BoxView b;
     b.data = data; b.mask = mask; b.H = H; b.W = W; b.bh = bh; b.bw = bw;
     const int box = blockIdx.x;
     b.r0 = (box / nx) * bh;
     b.c0 = (box % nx) * bw;
     const int npix = bh * bw;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if constexpr (RES) {
+        for (int r = wave; r < bh; r += NT / kWave)
+            for (int c = lane; c < bw; c += kWave) vals[r * bw + c] = box_value(b, r * bw + c);
+        __syncthreads();
+    }
+    // f(x) for every candidate value (RES: NaN marks the excluded ones and fails every comparison)
+    auto for_each = [&](auto f) {
+        if constexpr (RES) {
+            for (int e = threadIdx.x; e < npix; e += NT) f(vals[e]);
+        } else {
+            for (int r = wave; r < bh; r += NT / kWave) {
+                const int rr = b.r0 + r;
+                if (rr >= H) break;
+                const int64_t rowp = (int64_t)rr * W + b.c0;
+                const int cend = min(bw, W - b.c0);
+                for (int c = lane; c < cend; c += kWave) {
+                    if (mask && mask[rowp + c]) continue;
+                    f(data[rowp + c]);
+                }
+            }
+        }
+    };
+    auto zero_hist = [&]() {
+        for (int t = threadIdx.x; t < kBoxBins; t += NT) hist[t] = 0;
+        __syncthreads();
+    };
     // Working set of the clipping passes: values inside the running intersection [lo_run, hi_run] of all bounds so far
     // (astropy packs its buffer the same way).  The FINAL survivors are the values inside the LAST computed bounds
     // [lo_last, hi_last] applied to all data (astropy sigma_clipping.py:356-358: a value clipped by an earlier, tighter
     // pass can come back).  Bounds are float64 in astropy and applied to float32 data: lo <= (double)x <= hi is the
-    // same set as ceil32(lo) <= x <= floor32(hi).
-    float lo_run = -__builtin_inff(), hi_run = __builtin_inff(), lo_last = -__builtin_inff(), hi_last = __builtin_inff();
+    // same set as ceil32(lo) <= x <= floor32(hi).  Non-finite values fail lo <= x <= hi from the first pass on
+    // (+-inf only while the bounds are still infinite: excluded explicitly).
+    float lo_run = -3.4028234663852886e38f, hi_run = 3.4028234663852886e38f, lo_last = lo_run, hi_last = hi_run;
     double med = __builtin_nan(""), sd = __builtin_nan("");
     int n = 0, n_prev = -1, n_unmasked = -1;
     for (int pass = 0;; pass++) {
         const bool final_pass = pass >= maxiters || n_prev == -2;
         const float lo = final_pass ? lo_last : lo_run, hi = final_pass ? hi_last : hi_run;
         double cnt = 0.0, sum = 0.0;
-        for (int e = threadIdx.x; e < npix; e += kBlock) {
-            const float x = box_value(b, e);
+        for_each([&](float x) {
             if (x >= lo && x <= hi) {
                 cnt += 1.0;
                 sum += (double)x;
             }
-        }
-        n = (int)block_sum(cnt, scratch);
-        const double total = block_sum(sum, scratch);
+        });
+        n = (int)block_sum<NT>(cnt, scratch);
+        const double total = block_sum<NT>(sum, scratch);
         if (n_unmasked < 0) n_unmasked = n;
         if (n == 0) {
             med = sd = __builtin_nan("");
@@ -254,18 +309,72 @@ __global__ __launch_bounds__(kBlock) void box_stats_kernel(const float *__restri
             continue;
         }
         const double mean = total / (double)n;
+        const unsigned k = (unsigned)(n >> 1);              // upper middle element (the median itself for odd n)
+        // (b) spread + leading 11 key bits.  The sky values of a box share their leading digits: run-length coded per
+        // thread before they reach the LDS histogram.
+        zero_hist();
         double ss = 0.0;
-        for (int e = threadIdx.x; e < npix; e += kBlock) {
-            const float x = box_value(b, e);
+        unsigned cur_d = kNoDigit, cur_n = 0;
+        for_each([&](float x) {
             if (x >= lo && x <= hi) {
                 const double d = mean - (double)x;
                 ss += d * d;
+                const unsigned dg = f32_key(x) >> (32 - kBoxDigit);
+                if (dg != cur_d) {
+                    if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+                    cur_d = dg;
+                    cur_n = 0;
+                }
+                cur_n++;
+            }
+        });
+        if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+        sd = sqrt(block_sum<NT>(ss, scratch) / (double)n);   // (its barriers also close the histogram)
+        DigitPick pk = pick_digit(hist, k, &s_pick);
+        unsigned prefix = (unsigned)pk.digit;
+        unsigned kk = k - pk.cum;
+        // (c) next 11 bits
+        zero_hist();
+        for_each([&](float x) {
+            if (x >= lo && x <= hi) {
+                const unsigned key = f32_key(x);
+                if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & (kBoxBins - 1)], 1u);
+            }
+        });
+        __syncthreads();
+        pk = pick_digit(hist, kk, &s_pick);
+        prefix = (prefix << kBoxDigit) | (unsigned)pk.digit;
+        kk -= pk.cum;
+        // (d) last 10 bits + the largest survivor key below the 22-bit prefix
+        zero_hist();
+        unsigned below = 0;
+        for_each([&](float x) {
+            if (x >= lo && x <= hi) {
+                const unsigned key = f32_key(x);
+                const unsigned top = key >> 10;
+                if (top == prefix) atomicAdd(&hist[key & 1023u], 1u);
+                else if (top < prefix) below = key > below ? key : below;
+            }
+        });
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const unsigned o = __shfl_down(below, d);
+            below = o > below ? o : below;
+        }
+        if (lane == 0) s_below[wave] = below;
+        __syncthreads();
+        pk = pick_digit(hist, kk, &s_pick);
+        const unsigned key2 = (prefix << 10) | (unsigned)pk.digit;
+        unsigned key1 = key2;
+        if ((n & 1) == 0 && kk - pk.cum == 0) {             // rank k is the first of its key: the lower neighbour is another key
+            if (pk.dlow >= 0) key1 = (prefix << 10) | (unsigned)pk.dlow;
+            else {
+                unsigned mx = 0;
+                for (int w = 0; w < NT / kWave; w++) mx = s_below[w] > mx ? s_below[w] : mx;
+                key1 = mx;
             }
         }
-        sd = sqrt(block_sum(ss, scratch) / (double)n);
-        const float m1 = key_f32(box_select(b, npix, lo, hi, (n - 1) >> 1, hist));
-        const float m2 = (n & 1) ? m1 : key_f32(box_select(b, npix, lo, hi, n >> 1, hist));
-        med = ((double)m1 + (double)m2) / 2.0;
+        med = ((double)key_f32(key1) + (double)key_f32(key2)) / 2.0;
         if (final_pass) break;
         const double lo64 = med - sigma * sd, hi64 = med + sigma * sd;
         float lof = (float)lo64, hif = (float)hi64;
@@ -382,8 +491,27 @@ extern "C" int apgpu_box_clipped_stats_f32(const float *data, const uint8_t *mas
         return fail(APGPU_EINVAL, "box_clipped_stats: bad box size %d x %d", box_height, box_width);
     if (!(sigma >= 0.0) || maxiters < 0) return fail(APGPU_EINVAL, "box_clipped_stats: bad clip parameters");
     const int ny = (int)((height + box_height - 1) / box_height), nx = (int)((width + box_width - 1) / box_width);
-    hipLaunchKernelGGL(box_stats_kernel, dim3((unsigned)(ny * nx)), dim3(kBlock), 0, as_stream(stream), data, mask, (int)height, (int)width,
-                       box_height, box_width, nx, sigma, maxiters, stats_out);
+    const int64_t npix = (int64_t)box_height * box_width;
+    const dim3 grid((unsigned)(ny * nx));
+    hipStream_t st = as_stream(stream);
+    const int h = (int)height, w = (int)width;
+    if (npix <= 8192) {
+        hipLaunchKernelGGL((box_stats_kernel<256, true>), grid, dim3(256), (size_t)npix * sizeof(float), st, data, mask, h, w, box_height,
+                           box_width, nx, sigma, maxiters, stats_out);
+    } else if (npix <= kBoxLdsPixels) {
+        static bool raised = false;                         // above 64 KB of dynamic LDS needs the attribute once per process
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(box_stats_kernel<1024, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBoxLdsPixels * (int)sizeof(float)) != hipSuccess)
+                return fail(APGPU_ELAUNCH, "box_clipped_stats: cannot raise the dynamic LDS limit");
+            raised = true;
+        }
+        hipLaunchKernelGGL((box_stats_kernel<1024, true>), grid, dim3(1024), (size_t)npix * sizeof(float), st, data, mask, h, w, box_height,
+                           box_width, nx, sigma, maxiters, stats_out);
+    } else {
+        hipLaunchKernelGGL((box_stats_kernel<1024, false>), grid, dim3(1024), 0, st, data, mask, h, w, box_height, box_width, nx, sigma,
+                           maxiters, stats_out);
+    }
     return check_launch("box_clipped_stats");
 }
 
