@@ -262,14 +262,31 @@ __global__ __launch_bounds__(NT) void box_stats_kernel(const float *__restrict__
         if constexpr (RES) {
             for (int e = threadIdx.x; e < npix; e += NT) f(vals[e]);
         } else {
-            for (int r = wave; r < bh; r += NT / kWave) {
-                const int rr = b.r0 + r;
-                if (rr >= H) break;
-                const int64_t rowp = (int64_t)rr * W + b.c0;
-                const int cend = min(bw, W - b.c0);
-                for (int c = lane; c < cend; c += kWave) {
-                    if (mask && mask[rowp + c]) continue;
-                    f(data[rowp + c]);
+            // two rows x four 64-column chunks per trip: 16 independent loads in flight per lane (one load at a time leaves
+            // the pass bound by the Infinity Cache latency)
+            constexpr int RU = 2, CU = 4;
+            const int cend = min(bw, W - b.c0);
+            const int rend = min(bh, H - b.r0);
+            for (int r = wave * RU; r < rend; r += (NT / kWave) * RU) {
+                for (int c0 = 0; c0 < cend; c0 += CU * kWave) {
+                    float x[RU][CU];
+                    uint8_t m[RU][CU];
+#pragma unroll
+                    for (int u = 0; u < RU; u++) {
+                        const int64_t rowp = (int64_t)(b.r0 + r + u) * W + b.c0;
+#pragma unroll
+                        for (int q = 0; q < CU; q++) {
+                            const int c = c0 + q * kWave + lane;
+                            const bool in = (r + u) < rend && c < cend;
+                            m[u][q] = in ? (mask ? mask[rowp + c] : (uint8_t)0) : (uint8_t)1;
+                            x[u][q] = in ? data[rowp + c] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; u++)
+#pragma unroll
+                        for (int q = 0; q < CU; q++)
+                            if (!m[u][q]) f(x[u][q]);
                 }
             }
         }

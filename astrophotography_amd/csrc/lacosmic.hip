@@ -91,29 +91,47 @@ __global__ __launch_bounds__(kBlock) void subtract_kernel(float *__restrict__ a,
     APGPU_FOR_PIXELS(p, P) a[p] = a[p] - b[p];
 }
 
-// f = sum_k psf[k] * clean[shifted]  (7 x 7, zero outside the image), accumulated in row-major kernel order
+// f = sum_k psf[k] * clean[shifted]  (7 x 7, zero outside the image), accumulated in row-major kernel order.
+// A workgroup stages a (64 + 6) x (16 + 6) input tile in LDS (zeros outside the image: adding k * 0 leaves the running sum
+// as it is, so the tile version equals "skip the tap" bit for bit) and a lane forms 4 neighbouring outputs from 7 x 10
+// LDS values, each output its own 49-step multiply-then-add chain in the reference order.
+constexpr int kConvTW = 64, kConvTH = 16, kConvLW = kConvTW + 6 + 2;       // LDS row: 70 values + 2 pad
 __global__ __launch_bounds__(kBlock) void convolve7_kernel(const float *__restrict__ a, const float *__restrict__ psf, float *__restrict__ f,
                                                           int H, int W)
 {
-    __shared__ float k[49];
-    if (threadIdx.x < 49) k[threadIdx.x] = psf[threadIdx.x];
-    __syncthreads();
-    const int64_t P = (int64_t)H * W;
-    APGPU_FOR_PIXELS(p, P) {
-        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
-        float acc = 0.f;
+    __shared__ float tile[(kConvTH + 6) * kConvLW];
+    const int tilesx = (W + kConvTW - 1) / kConvTW, tilesy = (H + kConvTH - 1) / kConvTH;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    for (int t = blockIdx.x; t < tilesx * tilesy; t += gridDim.x) {
+        const int x0 = (t % tilesx) * kConvTW, y0 = (t / tilesx) * kConvTH;
+        __syncthreads();
+        for (int e = threadIdx.x; e < (kConvTH + 6) * (kConvTW + 6); e += kBlock) {
+            const int ly = e / (kConvTW + 6), lx = e - ly * (kConvTW + 6);
+            const int gy = y0 + ly - 3, gx = x0 + lx - 3;
+            tile[ly * kConvLW + lx] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? a[(int64_t)gy * W + gx] : 0.f;
+        }
+        __syncthreads();
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dy = -3; dy <= 3; dy++) {
-            const int rr = r + dy;
-            if (rr < 0 || rr >= H) continue;
+        for (int dy = 0; dy < 7; dy++) {
+            float row[10];
 #pragma unroll
-            for (int dx = -3; dx <= 3; dx++) {
-                const int cc = c + dx;
-                if (cc < 0 || cc >= W) continue;
-                acc = acc + k[(dy + 3) * 7 + (dx + 3)] * a[(int64_t)rr * W + cc];
+            for (int q = 0; q < 10; q++) row[q] = tile[(ty + dy) * kConvLW + 4 * tx + q];
+#pragma unroll
+            for (int dx = 0; dx < 7; dx++) {
+                const float k = psf[dy * 7 + dx];
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = acc[j] + k * row[j + dx];
             }
         }
-        f[p] = acc;
+        const int gy = y0 + ty;
+        if (gy < H) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int gx = x0 + 4 * tx + j;
+                if (gx < W) f[(int64_t)gy * W + gx] = acc[j];
+            }
+        }
     }
 }
 
@@ -132,26 +150,58 @@ __global__ __launch_bounds__(kBlock) void select_kernel(const float *__restrict_
 }
 
 // out = dilate(in) [& !mask] [& sp > thr].  SHAPE 3: 3x3 square; SHAPE 5: 5x5 without its corners.  Zero outside the image.
+// Four pixels per lane (one 16-byte read of sp, one 4-byte store); the cheap conditions come first - a grown cosmic ray also
+// has to stand above its threshold, which almost no pixel does - and only the pixels that pass look at their neighbours.
+template <int SHAPE>
+__device__ __forceinline__ bool dilate_any(const uint8_t *__restrict__ in, int64_t p, int H, int W)
+{
+    constexpr int R = SHAPE / 2;
+    const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+    bool any = false;
+#pragma unroll
+    for (int dy = -R; dy <= R; dy++)
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++) {
+            if (SHAPE == 5 && (dy == -2 || dy == 2) && (dx == -2 || dx == 2)) continue;
+            const int rr = r + dy, cc = c + dx;
+            if (rr >= 0 && rr < H && cc >= 0 && cc < W) any = any || in[(int64_t)rr * W + cc] != 0;
+        }
+    return any;
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restrict__ in, const float *__restrict__ sp, const uint8_t *__restrict__ mask,
                                                        float thr, uint8_t *__restrict__ out, int H, int W)
 {
-    constexpr int R = SHAPE / 2;
     const int64_t P = (int64_t)H * W;
-    APGPU_FOR_PIXELS(p, P) {
-        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
-        bool any = false;
-#pragma unroll
-        for (int dy = -R; dy <= R; dy++)
-#pragma unroll
-            for (int dx = -R; dx <= R; dx++) {
-                if (SHAPE == 5 && (dy == -2 || dy == 2) && (dx == -2 || dx == 2)) continue;
-                const int rr = r + dy, cc = c + dx;
-                if (rr >= 0 && rr < H && cc >= 0 && cc < W) any = any || in[(int64_t)rr * W + cc] != 0;
+    const int64_t P4 = P / 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
+    if (vec) {
+        APGPU_FOR_PIXELS(q, P4) {
+            const int64_t p = 4 * q;
+            bool cand[4] = {true, true, true, true};
+            if (sp) {
+                const float4 v = reinterpret_cast<const float4 *>(sp)[q];
+                cand[0] = v.x > thr; cand[1] = v.y > thr; cand[2] = v.z > thr; cand[3] = v.w > thr;
             }
-        if (mask && mask[p]) any = false;
-        if (sp && !(sp[p] > thr)) any = false;
-        out[p] = any ? 1 : 0;
+            if (mask) {
+                const unsigned m = reinterpret_cast<const unsigned *>(mask)[q];
+#pragma unroll
+                for (int j = 0; j < 4; j++) cand[j] = cand[j] && ((m >> (8 * j)) & 0xffu) == 0;
+            }
+            unsigned o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (cand[j] && dilate_any<SHAPE>(in, p + j, H, W)) o |= 1u << (8 * j);
+            reinterpret_cast<unsigned *>(out)[q] = o;
+        }
+    }
+    const int64_t done = vec ? 4 * P4 : 0;
+    APGPU_FOR_PIXELS(t, P - done) {
+        const int64_t p = done + t;
+        const bool cand = !(mask && mask[p]) && !(sp && !(sp[p] > thr));
+        out[p] = (cand && dilate_any<SHAPE>(in, p, H, W)) ? 1 : 0;
     }
 }
 
@@ -173,27 +223,42 @@ __global__ __launch_bounds__(kBlock) void merge_count_kernel(const uint8_t *__re
 // cleantype 'meanmask': every CR pixel at least 2 pixels from the border becomes the mean of the pixels of its 5x5
 // neighbourhood that are neither CR nor masked (the background level if there is none).  Only CR pixels are written and
 // only non-CR pixels are read: in place.
+__device__ __forceinline__ void clean_pixel(float *__restrict__ a, const uint8_t *__restrict__ crmask, const uint8_t *__restrict__ mask,
+                                            float background, int64_t p, int H, int W)
+{
+    const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+    if (r < 2 || r >= H - 2 || c < 2 || c >= W - 2) return;
+    float sum = 0.f;
+    int n = 0;
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++)
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) {
+            const int64_t q = p + (int64_t)dy * W + dx;
+            if (!crmask[q] && !(mask && mask[q])) {
+                sum = sum + a[q];
+                n++;
+            }
+        }
+    a[p] = n > 0 ? sum / (float)n : background;
+}
+
 __global__ __launch_bounds__(kBlock) void clean_meanmask_kernel(float *__restrict__ a, const uint8_t *__restrict__ crmask,
                                                                const uint8_t *__restrict__ mask, float background, int H, int W)
 {
     const int64_t P = (int64_t)H * W;
-    APGPU_FOR_PIXELS(p, P) {
-        if (!crmask[p]) continue;
-        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
-        if (r < 2 || r >= H - 2 || c < 2 || c >= W - 2) continue;
-        float sum = 0.f;
-        int n = 0;
+    // the cosmic-ray map is almost empty: it is scanned four pixels per 32-bit word
+    const int64_t P4 = (reinterpret_cast<uintptr_t>(crmask) & 3) == 0 ? P / 4 : 0;
+    APGPU_FOR_PIXELS(q, P4) {
+        const unsigned m = reinterpret_cast<const unsigned *>(crmask)[q];
+        if (m == 0) continue;
 #pragma unroll
-        for (int dy = -2; dy <= 2; dy++)
-#pragma unroll
-            for (int dx = -2; dx <= 2; dx++) {
-                const int64_t q = p + (int64_t)dy * W + dx;
-                if (!crmask[q] && !(mask && mask[q])) {
-                    sum = sum + a[q];
-                    n++;
-                }
-            }
-        a[p] = n > 0 ? sum / (float)n : background;
+        for (int j = 0; j < 4; j++)
+            if ((m >> (8 * j)) & 0xffu) clean_pixel(a, crmask, mask, background, 4 * q + j, H, W);
+    }
+    APGPU_FOR_PIXELS(t, P - 4 * P4) {
+        const int64_t p = 4 * P4 + t;
+        if (crmask[p]) clean_pixel(a, crmask, mask, background, p, H, W);
     }
 }
 
@@ -301,7 +366,9 @@ extern "C" int apgpu_lacosmic_iterate(float *clean, const uint8_t *mask, uint8_t
     sepmed<7>(w.s, w.t1, w.t2, H, W, st);
     hipLaunchKernelGGL(subtract_kernel, dim3(g), dim3(kBlock), 0, st, w.s, w.t1, P);        // sp = s - sepmed7(s)
     if (psfk) {
-        hipLaunchKernelGGL(convolve7_kernel, dim3(g), dim3(kBlock), 0, st, clean, psfk, w.f, H, W);
+        const int64_t tiles = (int64_t)((W + kConvTW - 1) / kConvTW) * ((H + kConvTH - 1) / kConvTH);
+        hipLaunchKernelGGL(convolve7_kernel, dim3((unsigned)(tiles < kNumCU * 64 ? tiles : kNumCU * 64)), dim3(kBlock), 0, st, clean, psfk,
+                           w.f, H, W);
     } else {
         sepmed<5>(clean, w.f, w.t2, H, W, st);                                              // fsmode 'median'
     }

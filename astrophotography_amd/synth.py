@@ -68,3 +68,44 @@ def make_frames(N, masters, nflat, config_id=2, dtype=torch.float32, first_frame
         else:
             out[f] = fr.round_().to(torch.int32).to(torch.uint16) if hasattr(torch, 'uint16') else fr
     return out
+
+
+def make_sky_frame(H, W, seed=7, nstars=None, ncr=None, sky=400.0, read_noise=8.0, device='cuda'):
+    """A calibrated light frame in electrons for the per-frame F4 steps (background mesh, cosmic rays): sky level with a
+    gentle gradient, Gaussian-PSF stars (sigma 1.5 px), shot + read noise, and `ncr` cosmic-ray hits (single pixels and short
+    tracks, sharper than the PSF).  Returns (frame float32 [H, W], cosmic-ray truth mask bool [H, W])."""
+    g = _gen(device, 1000 + seed)
+    P = H * W
+    nstars = max(4, P // 30000) if nstars is None else nstars
+    ncr = max(2, P // 8000) if ncr is None else ncr
+    yy = torch.linspace(-1.0, 1.0, H, device=device).view(H, 1)
+    xx = torch.linspace(-1.0, 1.0, W, device=device).view(1, W)
+    signal = sky * (1.0 + 0.05 * xx + 0.03 * yy)
+    stars = torch.zeros(H * W, device=device)
+    pos = torch.randint(0, P, (nstars,), generator=g, device=device)
+    amp = 10.0 ** (2.0 + 2.5 * torch.rand(nstars, generator=g, device=device))
+    stars.index_add_(0, pos, amp)
+    k = torch.arange(-6, 7, device=device, dtype=torch.float32)
+    k1 = torch.exp(-k * k / (2 * 1.5 ** 2))
+    k1 = k1 / k1.sum()
+    # separable 13-tap Gaussian by shifted adds (torch's conv2d would go through MIOpen's kernel search on first use)
+    st = stars.view(H, W)
+    for axis in (0, 1):
+        acc = torch.zeros_like(st)
+        for j in range(13):
+            acc += float(k1[j]) * torch.roll(st, j - 6, dims=axis)
+        st = acc
+    signal = signal + st.view(H, W) * (2 * 3.14159265 * 1.5 ** 2)
+    frame = signal + torch.randn(H, W, generator=g, device=device) * torch.sqrt(signal + read_noise ** 2)
+    truth = torch.zeros(P, dtype=torch.bool, device=device)
+    cpos = torch.randint(3 * W, P - 3 * W, (ncr,), generator=g, device=device)
+    camp = 300.0 + 5000.0 * torch.rand(ncr, generator=g, device=device)
+    length = torch.randint(1, 4, (ncr,), generator=g, device=device)
+    step = torch.where(torch.rand(ncr, generator=g, device=device) < 0.5, W + 1, W)
+    flat = frame.view(-1)
+    for j in range(3):
+        on = length > j
+        p = (cpos + j * step)[on]
+        flat.index_add_(0, p, camp[on] * (0.6 ** j))
+        truth[p] = True
+    return frame.to(torch.float32).contiguous(), truth.view(H, W)
