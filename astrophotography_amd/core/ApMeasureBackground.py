@@ -29,18 +29,13 @@ def _fill_excluded(mesh, good, n_neighbors=10, power=1.0):
     ny, nx = mesh.shape
     gy, gx = np.nonzero(good)
     vals = mesh[good]
-    out = np.empty_like(mesh)
+    out = mesh.copy()                       # a good box is its own nearest neighbour at distance 0: it keeps its value
     k = min(n_neighbors, len(vals))
-    for y in range(ny):
-        for x in range(nx):
-            d = np.hypot(gy - y, gx - x)
-            order = np.argsort(d, kind='stable')[:k]
-            dk = d[order]
-            if dk[0] == 0.0:
-                out[y, x] = vals[order[0]]
-            else:
-                w = 1.0 / dk ** power
-                out[y, x] = np.sum(w * vals[order]) / np.sum(w)
+    for y, x in zip(*np.nonzero(~good)):
+        d = np.hypot(gy - y, gx - x)
+        order = np.argsort(d, kind='stable')[:k]
+        w = 1.0 / d[order] ** power
+        out[y, x] = np.sum(w * vals[order]) / np.sum(w)
     return out
 
 
