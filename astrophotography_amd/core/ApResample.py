@@ -2,8 +2,8 @@
 
 The reference does this step outside Python: ``scripts/resample_all.sh`` collects the navigated files of one
 filter, derives a flux scale ``FSCALE = 1/EXPOSURE`` per file (:283-312; 1.0 in SUM mode), and runs SWarp with
-``RESAMPLING_TYPE LANCZOS3``, ``COMBINE_TYPE MEDIAN | AVERAGE | SUM`` and a weight-map output (:123-131,
-262-275, 330-342).  ``ApResample`` keeps that contract on the GPU for frames whose registration is a 2x3 affine
+``RESAMPLING_TYPE LANCZOS3``, ``OVERSAMPLING 4``, ``COMBINE_TYPE MEDIAN | WEIGHTED | SUM``, ``GAIN_KEYWORD EGAIN`` and a
+weight-map output (:60-73, 108-118, 330-342).  ``ApResample`` keeps that contract on the GPU for frames whose registration is a 2x3 affine
 transform per frame (output pixel -> input pixel): Lanczos-3 resampling onto the common grid
 (``ops.resample_affine``), the flux scaling, the combine, and a weight image (= number of frames that
 contributed to each pixel).  Files that carry a TAN WCS (astrometry.net) are registered through the sky with one
@@ -21,7 +21,8 @@ COMBINE_TYPES = ('MEDIAN', 'AVERAGE', 'WEIGHTED', 'SUM', 'CLIPPED')
 
 
 class ApResample:
-    def __init__(self, loglevel='INFO', combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024, conserve_flux=True):
+    def __init__(self, loglevel='INFO', combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024, conserve_flux=True, oversampling=1,
+                 gain_keyword='EGAIN'):
         self._name = 'ApResample'
         self._logger = _common.make_logger(self._name, loglevel)
         combine = str(combine).upper()
@@ -29,12 +30,31 @@ class ApResample:
             raise ValueError(f'Error, combine type {combine} is not one of the allowed types: {COMBINE_TYPES}')
         self.combine, self.sigma, self.maxiters, self.n_phases = combine, sigma, maxiters, n_phases
         self.conserve_flux = bool(conserve_flux)            # FSCALASTRO_TYPE VARIABLE (resample_all.sh:129)
+        self.oversampling = int(oversampling)               # OVERSAMPLING (resample_all.sh:112: 4)
+        self.gain_keyword = gain_keyword                    # GAIN_KEYWORD (resample_all.sh:111: EGAIN)
+        if not 1 <= self.oversampling <= 16:
+            raise ValueError(f'Error, oversampling {oversampling} is not in 1..16')
 
-    def coadd(self, frames, affines, fscale=None, mask=None, out_shape=None):
-        """frames [N,H,W] float32 device tensor -> dict(image, count) device tensors."""
+    def coadd(self, frames, affines, fscale=None, mask=None, out_shape=None, weights=None, fine_affines=None):
+        """frames [N,H,W] float32 device tensor -> dict(image, count[, weight]) device tensors."""
         from .. import ops
         return ops.coadd(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, combine=self.combine,
-                         sigma=self.sigma, maxiters=self.maxiters, n_phases=self.n_phases, conserve_flux=self.conserve_flux)
+                         sigma=self.sigma, maxiters=self.maxiters, n_phases=self.n_phases, conserve_flux=self.conserve_flux,
+                         oversampling=self.oversampling, weights=weights, fine_affines=fine_affines)
+
+    def _output_gain(self, gains, fscale, weights):
+        """Effective gain of the co-add in electrons per output unit, written as GAIN when every input carries the
+        GAIN_KEYWORD (resample_all.sh:111 passes EGAIN to SWarp for this purpose).  This build's definition, by propagating
+        the Poisson variance of frames of equal signal (SWarp's own formula is not reproduced): a frame with gain g_i scaled by
+        f_i has gain G_i = g_i / f_i; SUM: 1 / G = sum 1 / G_i; a mean with weights w_i (1 for AVERAGE, CLIPPED and - as an
+        approximation - MEDIAN): G = (sum w_i)^2 / sum(w_i^2 / G_i).  None without the keyword."""
+        if any(g is None for g in gains):
+            return None
+        g = np.asarray(gains, dtype=np.float64) / np.asarray(fscale, dtype=np.float64)
+        if self.combine == 'SUM':
+            return float(1.0 / np.sum(1.0 / g))
+        w = np.ones(len(g)) if weights is None or self.combine != 'WEIGHTED' else np.asarray(weights, dtype=np.float64)
+        return float(np.sum(w) ** 2 / np.sum(w * w / g))
 
     def _exposure(self, hdr, fname):
         for kw in ('EXPOSURE', 'EXPTIME'):                   # same order as resample_all.sh:283-297
@@ -59,11 +79,12 @@ class ApResample:
             affines = np.asarray(affines, dtype=np.float64).reshape(-1, 6)
             if len(affines) != len(input_files):
                 raise RuntimeError(f'Error, {len(affines)} transforms given for {len(input_files)} files.')
-        arrs, hdrs, fscale, texp = [], [], [], 0.0
+        arrs, hdrs, fscale, texp, gains = [], [], [], 0.0, []
         for f in input_files:
             data, hdr, _ = _common.read_fits(self._logger, f)
             exp = self._exposure(hdr, f)
             texp += exp
+            gains.append(float(hdr[self.gain_keyword]) if self.gain_keyword and self.gain_keyword in hdr else None)
             fscale.append(1.0 if self.combine == 'SUM' else 1.0 / exp)
             arrs.append(np.asarray(data, dtype=np.float32))
             hdrs.append(hdr)
@@ -87,10 +108,26 @@ class ApResample:
             else:
                 out_wcs = in_wcs[0]
                 out_shape = out_shape or arrs[0].shape
-            affines = np.stack([apwcs.tile_affines(out_wcs, w, out_shape) for w in in_wcs], 0)
+            fine_affines = None
+            if self.oversampling > 1:
+                n = self.oversampling
+                fine_wcs, fine_shape = out_wcs.oversampled(n), (out_shape[0] * n, out_shape[1] * n)
+                fine_affines = np.stack([apwcs.tile_affines(fine_wcs, w, fine_shape) for w in in_wcs], 0)
+                affines = np.zeros((len(in_wcs), 6))
+            else:
+                affines = np.stack([apwcs.tile_affines(out_wcs, w, out_shape) for w in in_wcs], 0)
             self._logger.info(f'Registered {len(in_wcs)} files through their TAN WCS onto a {out_shape[1]}x{out_shape[0]} grid.')
+        else:
+            fine_affines = None
         slab = torch.from_numpy(np.stack(arrs, 0)).cuda()
-        res = self.coadd(slab, affines, fscale=np.asarray(fscale, np.float32), mask=mask, out_shape=out_shape)
+        weights = None
+        if self.combine == 'WEIGHTED':
+            from .. import ops
+            weights = ops.background_weights(slab, np.asarray(fscale, np.float64))
+            for f, wgt in zip(input_files, weights):
+                self._logger.info(f'  File {Path(f).name:40s} WEIGHT {wgt:12.6g}')
+        res = self.coadd(slab, affines, fscale=np.asarray(fscale, np.float32), mask=mask, out_shape=out_shape, weights=weights,
+                         fine_affines=fine_affines)
         hdr = hdrs[0].copy()
         for kw in ('BSCALE', 'BZERO', 'PEDESTAL'):
             if kw in hdr:
@@ -98,6 +135,10 @@ class ApResample:
         hdr['NCOMBINE'] = (len(input_files), 'Number of frames combined')
         hdr['COMBINET'] = (self.combine, 'Co-add combine type')
         hdr['RESAMPT'] = ('LANCZOS3', 'Resampling kernel')
+        hdr['OVERSAMP'] = (self.oversampling, 'Sub-samples per output pixel and axis')
+        gain_out = self._output_gain(gains, fscale, weights)
+        if gain_out is not None:
+            hdr['GAIN'] = (gain_out, f'Effective gain from {self.gain_keyword} of the inputs')
         if out_wcs is not None:
             for k in ('CD1_1', 'CD1_2', 'CD2_1', 'CD2_2', 'CDELT1', 'CDELT2', 'CROTA1', 'CROTA2', 'PC1_1', 'PC1_2', 'PC2_1', 'PC2_2'):
                 if k in hdr:
@@ -117,7 +158,9 @@ class ApResample:
         if weight_file is not None:
             wh = fitsio.Header()
             wh['NCOMBINE'] = (len(input_files), 'Number of frames combined')
-            wh['HISTORY'] = f'Weight map (frames contributing per pixel) by {self._name} {__version__} at {tnow}'
-            fitsio.write(str(weight_file), res['count'].cpu().numpy().astype(np.float32), wh, overwrite=True)
+            wimg = res['weight'] if 'weight' in res else res['count']
+            what = 'sum of the contributing frames\' weights' if 'weight' in res else 'frames contributing per pixel'
+            wh['HISTORY'] = f'Weight map ({what}) by {self._name} {__version__} at {tnow}'
+            fitsio.write(str(weight_file), wimg.cpu().numpy().astype(np.float32), wh, overwrite=True)
             self._logger.info(f'Wrote weight image to {weight_file}')
         return res

@@ -260,3 +260,67 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
                            weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     return check_launch("resample_affine");
 }
+
+// ---- OVERSAMPLING n and COMBINE_TYPE WEIGHTED (include/apgpu.h, F3 continued) --------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void block_mean_kernel(const float *__restrict__ fine, int64_t h, int64_t w, int n, float *__restrict__ out)
+{
+    const int64_t P = h * w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t wf = w * n;
+    const double inv = 1.0 / (double)(n * n);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const int64_t i = p / w, j = p - i * w;
+        const float *src = fine + i * n * wf + j * n;
+        double acc = 0.0;                                       // a NaN sub-sample makes the sum, and the pixel, NaN
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b < n; b++) acc += (double)src[a * wf + b];
+        out[p] = (float)(acc * inv);
+    }
+}
+
+__global__ __launch_bounds__(256) void weighted_mean_kernel(const float *__restrict__ slab, int n_frames, int64_t P,
+                                                           const float *__restrict__ weights, float *__restrict__ mean_out,
+                                                           float *__restrict__ wsum_out)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        double num = 0.0, den = 0.0;
+        for (int i = 0; i < n_frames; i++) {
+            const float x = slab[(int64_t)i * P + p];
+            if (fabsf(x) < __builtin_inff()) {                  // false for NaN and +-inf
+                const double wi = (double)weights[i];
+                num += wi * (double)x;
+                den += wi;
+            }
+        }
+        if (mean_out) mean_out[p] = den > 0.0 ? (float)(num / den) : __builtin_nanf("");
+        if (wsum_out) wsum_out[p] = (float)den;
+    }
+}
+
+}  // namespace
+
+extern "C" int apgpu_block_mean_f32(const float *fine, int64_t h_out, int64_t w_out, int32_t oversampling, float *out, void *stream)
+{
+    if (!fine || !out) return fail(APGPU_EINVAL, "block_mean: NULL pointer argument");
+    if (h_out <= 0 || w_out <= 0 || oversampling < 1 || oversampling > 16)
+        return fail(APGPU_EINVAL, "block_mean: bad shape / oversampling %d (1..16)", oversampling);
+    int64_t g = (h_out * w_out + 255) / 256;
+    if (g > kNumCU * 16) g = kNumCU * 16;
+    hipLaunchKernelGGL(block_mean_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), fine, h_out, w_out, oversampling, out);
+    return check_launch("block_mean");
+}
+
+extern "C" int apgpu_weighted_mean_f32(const float *slab, int32_t n_frames, int64_t n_pixels, const float *weights, float *mean_out,
+                                       float *wsum_out, void *stream)
+{
+    if (!slab || !weights || (!mean_out && !wsum_out)) return fail(APGPU_EINVAL, "weighted_mean: NULL pointer argument");
+    if (n_frames < 1 || n_pixels <= 0) return fail(APGPU_EINVAL, "weighted_mean: bad shape");
+    int64_t g = (n_pixels + 255) / 256;
+    if (g > kNumCU * 16) g = kNumCU * 16;
+    hipLaunchKernelGGL(weighted_mean_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), slab, n_frames, n_pixels, weights,
+                       mean_out, wsum_out);
+    return check_launch("weighted_mean");
+}

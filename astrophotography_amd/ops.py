@@ -656,17 +656,125 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
     return out, wt
 
 
+def oversampled_affines(affines, oversampling, out_shape):
+    """The transforms of the n-times finer grid whose n x n blocks are the output pixels: fine pixel (u, v) has its centre at
+    output coordinates ((u + 0.5) / n - 0.5, (v + 0.5) / n - 0.5).  Single transform per frame only ([N, 6])."""
+    n = int(oversampling)
+    aff = torch.as_tensor(affines, dtype=torch.float64).reshape(-1, 6).clone()
+    off = 0.5 / n - 0.5
+    fine = aff.clone()
+    fine[:, 0] = aff[:, 0] / n
+    fine[:, 1] = aff[:, 1] / n
+    fine[:, 2] = aff[:, 2] + (aff[:, 0] + aff[:, 1]) * off
+    fine[:, 3] = aff[:, 3] / n
+    fine[:, 4] = aff[:, 4] / n
+    fine[:, 5] = aff[:, 5] + (aff[:, 3] + aff[:, 4]) * off
+    return fine, (int(out_shape[0]) * n, int(out_shape[1]) * n)
+
+
+def block_mean(fine, oversampling):
+    """[n*h, n*w] float32 -> [h, w]: mean of the n x n sub-samples of every output pixel (NaN if any is NaN)."""
+    _need_cuda(fine)
+    fine = _f32c(fine, 'fine')
+    n = int(oversampling)
+    hf, wf = fine.shape
+    if hf % n or wf % n:
+        raise ValueError('the fine grid must be a whole multiple of the oversampling factor')
+    out = torch.empty((hf // n, wf // n), dtype=torch.float32, device=fine.device)
+    check(_lib.load().apgpu_block_mean_f32(_ptr(fine), hf // n, wf // n, n, _ptr(out), _stream()))
+    return out
+
+
+def resample_oversampled(frames, affines, oversampling, fscale=None, mask=None, out_shape=None, n_phases=1024, conserve_flux=False,
+                         fine_affines=None):
+    """SWarp's OVERSAMPLING n (resample_all.sh:112, 339): every output pixel is the mean of n x n Lanczos-3 interpolations at
+    the centres of its sub-pixels.  One frame at a time through an n-times finer grid (n^2 x the output size in HBM), then
+    apgpu_block_mean_f32.  `fine_affines`: per-tile transforms of the FINE grid ([N, ty, tx, 6], e.g. wcs.tile_affines of the
+    n-times finer output WCS) instead of one transform per frame.  Returns [N, h, w] float32, NaN where undefined."""
+    frames = _f32c(frames, 'frames')
+    if frames.dim() == 2:
+        frames = frames[None]
+    N, H, W = frames.shape
+    n = int(oversampling)
+    if n < 1 or n > 16:
+        raise ValueError('oversampling must be 1..16')
+    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
+    if fine_affines is None:
+        fine_aff, fshape = oversampled_affines(affines, n, (h, w))
+        if fine_aff.shape[0] == 1 and N > 1:
+            fine_aff = fine_aff.expand(N, 6)
+    else:
+        fine_aff, fshape = torch.as_tensor(fine_affines, dtype=torch.float64), (h * n, w * n)
+    fs = None if fscale is None else torch.as_tensor(fscale, dtype=torch.float32).reshape(-1)
+    if fs is not None and fs.numel() == 1 and N > 1:
+        fs = fs.expand(N)
+    out = torch.empty((N, h, w), dtype=torch.float32, device=frames.device)
+    # |det| of the fine transform is 1 / n^2 of the output pixel's: the block MEAN of flux-conserving fine values times n^2
+    # is the output pixel's value, so the scale goes into the per-frame flux factor
+    area = float(n * n) if conserve_flux else 1.0
+    for i in range(N):
+        f_i = area * (1.0 if fs is None else float(fs[i]))
+        fine, _ = resample_affine(frames[i:i + 1], fine_aff[i:i + 1], fscale=[f_i], mask=mask, out_shape=fshape, n_phases=n_phases,
+                                  weight=False, conserve_flux=conserve_flux)
+        check(_lib.load().apgpu_block_mean_f32(_ptr(fine), h, w, n, _ptr(out[i]), _stream()))
+    return out
+
+
+def weighted_mean(slab, weights):
+    """COMBINE_TYPE WEIGHTED with one weight per frame: (sum w_i x_i / sum w_i over the finite x_i, sum of those w_i) per pixel:
+    float32 [H, W] each; NaN / 0 where no frame contributes."""
+    _need_cuda(slab)
+    slab = _f32c(slab, 'slab')
+    N = slab.shape[0]
+    wts = torch.as_tensor(weights, dtype=torch.float32).reshape(-1).to(slab.device).contiguous()
+    if wts.numel() != N:
+        raise ValueError('weights must hold one value per frame')
+    if not bool(torch.isfinite(wts).all()) or not bool((wts > 0).all()):
+        raise ValueError('weights must be finite and positive')
+    P = slab[0].numel()
+    mean = torch.empty(slab.shape[1:], dtype=torch.float32, device=slab.device)
+    wsum = torch.empty_like(mean)
+    check(_lib.load().apgpu_weighted_mean_f32(_ptr(slab), N, P, _ptr(wts), _ptr(mean), _ptr(wsum), _stream()))
+    return mean, wsum
+
+
+def background_weights(frames, fscale=None, sigma=3.0, maxiters=5):
+    """SWarp's weights without weight maps (WEIGHT_TYPE NONE): a frame counts with the inverse variance of its flux-scaled
+    background noise, w_i = 1 / (fscale_i * sigma_i)^2.  sigma_i here = the sigma-clipped standard deviation of the whole
+    frame (the A3 kernels); SWarp measures it on its own background mesh.  Returns float64 numpy [N]."""
+    import numpy as np
+    N = frames.shape[0]
+    fs = np.ones(N) if fscale is None else np.broadcast_to(np.asarray(fscale, dtype=np.float64).reshape(-1), (N,))
+    sd = np.array([float(sigclip_global(frames[i], sigma=sigma, maxiters=maxiters)[2].item()) for i in range(N)])
+    if not np.all(np.isfinite(sd)) or np.any(sd <= 0):
+        raise ValueError('a frame has no measurable background noise (constant or empty): give explicit weights')
+    return 1.0 / (fs * sd) ** 2
+
+
 def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024,
-          conserve_flux=False):
-    """Resample + combine: SWarp's COMBINE_TYPE MEDIAN / AVERAGE / SUM (resample_all.sh:262-275 add modes) plus
-    CLIPPED (sigma-clipped mean, median-centred).  Returns dict(image, count) - count = frames contributing."""
-    res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False,
-                             conserve_flux=conserve_flux)
+          conserve_flux=False, oversampling=1, weights=None, fine_affines=None):
+    """Resample + combine: SWarp's COMBINE_TYPE MEDIAN / AVERAGE / WEIGHTED / SUM (resample_all.sh:60-73 add modes) plus
+    CLIPPED (sigma-clipped mean, median-centred); oversampling = SWarp's OVERSAMPLING.  WEIGHTED takes one weight per frame
+    (default: background_weights).  Returns dict(image, count[, weight]) - count = frames contributing, weight = the sum
+    of their weights (WEIGHTED only)."""
+    if int(oversampling) > 1:
+        res = resample_oversampled(frames, affines, oversampling, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases,
+                                   conserve_flux=conserve_flux, fine_affines=fine_affines)
+    else:
+        res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False,
+                                 conserve_flux=conserve_flux)
     combine = combine.upper()
     if combine == 'MEDIAN':
         med, cnt = stack_median(res, want_count=True)
         return dict(image=med, count=cnt)
-    if combine in ('AVERAGE', 'WEIGHTED', 'SUM'):
+    if combine == 'WEIGHTED':
+        if weights is None:
+            fr = frames if frames.dim() == 3 else frames[None]
+            weights = background_weights(fr, fscale)
+        mean, wsum = weighted_mean(res, weights)
+        cnt = stack_sigclip(res, sigma=1e30, maxiters=1, cenfunc='mean', outputs=('count',))['count']
+        return dict(image=mean, count=cnt, weight=wsum)
+    if combine in ('AVERAGE', 'SUM'):
         # one pass with bounds nothing can exceed = np.nanmean / np.nansum along N
         r = stack_sigclip(res, sigma=1e30, maxiters=1, cenfunc='mean',
                           outputs=('mean', 'count') if combine != 'SUM' else ('moments', 'count'))

@@ -24,6 +24,10 @@ def command_line_opts(argv):
     parser.add_argument('--weight_image', default=None, metavar='WEIGHTS.FITS', help='Optional output weight image.')
     parser.add_argument('--badpix', default=None, metavar='BADPIX.FITS', help='Optional bad pixel mask shared by the inputs.')
     parser.add_argument('--image_size', default=None, metavar='NX,NY', help='Output size (default: input size).')
+    parser.add_argument('--oversampling', default=1, type=int, metavar='N',
+                        help='Sub-samples per output pixel and axis (SWarp OVERSAMPLING; resample_all.sh uses 4). Default: 1')
+    parser.add_argument('--gain_keyword', default='EGAIN', metavar='KEYWORD',
+                        help='Header keyword with the detector gain in e-/ADU (SWarp GAIN_KEYWORD). Default: EGAIN')
     parser.add_argument('--sigma', default=3.0, type=float, metavar='NSIGMA', help='CLIPPED only.')
     parser.add_argument('--maxiters', default=5, type=int, metavar='N', help='CLIPPED only; -1 = until convergence.')
     parser.add_argument('-l', '--loglevel', default='INFO', help='Logging message level. Default: INFO')
@@ -52,7 +56,8 @@ def main(args=None):
     if p.image_size:
         nx, ny = (int(v) for v in p.image_size.split(','))
         out_shape = (ny, nx)
-    rs = ApResample(p.loglevel, combine=p.combine, sigma=p.sigma, maxiters=None if p.maxiters < 0 else p.maxiters)
+    rs = ApResample(p.loglevel, combine=p.combine, sigma=p.sigma, maxiters=None if p.maxiters < 0 else p.maxiters,
+                    oversampling=p.oversampling, gain_keyword=p.gain_keyword)
     center = None
     if p.center:
         center = tuple(float(v) for v in p.center.split(','))

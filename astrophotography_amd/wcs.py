@@ -51,6 +51,13 @@ class TanWcs:
         s = pixscale_arcsec / 3600.0
         return cls(((nx + 1) / 2.0, (ny + 1) / 2.0), (ra, dec), [[-s, 0.0], [0.0, s]])
 
+    def oversampled(self, n):
+        """The same projection on a grid n times finer whose n x n blocks are this grid's pixels (FITS pixel centres are
+        integers: CRPIX' = (CRPIX - 0.5) * n + 0.5)."""
+        n = int(n)
+        return type(self)(((self.crpix[0] - 0.5) * n + 0.5, (self.crpix[1] - 0.5) * n + 0.5), (self.crval[0], self.crval[1]),
+                          [[self.cd[0, 0] / n, self.cd[0, 1] / n], [self.cd[1, 0] / n, self.cd[1, 1] / n]])
+
     def header_cards(self):
         return {'CTYPE1': 'RA---TAN', 'CTYPE2': 'DEC--TAN', 'CRPIX1': float(self.crpix[0]), 'CRPIX2': float(self.crpix[1]),
                 'CRVAL1': float(self.crval[0]), 'CRVAL2': float(self.crval[1]), 'CD1_1': float(self.cd[0, 0]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define APGPU_VERSION 110           /* 0.1.1 */
+#define APGPU_VERSION 111           /* 0.1.1 */
 
 /* error codes */
 #define APGPU_OK            0
@@ -290,6 +290,20 @@ int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_i
                               const double *affines, int32_t affines_per_tile, int32_t conserve_flux, const float *fscale,
                               const float *lut, int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out,
                               int64_t w_out, void *stream);
+
+/* F3 (continued)  The two SWarp settings of resample_all.sh that go beyond one interpolation per output pixel.
+ *     apgpu_block_mean_f32: OVERSAMPLING n (resample_all.sh:112, 339: 4) - the frame is resampled onto a grid n times finer
+ *     (apgpu_resample_affine_f32 with the transform of the sub-pixel centres) and every output pixel is the mean of its
+ *     n x n sub-samples: fine [n*h_out, n*w_out] float32 -> out [h_out, w_out] float32, float64 accumulation in row-major
+ *     order inside the block, NaN if any sub-sample is NaN.
+ *     apgpu_weighted_mean_f32: COMBINE_TYPE WEIGHTED (resample_all.sh:65-68) with one weight per frame (SWarp with
+ *     WEIGHT_TYPE NONE weighs a frame by the inverse variance of its scaled background noise): per pixel
+ *     mean = sum_i w_i x_i / sum_i w_i over the frames whose resampled value is finite (float64 accumulation in frame
+ *     order), wsum_out = that sum of weights = the -WEIGHTOUT_NAME image (resample_all.sh:342); NaN / 0 where no frame
+ *     contributes.  weights [n_frames] float32 on the device, all finite and > 0. */
+int apgpu_block_mean_f32(const float *fine, int64_t h_out, int64_t w_out, int32_t oversampling, float *out, void *stream);
+int apgpu_weighted_mean_f32(const float *slab, int32_t n_frames, int64_t n_pixels, const float *weights, float *mean_out,
+                            float *wsum_out, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F4  Sky-background mesh of ApMeasureBackground (core/ApMeasureBackground.py:142-175, 382-415).  The reference calls

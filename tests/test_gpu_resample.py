@@ -236,3 +236,152 @@ def test_flux_conservation(ops, apref):
     det = 0.8 * 0.8 + 0.02 * 0.02
     ok = np.isfinite(plain[0])
     np.testing.assert_allclose(got[0][ok], plain[0][ok] * np.float32(det), rtol=1e-6, atol=1e-6)
+
+
+def test_oversampling_vs_oracle_composition(ops, apref):
+    """SWarp OVERSAMPLING n (resample_all.sh:112, 339): every output pixel = mean of n x n interpolations at its sub-pixel
+    centres.  Oracle = the CPU resample on the n-times finer grid (transform of the sub-pixel centres, written out here
+    independently of ops.oversampled_affines) followed by a float64 block mean."""
+    import torch
+    rng = np.random.default_rng(77)
+    N, H, W = 3, 90, 120
+    out_shape = (70, 100)
+    frames = rng.normal(300, 30, (N, H, W)).astype(np.float32)
+    frames[1, 30, 40] = np.nan
+    A = _affines(rng, N, max_rot_deg=1.0, scale_jitter=0.3)          # output pixels up to 30 % larger than input pixels
+    fs = rng.uniform(0.5, 2.0, N).astype(np.float32)
+    for n in (2, 4):
+        for conserve in (False, True):
+            fine = np.empty((N, out_shape[0] * n, out_shape[1] * n), np.float32)
+            for i in range(N):
+                a0, a1, a2, a3, a4, a5 = A[i]
+                off = 0.5 / n - 0.5
+                Af = [[a0 / n, a1 / n, a2 + (a0 + a1) * off, a3 / n, a4 / n, a5 + (a3 + a4) * off]]
+                scale = np.float32(fs[i] * (n * n if conserve else 1))
+                r, _ = apref.resample_affine(frames[i], Af, fscale=[scale], out_shape=fine.shape[1:], conserve_flux=conserve)
+                fine[i] = r[0]
+            ref = fine.astype(np.float64).reshape(N, out_shape[0], n, out_shape[1], n)
+            ref = np.stack([sum(ref[:, :, a, :, b] for a in range(n) for b in range(n))], 0)[0] / (n * n)
+            got = ops.resample_oversampled(torch.from_numpy(frames).cuda(), A, n, fscale=fs, out_shape=out_shape, conserve_flux=conserve)
+            g = got.cpu().numpy()
+            assert np.array_equal(np.isnan(g), np.isnan(ref)), (n, conserve)
+            np.testing.assert_allclose(g, ref.astype(np.float32), rtol=2e-7, atol=0, equal_nan=True)
+    # oversampling 1 is the plain resample
+    one = ops.resample_oversampled(torch.from_numpy(frames).cuda(), A, 1, fscale=fs, out_shape=out_shape).cpu().numpy()
+    plain, _ = _run(ops, frames, A, fscale=fs, out_shape=out_shape)
+    assert_biteq(one, plain, 'oversampling 1')
+    # block mean on its own: row-major float64 accumulation, NaN poisons its block only
+    x = rng.normal(0, 1, (12, 20)).astype(np.float32)
+    x[5, 7] = np.nan
+    bm = ops.block_mean(torch.from_numpy(x).cuda(), 4).cpu().numpy()
+    want = np.array([[np.float32(sum(float(x[4 * i + a, 4 * j + b]) for a in range(4) for b in range(4)) / 16.0) for j in range(5)] for i in range(3)])
+    assert np.array_equal(bm, want, equal_nan=True) and np.isnan(bm[1, 1]) and np.isfinite(bm).sum() == 14
+
+
+def test_oversampling_conserves_flux_on_a_coarser_grid(ops):
+    """The case oversampling exists for: output pixels 2.5 input pixels wide.  One Lanczos sample per output pixel aliases (the
+    flux of a star depends on where it falls); 4 x 4 sub-samples recover the total to a few 1e-3."""
+    import torch
+    H, W = 200, 240
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    A = [[2.5, 0.0, 10.0, 0.0, 2.5, 8.0]]
+    out_shape = (70, 85)
+    err_over, err_single = [], []
+    for (cx, cy) in ((121.3, 97.8), (120.0, 98.0), (121.25, 99.25), (122.5, 98.4), (119.1, 96.9), (123.75, 100.5)):
+        img = (4000.0 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 1.6 ** 2))).astype(np.float32)
+        t = torch.from_numpy(img).cuda()
+        total_in = float(img.astype(np.float64).sum())
+        over = ops.resample_oversampled(t, A, 4, out_shape=out_shape, conserve_flux=True).cpu().numpy()
+        err_over.append(abs(float(np.nansum(over.astype(np.float64))) / total_in - 1.0))
+        single, _ = ops.resample_affine(t, A, out_shape=out_shape, weight=False, conserve_flux=True)
+        err_single.append(abs(float(np.nansum(single.cpu().numpy().astype(np.float64))) / total_in - 1.0))
+    assert max(err_over) < 5e-3, err_over
+    assert max(err_single) > 4 * max(err_over), (err_single, err_over)     # what the oversampling is for
+
+
+def test_weighted_combine(ops, apref):
+    """COMBINE_TYPE WEIGHTED with one weight per frame: sum w x / sum w over the finite values, float64, frame order; the weight
+    image is the sum of the contributing weights; default weights = 1 / (fscale * clipped std)^2 of every frame."""
+    import torch
+    rng = np.random.default_rng(78)
+    N, H, W = 6, 64, 80
+    noise = np.array([2.0, 2.0, 4.0, 8.0, 3.0, 5.0])
+    frames = np.stack([rng.normal(200.0, s, (H, W)) for s in noise]).astype(np.float32)
+    frames[2, 10:20, 10:30] = np.nan
+    frames[:, 40, 41] = np.nan
+    w = rng.uniform(0.2, 3.0, N).astype(np.float32)
+    mean, wsum = ops.weighted_mean(torch.from_numpy(frames).cuda(), w)
+    num, den = np.zeros((H, W)), np.zeros((H, W))
+    for i in range(N):
+        ok = np.isfinite(frames[i])
+        num += np.where(ok, float(w[i]) * frames[i].astype(np.float64), 0.0)
+        den += np.where(ok, float(w[i]), 0.0)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        ref = np.where(den > 0, num / den, np.nan).astype(np.float32)
+    assert_biteq(mean.cpu().numpy(), ref, 'weighted mean')
+    assert np.array_equal(wsum.cpu().numpy(), den.astype(np.float32)) and wsum[40, 41] == 0 and np.isnan(mean[40, 41].item())
+    with pytest.raises(ValueError):
+        ops.weighted_mean(torch.from_numpy(frames).cuda(), [1, 1, 0, 1, 1, 1])
+    # through coadd: identity registration, weights from the frames' own noise - the noisy frames count less
+    A = np.tile([1.0, 0, 0, 0, 1.0, 0], (N, 1))
+    fs = np.ones(N, np.float32)
+    wts = ops.background_weights(torch.from_numpy(np.nan_to_num(frames, nan=200.0)).cuda(), fs)
+    np.testing.assert_allclose(wts, 1.0 / noise ** 2, rtol=0.12)        # 3-sigma clipping reads the noise ~1.5 % low
+    r = ops.coadd(torch.from_numpy(frames).cuda(), A, fscale=fs, combine='WEIGHTED', weights=wts)
+    img = r['image'].cpu().numpy()
+    inner = (slice(8, H - 8), slice(8, W - 8))
+    avg = ops.coadd(torch.from_numpy(frames).cuda(), A, fscale=fs, combine='AVERAGE')['image'].cpu().numpy()
+    assert np.nanstd(img[inner]) < 0.8 * np.nanstd(avg[inner])
+    assert set(r) == {'image', 'count', 'weight'} and int(r['count'].max()) == N
+    np.testing.assert_allclose(float(r['weight'][30, 60]), wts.sum(), rtol=1e-6)
+
+
+def test_coadd_files_oversampled_weighted_wcs(tmp_path, ops):
+    """resample_all.sh's wgtavg mode through files: WCS registration on the oversampled grid, weighted mean, weight image =
+    sum of weights, GAIN from EGAIN, OVERSAMP card; star centroids land where the output WCS puts them."""
+    from astrophotography_amd import fitsio, wcs
+    from astrophotography_amd.scripts import ap_coadd
+    rng = np.random.default_rng(32)
+    N, H, W = 4, 200, 220
+    out_shape = (90, 100)
+    center = (150.1, 2.2)
+    out_w = wcs.TanWcs.from_center(center[0], center[1], 4.0, out_shape)        # output pixels twice the input scale
+    sx, sy = rng.uniform(15, 85, 6), rng.uniform(15, 75, 6)
+    ra, dec = out_w.pix2sky(sx, sy)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    names = []
+    for k in range(N):
+        th = np.deg2rad(rng.uniform(-3, 3))
+        s = 2.0 / 3600.0
+        w = wcs.TanWcs((W / 2 + rng.uniform(-4, 4), H / 2 + rng.uniform(-4, 4)), center,
+                       [[-s * np.cos(th), s * np.sin(th)], [s * np.sin(th), s * np.cos(th)]])
+        px, py = w.sky2pix(ra, dec)
+        img = np.full((H, W), 50.0)
+        for x0, y0 in zip(px, py):
+            img += 9000.0 * np.exp(-((xx - x0) ** 2 + (yy - y0) ** 2) / (2 * 2.5 ** 2))
+        img += rng.normal(0, 1.0 + k, (H, W))
+        h = fitsio.Header()
+        h['EXPOSURE'] = 30.0
+        h['EGAIN'] = 1.5
+        for key, val in w.header_cards().items():
+            h[key] = val
+        fn = tmp_path / f'nav{k}.fits'
+        fitsio.write(str(fn), img.astype(np.float32), h)
+        names.append(str(fn))
+    assert ap_coadd.main([str(tmp_path / 'co.fits'), *names, '--combine', 'WEIGHTED', '--oversampling', '4', '--center', '%f,%f' % center,
+                          '--pixelscale', '4.0', '--image_size', '%d,%d' % (out_shape[1], out_shape[0]),
+                          '--weight_image', str(tmp_path / 'w.fits'), '-l', 'CRITICAL']) == 0
+    co, hdr = fitsio.read(str(tmp_path / 'co.fits'))
+    wimg, _ = fitsio.read(str(tmp_path / 'w.fits'))
+    assert co.shape == out_shape and hdr['OVERSAMP'] == 4 and hdr['COMBINET'] == 'WEIGHTED' and hdr['GAIN'] > 1.5 * 30
+    sig = np.array([1.0, 2.0, 3.0, 4.0])
+    np.testing.assert_allclose(wimg.max(), np.sum(1.0 / (sig / 30.0) ** 2), rtol=0.1)
+    oy, ox = np.mgrid[0:out_shape[0], 0:out_shape[1]].astype(np.float64)
+    bg = np.nanmedian(co)
+    # flux-conserving resample onto pixels of 4x the area: 4 * 50 / 30 per output pixel
+    assert abs(bg - 4 * 50.0 / 30.0) < 0.05
+    for x0, y0 in zip(sx, sy):
+        sel = ((ox - x0) ** 2 + (oy - y0) ** 2 < 5 ** 2) & np.isfinite(co)
+        wgt = np.clip(co[sel] - bg, 0, None)
+        cx, cy = (wgt * ox[sel]).sum() / wgt.sum(), (wgt * oy[sel]).sum() / wgt.sum()
+        assert abs(cx - x0) < 0.1 and abs(cy - y0) < 0.1, (x0, y0, cx, cy)
