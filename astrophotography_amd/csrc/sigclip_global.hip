@@ -62,7 +62,7 @@ struct GState {
     double med, sd;
     double lo, hi;
     unsigned hist[kBins];
-    unsigned long long wg_lo[kMaxPassGroups], wg_hi[kMaxPassGroups];   // per-workgroup extremes of a statistics pass
+    unsigned long long wg_lo[kMaxPassGroups + 1], wg_hi[kMaxPassGroups + 1];   // per-workgroup extremes of a statistics pass
 };
 
 template <typename T> struct KeyOf;
@@ -173,6 +173,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(long long n_static, GSt
     if (MODE == 1 && s.done) {
         if (threadIdx.x == 0) *next = s;
         return;
+    }
+    if (MODE == 1) {                                        // the iteration's last histogram was read by the count kernel
+        for (int t = threadIdx.x; t < kBins; t += 1024) st->hist[t] = 0;
     }
     const long long m = (MODE == 0) ? n_static : s.m;
     const long long ntiles = (m + kTile - 1) / kTile;
@@ -321,6 +324,131 @@ __device__ __forceinline__ T var_mean(const GState *st, long long m)
     return (T)st->tot / (T)m;               // np.var: arrmean = true_divide(sum, n) in the array's dtype
 }
 
+// LDS index of element i of the ragged piece: one pad word per 64 elements, so that lanes walking different leaves
+// (starts 64 .. 128 elements apart) do not all sit on one bank.
+__device__ __forceinline__ int ridx(int i) { return i + (i >> 6); }
+constexpr int kRaggedLds = kPiece + kPiece / 64;
+
+template <int SQ, typename T>
+__device__ T ragged_leaf(const T *rag, int off, int n, T mean)
+{
+    if (n < 8) {
+        T res = 0;
+        for (int i = 0; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
+        return res;
+    }
+    T r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = tr<SQ, T>(rag[ridx(off + k)], mean);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ, T>(rag[ridx(off + i + k)], mean);
+    }
+    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
+    return res;
+}
+
+// numpy's recursion over the ragged piece (rem < 8192 values staged in LDS), in parallel: every 64th element descends the
+// split tree to its leaf (leaves are 64 .. 128 elements long, so each leaf is found by the thread at the first multiple of
+// 64 inside it), the leaves are summed side by side, and the tree is folded level by level, deepest first; a node's value
+// lives in the slot of the thread that owns its leftmost leaf.  Called by every thread of the workgroup (>= 128 threads);
+// the sum is returned to all of them.
+template <int SQ, typename T>
+__device__ T ragged_tree_sum(const T *ragged, int rem, T mean, T *vals /* LDS [kPiece / 64] */)
+{
+    const int t = threadIdx.x;
+    const int p = t * 64;
+    const bool valid = t < kPiece / 64 && p < rem;
+    int off = 0, n = rem;
+    int path_off[8], path_n[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const bool internal = valid && n > kLeaf;
+        path_off[d] = off;
+        path_n[d] = internal ? n : 0;
+        if (internal) {
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            if (p < off + n2) n = n2;
+            else { off += n2; n -= n2; }
+        }
+    }
+    const bool owner = valid && (off + 63) / 64 == t;
+    if (owner) vals[t] = ragged_leaf<SQ, T>(ragged, off, n, mean);
+    __syncthreads();
+#pragma unroll
+    for (int d = 7; d >= 0; d--) {
+        if (owner && path_n[d] > 0 && path_off[d] == off) {
+            int n2 = path_n[d] / 2;
+            n2 -= n2 % 8;
+            vals[t] = vals[t] + vals[(path_off[d] + n2 + 63) / 64];
+        }
+        __syncthreads();
+    }
+    return vals[0];
+}
+
+// One wavefront finds the bin of rank k in h[0 .. kBins): 32 bins per lane + a wavefront scan.
+struct DigitPick {
+    int digit;              // bin that holds rank k
+    long long newk;         // rank inside that bin
+    int dlow;               // highest occupied bin below it (-1: none)
+};
+
+__device__ void wave_pick_digit(const unsigned *h, long long k, int lane, DigitPick *pick /* LDS, pre-set to {0, 0, -1} */)
+{
+    unsigned long long c = 0;
+    constexpr int per = kBins / kWave;
+#pragma unroll 4
+    for (int j = 0; j < per; j++) c += h[lane * per + j];
+    unsigned long long inc = c;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    const unsigned long long exc = inc - c;
+    int dlow = -1;
+    if ((unsigned long long)k >= exc && (unsigned long long)k < inc) {
+        unsigned long long run = exc;
+        for (int j = 0; j < per; j++) {
+            const unsigned cnt = h[lane * per + j];
+            if ((unsigned long long)k < run + cnt) { pick->digit = lane * per + j; pick->newk = k - (long long)run; break; }
+            if (cnt) dlow = lane * per + j;
+            run += cnt;
+        }
+    } else if ((unsigned long long)k >= inc) {
+        for (int j = per - 1; j >= 0; j--)
+            if (h[lane * per + j]) { dlow = lane * per + j; break; }
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        const int o = __shfl_down(dlow, d);
+        dlow = o > dlow ? o : dlow;
+    }
+    if (lane == 0) pick->dlow = dlow;
+}
+
+// np.median from the last select level: `prefix` = the key bits found before it, `below` = the largest key under that prefix.
+template <typename T>
+__device__ double median_of_pick(long long m, unsigned long long prefix, int width, const DigitPick &pk, unsigned long long below)
+{
+    using K = KeyOf<T>;
+    if (m <= 0) return __builtin_nan("");
+    const T vhi = K::from((prefix << width) | (unsigned long long)pk.digit);
+    if (m & 1) return (double)vhi;
+    // rank m/2 - 1: the same key again if the searched rank is not the first of its bin; otherwise the highest occupied
+    // lower bin of this prefix, otherwise the largest key below the prefix
+    T vlo;
+    if (pk.newk >= 1) vlo = vhi;
+    else if (pk.dlow >= 0) vlo = K::from((prefix << width) | (unsigned long long)pk.dlow);
+    else vlo = K::from(below);
+    const T t = vlo + vhi;                                  // np.mean of the two middle values, in T
+    return (double)(T)((double)t / 2.0);
+}
+
 // ---- fused statistics pass ---------------------------------------------------------------------------
 // One read of the survivors does one level of the radix select (exact median) and, on the first two levels, one of
 // numpy's two sums:
@@ -360,7 +488,11 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
     const int g = lane / 8, kacc = lane % 8;
     unsigned cur_d = kSkip, cur_n = 0;
     KT below = 0, kmin = ~(KT)0, kmax = 0;
-    for (long long piece = (long long)blockIdx.x * wpb + wave; piece < npieces_full; piece += (long long)gridDim.x * wpb) {
+    // the last workgroup takes the ragged piece (below); the others share the full pieces
+    const bool tail_group = blockIdx.x == gridDim.x - 1;
+    const long long nworkers = gridDim.x - 1;
+    for (long long piece = tail_group ? npieces_full : (long long)blockIdx.x * wpb + wave; piece < npieces_full;
+         piece += nworkers * wpb) {
         const T *pbase = src + piece * kPiece + (long long)(8 * g) * kLeaf + kacc;
         constexpr int E = kLeaf / 8;                            // values of one leaf per lane
         // sum (numpy's leaf order) and bin one leaf's values
@@ -437,6 +569,34 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
         }
     }
     if (KIND == 0 && cur_d != kSkip) atomicAdd(&h[cur_d], cur_n);
+    if (tail_group) {
+        // the ragged last piece (m % 8192 values): its share of the histogram and the extremes, and its sum by numpy's
+        // irregular split tree - stored as one more piece sum, which the ordered fold adds last
+        __shared__ T ragged[kRaggedLds];
+        __shared__ T vals[kPiece / 64];
+        const int rem = (int)(m - npieces_full * kPiece);
+        for (int t = threadIdx.x; t < rem; t += kScanBlock) ragged[ridx(t)] = src[npieces_full * kPiece + t];
+        __syncthreads();
+        for (int t = threadIdx.x; t < rem; t += kScanBlock) {
+            const KT key = K::to(ragged[ridx(t)]);
+            if constexpr (KIND == 0) {
+                atomicAdd(&h[(unsigned)(key >> shift)], 1u);
+                kmin = key < kmin ? key : kmin;
+                kmax = key > kmax ? key : kmax;
+            } else {
+                const KT top = key >> (shift + width);
+                if (top == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
+                if constexpr (KIND == 2)
+                    if (top < prefix) below = key > below ? key : below;
+            }
+        }
+        if constexpr (SUM != 0) {
+            if (rem > 0) {
+                const T tail = ragged_tree_sum<SUM == 2, T>(ragged, rem, mean, vals);
+                if (threadIdx.x == 0) piece_sums[npieces_full] = tail;
+            }
+        }
+    }
     __syncthreads();
     for (int t = threadIdx.x; t < kBins; t += kScanBlock)
         if (h[t]) atomicAdd(&st->hist[t], h[t]);
@@ -472,85 +632,38 @@ __global__ __launch_bounds__(kScanBlock) void pass_kernel(const T *__restrict__ 
     }
 }
 
-// LDS index of element i of the ragged piece: one pad word per 64 elements, so that lanes walking different leaves
-// (starts 64 .. 128 elements apart) do not all sit on one bank.
-__device__ __forceinline__ int ridx(int i) { return i + (i >> 6); }
-
-template <int SQ, typename T>
-__device__ T ragged_leaf(const T *rag, int off, int n, T mean)
-{
-    if (n < 8) {
-        T res = 0;
-        for (int i = 0; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
-        return res;
-    }
-    T r[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = tr<SQ, T>(rag[ridx(off + k)], mean);
-    int i = 8;
-    for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = r[k] + tr<SQ, T>(rag[ridx(off + i + k)], mean);
-    }
-    T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + tr<SQ, T>(rag[ridx(off + i)], mean);
-    return res;
-}
-
-// Closes a statistics pass (one workgroup): the ragged last piece (its sums and its histogram share), the sequential
-// fold of the piece sums in numpy's order, the digit of the searched rank - and on the last level the median and, inside
-// a clipping iteration, the bounds.
+// Closes a statistics pass (one workgroup): the sequential fold of the piece sums in numpy's order (the ragged piece's sum
+// is the last of them), the digit of the searched rank - and on the last level the median and, inside a clipping iteration,
+// the bounds.  (Inside an iteration the last level is closed by the tile count kernel instead.)
 template <typename T, int SUM, int KIND>
-__global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0, const T *__restrict__ b1, GState *__restrict__ st,
-                                                      const T *__restrict__ piece_sums, int slot, int level, int final_pass,
-                                                      int ngroups, double sigma_lower, double sigma_upper)
+__global__ __launch_bounds__(kBlock) void after_kernel(GState *__restrict__ st, const T *__restrict__ piece_sums, int slot, int level,
+                                                      int final_pass, int ngroups, double sigma_lower, double sigma_upper)
 {
-    using K = KeyOf<T>;
-    using KT = typename K::type;
     if (blockIdx.x != 0) return;
     const IterState s = st->it[slot];
     if (s.done) return;
-    const T *src = s.cur ? b1 : b0;
     const long long m = s.m;
-    const T mean = SUM == 2 ? var_mean<T>(st, m) : (T)0;
-    const int shift = level_shift<T>(level), width = level_width<T>(level);
-    const KT prefix = (KT)st->prefix;
-    const unsigned dmask = (1u << width) - 1u;
-    const long long npieces_full = m / kPiece;
-    const int rem = (int)(m - npieces_full * kPiece);
+    const int width = level_width<T>(level);
+    const unsigned long long prefix = st->prefix;
+    const long long k = KIND == 0 ? m / 2 : st->k;          // upper median rank (0-based); odd m: the median itself
+    const long long nsums = m / kPiece + ((m % kPiece) ? 1 : 0);
     const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
 
     __shared__ unsigned h[kBins];
-    __shared__ T ragged[kPiece + kPiece / 64];
     __shared__ unsigned long long sh_lo, sh_hi;
-    __shared__ long long sh_newk;
-    __shared__ int sh_digit, sh_dlow;
+    __shared__ DigitPick pick;
     for (int t = threadIdx.x; t < kBins; t += kBlock) {
         h[t] = st->hist[t];
         st->hist[t] = 0;                            // ready for the next pass
     }
-    for (int t = threadIdx.x; t < rem; t += kBlock) ragged[ridx(t)] = src[npieces_full * kPiece + t];
-    if (threadIdx.x == 0) { sh_lo = ~0ull; sh_hi = 0; sh_digit = 0; sh_dlow = -1; sh_newk = 0; }
+    if (threadIdx.x == 0) { sh_lo = ~0ull; sh_hi = 0; pick.digit = 0; pick.newk = 0; pick.dlow = -1; }
     __syncthreads();
-    // the ragged piece's share of the histogram and of the extremes, and the workgroups' extremes
-    if constexpr (KIND == 0 || KIND == 2) {
+    if constexpr (KIND == 0 || KIND == 2) {         // the workgroups' extremes
         unsigned long long lo = ~0ull, hi = 0;
         for (int t = threadIdx.x; t < ngroups; t += kBlock) {
             const unsigned long long l = st->wg_lo[t], u = st->wg_hi[t];
             lo = l < lo ? l : lo;
             hi = u > hi ? u : hi;
-        }
-        for (int t = threadIdx.x; t < rem; t += kBlock) {
-            const KT key = K::to(ragged[ridx(t)]);
-            if constexpr (KIND == 0) {
-                atomicAdd(&h[(unsigned)(key >> shift)], 1u);
-                lo = key < lo ? key : lo;
-                hi = key > hi ? key : hi;
-            } else {
-                const KT top = key >> (shift + width);
-                if (top == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
-                if (top < prefix) hi = key > hi ? key : hi;
-            }
         }
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) {
@@ -559,58 +672,17 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
             hi = h2 > hi ? h2 : hi;
         }
         if (lane == 0) { atomicMin(&sh_lo, lo); atomicMax(&sh_hi, hi); }
-    } else {
-        for (int t = threadIdx.x; t < rem; t += kBlock) {
-            const KT key = K::to(ragged[ridx(t)]);
-            if ((key >> (shift + width)) == prefix) atomicAdd(&h[(unsigned)(key >> shift) & dmask], 1u);
-        }
     }
-    __syncthreads();
 
-    // digit of the searched rank: wavefront 1 scans the histogram (32 bins per lane) while lane 0 of wavefront 0 folds
-    auto scan_digit = [&]() {
-        const long long k = KIND == 0 ? m / 2 : st->k;      // upper median rank (0-based); odd m: the median itself
-        unsigned long long c = 0;
-        constexpr int per = kBins / kWave;
-#pragma unroll 4
-        for (int j = 0; j < per; j++) c += h[lane * per + j];
-        unsigned long long inc = c;
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            const unsigned long long o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-        }
-        const unsigned long long exc = inc - c;
-        int dlow = -1;
-        const bool mine = (unsigned long long)k >= exc && (unsigned long long)k < inc;
-        if (mine) {
-            unsigned long long run = exc;
-            for (int j = 0; j < per; j++) {
-                const unsigned cnt = h[lane * per + j];
-                if ((unsigned long long)k < run + cnt) { sh_digit = lane * per + j; sh_newk = k - (long long)run; break; }
-                if (cnt) dlow = lane * per + j;
-                run += cnt;
-            }
-        } else if ((unsigned long long)k >= inc) {
-            for (int j = per - 1; j >= 0; j--)
-                if (h[lane * per + j]) { dlow = lane * per + j; break; }
-        }
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) {
-            const int o = __shfl_down(dlow, d);
-            dlow = o > dlow ? o : dlow;
-        }
-        if (lane == 0) sh_dlow = dlow;                      // highest occupied bin below the digit (-1: none)
-    };
-
+    // wavefront 1 picks the digit (32 bins per lane) while lane 0 of wavefront 0 folds
     constexpr int kStage = 2048;
     constexpr int kBatch = 32;
     __shared__ __attribute__((aligned(16))) T stage[kStage];
     T res = 0;
     bool scanned = false;
     if constexpr (SUM != 0) {
-        for (long long i0 = 0; i0 < npieces_full; i0 += kStage) {
-            const int cnt = (int)((npieces_full - i0) < kStage ? (npieces_full - i0) : kStage);
+        for (long long i0 = 0; i0 < nsums; i0 += kStage) {
+            const int cnt = (int)((nsums - i0) < kStage ? (nsums - i0) : kStage);
             for (int t = threadIdx.x; t < cnt; t += blockDim.x) stage[t] = piece_sums[i0 + t];
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -620,68 +692,29 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
                 int t = 0;
                 if (cnt >= kBatch) {
 #pragma unroll
-                    for (int k = 0; k < kBatch; k++) cur[k] = stage[k];
+                    for (int q = 0; q < kBatch; q++) cur[q] = stage[q];
                     for (; t + kBatch <= cnt; t += kBatch) {
                         const bool more = t + 2 * kBatch <= cnt;
                         if (more) {
 #pragma unroll
-                            for (int k = 0; k < kBatch; k++) nxt[k] = stage[t + kBatch + k];
+                            for (int q = 0; q < kBatch; q++) nxt[q] = stage[t + kBatch + q];
                         }
 #pragma unroll
-                        for (int k = 0; k < kBatch; k++) res = res + cur[k];
+                        for (int q = 0; q < kBatch; q++) res = res + cur[q];
                         if (more) {
 #pragma unroll
-                            for (int k = 0; k < kBatch; k++) cur[k] = nxt[k];
+                            for (int q = 0; q < kBatch; q++) cur[q] = nxt[q];
                         }
                     }
                 }
                 for (; t < cnt; t++) res = res + stage[t];
             }
-            if (wave == 1 && !scanned) scan_digit();
+            if (wave == 1 && !scanned) wave_pick_digit(h, k, lane, &pick);
             scanned = true;
             __syncthreads();
         }
     }
-    if (!scanned && wave == 1) scan_digit();
-    if constexpr (SUM != 0) {
-        if (rem > 0) {
-            // numpy's recursion over the ragged piece, in parallel: every 64th element descends the split tree to its leaf
-            // (leaves are 64 .. 128 elements long, so each leaf is found by the thread at the first multiple of 64 inside
-            // it), the leaves are summed side by side, and the tree is folded level by level, deepest first; a node's value
-            // lives in the slot of the thread that owns its leftmost leaf.
-            __shared__ T vals[kPiece / 64];
-            const int t = threadIdx.x;
-            const int p = t * 64;
-            const bool valid = t < kPiece / 64 && p < rem;
-            int off = 0, n = rem;
-            int path_off[8], path_n[8];
-#pragma unroll
-            for (int d = 0; d < 8; d++) {
-                const bool internal = valid && n > kLeaf;
-                path_off[d] = off;
-                path_n[d] = internal ? n : 0;
-                if (internal) {
-                    int n2 = n / 2;
-                    n2 -= n2 % 8;
-                    if (p < off + n2) n = n2;
-                    else { off += n2; n -= n2; }
-                }
-            }
-            const bool owner = valid && (off + 63) / 64 == t;
-            if (owner) vals[t] = ragged_leaf<SUM == 2, T>(ragged, off, n, mean);
-            __syncthreads();
-#pragma unroll
-            for (int d = 7; d >= 0; d--) {
-                if (owner && path_n[d] > 0 && path_off[d] == off) {
-                    int n2 = path_n[d] / 2;
-                    n2 -= n2 % 8;
-                    vals[t] = vals[t] + vals[(path_off[d] + n2 + 63) / 64];
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) res = res + vals[0];
-        }
-    }
+    if (!scanned && wave == 1) wave_pick_digit(h, k, lane, &pick);
     __syncthreads();
     if (threadIdx.x != 0) return;
     if constexpr (SUM == 1) st->tot = (double)res;
@@ -694,28 +727,10 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
         st->min_key = sh_lo;
         st->max_key = sh_hi;
     }
-    const unsigned long long newprefix = KIND == 0 ? (unsigned long long)sh_digit
-                                                   : (((unsigned long long)prefix << width) | (unsigned long long)sh_digit);
-    st->prefix = newprefix;
-    st->k = sh_newk;
+    st->prefix = KIND == 0 ? (unsigned long long)pick.digit : ((prefix << width) | (unsigned long long)pick.digit);
+    st->k = pick.newk;
     if constexpr (KIND == 2) {
-        if (m <= 0) {
-            st->med = __builtin_nan("");
-        } else {
-            const T vhi = K::from(newprefix);
-            if (m & 1) {
-                st->med = (double)vhi;
-            } else {
-                // rank m/2 - 1: the same key again if the searched rank is not the first of its bin; otherwise the highest
-                // occupied lower bin of this prefix, otherwise the largest key below the prefix
-                T vlo;
-                if (sh_newk >= 1) vlo = vhi;
-                else if (sh_dlow >= 0) vlo = K::from(((unsigned long long)prefix << width) | (unsigned long long)sh_dlow);
-                else vlo = K::from(sh_hi);
-                const T t = vlo + vhi;                      // np.mean of the two middle values, in T
-                st->med = (double)(T)((double)t / 2.0);
-            }
-        }
+        st->med = median_of_pick<T>(m, prefix, width, pick, sh_hi);
         if (!final_pass) {
             if (m <= 0) { st->lo = st->hi = __builtin_nan(""); }
             else {
@@ -724,6 +739,93 @@ __global__ __launch_bounds__(kBlock) void after_kernel(const T *__restrict__ b0,
                 st->hi = st->med + st->sd * sigma_upper;
             }
         }
+    }
+}
+
+// Last select level of a clipping iteration, closed inside the tile count: every workgroup redoes the small closing step
+// (2048-bin histogram -> digit -> median -> bounds; 8 KB of L2-resident reads) instead of waiting for a one-workgroup
+// kernel, then counts its tiles against the bounds.  Workgroup 0 also publishes median and bounds for the scatter;
+// the tile scan clears the histogram.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void close_count_kernel(const T *__restrict__ src0, const T *__restrict__ src1, GState *__restrict__ st,
+                                                            int slot, int level, int ngroups, double sigma_lower, double sigma_upper,
+                                                            unsigned *__restrict__ tile_counts)
+{
+    const IterState s = st->it[slot];
+    if (s.done) return;
+    const T *src = s.cur ? src1 : src0;
+    const long long m = s.m;
+    const int width = level_width<T>(level);
+    const unsigned long long prefix = st->prefix;
+    const long long k = st->k;
+    const double sd = st->sd;
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    __shared__ unsigned h[kBins];
+    __shared__ unsigned long long sh_hi;
+    __shared__ DigitPick pick;
+    __shared__ double sh_bounds[2];
+    for (int t = threadIdx.x; t < kBins; t += kBlock) h[t] = st->hist[t];
+    if (threadIdx.x == 0) { sh_hi = 0; pick.digit = 0; pick.newk = 0; pick.dlow = -1; }
+    __syncthreads();
+    if (wave == 1) wave_pick_digit(h, k, lane, &pick);
+    __syncthreads();
+    // the largest key below the prefix is needed only when the searched rank opens its key AND its bin AND the count is even
+    if ((m & 1) == 0 && pick.newk == 0 && pick.dlow < 0) {
+        unsigned long long hi = 0;
+        for (int t = threadIdx.x; t < ngroups; t += kBlock) {
+            const unsigned long long u = st->wg_hi[t];
+            hi = u > hi ? u : hi;
+        }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            const unsigned long long h2 = __shfl_down(hi, d);
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0 && hi) atomicMax(&sh_hi, hi);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double med = median_of_pick<T>(m, prefix, width, pick, sh_hi);
+        // SigmaClip._compute_bounds: float32 scalars * python float -> float64 (numpy 1.26)
+        const double lo = m > 0 ? med - sd * sigma_lower : __builtin_nan(""), hi = m > 0 ? med + sd * sigma_upper : __builtin_nan("");
+        sh_bounds[0] = lo;
+        sh_bounds[1] = hi;
+        if (blockIdx.x == 0) {
+            st->med = med;                                  // outputs only: prefix / k / sd are still being read by
+            st->lo = lo;                                    // workgroups that start later
+            st->hi = hi;
+        }
+    }
+    __syncthreads();
+    // float32: the float64 bounds are demoted to float32 for the comparison, as numpy 1.26 does
+    const T lof = (T)sh_bounds[0], hif = (T)sh_bounds[1];
+    const long long ntiles = (m + kTile - 1) / kTile;
+    __shared__ unsigned wsum[kBlock / kWave];
+    constexpr int V = 16 / sizeof(T);
+    struct alignas(16) Vec { T x[V]; };
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long base = tile * kTile + (long long)threadIdx.x * 8;
+        unsigned c = 0;
+        if (base + 8 <= m) {                                // the survivors live in the 256-byte aligned workspace buffers
+#pragma unroll
+            for (int j = 0; j < 8 / V; j++) {
+                const Vec v = reinterpret_cast<const Vec *>(src + base)[j];
+#pragma unroll
+                for (int q = 0; q < V; q++) c += keep_pred<1, T>(v.x[q], lof, hif) ? 1u : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const long long i = base + j;
+                if (i < m) c += keep_pred<1, T>(src[i], lof, hif) ? 1u : 0u;
+            }
+        }
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) c += __shfl_down(c, d);
+        if (lane == 0) wsum[wave] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_counts[tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
     }
 }
 
@@ -759,7 +861,7 @@ WsLayout layout(int64_t n, size_t elem)
     L.state = off; off = up(off + sizeof(GState));
     L.buf0 = off; off = up(off + elem * (size_t)n);
     L.buf1 = off; off = up(off + elem * (size_t)n);
-    L.pieces = off; off = up(off + elem * (size_t)(n / kPiece + 1));
+    L.pieces = off; off = up(off + elem * (size_t)(n / kPiece + 2));
     const size_t ntiles = (size_t)((n + kTile - 1) / kTile);
     L.tcounts = off; off = up(off + sizeof(unsigned) * (ntiles + 1));
     L.toffsets = off; off = up(off + sizeof(unsigned long long) * (ntiles + 1));
@@ -804,34 +906,40 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     hipLaunchKernelGGL((tile_scatter_kernel<0, T>), dim3(gtile), dim3(kBlock), 0, s, data, data, b0, b0, n, st, 0, toffs);
     if (int rc = check_launch("sigclip_global: compact finite")) return rc;
 
-    auto stats_pass = [&](int slot, int final_pass) {
-        hipLaunchKernelGGL((pass_kernel<T, 1, 0>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 0);
-        hipLaunchKernelGGL((after_kernel<T, 1, 0>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 0, final_pass, (int)gpass,
-                           sigma_lower, sigma_upper);
-        hipLaunchKernelGGL((pass_kernel<T, 2, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 1);
-        hipLaunchKernelGGL((after_kernel<T, 2, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, 1, final_pass, (int)gpass,
-                           sigma_lower, sigma_upper);
+    const unsigned gp1 = gpass + 1;                          // + the workgroup of the ragged piece
+    // close + count: every workgroup repeats the closing step, so few, fat workgroups (16 tiles each at 4096^2)
+    const unsigned gclose = (unsigned)(ntiles < kNumCU * 2 ? ntiles : kNumCU * 2);
+    // close_last: the last level is closed by after_kernel (final statistics) or left to close_count_kernel (iterations)
+    auto stats_pass = [&](int slot, int final_pass, bool close_last) {
+        hipLaunchKernelGGL((pass_kernel<T, 1, 0>), dim3(gp1), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 0);
+        hipLaunchKernelGGL((after_kernel<T, 1, 0>), dim3(1), dim3(kBlock), 0, s, st, pieces, slot, 0, final_pass, (int)gp1, sigma_lower,
+                           sigma_upper);
+        hipLaunchKernelGGL((pass_kernel<T, 2, 1>), dim3(gp1), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, 1);
+        hipLaunchKernelGGL((after_kernel<T, 2, 1>), dim3(1), dim3(kBlock), 0, s, st, pieces, slot, 1, final_pass, (int)gp1, sigma_lower,
+                           sigma_upper);
         for (int level = 2; level < levels - 1; level++) {
-            hipLaunchKernelGGL((pass_kernel<T, 0, 1>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, level);
-            hipLaunchKernelGGL((after_kernel<T, 0, 1>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, level, final_pass,
-                               (int)gpass, sigma_lower, sigma_upper);
+            hipLaunchKernelGGL((pass_kernel<T, 0, 1>), dim3(gp1), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, level);
+            hipLaunchKernelGGL((after_kernel<T, 0, 1>), dim3(1), dim3(kBlock), 0, s, st, pieces, slot, level, final_pass, (int)gp1,
+                               sigma_lower, sigma_upper);
         }
-        hipLaunchKernelGGL((pass_kernel<T, 0, 2>), dim3(gpass), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, levels - 1);
-        hipLaunchKernelGGL((after_kernel<T, 0, 2>), dim3(1), dim3(kBlock), 0, s, b0, b1, st, pieces, slot, levels - 1, final_pass,
-                           (int)gpass, sigma_lower, sigma_upper);
+        hipLaunchKernelGGL((pass_kernel<T, 0, 2>), dim3(gp1), dim3(kScanBlock), 0, s, b0, b1, st, pieces, slot, levels - 1);
+        if (close_last)
+            hipLaunchKernelGGL((after_kernel<T, 0, 2>), dim3(1), dim3(kBlock), 0, s, st, pieces, slot, levels - 1, final_pass, (int)gp1,
+                               sigma_lower, sigma_upper);
     };
 
     for (int it = 0; it < iters; it++) {
         const int slot = it & 1;
-        stats_pass(slot, 0);
-        hipLaunchKernelGGL((tile_count_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, n, st, slot, tcounts);
+        stats_pass(slot, 0, false);
+        hipLaunchKernelGGL(close_count_kernel<T>, dim3(gclose), dim3(kBlock), 0, s, b0, b1, st, slot, levels - 1, (int)gp1, sigma_lower,
+                           sigma_upper, tcounts);
         hipLaunchKernelGGL(tile_scan_kernel<1>, dim3(1), dim3(1024), 0, s, n, st, slot, tcounts, toffs);
         hipLaunchKernelGGL((tile_scatter_kernel<1, T>), dim3(gtile), dim3(kBlock), 0, s, b0, b1, b0, b1, n, st, slot, toffs);
         if (int rc = check_launch("sigclip_global: iteration")) return rc;
     }
     // statistics of the survivors: the last iteration's statistics belong to the pre-clip set unless it removed nothing
     // (state `done`), in which case they are final already and these launches return at once
-    stats_pass(iters & 1, 1);
+    stats_pass(iters & 1, 1, true);
     hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, iters & 1, stats_out);
     return check_launch("sigclip_global: publish");
 }
