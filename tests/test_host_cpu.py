@@ -335,3 +335,47 @@ def test_tile_affines_follow_the_exact_map():
     I = wcs.tile_affines(out, out, (1080, 1920))
     np.testing.assert_allclose(I[..., [0, 4]], 1.0, atol=1e-9)
     np.testing.assert_allclose(I[..., [1, 2, 3, 5]], 0.0, atol=1e-6)
+
+
+def test_oversampling_geometry_host_logic():
+    """OVERSAMPLING n geometry on the host: the fine-grid transform maps sub-pixel centres, the oversampled WCS keeps the sky
+    position of every block of n x n fine pixels, the fill of excluded mesh boxes equals the oracle's."""
+    import numpy as np
+    from astrophotography_amd import ops, wcs
+    A = np.array([[1.01, -0.02, 3.5, 0.02, 0.99, -1.25]])
+    for n in (2, 4):
+        fine, shape = ops.oversampled_affines(A, n, (10, 12))
+        assert shape == (10 * n, 12 * n)
+        f = fine.numpy()[0]
+        for (i, j, a, b) in ((0, 0, 0, 0), (3, 7, 1, n - 1), (9, 11, n - 1, 0)):
+            cx, cy = j + (b + 0.5) / n - 0.5, i + (a + 0.5) / n - 0.5           # sub-pixel centre in output coordinates
+            want = (A[0, 0] * cx + A[0, 1] * cy + A[0, 2], A[0, 3] * cx + A[0, 4] * cy + A[0, 5])
+            u, v = n * j + b, n * i + a
+            got = (f[0] * u + f[1] * v + f[2], f[3] * u + f[4] * v + f[5])
+            assert abs(got[0] - want[0]) < 1e-12 and abs(got[1] - want[1]) < 1e-12
+        w = wcs.TanWcs.from_center(83.8, -5.4, 2.0, (40, 50))
+        wf = w.oversampled(n)
+        # the centre of the n x n block of output pixel (x, y) is that pixel's own centre
+        for (x, y) in ((0.0, 0.0), (17.0, 31.0), (49.0, 39.0)):
+            ra, dec = w.pix2sky(x, y)
+            raf, decf = wf.pix2sky(n * x + (n - 1) / 2.0, n * y + (n - 1) / 2.0)
+            assert abs(ra - raf) < 1e-10 and abs(dec - decf) < 1e-10
+    from astrophotography_amd.core.ApMeasureBackground import _fill_excluded
+    from oracle import background_ref as br
+    rng = np.random.default_rng(5)
+    mesh = rng.normal(100, 5, (9, 11))
+    good = rng.random((9, 11)) > 0.2
+    mesh_nan = np.where(good, mesh, np.nan)
+    assert np.array_equal(_fill_excluded(mesh_nan, good), br.fill_excluded(mesh_nan, good))
+
+
+def test_coadd_output_gain_bookkeeping():
+    from astrophotography_amd.core.ApResample import ApResample
+    g = [1.5, 1.5, 1.5, 1.5]
+    f = [1 / 30.0] * 4
+    assert abs(ApResample('CRITICAL', combine='SUM')._output_gain(g, [1.0] * 4, None) - 1.5 / 4) < 1e-12
+    assert abs(ApResample('CRITICAL', combine='AVERAGE')._output_gain(g, f, None) - 4 * 1.5 * 30) < 1e-9
+    # equal weights = plain average; one dominant weight -> the gain of that frame alone
+    assert abs(ApResample('CRITICAL', combine='WEIGHTED')._output_gain(g, f, [2, 2, 2, 2]) - 4 * 45.0) < 1e-9
+    assert abs(ApResample('CRITICAL', combine='WEIGHTED')._output_gain(g, f, [1, 1e-9, 1e-9, 1e-9]) - 45.0) < 1e-6
+    assert ApResample('CRITICAL', combine='MEDIAN')._output_gain([1.5, None], [1, 1], None) is None
