@@ -246,8 +246,8 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     // the two middle values of the finite range: the lower one is the pivot, and together they are the first pass's median
     float m1, m2;
     pick_middle<NP>(v, (n - 1) >> 1, n >> 1, m1, m2);
-    const float cf = n > 0 ? m1 : 0.f;
-    const double c = (double)cf;
+    float cf = n > 0 ? m1 : 0.f;
+    double c = (double)cf;
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
     if (wave_all(n == ns)) {               // the usual case: no rejected value in the whole wave (padding: scalar skips)
@@ -285,15 +285,55 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     st.Thi = 0.0;
     bool active = n > 0;
     int it = 0;
+    // S and Q are updated by subtraction: their absolute error stays at the scale of the values they were last summed
+    // from (~ 2^-50 n Q).  When the spread of the survivors has collapsed below 2^-22 of that scale - a huge outlier gone,
+    // or the clip converging on a handful of near-identical values - the variance n Q - S^2 is no longer good to the ~1e-9
+    // the keep / reject decisions need, and the moments are summed afresh about a pivot inside the survivors.
+    double refresh_below = ldexp((double)n * Q0, -22);
 
     while (wave_any(active)) {
         const int a0 = st.a, b0 = st.b;
+        double V = 0.0;
+        if (active) {
+            st.nn = (double)(st.b - st.a);
+            V = fma(st.nn, st.Q, -(st.S * st.S));            // n^2 * variance
+        }
+#ifdef APGPU_VARIANT_NO_REFRESH
+        const bool refresh = false;
+#else
+        const bool refresh = active && (st.b > st.a) && (V < refresh_below);
+#endif
+        if (wave_any(refresh)) {                             // rare: see above
+            float p1, p2;
+            pick_middle<NP>(v, (st.a + st.b - 1) >> 1, (st.a + st.b) >> 1, p1, p2);
+            const double cn = refresh ? (double)p1 : st.c;
+            double Sn = 0.0, Qn = 0.0;
+            // one wave-uniform test per slot even for full stacks: the scalar branches keep this pass as NP short blocks
+            // (as one straight-line block the register allocator keeps every converted value alive: 250 VGPRs)
+            int nslots = ns;
+            asm volatile("" : "+s"(nslots));
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                if (i >= nslots) continue;
+                const double d0 = widen(v[i]) - cn;
+                const double d = (refresh && i >= st.a && i < st.b) ? d0 : 0.0;
+                Sn += d;
+                Qn = fma(d, d, Qn);
+            }
+            if (refresh) {
+                st.S = Sn;
+                st.Q = Qn;
+                st.c = cn;
+                c = cn;
+                cf = p1;
+                V = fma(st.nn, Qn, -(Sn * Sn));
+                refresh_below = ldexp(st.nn * Qn, -22);
+            }
+        }
         if (active) {
             const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
-            st.nn = (double)(st.b - st.a);
             st.cen = use_median ? med : c + st.S / st.nn;
             st.wscale = st.nn;
-            double V = fma(st.nn, st.Q, -(st.S * st.S));     // n^2 * variance
             V = V > 0.0 ? V : 0.0;
             st.Tlo = sl2 * V;
             st.Thi = su2 * V;
@@ -403,8 +443,8 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     }
 
     // pivot: the lower median of the finite values; S = sum(x - c), Q = sum((x - c)^2) as in the lean kernel
-    const float cf = n > 0 ? col_read<NP, B>(col, (n - 1) >> 1) : 0.f;
-    const double c = (double)cf;
+    float cf = n > 0 ? col_read<NP, B>(col, (n - 1) >> 1) : 0.f;
+    double c = (double)cf;
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (FROM_REGS) {
 #pragma unroll
@@ -440,6 +480,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     st.Thi = 0.0;
     bool active = n > 0;
     int it = 0;
+    double refresh_below = ldexp((double)n * st.Q, -22);     // see the lean kernel: when to sum the moments afresh
 
     while (wave_any(active)) {
         const int a0 = st.a, b0 = st.b;
@@ -448,8 +489,40 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
         const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
         double mad = 0.0;
         if (use_mad) mad = mad_std_window<NP, B>(col, active, st.a, st.b, med);
+        double V = 0.0;
         if (active) {
             st.nn = (double)(st.b - st.a);
+            V = fma(st.nn, st.Q, -(st.S * st.S));            // n^2 * variance
+        }
+        const bool refresh = active && (st.b > st.a) && (V < refresh_below);
+        if (wave_any(refresh)) {
+            const double cn = refresh ? (double)m1 : st.c;
+            double Sn = 0.0, Qn = 0.0;
+            constexpr int CH = NP >= 8 ? 8 : NP;
+            for (int i0 = 0; i0 < NP; i0 += CH) {
+                if (!wave_any(refresh && i0 + CH > st.a && i0 < st.b)) continue;
+                float x[CH];
+#pragma unroll
+                for (int j = 0; j < CH; j++) x[j] = col_read<NP, B>(col, i0 + j);
+#pragma unroll
+                for (int j = 0; j < CH; j++) {
+                    const double d0 = (double)x[j] - cn;
+                    const double d = (refresh && i0 + j >= st.a && i0 + j < st.b) ? d0 : 0.0;
+                    Sn += d;
+                    Qn = fma(d, d, Qn);
+                }
+            }
+            if (refresh) {
+                st.S = Sn;
+                st.Q = Qn;
+                st.c = cn;
+                c = cn;
+                cf = m1;
+                V = fma(st.nn, Qn, -(Sn * Sn));
+                refresh_below = ldexp(st.nn * Qn, -22);
+            }
+        }
+        if (active) {
             st.cen = use_median ? med : c + st.S / st.nn;
             if (use_mad) {
                 st.wscale = 1.0;
@@ -457,7 +530,6 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
                 st.Thi = su2 * (mad * mad);
             } else {
                 st.wscale = st.nn;
-                double V = fma(st.nn, st.Q, -(st.S * st.S)); // n^2 * variance
                 V = V > 0.0 ? V : 0.0;
                 st.Tlo = sl2 * V;
                 st.Thi = su2 * V;

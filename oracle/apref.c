@@ -293,6 +293,11 @@ static double kth_smallest(double *a, int n, int k)
 
 static double wirth_median(double *a, int n)
 {
+    /* An empty buffer: astropy's wirth_median reads a[0] and a[-1] here - outside the data, undefined.  Defined for this
+       build (oracle and kernels alike) as NaN, which is what the NumPy path gives for an empty slice: the bounds become
+       NaN, nothing is masked, and every finite value of the pixel survives - the same outcome the C loop reaches by
+       itself for stdfunc='std' (0/0 mean and variance). */
+    if (n <= 0) return NAN;
     if (n % 2 == 0)
         return 0.5 * (kth_smallest(a, n, n / 2) + kth_smallest(a, n, n / 2 - 1));
     return kth_smallest(a, n, (n - 1) / 2);
