@@ -11,21 +11,25 @@ using namespace apgpu;
 struct ClipState {
     double S, Q;            // sum(x - c), sum((x - c)^2) over the survivors
     double c;               // pivot
-    double cen, nn;         // centre and count the last bounds were computed with
+    double cen, woff, nn;   // the last bounds: w = wscale (x - cen) - woff is the scaled distance from their centre; count
     double wscale;          // scale of the bound test: n (std mode, T = sigma^2 n^2 var) or 1 (mad_std mode)
     double Tlo, Thi;        // sigma^2 * (n*Q - S^2): squared, n^2-scaled half-widths of the bounds
     int a, b;
 };
 
+// Centre = median: cen = med, woff = 0.  Centre = mean = c + S / n: cen = c, woff = wscale S / n, i.e. n (x - mean) is formed
+// as n (x - c) - S without the division - exact for integer-valued frames, so that a value that EQUALS a bound (few discrete
+// levels: levels L, L+d, L+2d with counts 3, 5, 5 give mean - 1.5 std = L) is kept, as x >= lower_bound keeps it in astropy
+// whenever its own rounding lands on the tie.
 __device__ __forceinline__ bool below(const ClipState &st, double xd)
 {
-    const double w = st.wscale * (xd - st.cen);
+    const double w = fma(st.wscale, xd - st.cen, -st.woff);
     return (w < 0.0) && (w * w > st.Tlo);
 }
 
 __device__ __forceinline__ bool above(const ClipState &st, double xd)
 {
-    const double w = st.wscale * (xd - st.cen);
+    const double w = fma(st.wscale, xd - st.cen, -st.woff);
     return (w > 0.0) && (w * w > st.Thi);
 }
 
@@ -279,6 +283,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     st.b = n;
     // parameters of the last bounds computed for this lane
     st.cen = c;
+    st.woff = 0.0;
     st.nn = (double)n;
     st.wscale = (double)n;
     st.Tlo = 0.0;
@@ -332,7 +337,8 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         }
         if (active) {
             const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
-            st.cen = use_median ? med : c + st.S / st.nn;
+            st.cen = use_median ? med : c;
+            st.woff = (use_median || st.nn == 0.0) ? 0.0 : st.S;      // n (x - mean) = n (x - c) - S
             st.wscale = st.nn;
             V = V > 0.0 ? V : 0.0;
             st.Tlo = sl2 * V;
@@ -474,6 +480,7 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     st.a = 0;
     st.b = n;
     st.cen = c;
+    st.woff = 0.0;
     st.nn = (double)n;
     st.wscale = (double)n;
     st.Tlo = 0.0;
@@ -523,13 +530,15 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
             }
         }
         if (active) {
-            st.cen = use_median ? med : c + st.S / st.nn;
+            st.cen = use_median ? med : c;
             if (use_mad) {
                 st.wscale = 1.0;
+                st.woff = (use_median || st.nn == 0.0) ? 0.0 : st.S / st.nn;
                 st.Tlo = sl2 * (mad * mad);
                 st.Thi = su2 * (mad * mad);
             } else {
                 st.wscale = st.nn;
+                st.woff = (use_median || st.nn == 0.0) ? 0.0 : st.S;  // n (x - mean) = n (x - c) - S
                 V = V > 0.0 ? V : 0.0;
                 st.Tlo = sl2 * V;
                 st.Thi = su2 * V;
