@@ -879,9 +879,10 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     const WsLayout L = layout(n_pixels, sizeof(T));
     if (ws_bytes < L.total) return fail(APGPU_EWORKSPACE, "sigclip_global: workspace %zu < %zu bytes", ws_bytes, L.total);
     if (reinterpret_cast<uintptr_t>(ws) & 15) return fail(APGPU_EINVAL, "sigclip_global: workspace must be 16-byte aligned");
-    // maxiters < 0 (until convergence): the device loop is a launch-time constant; 32 passes always
-    // converge in practice (every pass but the last removes at least one value).
-    const int iters = (maxiters < 0 || maxiters > kMaxItersCap) ? kMaxItersCap : maxiters;
+    // Up to 32 iterations are queued without looking back (the `done` flag turns the ones after convergence into no-ops).
+    // More than that - maxiters < 0 = until convergence, which a small sigma stretches to hundreds of passes - goes in
+    // batches of 32 with one read of the flag in between (the only host synchronisation of this entry point).
+    const long long iters_max = maxiters < 0 ? n_pixels + 1 : maxiters;       // every pass but the last removes a value
     char *w = static_cast<char *>(ws);
     GState *st = reinterpret_cast<GState *>(w + L.state);
     T *b0 = reinterpret_cast<T *>(w + L.buf0);
@@ -928,8 +929,17 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
                                sigma_lower, sigma_upper);
     };
 
-    for (int it = 0; it < iters; it++) {
-        const int slot = it & 1;
+    long long iters = 0;
+    for (long long it = 0; it < iters_max; it++) {
+        if (it > 0 && it % kMaxItersCap == 0) {
+            int done = 0;
+            if (hipMemcpyAsync(&done, &st->it[it & 1].done, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                return fail(APGPU_ELAUNCH, "sigclip_global: reading the convergence flag failed");
+            if (done) break;
+        }
+        iters = it + 1;
+        const int slot = (int)(it & 1);
         stats_pass(slot, 0, false);
         hipLaunchKernelGGL(close_count_kernel<T>, dim3(gclose), dim3(kBlock), 0, s, b0, b1, st, slot, levels - 1, (int)gp1, sigma_lower,
                            sigma_upper, tcounts);
@@ -939,8 +949,8 @@ int run_sigclip_global(const T *data, int64_t n_pixels, double sigma_lower, doub
     }
     // statistics of the survivors: the last iteration's statistics belong to the pre-clip set unless it removed nothing
     // (state `done`), in which case they are final already and these launches return at once
-    stats_pass(iters & 1, 1, true);
-    hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, iters & 1, stats_out);
+    stats_pass((int)(iters & 1), 1, true);
+    hipLaunchKernelGGL(publish_kernel<T>, dim3(1), dim3(64), 0, s, st, (int)(iters & 1), stats_out);
     return check_launch("sigclip_global: publish");
 }
 

@@ -30,17 +30,173 @@ def big_case(seed):
     return tf.wide_case(ops, apref, seed)
 
 
+def global_case(seed):
+    """ops.sigclip_global (float32 / float64 / uint16) against the oracle over awkward populations: few discrete levels,
+    constants, heavy tails, NaN / inf, sizes around the 8192-element piece and tile edges, sigma from 0.5, any iteration count."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 9000)), int(rng.integers(8000, 70000)), 8192 * int(rng.integers(1, 6)),
+                        2048 * int(rng.integers(1, 9)) + int(rng.integers(-2, 3))]))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        x = rng.normal(20, 3, n)
+    elif kind == 1:
+        x = rng.choice(rng.normal(100, 5, int(rng.integers(1, 5))), n)                 # a few discrete levels
+    elif kind == 2:
+        x = np.full(n, rng.normal(0, 100))
+    elif kind == 3:
+        x = rng.standard_cauchy(n) * 10 + 500
+    else:
+        x = np.rint(rng.normal(1000, 8, n))
+    dt = [np.float32, np.float64, np.uint16][int(rng.integers(0, 3))]
+    if dt == np.uint16:
+        x = np.clip(np.rint(np.abs(x)), 0, 65535).astype(np.uint16)
+    else:
+        x = x.astype(dt)
+        if n > 10 and rng.integers(0, 2):
+            x[rng.integers(0, n, 3)] = np.nan
+            x[rng.integers(0, n, 2)] = np.inf * rng.choice([-1, 1])
+    sigma = float(rng.choice([0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 5.0]))
+    mi = rng.choice([1, 2, 5, 10, None])
+    mi = None if mi is None else int(mi)
+    what = f'global seed={seed} n={n} kind={kind} {np.dtype(dt).name} s={sigma} it={mi}'
+    with np.errstate(all='ignore'):
+        ref = apref.sigclip_global(x, sigma=sigma, maxiters=mi)
+    t = ops.to_device_u16(x) if dt == np.uint16 else torch.from_numpy(x).cuda()
+    st = ops.sigclip_global(t, sigma=sigma, maxiters=mi).cpu().numpy()
+    got = [st[0], st[1], st[2]]
+    want = [ref['mean'], ref['median'], ref['std']]
+    if dt == np.float32:
+        got, want = [np.float32(v) for v in got], [np.float32(v) for v in want]
+    same = all((g == w) or (g != g and w != w) for g, w in zip(got, want))
+    assert same, f'{what}: {got} vs {want}'
+    assert int(st[6]) == ref['nkeep'] and int(st[5]) == ref['niter'], f'{what}: kept {st[6]} iter {st[5]} vs {ref["nkeep"]} {ref["niter"]}'
+
+
+def calibrate_case(seed):
+    """Mixed-precision calibrate + flat normalisation + bad-pixel repair (any dtype mix, any deltapix) against the oracle."""
+    rng = np.random.default_rng(seed)
+    H, W = int(rng.integers(1, 40)), int(rng.integers(1, 200))
+    N = int(rng.integers(1, 5))
+    bias, dark, flat = synth_masters(rng, (H, W))
+    if W > 6 and rng.integers(0, 2):
+        flat[0, :6] = [0.0, np.nan, -1.25, np.inf, 1e-30, 2.0]
+    mdt = [np.float32, np.float64]
+    bias = bias.astype(mdt[int(rng.integers(0, 2))])
+    dark = dark.astype(mdt[int(rng.integers(0, 2))])
+    flat = flat.astype(mdt[int(rng.integers(0, 2))])
+    rdt = [np.uint16, np.float32, np.float64][int(rng.integers(0, 3))]
+    raw = synth_cube(rng, N, (H, W), dtype=np.uint16 if rdt == np.uint16 else np.float32).astype(rdt)
+    use_flat = bool(rng.integers(0, 3))
+    nflat_ref = apref.flat_normalize(flat)[0] if use_flat else None
+    e = rng.uniform(0.2, 2.0, N)
+    ped = np.where(rng.random(N) < 0.4, rng.uniform(-100, 100, N), 0.0) if rng.integers(0, 2) else None
+    sb = bool(rng.integers(0, 2))
+    what = f'calibrate seed={seed} {N}x{H}x{W} raw={np.dtype(rdt).name} bias={bias.dtype} dark={dark.dtype} flat={flat.dtype if use_flat else None} ped={ped is not None} sb={sb}'
+    ref = apref.calibrate_mixed(raw, bias, dark, nflat_ref, e, ped, sb)
+    nflat = None
+    if use_flat:
+        nflat, _ = ops.flat_normalize(dev(flat))
+        assert np.array_equal(nflat.cpu().numpy(), nflat_ref, equal_nan=True), 'nflat ' + what
+    out = ops.calibrate(dev(raw), dev(bias), dev(dark), nflat, e, pedestal=ped, dark_still_biased=sb)
+    assert out.cpu().numpy().dtype == ref.dtype and np.array_equal(out.cpu().numpy(), ref, equal_nan=True), what
+    mask = (rng.random((H, W)) < float(rng.choice([0.0, 0.02, 0.3]))).astype(np.uint8)
+    delta = int(rng.integers(1, 6))
+    img = ref[0]
+    fr, _ = apref.fix_badpix(img, mask, delta)
+    fg, _ = ops.fix_badpix(out[0].contiguous(), dev(mask), delta)
+    assert np.array_equal(fg.cpu().numpy(), fr, equal_nan=True), f'fix_badpix delta={delta} ' + what
+
+
+def frame_case(seed):
+    """The F4 kernels against their restatements on small random fields: box statistics (any box size, both LDS-resident and
+    streamed boxes), source mask, L.A.Cosmic (both fine-structure modes)."""
+    from oracle import background_ref as br
+    from oracle import lacosmic_ref as lr
+    rng = np.random.default_rng(seed)
+    H, W = int(rng.integers(20, 120)), int(rng.integers(20, 160))
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = rng.normal(400.0, 8.0, (H, W))
+    for _ in range(int(rng.integers(0, 12))):
+        cy, cx, amp = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(100, 8000)
+        img += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * rng.uniform(1.0, 2.5) ** 2))
+    if rng.integers(0, 2):
+        img = np.rint(img)                                   # integer-valued: ties in the box medians
+    img = img.astype(np.float32)
+    if rng.integers(0, 2):
+        img[rng.integers(0, H), rng.integers(0, W)] = np.nan
+    mask = (rng.random((H, W)) < float(rng.choice([0.0, 0.03, 0.4]))).astype(np.uint8)
+    bh, bw = int(rng.integers(3, H + 10)), int(rng.integers(3, W + 10))
+    if rng.integers(0, 3) == 0:
+        bh, bw = H, W                                        # one box: the streamed (non-resident) path for larger fields
+    sigma = float(rng.choice([1.5, 2.0, 3.0]))
+    mi = int(rng.choice([1, 5, 10]))
+    what = f'frame seed={seed} {H}x{W} boxes {bh}x{bw} s={sigma} it={mi}'
+    st = ops.box_clipped_stats(torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda(), bh, bw, sigma=sigma, maxiters=mi).cpu().numpy()
+    med, std, nfin, nm0 = br.box_clipped_stats(img, mask, bh, bw, sigma, mi)
+    lo = br.box_clipped_stats(img, mask, bh, bw, sigma * (1 - 1e-10), mi)[2]
+    hi = br.box_clipped_stats(img, mask, bh, bw, sigma * (1 + 1e-10), mi)[2]
+    firm = (lo == nfin) & (hi == nfin)                       # boxes on an exact tie are left out (see DESIGN)
+    assert np.array_equal(st[..., 2].astype(np.int64)[firm], nfin[firm]), 'box survivors ' + what
+    assert np.array_equal(st[..., 3].astype(np.int64), nm0), 'box masked ' + what
+    assert np.array_equal(st[..., 0][firm], med[firm], equal_nan=True), 'box median ' + what
+    np.testing.assert_allclose(st[..., 1][firm], std[firm], rtol=1e-11, equal_nan=True, err_msg=what)
+    # cosmic rays
+    clean_img = np.nan_to_num(img, nan=400.0)
+    for _ in range(int(rng.integers(0, 30))):
+        clean_img[rng.integers(3, H - 3), rng.integers(3, W - 3)] += rng.uniform(300, 6000)
+    gain = float(rng.choice([1.0, 1.3]))
+    fsmode = str(rng.choice(['convolve', 'median']))
+    rc, rm = lr.detect_cosmics(clean_img, gain=gain, satlevel=gain * 65535, fsmode=fsmode)
+    e = torch.from_numpy(clean_img).cuda() * np.float32(gain)
+    gc, gm, _ = ops.lacosmic(e, satlevel=gain * 65535, fsmode=fsmode)
+    assert np.array_equal(gm.cpu().numpy().astype(bool), rm), f'lacosmic mask {fsmode} ' + what
+    assert np.array_equal(gc.cpu().numpy(), rc, equal_nan=True), f'lacosmic image {fsmode} ' + what
+
+
+def resample_case(seed):
+    """apgpu_resample_affine_f32 against the oracle: any rotation / scale / shift (LDS-staged and direct-gather tiles), masks,
+    flux scales, output shapes, table resolutions."""
+    rng = np.random.default_rng(seed)
+    N, H, W = int(rng.integers(1, 4)), int(rng.integers(6, 150)), int(rng.integers(6, 200))
+    frames = rng.normal(300, 30, (N, H, W)).astype(np.float32)
+    if rng.integers(0, 2):
+        frames[rng.integers(0, N), rng.integers(0, H), rng.integers(0, W)] = np.nan
+    A = []
+    for _ in range(N):
+        th = np.deg2rad(rng.uniform(-180, 180) if rng.integers(0, 4) == 0 else rng.uniform(-1, 1))
+        sc = float(rng.choice([1.0, rng.uniform(0.3, 3.0)]))
+        c, sn = sc * np.cos(th), sc * np.sin(th)
+        A.append([c, -sn, rng.uniform(-20, 20), sn, c, rng.uniform(-20, 20)])
+    A = np.array(A)
+    out_shape = None if rng.integers(0, 2) else (int(rng.integers(1, 180)), int(rng.integers(1, 260)))
+    mask = (rng.random((H, W)) < 0.01).astype(np.uint8) if rng.integers(0, 2) else None
+    fs = rng.uniform(0.1, 3.0, N).astype(np.float32) if rng.integers(0, 2) else None
+    nph = int(rng.choice([64, 1024, 4096]))
+    cf = bool(rng.integers(0, 2))
+    what = f'resample seed={seed} {N}x{H}x{W} -> {out_shape} phases={nph} conserve={cf}'
+    ref, wref = apref.resample_affine(frames, A, fscale=fs, mask=mask, out_shape=out_shape, n_phases=nph, conserve_flux=cf)
+    got, wgot = ops.resample_affine(torch.from_numpy(frames).cuda(), A, fscale=fs, mask=None if mask is None else torch.from_numpy(mask).cuda(),
+                                    out_shape=out_shape, n_phases=nph, conserve_flux=cf)
+    assert np.array_equal(got.cpu().numpy(), ref, equal_nan=True), what
+    assert np.array_equal(wgot.cpu().numpy(), wref), 'weights ' + what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=5.0)
     ap.add_argument('--seed0', type=int, default=100000)
+    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample')
     a = ap.parse_args()
     t_end = time.time() + 60.0 * a.minutes
-    fails, runs = [], {'big': 0, 'stack': 0, 'image': 0}
+    fails, runs = [], {}
+    only = set(a.only.split(',')) if a.only else None
     seed = a.seed0
     while time.time() < t_end:
-        for name, fn in (('big', lambda s: big_case(s)), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
-                         ('image', lambda s: tf.test_random_image_kernels(ops, apref, s))):
+        for name, fn in (('big', big_case), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
+                         ('image', lambda s: tf.test_random_image_kernels(ops, apref, s)), ('global', global_case),
+                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case)):
+            if only and name not in only:
+                continue
             try:
                 fn(seed)
             except Exception as ex:                       # noqa: BLE001 - a fuzz driver reports everything
@@ -48,7 +204,7 @@ def main():
                 print('FAIL', name, seed, str(ex)[:600], flush=True)
                 if not isinstance(ex, AssertionError):
                     traceback.print_exc()
-            runs[name] += 1
+            runs[name] = runs.get(name, 0) + 1
         seed += 1
     print('runs', runs, 'failures', len(fails))
     return 1 if fails else 0
