@@ -38,12 +38,16 @@ for seed in [int(s) for s in sys.argv[1:]]:
     mi = None if mi is None else int(mi)
     cen = str(rng.choice(['median', 'mean']))
     dv = str(rng.choice(['std', 'std', 'mad_std']))
+    outs_i = int(rng.integers(0, 7))
+    sl, su = (sigma, sigma) if rng.integers(0, 3) else (float(rng.choice([0.5, 1.25, 2.0, 3.0, 1e30])), float(rng.choice([0.5, 1.5, 3.0, 4.0, 1e30])))
     with np.errstate(all='ignore'):
-        ref = apref.stack_sigclip(cal, sigma=sigma, maxiters=mi, cenfunc=cen, stdfunc=dv, pixmask=pixmask)
-    r = ops.stack_sigclip(dev(cube), sigma=sigma, maxiters=mi, cenfunc=cen, stdfunc=dv, calib=calib,
+        ref = apref.stack_sigclip(cal, sigma_lower=sl, sigma_upper=su, maxiters=mi, cenfunc=cen, stdfunc=dv, pixmask=pixmask)
+    r = ops.stack_sigclip(dev(cube), sigma_lower=sl, sigma_upper=su, maxiters=mi, cenfunc=cen, stdfunc=dv, calib=calib,
                           pixmask=None if pixmask is None else dev(pixmask), outputs=('mean', 'count'))
     got = r['count'].cpu().numpy()
-    bad = np.argwhere(got != ref['count'])
+    gm = r['mean'].cpu().numpy()
+    bad = np.argwhere((got != ref['count']) | ~((gm == ref['mean'].astype(np.float32)) | (np.isnan(gm) & np.isnan(ref['mean']))))
+    sigma = (sl, su)
     print(f'seed {seed}: N={N} {H}x{W} u16={u16} calib={use_calib} {cen}/{dv} sigma={sigma} maxiters={mi}: {len(bad)} of {H * W} columns differ')
     for (y, x) in bad[:3]:
         col = np.sort(cal[:, y, x].astype(np.float64))
