@@ -181,11 +181,47 @@ def resample_case(seed):
     assert np.array_equal(wgot.cpu().numpy(), wref), 'weights ' + what
 
 
+def arith_case(seed):
+    """ApImArith.apply over dtype mixes against NumPy itself: the reference computes ufunc(data1, data2, out=zeros_like(data1))
+    (core/ApImArith.py:210-232), so values, wrap-around and the operand combinations NumPy refuses all follow from NumPy."""
+    from astrophotography_amd.core.ApImArith import ApImArith
+    rng = np.random.default_rng(seed)
+    H, W = int(rng.integers(1, 30)), int(rng.integers(1, 70))
+    dt1 = [np.uint16, np.float32, np.float64][int(rng.integers(0, 3))]
+    a = (rng.integers(0, 65536, (H, W)) if dt1 == np.uint16 else rng.normal(100, 50, (H, W))).astype(dt1)
+    if dt1 != np.uint16 and rng.integers(0, 2):
+        a[rng.integers(0, H), rng.integers(0, W)] = [np.nan, np.inf, 0.0][int(rng.integers(0, 3))]
+    if rng.integers(0, 3) == 0:
+        b = float(rng.choice([0.0, 2.5, -3.0, 1e30]))
+    else:
+        dt2 = [np.uint16, np.int16, np.float32, np.float64, dt1, dt1][int(rng.integers(0, 6))]
+        b = (rng.integers(0, 3000, (H, W)) if np.dtype(dt2).kind in 'ui' else rng.normal(5, 2, (H, W))).astype(dt2)
+        if np.dtype(dt2).kind == 'f' and rng.integers(0, 2):
+            b[rng.integers(0, H), rng.integers(0, W)] = 0.0
+    op = ['ADD', 'SUB', 'MUL', 'DIV'][int(rng.integers(0, 4))]
+    uf = {'ADD': np.add, 'SUB': np.subtract, 'MUL': np.multiply, 'DIV': np.divide}[op]
+    what = f'arith seed={seed} {np.dtype(dt1).name} {op} {b if isinstance(b, float) else b.dtype.name}'
+    want, err = None, None
+    with np.errstate(all='ignore'):
+        try:
+            want = np.zeros_like(a)
+            uf(a, b, out=want)
+        except TypeError as ex:                              # UFuncTypeError: casting refused
+            err = ex
+    try:
+        got = ApImArith('CRITICAL').apply(a, op, b)
+    except TypeError:
+        assert err is not None, 'GPU path raised TypeError, NumPy did not: ' + what
+        return
+    assert err is None, f'NumPy refuses ({err}), GPU path did not: ' + what
+    assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), what
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=5.0)
     ap.add_argument('--seed0', type=int, default=100000)
-    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample')
+    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith')
     a = ap.parse_args()
     t_end = time.time() + 60.0 * a.minutes
     fails, runs = [], {}
@@ -194,7 +230,7 @@ def main():
     while time.time() < t_end:
         for name, fn in (('big', big_case), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
                          ('image', lambda s: tf.test_random_image_kernels(ops, apref, s)), ('global', global_case),
-                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case)):
+                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case)):
             if only and name not in only:
                 continue
             try:
