@@ -217,11 +217,82 @@ def arith_case(seed):
     assert got.dtype == want.dtype and np.array_equal(got, want, equal_nan=True), what
 
 
+def fits_case(seed):
+    """FITS round trips: host write -> device read (every BITPIX, the uint16 BZERO convention, odd shapes) equals the host
+    read; device write of float32 / float64 -> host read gives the tensor back bit for bit, headers included."""
+    import tempfile
+    from astrophotography_amd import fitsio
+    rng = np.random.default_rng(seed)
+    H, W = int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    dt = [np.uint8, np.int16, np.uint16, np.int32, np.float32, np.float64][int(rng.integers(0, 6))]
+    if np.dtype(dt).kind in 'ui':
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, int(info.max) + 1, (H, W)).astype(dt)
+    else:
+        a = rng.normal(0, 1e3, (H, W)).astype(dt)
+        a[rng.integers(0, H), rng.integers(0, W)] = [np.nan, np.inf, -0.0][int(rng.integers(0, 3))]
+    hdr = fitsio.Header()
+    hdr['EXPTIME'] = float(rng.uniform(0.1, 600))
+    hdr['OBJECT'] = 'x' * int(rng.integers(0, 120))
+    what = f'fits seed={seed} {np.dtype(dt).name} {H}x{W}'
+    with tempfile.TemporaryDirectory() as d:
+        f = os.path.join(d, 'a.fits')
+        fitsio.write(f, a, hdr)
+        back, h2 = fitsio.read(f)
+        assert back.dtype == a.dtype and np.array_equal(back, a, equal_nan=True), 'host round trip ' + what
+        assert h2['OBJECT'] == hdr['OBJECT'] and h2['EXPTIME'] == hdr['EXPTIME'], 'header ' + what
+        t, h3 = fitsio.read_device(f)
+        got = t.view(torch.int16).cpu().numpy().view(np.uint16) if t.dtype == torch.uint16 else t.cpu().numpy()
+        want = a if a.dtype in (np.uint16, np.float32, np.float64) else a.astype(got.dtype)
+        assert np.array_equal(got, want, equal_nan=True), f'device read ({got.dtype}) ' + what
+        if a.dtype in (np.float32, np.float64):
+            g = os.path.join(d, 'b.fits')
+            fitsio.write_device(g, torch.from_numpy(a).cuda(), h2)
+            again, h4 = fitsio.read(g)
+            assert again.dtype == a.dtype and np.array_equal(again.view(np.uint8), a.view(np.uint8)), 'device write ' + what
+            assert h4['OBJECT'] == hdr['OBJECT'], 'device write header ' + what
+
+
+def chunked_case(seed):
+    """More than 512 frames on one GPU (ops.stack_sigclip_chunked / ApStack): an unclipped mean is exact to the float64 sum; a
+    clipped one equals "oracle per chunk, moments added" (the hierarchical semantics of the N-shard combine)."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(513, 1400))
+    H, W = int(rng.integers(1, 4)), int(rng.integers(1, 90))
+    cube = synth_cube(rng, N, (H, W), nan_frac=float(rng.choice([0.0, 0.05])))
+    chunk = int(rng.choice([0, int(rng.integers(64, 513))]))
+    sigma = float(rng.choice([2.0, 3.0, 1e30]))
+    mi = int(rng.choice([1, 5]))
+    what = f'chunked seed={seed} N={N} {H}x{W} chunk={chunk} s={sigma} it={mi}'
+    r = ops.stack_sigclip_chunked(torch.from_numpy(cube).cuda(), chunk=chunk or None, want_std=True, sigma=sigma, maxiters=mi)
+    if chunk == 0:
+        parts = -(-N // 512)
+        chunk = -(-N // parts)
+    tot, cnt, sq = np.zeros((H, W)), np.zeros((H, W), np.int64), np.zeros((H, W))
+    for i0 in range(0, N, chunk):
+        part = cube[i0:i0 + chunk]
+        with np.errstate(all='ignore'):
+            ref = apref.stack_sigclip(part, sigma=sigma, maxiters=mi)
+        kept = np.where(ref['keep'], part.astype(np.float64), 0.0)
+        tot += kept.sum(0)
+        sq += (kept * kept).sum(0)
+        cnt += ref['count']
+    assert np.array_equal(r['count'].cpu().numpy(), cnt), 'count ' + what
+    with np.errstate(all='ignore'):
+        mean = (tot / cnt).astype(np.float32)
+    assert_ulp(r['mean'].cpu().numpy(), mean, 1, 'mean ' + what)
+    with np.errstate(all='ignore'):
+        var = sq / cnt - (tot / cnt) ** 2
+    got = r['std'].cpu().numpy().astype(np.float64)
+    ok = cnt > 0
+    np.testing.assert_allclose(got[ok] ** 2, np.maximum(var[ok], 0), rtol=1e-4, atol=1e-3, err_msg=what)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=5.0)
     ap.add_argument('--seed0', type=int, default=100000)
-    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith')
+    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith,fits,chunked')
     a = ap.parse_args()
     t_end = time.time() + 60.0 * a.minutes
     fails, runs = [], {}
@@ -230,7 +301,7 @@ def main():
     while time.time() < t_end:
         for name, fn in (('big', big_case), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
                          ('image', lambda s: tf.test_random_image_kernels(ops, apref, s)), ('global', global_case),
-                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case)):
+                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case), ('fits', fits_case), ('chunked', chunked_case)):
             if only and name not in only:
                 continue
             try:
