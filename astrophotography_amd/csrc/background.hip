@@ -233,15 +233,16 @@ __device__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *sha
 // NT threads per box: 256 for small boxes, 1024 for the 16 x 16 meshes of full frames (one workgroup per CU, 16 wavefronts).
 // RES: the box (<= kBoxLdsPixels pixels) is staged in LDS once, masked / outside / non-finite pixels as NaN; otherwise every
 // pass walks the image rows of the box (coalesced runs, L2 / Infinity Cache resident after the first pass).
-// Passes per clipping iteration: (a) count + sum, (b) sum of squared deviations + first select level, (c) second level,
-// (d) third level + the largest survivor below the found prefix - the lower middle element of an even count comes from the
-// last histogram or from (d)'s maximum, not from a second select.
+// Passes: the first iteration makes four - (a) count + sum, (b) sum of squared deviations + first select level, (c) second
+// level, (d) third level + the largest survivor below the found prefix (the lower middle element of an even count comes from
+// the last histogram or from (d)'s maximum, not from a second select); every later iteration makes two - count, moments about
+// the previous median, first level and a speculated second level in one, then (d).
 template <int NT, bool RES>
 __global__ __launch_bounds__(NT) void box_stats_kernel(const float *__restrict__ data, const uint8_t *__restrict__ mask, int H, int W,
                                                       int bh, int bw, int nx, double sigma, int maxiters, double *__restrict__ out)
 {
     extern __shared__ float vals[];
-    __shared__ unsigned hist[kBoxBins];
+    __shared__ unsigned hist[kBoxBins], hist2[kBoxBins];
     __shared__ double scratch[NT / kWave];
     __shared__ unsigned s_below[NT / kWave];
     __shared__ DigitPick s_pick;
@@ -304,64 +305,132 @@ __global__ __launch_bounds__(NT) void box_stats_kernel(const float *__restrict__
     float lo_run = -3.4028234663852886e38f, hi_run = 3.4028234663852886e38f, lo_last = lo_run, hi_last = hi_run;
     double med = __builtin_nan(""), sd = __builtin_nan("");
     int n = 0, n_prev = -1, n_unmasked = -1;
+    unsigned guess0 = 0;                                    // first-level digit of the previous iteration's median
     for (int pass = 0;; pass++) {
         const bool final_pass = pass >= maxiters || n_prev == -2;
         const float lo = final_pass ? lo_last : lo_run, hi = final_pass ? hi_last : hi_run;
-        double cnt = 0.0, sum = 0.0;
-        for_each([&](float x) {
-            if (x >= lo && x <= hi) {
-                cnt += 1.0;
-                sum += (double)x;
-            }
-        });
-        n = (int)block_sum<NT>(cnt, scratch);
-        const double total = block_sum<NT>(sum, scratch);
-        if (n_unmasked < 0) n_unmasked = n;
-        if (n == 0) {
-            med = sd = __builtin_nan("");
-            break;
-        }
-        if (!final_pass && n == n_prev) {                   // the last bounds removed nothing: converged, evaluate the survivors
-            n_prev = -2;
-            continue;
-        }
-        const double mean = total / (double)n;
-        const unsigned k = (unsigned)(n >> 1);              // upper middle element (the median itself for odd n)
-        // (b) spread + leading 11 key bits.  The sky values of a box share their leading digits: run-length coded per
-        // thread before they reach the LDS histogram.
-        zero_hist();
-        double ss = 0.0;
-        unsigned cur_d = kNoDigit, cur_n = 0;
-        for_each([&](float x) {
-            if (x >= lo && x <= hi) {
-                const double d = mean - (double)x;
-                ss += d * d;
-                const unsigned dg = f32_key(x) >> (32 - kBoxDigit);
-                if (dg != cur_d) {
-                    if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
-                    cur_d = dg;
-                    cur_n = 0;
+        unsigned prefix, kk;
+        if (pass == 0 || RES) {
+            // first iteration (and every iteration of an LDS-resident box, which is bound by its LDS atomics and gains nothing
+            // from fewer reads): count + sum, then spread + first select level, then the second level (3 passes)
+            double cnt = 0.0, sum = 0.0;
+            for_each([&](float x) {
+                if (x >= lo && x <= hi) {
+                    cnt += 1.0;
+                    sum += (double)x;
                 }
-                cur_n++;
+            });
+            n = (int)block_sum<NT>(cnt, scratch);
+            const double total = block_sum<NT>(sum, scratch);
+            if (n_unmasked < 0) n_unmasked = n;
+            if (n == 0) {
+                med = sd = __builtin_nan("");
+                break;
             }
-        });
-        if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
-        sd = sqrt(block_sum<NT>(ss, scratch) / (double)n);   // (its barriers also close the histogram)
-        DigitPick pk = pick_digit(hist, k, &s_pick);
-        unsigned prefix = (unsigned)pk.digit;
-        unsigned kk = k - pk.cum;
-        // (c) next 11 bits
-        zero_hist();
-        for_each([&](float x) {
-            if (x >= lo && x <= hi) {
-                const unsigned key = f32_key(x);
-                if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & (kBoxBins - 1)], 1u);
+            if (!final_pass && n == n_prev) {               // the last bounds removed nothing: converged, evaluate the survivors
+                n_prev = -2;
+                continue;
             }
-        });
-        __syncthreads();
-        pk = pick_digit(hist, kk, &s_pick);
-        prefix = (prefix << kBoxDigit) | (unsigned)pk.digit;
-        kk -= pk.cum;
+            const double mean = total / (double)n;
+            const unsigned k = (unsigned)(n >> 1);          // upper middle element (the median itself for odd n)
+            // spread + leading 11 key bits.  The sky values of a box share their leading digits: run-length coded per
+            // thread before they reach the LDS histogram.
+            zero_hist();
+            double ss = 0.0;
+            unsigned cur_d = kNoDigit, cur_n = 0;
+            for_each([&](float x) {
+                if (x >= lo && x <= hi) {
+                    const double d = mean - (double)x;
+                    ss += d * d;
+                    const unsigned dg = f32_key(x) >> (32 - kBoxDigit);
+                    if (dg != cur_d) {
+                        if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+                        cur_d = dg;
+                        cur_n = 0;
+                    }
+                    cur_n++;
+                }
+            });
+            if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+            sd = sqrt(block_sum<NT>(ss, scratch) / (double)n);   // (its barriers also close the histogram)
+            DigitPick pk = pick_digit(hist, k, &s_pick);
+            prefix = (unsigned)pk.digit;
+            kk = k - pk.cum;
+            guess0 = prefix;
+            zero_hist();
+            for_each([&](float x) {
+                if (x >= lo && x <= hi) {
+                    const unsigned key = f32_key(x);
+                    if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & (kBoxBins - 1)], 1u);
+                }
+            });
+            __syncthreads();
+            pk = pick_digit(hist, kk, &s_pick);
+            prefix = (prefix << kBoxDigit) | (unsigned)pk.digit;
+            kk -= pk.cum;
+        } else {
+            // later iterations: ONE pass for count, moments about the previous median (S1 = sum(x - p), S2 = sum((x - p)^2):
+            // mean = p + S1 / n, n var = S2 - S1^2 / n - p sits inside the survivors, so nothing cancels), the first select
+            // level, and the second level speculated on the first level's digit of the previous iteration (the median hardly
+            // moves); a wrong guess costs the separate second-level pass.
+            const double p = med;
+            zero_hist();
+            const unsigned g0 = guess0;
+            for (int t = threadIdx.x; t < kBoxBins; t += NT) hist2[t] = 0;
+            __syncthreads();
+            double cnt = 0.0, s1 = 0.0, s2 = 0.0;
+            unsigned cur_d = kNoDigit, cur_n = 0;
+            for_each([&](float x) {
+                if (x >= lo && x <= hi) {
+                    cnt += 1.0;
+                    const double d = (double)x - p;
+                    s1 += d;
+                    s2 = fma(d, d, s2);
+                    const unsigned key = f32_key(x);
+                    const unsigned dg = key >> (32 - kBoxDigit);
+                    if (dg != cur_d) {
+                        if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+                        cur_d = dg;
+                        cur_n = 0;
+                    }
+                    cur_n++;
+                    if (dg == g0) atomicAdd(&hist2[(key >> 10) & (kBoxBins - 1)], 1u);
+                }
+            });
+            if (cur_d != kNoDigit) atomicAdd(&hist[cur_d], cur_n);
+            n = (int)block_sum<NT>(cnt, scratch);
+            const double S1 = block_sum<NT>(s1, scratch), S2 = block_sum<NT>(s2, scratch);
+            if (n == 0) {
+                med = sd = __builtin_nan("");
+                break;
+            }
+            if (!final_pass && n == n_prev) {               // the last bounds removed nothing: converged, evaluate the survivors
+                n_prev = -2;
+                continue;
+            }
+            const double nv = S2 - S1 * S1 / (double)n;
+            sd = sqrt((nv > 0.0 ? nv : 0.0) / (double)n);
+            const unsigned k = (unsigned)(n >> 1);
+            DigitPick pk = pick_digit(hist, k, &s_pick);
+            prefix = (unsigned)pk.digit;
+            kk = k - pk.cum;
+            if (prefix == g0) {
+                pk = pick_digit(hist2, kk, &s_pick);
+            } else {
+                guess0 = prefix;
+                zero_hist();
+                for_each([&](float x) {
+                    if (x >= lo && x <= hi) {
+                        const unsigned key = f32_key(x);
+                        if ((key >> 21) == prefix) atomicAdd(&hist[(key >> 10) & (kBoxBins - 1)], 1u);
+                    }
+                });
+                __syncthreads();
+                pk = pick_digit(hist, kk, &s_pick);
+            }
+            prefix = (prefix << kBoxDigit) | (unsigned)pk.digit;
+            kk -= pk.cum;
+        }
         // (d) last 10 bits + the largest survivor key below the 22-bit prefix
         zero_hist();
         unsigned below = 0;
@@ -380,7 +449,7 @@ __global__ __launch_bounds__(NT) void box_stats_kernel(const float *__restrict__
         }
         if (lane == 0) s_below[wave] = below;
         __syncthreads();
-        pk = pick_digit(hist, kk, &s_pick);
+        const DigitPick pk = pick_digit(hist, kk, &s_pick);
         const unsigned key2 = (prefix << 10) | (unsigned)pk.digit;
         unsigned key1 = key2;
         if ((n & 1) == 0 && kk - pk.cum == 0) {             // rank k is the first of its key: the lower neighbour is another key
