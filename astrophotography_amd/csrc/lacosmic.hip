@@ -30,9 +30,19 @@ inline unsigned grid1d(int64_t n)
 #define APGPU_FOR_PIXELS(p, P) \
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, _stride = (int64_t)gridDim.x * blockDim.x; p < (P); p += _stride)
 
+// What the second (column) pass of a separable median does with the median m of pixel p - the elementwise kernels that
+// used to follow it, fused in (same operations, same order):
+//   POST_STORE   out[p] = m
+//   POST_MINUS   out[p] = aux[p] - m                                   sp = s - sepmed7(s)
+//   POST_NOISE   n = sqrt(max(m, 1e-5) + rn2); out[p] = n; aux2[p] = aux2[p] / (2 n)     noise model and significance map
+//   POST_FINE    out[p] = max((aux[p] - m) / aux2[p], 0.01)            fine-structure image (aux = f, aux2 = noise)
+enum { POST_STORE = 0, POST_MINUS = 1, POST_NOISE = 2, POST_FINE = 3 };
+
 // 1-D median of K (odd) along rows (ALONG_X) or columns; pixels closer than K/2 to the border are copied.
-template <int K, bool ALONG_X>
-__global__ __launch_bounds__(kBlock) void median1d_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W)
+template <int K, bool ALONG_X, int POST = POST_STORE>
+__global__ __launch_bounds__(kBlock) void median1d_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int W,
+                                                         const float *__restrict__ aux = nullptr, float *__restrict__ aux2 = nullptr,
+                                                         float rn2 = 0.f)
 {
     constexpr int NP = K <= 8 ? 8 : 16;
     constexpr int HALF = K / 2;
@@ -40,18 +50,30 @@ __global__ __launch_bounds__(kBlock) void median1d_kernel(const float *__restric
     APGPU_FOR_PIXELS(p, P) {
         const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
         const int pos = ALONG_X ? c : r, len = ALONG_X ? W : H;
+        float m;
         if (pos < HALF || pos >= len - HALF) {
-            out[p] = in[p];
-            continue;
-        }
-        float v[NP];
+            m = in[p];
+        } else {
+            float v[NP];
 #pragma unroll
-        for (int k = 0; k < NP; k++) {
-            if (k < K) v[k] = in[ALONG_X ? p + (k - HALF) : p + (int64_t)(k - HALF) * W];
-            else v[k] = __builtin_inff();
+            for (int k = 0; k < NP; k++) {
+                if (k < K) v[k] = in[ALONG_X ? p + (k - HALF) : p + (int64_t)(k - HALF) * W];
+                else v[k] = __builtin_inff();
+            }
+            apgpu_stack::sort_column<NP>(v);
+            m = v[HALF];
         }
-        apgpu_stack::sort_column<NP>(v);
-        out[p] = v[HALF];
+        if constexpr (POST == POST_STORE) {
+            out[p] = m;
+        } else if constexpr (POST == POST_MINUS) {
+            out[p] = aux[p] - m;
+        } else if constexpr (POST == POST_NOISE) {
+            const float n = sqrtf(fmaxf(m, 0.00001f) + rn2);
+            out[p] = n;
+            aux2[p] = aux2[p] / (2.0f * n);
+        } else {
+            out[p] = fmaxf((aux[p] - m) / aux2[p], 0.01f);
+        }
     }
 }
 
@@ -73,22 +95,6 @@ __global__ __launch_bounds__(kBlock) void laplace_kernel(const float *__restrict
         const float br = 4.f * v - d - rr - v - v;
         s[p] = (fmaxf(tl, 0.f) + fmaxf(tr, 0.f) + fmaxf(bl, 0.f) + fmaxf(br, 0.f)) * 0.25f;
     }
-}
-
-__global__ __launch_bounds__(kBlock) void noise_sigmap_kernel(const float *__restrict__ m5, float *__restrict__ s, float *__restrict__ noise,
-                                                             float rn2, int64_t P)
-{
-    APGPU_FOR_PIXELS(p, P) {
-        const float m = fmaxf(m5[p], 0.00001f);
-        const float n = sqrtf(m + rn2);
-        noise[p] = n;
-        s[p] = s[p] / (2.0f * n);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void subtract_kernel(float *__restrict__ a, const float *__restrict__ b, int64_t P)
-{
-    APGPU_FOR_PIXELS(p, P) a[p] = a[p] - b[p];
 }
 
 // f = sum_k psf[k] * clean[shifted]  (7 x 7, zero outside the image), accumulated in row-major kernel order.
@@ -132,20 +138,6 @@ __global__ __launch_bounds__(kBlock) void convolve7_kernel(const float *__restri
                 if (gx < W) f[(int64_t)gy * W + gx] = acc[j];
             }
         }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void fine_kernel(float *__restrict__ f, const float *__restrict__ m7, const float *__restrict__ noise, int64_t P)
-{
-    APGPU_FOR_PIXELS(p, P) f[p] = fmaxf((f[p] - m7[p]) / noise[p], 0.01f);
-}
-
-__global__ __launch_bounds__(kBlock) void select_kernel(const float *__restrict__ sp, const float *__restrict__ f, const uint8_t *__restrict__ mask,
-                                                       float sigclip, float objlim, uint8_t *__restrict__ cr, int64_t P)
-{
-    APGPU_FOR_PIXELS(p, P) {
-        const float x = sp[p];
-        cr[p] = (!(mask && mask[p]) && x > sigclip && (x / f[p]) > objlim) ? 1 : 0;
     }
 }
 
@@ -202,6 +194,60 @@ __global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restric
         const int64_t p = done + t;
         const bool cand = !(mask && mask[p]) && !(sp && !(sp[p] > thr));
         out[p] = (cand && dilate_any<SHAPE>(in, p, H, W)) ? 1 : 0;
+    }
+}
+
+// Candidate selection + first growth step in one pass: out = dilate3(cr) & !mask & (sp > sigclip) with
+// cr[q] = !mask[q] & (sp[q] > sigclip) & (sp[q] / f[q] > objlim) evaluated on the fly for the nine neighbours of the few
+// pixels that pass the cheap conditions themselves (the candidate map is never written).
+__device__ __forceinline__ bool selected(const float *__restrict__ sp, const float *__restrict__ f, const uint8_t *__restrict__ mask,
+                                         float sigclip, float objlim, int64_t q)
+{
+    const float x = sp[q];
+    return !(mask && mask[q]) && x > sigclip && (x / f[q]) > objlim;
+}
+
+__global__ __launch_bounds__(kBlock) void select_grow_kernel(const float *__restrict__ sp, const float *__restrict__ f,
+                                                            const uint8_t *__restrict__ mask, float sigclip, float objlim,
+                                                            uint8_t *__restrict__ out, int H, int W)
+{
+    const int64_t P = (int64_t)H * W;
+    auto grown = [&](int64_t p) -> bool {
+        const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);
+        bool any = false;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int rr = r + dy, cc = c + dx;
+                if (rr >= 0 && rr < H && cc >= 0 && cc < W) any = any || selected(sp, f, mask, sigclip, objlim, (int64_t)rr * W + cc);
+            }
+        return any;
+    };
+    const int64_t P4 = P / 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
+    if (vec) {
+        APGPU_FOR_PIXELS(q, P4) {
+            const float4 v = reinterpret_cast<const float4 *>(sp)[q];
+            bool cand[4] = {v.x > sigclip, v.y > sigclip, v.z > sigclip, v.w > sigclip};
+            if (mask) {
+                const unsigned m = reinterpret_cast<const unsigned *>(mask)[q];
+#pragma unroll
+                for (int j = 0; j < 4; j++) cand[j] = cand[j] && ((m >> (8 * j)) & 0xffu) == 0;
+            }
+            unsigned o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (cand[j] && grown(4 * q + j)) o |= 1u << (8 * j);
+            reinterpret_cast<unsigned *>(out)[q] = o;
+        }
+    }
+    const int64_t done = vec ? 4 * P4 : 0;
+    APGPU_FOR_PIXELS(t, P - done) {
+        const int64_t p = done + t;
+        const bool cand = !(mask && mask[p]) && sp[p] > sigclip;
+        out[p] = (cand && grown(p)) ? 1 : 0;
     }
 }
 
@@ -273,12 +319,13 @@ __global__ __launch_bounds__(kBlock) void or_kernel(const uint8_t *__restrict__ 
     APGPU_FOR_PIXELS(p, P) out[p] = (a[p] || (b && b[p])) ? 1 : 0;
 }
 
-template <int K>
-void sepmed(const float *in, float *out, float *tmp, int H, int W, hipStream_t st)
+template <int K, int POST = POST_STORE>
+void sepmed(const float *in, float *out, float *tmp, int H, int W, hipStream_t st, const float *aux = nullptr, float *aux2 = nullptr,
+            float rn2 = 0.f)
 {
     const unsigned g = grid1d((int64_t)H * W);
-    hipLaunchKernelGGL((median1d_kernel<K, true>), dim3(g), dim3(kBlock), 0, st, in, tmp, H, W);
-    hipLaunchKernelGGL((median1d_kernel<K, false>), dim3(g), dim3(kBlock), 0, st, tmp, out, H, W);
+    hipLaunchKernelGGL((median1d_kernel<K, true>), dim3(g), dim3(kBlock), 0, st, in, tmp, H, W, (const float *)nullptr, (float *)nullptr, 0.f);
+    hipLaunchKernelGGL((median1d_kernel<K, false, POST>), dim3(g), dim3(kBlock), 0, st, tmp, out, H, W, aux, aux2, rn2);
 }
 
 struct Work {
@@ -361,10 +408,10 @@ extern "C" int apgpu_lacosmic_iterate(float *clean, const uint8_t *mask, uint8_t
     const unsigned g = grid1d(P);
     if (hipMemsetAsync(ncr_out, 0, sizeof(int64_t), st) != hipSuccess) return fail(APGPU_ELAUNCH, "lacosmic_iterate: memset failed");
     hipLaunchKernelGGL(laplace_kernel, dim3(g), dim3(kBlock), 0, st, clean, w.s, H, W);
-    sepmed<7>(clean, w.t1, w.t2, H, W, st);                                                 // m5
-    hipLaunchKernelGGL(noise_sigmap_kernel, dim3(g), dim3(kBlock), 0, st, w.t1, w.s, w.noise, readnoise * readnoise, P);
-    sepmed<7>(w.s, w.t1, w.t2, H, W, st);
-    hipLaunchKernelGGL(subtract_kernel, dim3(g), dim3(kBlock), 0, st, w.s, w.t1, P);        // sp = s - sepmed7(s)
+    // noise = sqrt(max(sepmed7(clean), 1e-5) + rn^2), s /= 2 noise - in the median's column pass
+    sepmed<7, POST_NOISE>(clean, w.noise, w.t2, H, W, st, nullptr, w.s, readnoise * readnoise);
+    sepmed<7, POST_MINUS>(w.s, w.t1, w.t2, H, W, st, w.s);                                  // sp = s - sepmed7(s)  -> t1
+    const float *sp = w.t1;
     if (psfk) {
         const int64_t tiles = (int64_t)((W + kConvTW - 1) / kConvTW) * ((H + kConvTH - 1) / kConvTH);
         hipLaunchKernelGGL(convolve7_kernel, dim3((unsigned)(tiles < kNumCU * 64 ? tiles : kNumCU * 64)), dim3(kBlock), 0, st, clean, psfk,
@@ -372,11 +419,10 @@ extern "C" int apgpu_lacosmic_iterate(float *clean, const uint8_t *mask, uint8_t
     } else {
         sepmed<5>(clean, w.f, w.t2, H, W, st);                                              // fsmode 'median'
     }
-    sepmed<9>(w.f, w.t1, w.t2, H, W, st);
-    hipLaunchKernelGGL(fine_kernel, dim3(g), dim3(kBlock), 0, st, w.f, w.t1, w.noise, P);
-    hipLaunchKernelGGL(select_kernel, dim3(g), dim3(kBlock), 0, st, w.s, w.f, mask, sigclip, objlim, w.u1, P);
-    hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, w.u1, w.s, mask, sigclip, w.u2, H, W);
-    hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, w.u2, w.s, mask, sigfrac * sigclip, w.u1, H, W);
+    sepmed<9, POST_FINE>(w.f, w.s, w.t2, H, W, st, w.f, w.noise);                           // fine structure -> s (free by now)
+    const float *fine = w.s;
+    hipLaunchKernelGGL(select_grow_kernel, dim3(g), dim3(kBlock), 0, st, sp, fine, mask, sigclip, objlim, w.u2, H, W);
+    hipLaunchKernelGGL(dilate_kernel<3>, dim3(g), dim3(kBlock), 0, st, w.u2, sp, mask, sigfrac * sigclip, w.u1, H, W);
     hipLaunchKernelGGL(merge_count_kernel, dim3(g), dim3(kBlock), 0, st, w.u1, crmask, reinterpret_cast<unsigned long long *>(ncr_out), P);
     hipLaunchKernelGGL(clean_meanmask_kernel, dim3(g), dim3(kBlock), 0, st, clean, crmask, mask, background_level, H, W);
     return check_launch("lacosmic_iterate");
