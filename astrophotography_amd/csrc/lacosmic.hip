@@ -169,6 +169,7 @@ __global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restric
     const int64_t P4 = P / 4;
     const bool vec = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(mask)) & 3) == 0 &&
                      (reinterpret_cast<uintptr_t>(sp) & 15) == 0;
+    const bool rows_aligned = (W % 4) == 0 && (reinterpret_cast<uintptr_t>(in) & 3) == 0;      // every row starts on a word
     if (vec) {
         APGPU_FOR_PIXELS(q, P4) {
             const int64_t p = 4 * q;
@@ -181,6 +182,26 @@ __global__ __launch_bounds__(kBlock) void dilate_kernel(const uint8_t *__restric
                 const unsigned m = reinterpret_cast<const unsigned *>(mask)[q];
 #pragma unroll
                 for (int j = 0; j < 4; j++) cand[j] = cand[j] && ((m >> (8 * j)) & 0xffu) == 0;
+            }
+            // without a threshold to test first (the saturation mask): the map is sparse, so look at the neighbourhood of the
+            // four pixels as 32-bit words - 3 words x (2R+1) rows - and only walk it pixel by pixel when one is non-zero
+            if (!sp && rows_aligned) {
+                constexpr int R = SHAPE / 2;
+                const int r = (int)(p / W), c = (int)(p - (int64_t)r * W);          // c is a multiple of 4
+                unsigned seen = 0;
+#pragma unroll
+                for (int dy = -R; dy <= R; dy++) {
+                    const int rr = r + dy;
+                    if (rr < 0 || rr >= H) continue;
+                    const unsigned *row = reinterpret_cast<const unsigned *>(in + (int64_t)rr * W);
+                    seen |= row[c / 4];
+                    if (c >= 4) seen |= row[c / 4 - 1];
+                    if (c + 4 < W) seen |= row[c / 4 + 1];
+                }
+                if (seen == 0) {
+                    reinterpret_cast<unsigned *>(out)[q] = 0;
+                    continue;
+                }
             }
             unsigned o = 0;
 #pragma unroll

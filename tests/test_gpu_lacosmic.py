@@ -51,7 +51,7 @@ def test_sepmedfilt_vs_oracle(ops):
 def test_detect_cosmics_vs_oracle(ops):
     from oracle import lacosmic_ref as L
     rng = np.random.default_rng(62)
-    for (H, W, gain, fsmode) in ((120, 150, 1.3, 'convolve'), (90, 64, 1.0, 'median')):
+    for (H, W, gain, fsmode) in ((120, 150, 1.3, 'convolve'), (90, 64, 1.0, 'median'), (96, 128, 1.0, 'convolve')):     # W % 4 == 0: word-wise dilation
         img, truth = _field(rng, H, W)
         ref_clean, ref_mask = L.detect_cosmics(img, gain=gain, satlevel=gain * 65535, fsmode=fsmode)
         e = (torch.from_numpy(img).cuda() * np.float32(gain))
