@@ -255,6 +255,19 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
     if (wave_all(n == ns)) {               // the usual case: no rejected value in the whole wave (padding: scalar skips)
+#ifdef APGPU_VARIANT_F32_MOMENTS
+        // measurement only (tools/variant_lib.sh): what float32 moments would save - NOT parity-exact
+        float Sf[4] = {0.f, 0.f, 0.f, 0.f}, Qf[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (i >= MINN && i >= ns) continue;
+            const float d = v[i] - cf;
+            Sf[i & 3] += d;
+            Qf[i & 3] = fmaf(d, d, Qf[i & 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Sa[k] = (double)Sf[k]; Qa[k] = (double)Qf[k]; }
+#else
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             if (i >= MINN && i >= ns) continue;
@@ -262,6 +275,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
             Sa[i & 3] += d;
             Qa[i & 3] = fma(d, d, Qa[i & 3]);
         }
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
