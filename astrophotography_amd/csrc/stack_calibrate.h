@@ -30,7 +30,7 @@ struct StackParams {
 // Padded stacks of 112 / 128 slots keep the older scheme (every slot loaded and calibrated, padding lifted to +inf with
 // one v_max per slot): the per-slot scalar tests cost them ~50 VGPRs, i.e. the second wavefront per SIMD.
 constexpr int prev_slots(int np);
-constexpr int padded_minn(int np, bool full) { return (full || np >= 112) ? np : prev_slots(np); }
+constexpr int padded_minn(int np, bool full) { return (full || np >= 128) ? np : prev_slots(np); }
 
 constexpr int prev_slots(int np)
 {

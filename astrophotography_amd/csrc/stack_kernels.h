@@ -174,7 +174,9 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
             float v[NP];
             StackParams q = prm;
             asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
-            const int n = load_sorted_column<NP, uint16_t, CALIB, false, FULL>(q, fs, base, lane, v);
+            // (rare path: the plain padding scheme, MINN = NP - the per-slot tests of the other one would set this kernel's
+            // register count, and with it the occupancy of the packed path above)
+            const int n = load_sorted_column<NP, uint16_t, CALIB, false, FULL, NP>(q, fs, base, lane, v);
             const float m1 = pick_at<NP>(v, (n - 1) >> 1);
             const float m2 = pick_at<NP>(v, n >> 1);
             const double med = ((double)m1 + (double)m2) / 2.0;
