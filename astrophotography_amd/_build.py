@@ -23,6 +23,10 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_g.hip',
     'stack_inst_u16_calib_g.hip',
     'stack_inst_u16_plain_g.hip',
+    'stack_inst_f32_calib_j.hip',
+    'stack_inst_f32_plain_j.hip',
+    'stack_inst_u16_calib_j.hip',
+    'stack_inst_u16_plain_j.hip',
     'stack_inst_f32_calib_f.hip',
     'stack_inst_f32_plain_f.hip',
     'stack_inst_u16_calib_f.hip',
@@ -31,6 +35,10 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_e.hip',
     'stack_inst_u16_calib_e.hip',
     'stack_inst_u16_plain_e.hip',
+    'stack_inst_f32_calib_i.hip',
+    'stack_inst_f32_plain_i.hip',
+    'stack_inst_u16_calib_i.hip',
+    'stack_inst_u16_plain_i.hip',
     'stack_inst_f32_calib_d.hip',
     'stack_inst_f32_plain_d.hip',
     'stack_inst_u16_calib_d.hip',

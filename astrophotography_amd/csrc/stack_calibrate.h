@@ -34,7 +34,7 @@ constexpr int padded_minn(int np, bool full) { return (full || np >= 128) ? np :
 
 constexpr int prev_slots(int np)
 {
-    constexpr int counts[] = {1, 4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128};
+    constexpr int counts[] = {1, 4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 104, 112, 128};
     int prev = 0;
     for (int c : counts) {
         if (c >= np) break;
@@ -276,10 +276,10 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 {
     const int N = prm.N;
     const int64_t p = base + lane;
-    constexpr bool HALVES = CALIB && NP >= 112;           // 112 / 128 slots: two half columns (register budget: 2 waves/SIMD)
+    constexpr bool HALVES = CALIB && NP >= 104;           // 104 .. 128 slots: two half columns (register budget: 2 waves/SIMD)
     // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
     // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
-    constexpr bool GUARD = NP >= 112;
+    constexpr bool GUARD = NP >= 104;
     RawT raw[HALVES ? 1 : NP];
     if constexpr (!HALVES) load_raw<NP, RawT, FULL, 0, NP, MINN>(prm, base, lane, raw);
     cx.b = 0.f; cx.D = 0.f; cx.nf = 1.f;

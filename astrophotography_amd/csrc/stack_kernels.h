@@ -448,7 +448,8 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t, char *);
 APGPU_DECLARE_LAUNCH(1) APGPU_DECLARE_LAUNCH(4) APGPU_DECLARE_LAUNCH(8) APGPU_DECLARE_LAUNCH(12) APGPU_DECLARE_LAUNCH(16)
 APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(40) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(56)
-APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(128)
+APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(72) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(104)
+APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(128)
 #undef APGPU_DECLARE_LAUNCH
 #endif
 
@@ -456,7 +457,8 @@ template <typename RawT, bool CALIB>
 int launch_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe = nullptr)
 {
     const int N = prm.N;
-    // slot counts: powers of two, their 3/4 points and, from 32 up, the 5/8 and 7/8 points (pruned networks)
+    // slot counts: powers of two, their 3/4 points and, from 32 up, the 5/8 and 7/8 points (pruned networks); 72 and 104 fill
+    // the two widest gaps (65..80, 97..112)
     if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st, describe);
@@ -468,8 +470,10 @@ int launch_np(const StackParams &prm, bool median_only, hipStream_t st, char *de
     if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 56) return launch_one<56, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 72) return launch_one<72, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 80) return launch_one<80, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 104) return launch_one<104, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 112) return launch_one<112, RawT, CALIB>(prm, median_only, st, describe);
     return launch_one<128, RawT, CALIB>(prm, median_only, st, describe);
 }
