@@ -15,6 +15,7 @@ so its published algorithms are restated (oracle/background_ref.py: PARITY UNPIN
           by inverse-distance weighting, 3 x 3 median filter, cubic B-spline prefilter
   device  the spline evaluated at every pixel (apgpu_spline_zoom_f64 = scipy.ndimage.zoom order 3, 'reflect', grid mode)
 """
+import logging
 from datetime import datetime
 from pathlib import Path
 
@@ -116,9 +117,10 @@ class ApMeasureBackground:
         th = torch.stack([torch.full_like(thr, -float('inf')), thr]).contiguous()
         above, _ = ops.threshold_mask(data_t, thresholds=th)
         mask, nsrc = ops.source_mask(above, min_pixels=5, dilate_size=13)
-        npix = mask.numel()
-        npos = int(mask.sum(dtype=torch.int64))
-        self._logger.debug(f'Source mask: {int(nsrc.item())} sources, {npos} of {npix} pixels masked ({100.0 * npos / npix:.2f} percent).')
+        if self._logger.isEnabledFor(logging.DEBUG):        # the two counts cost a reduction and two host round trips
+            npix = mask.numel()
+            npos = int(mask.sum(dtype=torch.int64))
+            self._logger.debug(f'Source mask: {int(nsrc.item())} sources, {npos} of {npix} pixels masked ({100.0 * npos / npix:.2f} percent).')
         return mask
 
     # -- box size (:251-329) -------------------------------------------------------------------------
