@@ -14,6 +14,7 @@ OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
 CENTER = {'median': 0, 'mean': 1}
 DEV = {'std': 0, 'mad_std': 1}
 MAX_STACK = 512
+STACK_EXACT_MOMENTS, STACK_MOMENTS_MEAN = 1, 2          # apgpu_stack_args.flags
 
 E_INVAL, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4
 
@@ -33,7 +34,7 @@ class StackArgs(C.Structure):
         ('dev', C.c_int32), ('maxiters', C.c_int32), ('sigma_lower', C.c_double), ('sigma_upper', C.c_double),
         ('pixmask', C.c_void_p), ('mean', C.c_void_p), ('median', C.c_void_p), ('std', C.c_void_p),
         ('count', C.c_void_p), ('moments', C.c_void_p), ('frame_stride', C.c_int64),
-        ('mean_f64', C.c_void_p), ('std_f64', C.c_void_p), ('moments_f64', C.c_int32), ('reserved0', C.c_int32),
+        ('mean_f64', C.c_void_p), ('std_f64', C.c_void_p), ('moments_f64', C.c_int32), ('flags', C.c_int32),
     ]
 
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     'apgpu_moments_finalize': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'apgpu_moments_finalize_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int64, C.c_void_p]),
+    'apgpu_moments_finalize_f64p': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_int64, C.c_void_p]),
     'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
     'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -70,8 +70,12 @@ class ApFixCosmicRays:
         perf_time_start = time.perf_counter()
         self._imdata = inpdata
         self._gain = gain
+        if len(tuple(inpdata.shape)) != 2 or min(inpdata.shape) < 5:
+            raise ValueError(f'Error, L.A.Cosmic needs a 2-D image of at least 5 x 5 pixels, got shape {tuple(inpdata.shape)}')
         if torch.is_tensor(inpdata):
             data_t = inpdata.cuda()
+            if not data_t.dtype.is_floating_point:           # integer frames are widened like the NumPy branch below
+                data_t = (data_t.view(torch.int16).to(torch.int32) & 0xFFFF).double() if data_t.dtype == torch.uint16 else data_t.double()
         else:
             a = np.ascontiguousarray(inpdata)
             if a.dtype not in (np.float32, np.float64):
@@ -79,13 +83,17 @@ class ApFixCosmicRays:
             data_t = torch.from_numpy(a).cuda()
         clean, crmask, _ = self.process_tensor(data_t, float(gain))
         self._cleandata_dev = clean
-        self._cleandata = clean if torch.is_tensor(inpdata) else clean.cpu().numpy()
-        self._crmask = crmask if torch.is_tensor(inpdata) else crmask.cpu().numpy()
+        if torch.is_tensor(inpdata):                          # results live where (and, for floats, as what) the input does
+            self._cleandata = clean.to(device=inpdata.device, dtype=inpdata.dtype if inpdata.dtype.is_floating_point else clean.dtype)
+            self._crmask = crmask.to(inpdata.device)
+        else:
+            self._cleandata = clean.cpu().numpy()
+            self._crmask = crmask.cpu().numpy()
         numbad = int(crmask.sum(dtype=torch.int64))
         self._logger.info(f'{numbad} pixels in image identified as affected by cosmic rays.')
         kw_dict = {'CR_CLEAN': (True, 'Has cosmic ray removal been performed?'),
                    'CR_NPIX': (numbad, 'Number of pixels modified by lacosmic.')}
-        self._crdiff = self._imdata - self._cleandata
+        self._crdiff = (data_t.to(self._cleandata.device) if torch.is_tensor(inpdata) else self._imdata) - self._cleandata
         self._cr_kw = kw_dict
         run_time_secs = time.perf_counter() - perf_time_start
         if numbad > 0:                                        # the reference divides by numbad unconditionally (:320)

@@ -69,7 +69,18 @@ class ApStack:
         calib = None
         if calibrator is not None:
             slab, hdrs, ratios, peds = calibrator.load_slab(input_files)
-            calib = dict(calibrator.masters(), exp_ratio=ratios, pedestal=peds)
+            masters = calibrator.masters()
+            wide = slab.dtype == torch.float64 or any(getattr(masters[k], 'dtype', None) == torch.float64
+                                                      for k in ('bias', 'dark', 'nflat'))
+            if wide:
+                # float64 masters (what ApMasterCal / ccdproc write, ap_combine_darks.py:437) or float64 frames: the fused
+                # kernel is float32, so the frames are calibrated with NumPy's promotion first (ApCalibrate.py:439-464 in
+                # float64, apgpu_calibrate_mixed) and the calibrated slab is stacked
+                self._logger.warning('float64 masters / frames: calibrating in float64 before the stack (not fused); the '
+                                     'calibrated values are rounded to float32 for the stack kernel.')
+                slab = calibrator.calibrate_slab(slab, ratios, peds).to(torch.float32)
+            else:
+                calib = dict(masters, exp_ratio=ratios, pedestal=peds)
         else:
             arrs, hdrs = [], []
             for f in input_files:

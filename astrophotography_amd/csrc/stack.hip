@@ -44,6 +44,27 @@ __global__ __launch_bounds__(256) void moments_finalize_f64_kernel(const double 
     }
 }
 
+// the packed float64 layout (3): planes sum, count, sumsq as three pointers (the caller passes buffer, buffer + P, buffer + 2 P)
+__global__ __launch_bounds__(256) void moments_finalize_f64p_kernel(const double *__restrict__ sum, const double *__restrict__ count,
+                                                                   const double *__restrict__ sumsq, float *mean, float *std,
+                                                                   double *mean64, double *std64, int64_t P)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const double n = count[p];
+    const double nan = __builtin_nan("");
+    const double m = n > 0.0 ? sum[p] / n : nan;
+    if (mean) mean[p] = (float)m;
+    if (mean64) mean64[p] = m;
+    if (sumsq && (std || std64)) {
+        double var = sumsq[p] / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        const double sd = n > 0.0 ? sqrt(var) : nan;
+        if (std) std[p] = (float)sd;
+        if (std64) std64[p] = sd;
+    }
+}
+
 int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream, char *describe = nullptr)
 {
     if (!args) return fail(APGPU_EINVAL, "stack: args is NULL");
@@ -69,9 +90,11 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
             return fail(APGPU_EINVAL, "stack: sigma must be >= 0");
         if (!args->mean && !args->median && !args->std && !args->count && !args->moments && !args->mean_f64 && !args->std_f64)
             return fail(APGPU_EINVAL, "stack: no output requested");
+        if (args->moments_f64 < 0 || args->moments_f64 > 4) return fail(APGPU_EINVAL, "stack: bad moments_f64 %d", args->moments_f64);
         if (args->moments && args->moments_f64 && (reinterpret_cast<uintptr_t>(args->moments) & 7))
             return fail(APGPU_EINVAL, "stack: float64 moments must be 8-byte aligned");
-        if (args->reserved0 != 0) return fail(APGPU_EINVAL, "stack: reserved0 must be 0");
+        if (args->flags & ~(APGPU_STACK_EXACT_MOMENTS | APGPU_STACK_MOMENTS_MEAN))
+            return fail(APGPU_EINVAL, "stack: unknown flags 0x%x", args->flags);
     } else if (!args->median) {
         return fail(APGPU_EINVAL, "stack_median: median output is NULL");
     }
@@ -100,9 +123,11 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     prm.moments64 = median_only ? 0 : args->moments_f64;
     prm.mean64 = median_only ? nullptr : args->mean_f64;
     prm.std64 = median_only ? nullptr : args->std_f64;
+    prm.fast32 = (median_only || (args->flags & APGPU_STACK_EXACT_MOMENTS)) ? 0 : ((args->flags & APGPU_STACK_MOMENTS_MEAN) ? 2 : 1);
 #ifdef APGPU_DEVELOPMENT                                     // measurement knobs, never in a release build
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;      // all frames alias frame 0: compute-only timing
     if (const char *e = getenv("APGPU_DEBUG_MAXITERS")) prm.maxiters = atoi(e);
+    if (getenv("APGPU_DEBUG_EXACT")) prm.fast32 = 0;
 #endif
     hipStream_t st = as_stream(stream);
     if (prm.N > 128)                                        // the column does not fit the registers: LDS-resident path
@@ -144,6 +169,18 @@ extern "C" int apgpu_moments_finalize(const float *moments, float *mean, float *
     hipLaunchKernelGGL(moments_finalize_kernel, dim3((unsigned)grid), dim3(block), 0, as_stream(stream), moments, mean,
                        std, n_pixels);
     return check_launch("moments_finalize");
+}
+
+extern "C" int apgpu_moments_finalize_f64p(const double *sum, const double *count, const double *sumsq, float *mean, float *std,
+                                           double *mean_f64, double *std_f64, int64_t n_pixels, void *stream)
+{
+    if (!sum || !count || n_pixels <= 0) return fail(APGPU_EINVAL, "moments_finalize_f64p: bad arguments");
+    if ((std || std_f64) && !sumsq) return fail(APGPU_EINVAL, "moments_finalize_f64p: std wanted but sumsq is NULL");
+    const int block = 256;
+    const int64_t grid = (n_pixels + block - 1) / block;
+    hipLaunchKernelGGL(moments_finalize_f64p_kernel, dim3((unsigned)grid), dim3(block), 0, as_stream(stream), sum, count, sumsq,
+                       mean, std, mean_f64, std_f64, n_pixels);
+    return check_launch("moments_finalize_f64p");
 }
 
 extern "C" int apgpu_moments_finalize_f64(const double *sum, const double *sumsq, const int32_t *count, float *mean, float *std,

@@ -23,6 +23,7 @@ struct StackParams {
     int maxiters;           // < 0: until convergence
     int moments64;          // layout of `moments` (see above)
     double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
+    int fast32;             // 0: float64 clip only; 1: float32 fast path for mean / count / float32 moments; 2: also float64-layout moments
 };
 
 // The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a
@@ -329,22 +330,49 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
     return load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, p, cx, raw, v);
 }
 
+// Slot counts / padding schemes for which the float32 fast path exists: full columns with a core between two tails.
+constexpr int kFastTail = 4;
+constexpr bool fast32_possible(int np, int minn) { return np >= 16 && np % 4 == 0 && minn >= np; }
+
+// Whether the lean reduction will try its float32 fast path (stack_reduce.h, clip_fast32) - wave-uniform, from the arguments.
+__device__ __forceinline__ bool fast32_wanted(const StackParams &prm)
+{
+#ifdef APGPU_VARIANT_NO_FAST32
+    return false;
+#endif
+    return prm.fast32 != 0 && prm.center == APGPU_CENTER_MEDIAN && (prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2);
+}
+
 // Column loaded AND sorted ascending (sentinels last).  When the fast calibration deferred its range guards, they are
 // evaluated on the sorted column; a failing lane sends the wave through the exact path and a second sort (rare).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL)>
+// PRUNE_T > 0 and *pruned on entry (wave-uniform: the caller wants the fast path): a column without sentinels in the whole
+// wave is sorted with the pruned network (its ends and middle window only, make_pruned_net) and *pruned stays true;
+// otherwise the sort is complete and *pruned is cleared.
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
-                                                  int lane, float (&v)[NP])
+                                                  int lane, float (&v)[NP], bool *pruned = nullptr)
 {
     ColumnCtx cx;
     int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN>(prm, fs, base, lane, v, cx);
-    sort_column<NP>(v);
+    bool prune = false;
+    if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == NP);
+    if constexpr (PRUNE_T > 0) {
+        if (prune) sort_column<NP, PRUNE_T>(v);
+        else sort_column<NP>(v);
+    } else {
+        sort_column<NP>(v);
+    }
     if constexpr (CALIB) {
+        // (the range test reads the two ends of the column - sorted by the pruned network too - and, for columns of mixed
+        // sign, scans all magnitudes, in any order)
         if (cx.range_pending && !wave_all(range_ok_sorted<NP, MINN>(v, cx.dodiv, n))) {
             RawT none[1] = {};
             n = load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base + lane, cx, none, v);
             sort_column<NP>(v);
+            prune = false;
         }
     }
+    if constexpr (PRUNE_T > 0) *pruned = prune;
     return n;
 }
 

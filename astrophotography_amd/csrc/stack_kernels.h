@@ -47,9 +47,19 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) v
 
     float v[NP];
     APGPU_MARK("load_calibrate_sort");
-    const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
-    if constexpr (EXTRA) reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
-    else reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p);
+    if constexpr (EXTRA) {
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
+        reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
+    } else if constexpr (fast32_possible(NP, padded_minn(NP, FULL))) {
+        // full stacks headed for the float32 fast path only sort what it reads (pruned network); `pruned` tells the reduction
+        // to complete the sort should it have to fall back to the exact path
+        bool pruned = fast32_wanted(prm);
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, padded_minn(NP, FULL), kFastTail>(prm, fs, base, lane, v, &pruned);
+        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p, pruned);
+    } else {
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
+        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p);
+    }
 }
 
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.

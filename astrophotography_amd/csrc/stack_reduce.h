@@ -205,17 +205,25 @@ __device__ __forceinline__ double mad_std_window(const float *col, bool active, 
 }
 
 // N-shard partial moments of the survivors: sum(x) = n c + S, sum(x^2) = Q + 2 c S + n c^2 (exact identities, float64).
-//   float32 layout  [3][P]: sum, count, sum of squares - the first two are all a mean needs, so an exchange that does
-//                           not want std all-reduces a contiguous [2][P] prefix (8 bytes per pixel);
-//   float64 layout: double sum[P], double sumsq[P], int32 count[P] - the combine of SURVEY 8(e) "f64 sum + i32 count":
-//                           ranks add float64 sums, so the combined mean is the float64 mean rounded once
-//                           (layout value 2: add to what the buffer holds - the chunks of a stack beyond APGPU_MAX_STACK).
+//   layout 0  float32 [3][P]: sum, count, sum of squares - the first two are all a mean needs, so an exchange that does
+//             not want std all-reduces a contiguous [2][P] prefix (8 bytes per pixel);
+//   layout 1  double sum[P], double sumsq[P], int32 count[P] - the combine of SURVEY 8(e) "f64 sum + i32 count"
+//             (layout 2: add to what the buffer holds - the chunks of a stack beyond APGPU_MAX_STACK);
+//   layout 3  packed float64 [3][P]: sum, count, sum of squares - the count as a float64 (exact to 2^53), so that ONE
+//             all-reduce of the contiguous [2][P] prefix (16 bytes per pixel; [3][P] = 24 with a std) carries everything
+//             (layout 4: add to what the buffer holds).
 __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t Pn, int64_t p, int cnt, double c, double S, double Q)
 {
     const double nf = (double)cnt;
     const double sum = cnt > 0 ? fma(nf, c, S) : 0.0;
     const double sq = cnt > 0 ? Q + 2.0 * c * S + nf * c * c : 0.0;
-    if (f64_layout) {
+    if (f64_layout >= 3) {
+        double *d = static_cast<double *>(out);
+        const bool acc = f64_layout == 4;
+        d[p] = acc ? d[p] + sum : sum;
+        d[Pn + p] = acc ? d[Pn + p] + nf : nf;
+        d[2 * Pn + p] = acc ? d[2 * Pn + p] + sq : sq;
+    } else if (f64_layout) {
         double *d = static_cast<double *>(out);
         int32_t *k = reinterpret_cast<int32_t *>(d + 2 * Pn);
         const bool acc = f64_layout == 2;                   // accumulate onto the moments of earlier chunks of the stack
@@ -230,23 +238,194 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
     }
 }
 
-// Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
-// the column load is in registers: sort, moments, clipping iterations, outputs.
-template <int NP, int MINN = NP, bool PLUS = false>
-__device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p)
-{
-    const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
-    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
-    float *const out_mean = park_in_vgpr(prm.mean);
-    int32_t *const out_count = park_in_vgpr(prm.count);
-    void *const out_moments = park_in_vgpr(prm.moments);
-    const int mom64 = park_in_vgpr(prm.moments64);
-    const int64_t Pn = park_in_vgpr(prm.P);
-    const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
-    const int maxiters = park_in_vgpr(prm.maxiters);
-    const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
-    APGPU_MARK("moments");                                   // v: sorted ascending, sentinels last (load_sorted_column)
+// -------------------------------------------------------------------------------------------------
+// float32 fast path of the lean reduction (round 3).  The exact path below keeps S, Q and every bound test in float64
+// (4-cycle instructions on gfx950); here the moments and the tests are float32 (2-cycle class: v_sub/v_add/v_mul/v_fmac_f32)
+// with an ERROR MARGIN: a comparison whose outcome the float32 rounding errors could change marks the lane "unsure", and a
+// wave with an unsure lane redoes the column on the exact path - so the survivor sets are those of the exact path, always.
+//
+// Layout of the sums: the clip only trims the ends of the sorted column, so the column is cut into a core [T, NP-T) that
+// is summed once (Sc, Qc) and two tails of T = 4 elements whose partial sums are tabulated from the inside out
+// (SL[k] = sum of d_k .. d_(T-1), SH[k] = sum of the first k upper-tail values).  S and Q of the current range are then
+// Sc + SL[a] + SH[b - (NP-T)]: sums of what is IN the range only - no subtraction of an outlier from a total that it
+// dominates, which in float32 would leave no digits (a 5000 ADU cosmic ray in a 30 ADU column is 4 decimal digits of Q).
+// A lane that wants to trim into the core leaves the fast path.
+//
+// Error budget (u = 2^-24, all quantities relative unless noted; d_i = fl(x_i - c) with c the lower median):
+//   Q  = sum d_i^2 : every term and partial sum is positive, 14 + 2 + 4 roundings deep, inputs 2u      -> |dQ| <= 20u Q
+//   S  = sum d_i   : 19u sum|d_i| <= 19u sqrt(n Q)   (absolute; Cauchy-Schwarz)
+//   V  = n Q - S^2 : |dV| <= 21u nQ + 2 sqrt(nQ) 19u sqrt(nQ) + u V <= 60u nQ + u V; the guard V >= nQ / 4 makes it <= 250u V
+//   T  = 4 sigma^2 V (float32 sigma^2: u, two products: 2u)                                            -> <= 253u
+//   w  = n ((x - m1) + (x - m2)) = 2 n (x - median): differences u each, same-sign sum u, product u     -> <= 3u, w^2 <= 7u
+//   reject <=> w^2 > T exactly; decided in float32 as w^2 > T (1 + rho) [sure reject] / w^2 <= T (1 - rho) [sure keep] with
+//   rho = 2^-15 = 512u > (1 + 7u) / (1 - 253u) - 1 = 261u (+ u for each threshold product): twice the worst case.
+//   The sign tests of the exact path are implied here: the lowest survivor of a sorted column is <= its median.
+// Range guards: |d| of the two column ends in (2^-40, 2^40) or all d = 0 (no underflow of d^2, no overflow of n^2 w^2).
+// The output mean c + S / n inherits S's float32 rounding (a few 1e-3 ulp(float32) of the mean for rms(d) << |c|); the
+// guard rms(d) <= |c| / 2 keeps columns whose mean is small against their spread (sky-subtracted data) on the exact path.
+// Requirements: full stack (n = NP for the whole wave, no sentinel), median centre, std deviation, NP >= 16.
+// -------------------------------------------------------------------------------------------------
+#ifndef APGPU_FAST32_RHO
+#define APGPU_FAST32_RHO 0x1p-15f
+#endif
 
+struct Fast32 {
+    float m1, m2;                       // the middle pair of the current range (its median is their mean)
+    float nf;                           // b - a
+    float tl_hi, tl_lo, th_hi, th_lo;   // 4 sigma^2 V (1 +- rho) for the low / high side
+    float Slo, Qlo, Shi, Qhi;           // tail sums inside the current range
+    int a, b;
+    bool unsure;
+};
+
+__device__ __forceinline__ float fast32_t(const Fast32 &f, float x)
+{
+    const float w = f.nf * ((x - f.m1) + (x - f.m2));
+    return w * w;
+}
+
+template <int I, int NP>
+__device__ __forceinline__ void trim_low_fast(const float (&v)[NP], Fast32 &f, const float (&SL)[kFastTail + 1], const float (&QL)[kFastTail + 1])
+{
+    const float t = fast32_t(f, v[I]);
+    const bool at = f.a == I;
+    if constexpr (I < kFastTail) {
+        const bool rej = at && (t > f.tl_hi);
+        const bool maybe = at && (t > f.tl_lo);
+        f.unsure = f.unsure || (maybe != rej);
+        if (rej) {
+            f.a = I + 1;
+            f.Slo = SL[I + 1];
+            f.Qlo = QL[I + 1];
+        }
+        if (wave_any(f.a > I)) trim_low_fast<I + 1, NP>(v, f, SL, QL);   // some lane's cursor is (now or from an earlier pass) past I
+    } else {
+        f.unsure = f.unsure || (at && (t > f.tl_lo));       // would trim into the core
+    }
+}
+
+template <int K, int NP>                                     // K = number of upper-tail elements still in the range
+__device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, const float (&SH)[kFastTail + 1], const float (&QH)[kFastTail + 1])
+{
+    constexpr int I = NP - kFastTail + K - 1;               // the element under test: the highest one in the range
+    const float t = fast32_t(f, v[I]);
+    const bool at = f.b == I + 1;
+    if constexpr (K > 0) {
+        const bool rej = at && (t > f.th_hi);
+        const bool maybe = at && (t > f.th_lo);
+        f.unsure = f.unsure || (maybe != rej);
+        if (rej) {
+            f.b = I;
+            f.Shi = SH[K - 1];
+            f.Qhi = QH[K - 1];
+        }
+        if (wave_any(f.b <= I)) trim_high_fast<K - 1, NP>(v, f, SH, QH);
+    } else {
+        f.unsure = f.unsure || (at && (t > f.th_lo));
+    }
+}
+
+// Returns true (wave-uniform) when every lane of the wave completed on the fast path; a, b, cf, S, Q are then final.
+template <int NP>
+__device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, float su2f, int maxiters, int &a_out, int &b_out,
+                                            float &cf_out, float &S_out, float &Q_out)
+{
+    constexpr int T = kFastTail;
+    static_assert(NP >= 16 && NP % 4 == 0, "fast path needs a core");
+    const float cf = v[(NP - 1) >> 1];
+    // core sums: four chains, fixed association.  S adds the deviations in mirror pairs (i, NP-1-i) of the sorted column:
+    // a pair nearly cancels, so the partial sums - and with them the float32 rounding errors, which scale with the
+    // magnitude of what is being added - stay at the column's asymmetry instead of its spread (same number of additions).
+    float Sa[4] = {0.f, 0.f, 0.f, 0.f}, Qa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = T; i < NP / 2; i++) {
+        const float d1 = v[i] - cf, d2 = v[NP - 1 - i] - cf;
+        Sa[i & 3] += d1 + d2;
+        Qa[i & 3] = __builtin_fmaf(d1, d1, Qa[i & 3]);
+        Qa[(i + 2) & 3] = __builtin_fmaf(d2, d2, Qa[(i + 2) & 3]);
+    }
+    const float Sc = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+    const float Qc = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+    // tails, summed from the inside out
+    float SL[T + 1], QL[T + 1], SH[T + 1], QH[T + 1];
+    SL[T] = 0.f; QL[T] = 0.f; SH[0] = 0.f; QH[0] = 0.f;
+#pragma unroll
+    for (int k = T - 1; k >= 0; k--) {
+        const float d = v[k] - cf;
+        SL[k] = SL[k + 1] + d;
+        QL[k] = __builtin_fmaf(d, d, QL[k + 1]);
+    }
+#pragma unroll
+    for (int k = 1; k <= T; k++) {
+        const float d = v[NP - T + k - 1] - cf;
+        SH[k] = SH[k - 1] + d;
+        QH[k] = __builtin_fmaf(d, d, QH[k - 1]);
+    }
+    Fast32 f;
+    f.a = 0;
+    f.b = NP;
+    f.Slo = SL[0]; f.Qlo = QL[0]; f.Shi = SH[T]; f.Qhi = QH[T];
+    f.m1 = cf;
+    f.m2 = v[NP >> 1];
+    // range guard on the extreme deviations (sorted column: they sit at the ends)
+    const float dmax = fmaxf(cf - v[0], v[NP - 1] - cf);
+    f.unsure = !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
+    const float rho = APGPU_FAST32_RHO;
+    const float sl4 = 4.f * sl2f, su4 = 4.f * su2f;
+    float S, Q;
+    int it = 0;
+    for (;;) {
+        const int a0 = f.a, b0 = f.b;
+        f.nf = (float)(f.b - f.a);
+        S = (Sc + f.Slo) + f.Shi;
+        Q = (Qc + f.Qlo) + f.Qhi;
+        const float nQ = f.nf * Q;
+        const float V = __builtin_fmaf(-S, S, nQ);
+        f.unsure = f.unsure || !(V >= 0.25f * nQ);
+        const float tl = sl4 * V, th = su4 * V;
+        f.tl_hi = __builtin_fmaf(tl, rho, tl);
+        f.tl_lo = __builtin_fmaf(tl, -rho, tl);
+        f.th_hi = __builtin_fmaf(th, rho, th);
+        f.th_lo = __builtin_fmaf(th, -rho, th);
+        trim_low_fast<0, NP>(v, f, SL, QL);
+        trim_high_fast<T, NP>(v, f, SH, QH);
+        it++;
+        const bool changed = (f.a != a0) || (f.b != b0);
+        if (!(wave_any(changed) && (maxiters < 0 || it < maxiters))) break;
+        // the middle pair of the new range: a <= T, b >= NP - T keep it inside a 5-slot window around NP / 2
+        constexpr int LO1 = (NP - T - 1) >> 1, LO2 = (NP - T) >> 1;
+        f.m1 = pick_rel<LO1, T + 1, NP>(v, ((f.a + f.b - 1) >> 1) - LO1);
+        f.m2 = pick_rel<LO2, T + 1, NP>(v, ((f.a + f.b) >> 1) - LO2);
+    }
+    // astropy applies the FINAL bounds to every value: a value trimmed by an earlier pass comes back if it lies inside them.
+    // Here: the innermost trimmed value of either side must be surely outside, otherwise the exact path decides.
+    if (wave_any(f.a > 0)) {
+        const float t = fast32_t(f, pick_rel<0, T, NP>(v, (f.a - 1) & (T - 1)));
+        f.unsure = f.unsure || (f.a > 0 && !(t > f.tl_hi));
+    }
+    if (wave_any(f.b < NP)) {
+        const float t = fast32_t(f, pick_rel<NP - T, T, NP>(v, f.b & (T - 1)));        // NP % 4 == 0: (b - (NP - T)) & 3
+        f.unsure = f.unsure || (f.b < NP && !(t > f.th_hi));
+    }
+    // the final sums (the last pass may have trimmed) and the mean-accuracy guard rms(d) <= |c| / 2
+    S = (Sc + f.Slo) + f.Shi;
+    Q = (Qc + f.Qlo) + f.Qhi;
+    f.unsure = f.unsure || !(4.f * Q <= (float)(f.b - f.a) * (cf * cf));
+    a_out = f.a;
+    b_out = f.b;
+    cf_out = cf;
+    S_out = S;
+    Q_out = Q;
+    return !wave_any(f.unsure);
+}
+
+// Exact clip of a sorted column (float64 moments and tests): the survivors v[a .. b), the pivot c and S, Q about it.
+template <int NP, int MINN>
+__device__ __forceinline__ void clip_exact(const float (&v)[NP], const int n, const int ns, const double sl2, const double su2,
+                                           const int maxiters, const bool use_median, int &a_out, int &b_out, float &cf_out,
+                                           double &S_out, double &Q_out)
+{
+    APGPU_MARK("moments");
     // the two middle values of the finite range: the lower one is the pivot, and together they are the first pass's median
     float m1, m2;
     pick_middle<NP>(v, (n - 1) >> 1, n >> 1, m1, m2);
@@ -255,19 +434,6 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     // S = sum(x - c), Q = sum((x - c)^2): four independent float64 chains (ILP), fixed association
     double Sa[4] = {0.0, 0.0, 0.0, 0.0}, Qa[4] = {0.0, 0.0, 0.0, 0.0};
     if (wave_all(n == ns)) {               // the usual case: no rejected value in the whole wave (padding: scalar skips)
-#ifdef APGPU_VARIANT_F32_MOMENTS
-        // measurement only (tools/variant_lib.sh): what float32 moments would save - NOT parity-exact
-        float Sf[4] = {0.f, 0.f, 0.f, 0.f}, Qf[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            if (i >= MINN && i >= ns) continue;
-            const float d = v[i] - cf;
-            Sf[i & 3] += d;
-            Qf[i & 3] = fmaf(d, d, Qf[i & 3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { Sa[k] = (double)Sf[k]; Qa[k] = (double)Qf[k]; }
-#else
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             if (i >= MINN && i >= ns) continue;
@@ -275,7 +441,6 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
             Sa[i & 3] += d;
             Qa[i & 3] = fma(d, d, Qa[i & 3]);
         }
-#endif
     } else {
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -398,8 +563,54 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
             st.b = b_new;
         }
     }
-    const int a = st.a, b = st.b;
-    const double S = st.S, Q = st.Q;
+    a_out = st.a;
+    b_out = st.b;
+    cf_out = cf;
+    S_out = st.S;
+    Q_out = st.Q;
+}
+
+// Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
+// the column load is in registers: sort, moments, clipping iterations, outputs.
+// pruned (wave-uniform): the column came out of the pruned network (load_sorted_column) - the caller has established
+// fast32_wanted(prm) and n == NP for the whole wave; before the exact path may read it the sort is completed.
+template <int NP, int MINN = NP, bool PLUS = false>
+__device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
+                                                 const bool pruned = false)
+{
+    const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
+    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
+    float *const out_mean = park_in_vgpr(prm.mean);
+    int32_t *const out_count = park_in_vgpr(prm.count);
+    void *const out_moments = park_in_vgpr(prm.moments);
+    const int mom64 = park_in_vgpr(prm.moments64);
+    const int64_t Pn = park_in_vgpr(prm.P);
+    const double sl2 = park_in_vgpr(prm.sl2), su2 = park_in_vgpr(prm.su2);
+    const int maxiters = park_in_vgpr(prm.maxiters);
+    const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
+    const int fast32 = park_in_vgpr(prm.fast32);
+    APGPU_MARK("fast32");                                    // v: sorted ascending, sentinels last (load_sorted_column)
+
+    int a, b;
+    float cf;
+    double S, Q;
+    bool done = false;
+#ifndef APGPU_VARIANT_NO_FAST32
+    if constexpr (fast32_possible(NP, MINN)) {
+        // float32 fast path (see clip_fast32): full columns, median centre; float64-layout moments carry a sum of squares
+        // that callers turn into a std, so they stay on the exact path (the float32 layout is refused a std anyway)
+        if (pruned || (use_median && fast32 && (out_moments == nullptr || mom64 == 0 || fast32 == 2) && wave_all(n == NP))) {
+            float Sf, Qf;
+            done = clip_fast32<NP>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf);
+            S = (double)Sf;
+            Q = (double)Qf;
+            if (!done && pruned) sort_column<NP>(v);
+        }
+    }
+#endif
+    if (!done) clip_exact<NP, MINN>(v, n, ns, sl2, su2, maxiters, use_median, a, b, cf, S, Q);
+    APGPU_MARK("output");
+    const double c = (double)cf;
 
     const int cnt = b - a;
     const double nf = (double)cnt;

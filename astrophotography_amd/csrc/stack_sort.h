@@ -44,13 +44,14 @@ constexpr int next_pow2(int n)
     return p;
 }
 
-template <int NP>
+// P0: first merge level generated (1 = the whole sort; 4 = the merges after every aligned group of four has been sorted).
+template <int NP, int P0 = 1>
 constexpr Net<NP> make_net()
 {
     constexpr int P2 = next_pow2(NP);
     Net<NP> net{};
     int c = 0;
-    for (int p = 1; p < P2; p *= 2)
+    for (int p = P0; p < P2; p *= 2)
         for (int k = p; k >= 1; k /= 2)
             for (int j = k % p; j <= P2 - 1 - k; j += 2 * k) {
                 int lim = (k - 1 < P2 - j - k - 1) ? k - 1 : P2 - j - k - 1;
@@ -62,6 +63,35 @@ constexpr Net<NP> make_net()
                     }
             }
     net.n = c;
+    return net;
+}
+
+// The network pruned to what the float32 fast path of the lean reduction reads (stack_reduce.h, clip_fast32): the T lowest
+// and T highest outputs and the middle window [(NP-T-1)/2, (NP+T)/2] in sorted order; the core in between is only ever
+// SUMMED, so its internal order is irrelevant - it only has to hold the right set of values, which it does: a
+// compare-exchange permutes values, and dropping one whose two outputs feed no needed output (backward liveness over the
+// network) changes nothing on the needed wires.  64 slots: 469 of 543 compare-exchanges.  A wave that leaves the fast path
+// sorts the column completely (sort_column) before the exact path reads it.
+template <int NP, int P0, int T>
+constexpr Net<NP> make_pruned_net()
+{
+    constexpr Net<NP> full = make_net<NP, P0>();
+    bool live[NP] = {};
+    for (int i = 0; i < T; i++) live[i] = live[NP - 1 - i] = true;
+    for (int i = (NP - T - 1) / 2; i <= (NP + T) / 2; i++) live[i] = true;
+    bool keep[NP * 12 + 1] = {};
+    for (int c = full.n - 1; c >= 0; c--) {
+        const int a = full.ce[c].a, b = full.ce[c].b;
+        if (live[a] || live[b]) {
+            keep[c] = true;
+            live[a] = live[b] = true;
+        }
+    }
+    Net<NP> net{};
+    int n = 0;
+    for (int c = 0; c < full.n; c++)
+        if (keep[c]) net.ce[n++] = full.ce[c];
+    net.n = n;
     return net;
 }
 
@@ -77,29 +107,55 @@ __device__ __forceinline__ void cmpx(float &x, float &y)
     y = hi;
 }
 
-template <int NP, int BASE, int... I>
+// Four values sorted with the three-input instructions: min3 / med3 / max3 sort three (one instruction per output where a
+// compare-exchange network needs two per pair), and the fourth is inserted with min, med3, med3, max - 7 instructions
+// instead of the 10 of the 5-comparator network (all of the same 4-cycle class, tools/issue_cost.hip).
+__device__ __forceinline__ void sort4(float &a, float &b, float &c, float &d)
+{
+    float x0, x1, x2, o0, o1, o2, o3;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(a), "v"(b), "v"(c));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(a), "v"(b), "v"(c));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(x2) : "v"(a), "v"(b), "v"(c));
+    asm("v_min_f32 %0, %1, %2" : "=v"(o0) : "v"(x0), "v"(d));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(o1) : "v"(x0), "v"(x1), "v"(d));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(o2) : "v"(x1), "v"(x2), "v"(d));
+    asm("v_max_f32 %0, %1, %2" : "=v"(o3) : "v"(x2), "v"(d));
+    a = o0;
+    b = o1;
+    c = o2;
+    d = o3;
+}
+
+template <int NP, int P0, int T, int BASE, int... I>
 __device__ __forceinline__ void net_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
 {
-    constexpr Net<NP> net = make_net<NP>();
+    constexpr Net<NP> net = T > 0 ? make_pruned_net<NP, P0, (T > 0 ? T : 1)>() : make_net<NP, P0>();
     (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
 }
 
-template <int NP, int BASE>
+template <int NP, int P0, int T, int BASE>
 __device__ __forceinline__ void net_from(float (&v)[NP])
 {
-    constexpr int total = make_net<NP>().n;
+    constexpr int total = T > 0 ? make_pruned_net<NP, P0, (T > 0 ? T : 1)>().n : make_net<NP, P0>().n;
     constexpr int CH = 64;
     if constexpr (BASE < total) {
         constexpr int len = (total - BASE < CH) ? total - BASE : CH;
-        net_chunk<NP, BASE>(v, std::make_integer_sequence<int, len>{});
-        net_from<NP, BASE + len>(v);
+        net_chunk<NP, P0, T, BASE>(v, std::make_integer_sequence<int, len>{});
+        net_from<NP, P0, T, BASE + len>(v);
     }
 }
 
-template <int NP>
+// PRUNE_T > 0: only the outputs clip_fast32 reads come out sorted (make_pruned_net).
+template <int NP, int PRUNE_T = 0>
 __device__ __forceinline__ void sort_column(float (&v)[NP])
 {
-    if constexpr (NP > 1) net_from<NP, 0>(v);
+    if constexpr (NP >= 4 && NP % 4 == 0) {
+#pragma unroll
+        for (int g = 0; g < NP; g += 4) sort4(v[g], v[g + 1], v[g + 2], v[g + 3]);
+        net_from<NP, 4, PRUNE_T, 0>(v);
+    } else if constexpr (NP > 1) {
+        net_from<NP, 1, PRUNE_T, 0>(v);
+    }
 }
 
 // v[LO + rel] for a per-lane rel in [0, LEN): binary multiplexer tree (LEN-1 v_cndmask), static

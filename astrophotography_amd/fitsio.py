@@ -106,8 +106,11 @@ def _long_string_cards(head, value, comment):
     '&', the following cards are `CONTINUE  'piece&'`, the comment rides on the last cards."""
     esc = str(value).replace("'", "''")
     pieces = []
+    first = 80 - len(head) - 3                              # quote + piece + '&' + quote after the head: 67 for 'KEYWORD = ',
+    if first < 1:                                           # less for a 'HIERARCH LONGKEY = ' head (ADVICE r2)
+        raise ValueError('keyword too long for a FITS card: %r' % head)
     while esc:
-        n = 67
+        n = first if not pieces else 67
         if len(esc) > n and esc[:n].endswith("'") and (len(esc[:n]) - len(esc[:n].rstrip("'"))) % 2 == 1:
             n -= 1                                          # never split an escaped quote pair
         pieces.append(esc[:n])
@@ -130,6 +133,7 @@ def _long_string_cards(head, value, comment):
             while text:
                 chunk, text = text[:62], text[62:]
                 cards.append("CONTINUE  '%s' / %s" % ('&' if text else '', chunk))
+    assert all(len(c) <= 80 for c in cards), 'FITS card longer than 80 bytes'
     return ''.join(c.ljust(80) for c in cards)
 
 

@@ -209,15 +209,19 @@ def _stack_args(frames, calib, pixmask, keep):
 
 
 def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
-                  stdfunc='std', calib=None, pixmask=None, outputs=('mean',)):
+                  stdfunc='std', calib=None, pixmask=None, outputs=('mean',), exact=False, moments_mean_only=False):
     """Per-pixel sigma-clipped reduction along N = astropy sigma_clipped_stats(cube, axis=0)
     (sigma_clipping.py:298-383, 924-937), optionally fused with the calibration of each value.
 
     calib: None or dict(bias, dark, nflat=None, exp_ratio, pedestal=None, dark_still_biased=False).
     outputs: any of 'mean', 'median', 'std', 'count' (float32 / int32 planes), 'mean_f64', 'std_f64' (the unrounded
     float64 statistics, as ccdproc.combine keeps them), 'moments' (float32 [3, ...]: sum, count, sumsq) or
-    'moments_f64' (dict(sum, sumsq: float64 planes, count: int32 plane) - views of one 20-byte-per-pixel buffer)
+    'moments_f64' (dict(sum, sumsq: float64 planes, count: int32 plane) - views of one 20-byte-per-pixel buffer) or
+    'moments_f64p' (the packed float64 layout float64 [3, ...] = sum, count, sumsq: dict(sum, count, sumsq, buffer,
+    prefix = buffer[:2]) - what parallel.stack_nshard all-reduces in ONE call per stripe)
     -> dict of device tensors.
+    exact: APGPU_STACK_EXACT_MOMENTS (float64 clip only: the mean is the float64 mean of the survivors rounded once);
+    moments_mean_only: APGPU_STACK_MOMENTS_MEAN (the float64 moments will only be turned into a mean).
     """
     _need_cuda(frames)
     lib = _lib.load()
@@ -237,27 +241,34 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
         elif k in ('mean_f64', 'std_f64'):
             res[k] = torch.empty(shp, dtype=torch.float64, device=dev)
         elif k == 'moments':
-            if 'moments_f64' in outputs:
-                raise ValueError("ask for either 'moments' or 'moments_f64'")
+            if a.moments:
+                raise ValueError('ask for one moment layout')
             res[k] = torch.empty((3,) + shp, dtype=torch.float32, device=dev)
-        elif k == 'moments_f64':
-            res[k] = alloc_moments_f64(shp, dev)
+            a.moments = res[k].data_ptr()
+            continue
+        elif k in ('moments_f64', 'moments_f64p'):
+            if a.moments:
+                raise ValueError('ask for one moment layout')
+            res[k] = alloc_moments_f64(shp, dev, packed=(k == 'moments_f64p'))
             a.moments = res[k]['buffer'].data_ptr()
-            a.moments_f64 = 1
+            a.moments_f64 = 3 if k == 'moments_f64p' else 1
             continue
         else:
             raise ValueError('unknown output %r' % (k,))
         setattr(a, k, res[k].data_ptr())
+    a.flags = (_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0)
     check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
     return res
 
 
-def stack_sigclip_chunked(frames, chunk=None, want_std=False, **clip):
+def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, finalize=True, **clip):
     """A stack of MORE than APGPU_MAX_STACK (512) frames on one GPU: the frames are reduced in chunks of at most `chunk`
     (default: the largest equal split not above 512), every chunk clipped against its own statistics, and the float64
     moments of the chunks accumulate in one buffer (apgpu_stack_args.moments_f64 = 2) - the single-GPU form of the
     N-shard combine (parallel.stack_nshard).  Exact for an unclipped mean; for a clipped stack the semantics are
     hierarchical (SURVEY 8(e) option ii), NOT the full-N clip.  clip: sigma, maxiters, cenfunc, stdfunc, calib, pixmask.
+    packed: accumulate in the packed float64 layout (sum, count, sumsq planes) the N-shard exchange all-reduces;
+    finalize=False returns the moment dict itself (a rank's share of a hierarchical stack, parallel.stack_nshard).
     Returns dict(mean, count[, std])."""
     _need_cuda(frames)
     lib = _lib.load()
@@ -267,7 +278,7 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, **clip):
         chunk = -(-N // parts)
     chunk = int(min(chunk, _lib.MAX_STACK))
     shp = tuple(frames.shape[1:])
-    mom = alloc_moments_f64(shp, frames.device)
+    mom = alloc_moments_f64(shp, frames.device, packed=packed)
     calib = clip.pop('calib', None)
     pixmask = clip.pop('pixmask', None)
     for k, lo in enumerate(range(0, N, chunk)):
@@ -286,13 +297,17 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, **clip):
         mi = clip.get('maxiters', 5)
         a.maxiters = -1 if mi is None else int(mi)
         sg = clip.get('sigma', 3.0)
-        a.sigma_lower = float(clip.get('sigma_lower') or sg)
-        a.sigma_upper = float(clip.get('sigma_upper') or sg)
+        sl, su = clip.get('sigma_lower'), clip.get('sigma_upper')
+        a.sigma_lower = float(sg if sl is None else sl)      # an explicit 0.0 is a value, not "unset"
+        a.sigma_upper = float(sg if su is None else su)
         a.moments = mom['buffer'].data_ptr()
-        a.moments_f64 = 1 if k == 0 else 2
+        a.moments_f64 = (3 if k == 0 else 4) if packed else (1 if k == 0 else 2)
+        a.flags = 0 if want_std else _lib.STACK_MOMENTS_MEAN
         check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
+    if not finalize:
+        return mom
     out = moments_finalize(mom, want_std=want_std)
-    res = dict(count=mom['count'])
+    res = dict(count=mom['count'].to(torch.int32) if packed else mom['count'])
     if want_std:
         res['mean'], res['std'] = out
     else:
@@ -317,8 +332,10 @@ def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',),
     if median_only:
         a.median = 0x1000
     for k in outputs:
-        if k == 'moments_f64':
-            a.moments, a.moments_f64 = 0x1000, 1
+        if k in ('moments_f64', 'moments_f64p'):
+            a.moments, a.moments_f64 = 0x1000, (3 if k == 'moments_f64p' else 1)
+        elif k == 'moments':
+            a.moments = 0x1000
         else:
             setattr(a, k, 0x1000)
     buf = C.create_string_buffer(256)
@@ -342,11 +359,15 @@ def stack_median(frames, calib=None, pixmask=None, want_count=False):
     return (med, cnt) if want_count else med
 
 
-def alloc_moments_f64(shape, device):
-    """The float64 moment layout of include/apgpu.h: one buffer = double sum[P], double sumsq[P], int32 count[P];
-    returns dict(sum, sumsq, count, buffer) of views with the image shape."""
+def alloc_moments_f64(shape, device, packed=False):
+    """The float64 moment layouts of include/apgpu.h.  Default: one buffer = double sum[P], double sumsq[P], int32 count[P]
+    -> dict(sum, sumsq, count, buffer) of views with the image shape.  packed: float64 [3][P] = sum, count, sumsq ->
+    dict(sum, count, sumsq, buffer, prefix) with prefix = the contiguous (sum, count) planes a mean-only exchange sends."""
     shape = tuple(shape)
     P = int(np.prod(shape)) if shape else 1
+    if packed:
+        buf = torch.empty((3,) + shape, dtype=torch.float64, device=device)
+        return dict(sum=buf[0], count=buf[1], sumsq=buf[2], buffer=buf, prefix=buf[:2], packed=True)
     buf = torch.empty(2 * P + (P + 1) // 2, dtype=torch.float64, device=device)
     return dict(sum=buf[:P].view(shape), sumsq=buf[P:2 * P].view(shape),
                 count=buf[2 * P:].view(torch.int32)[:P].view(shape), buffer=buf)
@@ -367,7 +388,8 @@ def moments_finalize(moments, want_std=None, out_mean=None, want_f64=False):
         _need_cuda(sm, sq, cnt)
         shp = tuple(sm.shape)
         P = sm.numel()
-        for t, dt, nm in ((sm, torch.float64, 'sum'), (sq, torch.float64, 'sumsq'), (cnt, torch.int32, 'count')):
+        packed = cnt.dtype == torch.float64                  # the packed layout carries the count as a float64 plane
+        for t, dt, nm in ((sm, torch.float64, 'sum'), (sq, torch.float64, 'sumsq'), (cnt, torch.float64 if packed else torch.int32, 'count')):
             if t is not None and (t.dtype != dt or t.numel() != P or not t.is_contiguous()):
                 raise TypeError('moments_f64[%r] must be a contiguous %s plane' % (nm, dt))
         if want_std and sq is None:
@@ -381,8 +403,12 @@ def moments_finalize(moments, want_std=None, out_mean=None, want_f64=False):
         std = torch.empty(shp, dtype=torch.float32, device=sm.device) if want_std else None
         m64 = torch.empty(shp, dtype=torch.float64, device=sm.device) if want_f64 else None
         s64 = torch.empty(shp, dtype=torch.float64, device=sm.device) if (want_f64 and want_std) else None
-        check(lib.apgpu_moments_finalize_f64(_ptr(sm), _ptr(sq) if want_std else None, _ptr(cnt), _ptr(mean), _ptr(std),
-                                             _ptr(m64), _ptr(s64), P, _stream()))
+        if packed:
+            check(lib.apgpu_moments_finalize_f64p(_ptr(sm), _ptr(cnt), _ptr(sq) if want_std else None, _ptr(mean), _ptr(std),
+                                                  _ptr(m64), _ptr(s64), P, _stream()))
+        else:
+            check(lib.apgpu_moments_finalize_f64(_ptr(sm), _ptr(sq) if want_std else None, _ptr(cnt), _ptr(mean), _ptr(std),
+                                                 _ptr(m64), _ptr(s64), P, _stream()))
         out = (mean, std) if want_std else mean
         if want_f64:
             return out, ((m64, s64) if want_std else m64)

@@ -12,13 +12,17 @@ Two partitionings of a stack job:
   communication stream while stripe k+1 is being reduced, so the collective hides behind the kernel
   instead of following it.
 
-  Two exchange payloads (``exchange=``):
-    'f64' (default)  float64 sum + int32 count per pixel (12 bytes; + float64 sum of squares = 20 bytes
-                     when a std is wanted): the ranks' float64 partial sums are added in float64, so the
-                     combined mean is the float64 combine of SURVEY 8(e) rounded ONCE to float32;
+  Two exchange payloads (``exchange=``), each ONE all-reduce per stripe:
+    'f64' (default)  the packed float64 moment planes (sum, count[, sumsq]) of include/apgpu.h's layout 3 - 16 bytes per
+                     pixel, 24 with a std: the count rides along as a float64 (exact to 2^53), so a single call carries
+                     everything; the ranks' float64 partial sums are added in float64 and the combined mean is the
+                     float64 combine of SURVEY 8(e) rounded ONCE to float32;
     'f32'            float32 sum + float32 count (8 bytes): every rank rounds its sum to float32 and
                      RCCL adds in float32 - about 1e-7 relative per rank, mean only (no std: float32
                      sums of squares about zero cancel catastrophically for CCD-range data).
+  ``hier_chunk``: a rank clips its own frames in chunks of that many (ops.stack_sigclip_chunked, moments accumulated on
+  the device) - with chunk = n_total / 8 a job has the SAME semantics on 1, 2, 4 and 8 ranks ("8 shards of n_total / 8
+  frames, clipped per shard, moments added"), which is what makes a strong-scaling curve compare like with like.
 
 * ``stack_rowshard`` - exact for any centre/deviation function and needs no data-path collective:
   every rank holds all N frames of its row block (``row_block``) and reduces it on its own;
@@ -71,16 +75,20 @@ def _slice_calib(calib, r0, r1):
     return c
 
 
-def _default_local_moments(frames, calib, r0, r1, clip, exchange):
-    """Partial moments of rows [r0, r1): dict(sum, count[, sumsq]) of [r1 - r0, W] planes."""
+def _default_local_moments(frames, calib, r0, r1, clip, exchange, want_std=False, hier_chunk=None):
+    """Partial moments of rows [r0, r1): dict(sum, count[, sumsq], prefix[, buffer]) of [r1 - r0, W] planes."""
     from . import ops
     sub = frames[:, r0:r1]
     c = _slice_calib(calib, r0, r1)
+    chunked = hier_chunk is not None and sub.shape[0] > hier_chunk
     if exchange == 'f32':
+        if chunked:
+            raise ValueError("hierarchical chunks accumulate float64 moments: use exchange='f64'")
         m = ops.stack_sigclip(sub, calib=c, outputs=('moments',), **clip)['moments']
         return dict(sum=m[0], count=m[1], prefix=m[:2])         # (sum, count) is one contiguous float32 block
-    m = ops.stack_sigclip(sub, calib=c, outputs=('moments_f64',), **clip)['moments_f64']
-    return dict(sum=m['sum'], count=m['count'], sumsq=m['sumsq'], buffer=m['buffer'])
+    if chunked:
+        return ops.stack_sigclip_chunked(sub, chunk=hier_chunk, want_std=want_std, packed=True, finalize=False, calib=c, **clip)
+    return ops.stack_sigclip(sub, calib=c, outputs=('moments_f64p',), moments_mean_only=not want_std, **clip)['moments_f64p']
 
 
 def _default_finalize(m, out_mean, out_std, exchange):
@@ -96,21 +104,23 @@ def _default_finalize(m, out_mean, out_std, exchange):
 
 
 def _exchange(m, exchange, want_std, group):
-    """The all-reduce(s) of one stripe: float32 (sum, count) block, or float64 sum (+ sumsq) and int32 count."""
-    if exchange == 'f32':
-        dist.all_reduce(m['prefix'], op=dist.ReduceOp.SUM, group=group)
-        return
-    dist.all_reduce(m['sum'], op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(m['count'], op=dist.ReduceOp.SUM, group=group)
-    if want_std:
-        dist.all_reduce(m['sumsq'], op=dist.ReduceOp.SUM, group=group)
+    """THE all-reduce of one stripe: the contiguous (sum, count) planes - float32 or float64 - or, with a std, the whole
+    packed float64 buffer (sum, count, sumsq)."""
+    dist.all_reduce(m['buffer'] if (want_std and exchange == 'f64') else m['prefix'], op=dist.ReduceOp.SUM, group=group)
 
 
 def exchange_bytes_per_pixel(exchange='f64', want_std=False):
-    """Bytes per output pixel each rank contributes to the all-reduce(s)."""
+    """Bytes per output pixel each rank contributes to the all-reduce."""
     if exchange == 'f32':
         return 8
-    return 20 if want_std else 12
+    return 24 if want_std else 16
+
+
+def default_stripes(H, W, exchange='f64', want_std=False):
+    """Row stripes per step: enough to overlap the exchange with the reduction, few enough that every all-reduce stays a
+    large transfer (>= 64 MB) - 4 for a 4096 x 4096 image, never more than 8."""
+    payload = H * W * exchange_bytes_per_pixel(exchange, want_std)
+    return int(max(1, min(8, payload // (64 << 20))))
 
 
 _COMM_STREAMS = {}
@@ -131,23 +141,29 @@ def _record(m, stream):
 
 
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
-                 n_stripes=8, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
-                 exchange='f64', want_std=False):
+                 n_stripes=None, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
+                 exchange='f64', want_std=False, hier_chunk=None, timings=None):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank
     (want_std: (mean, std)).
 
     One exchange per stripe on a side stream, overlapped with the reduction of the next stripes.  `exchange`
     selects the payload (module docstring); want_std needs 'f64'.  return_moments appends the combined per-stripe
-    moment dicts (sum, count[, sumsq]) for inspection.
+    moment dicts (sum, count[, sumsq]) for inspection.  n_stripes None = default_stripes().  hier_chunk: see the module
+    docstring.  timings: a list that receives one (start, end) pair of CUDA events per stripe around its all-reduce on the
+    communication stream (bench.py's exchange_ms).
     """
     if exchange not in ('f64', 'f32'):
         raise ValueError("exchange must be 'f64' or 'f32'")
     if want_std and exchange != 'f64':
         raise ValueError("a standard deviation needs exchange='f64' (float32 sums of squares cancel)")
-    local_moments = local_moments or _default_local_moments
+    if local_moments is None:
+        import functools
+        local_moments = functools.partial(_default_local_moments, want_std=want_std, hier_chunk=hier_chunk)
     finalize = finalize or _default_finalize
     world, _ = _world(group)
     n_local, H, W = frames_local.shape
+    if n_stripes is None:
+        n_stripes = default_stripes(H, W, exchange, want_std)
     clip = dict(sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc)
     on_gpu = frames_local.is_cuda
     collective = (world > 1) or (force_collective and dist.is_available() and dist.is_initialized())
@@ -174,7 +190,13 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
             with torch.cuda.stream(comm):
                 # exchange and finalise stripe k on the side stream while the compute streams reduce the next stripes
                 comm.wait_event(ev)
+                if timings is not None:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(comm)
                 _exchange(m, exchange, want_std, group)
+                if timings is not None:
+                    t1.record(comm)
+                    timings.append((t0, t1))
                 finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, exchange)
                 _record(m, comm)
             parts.append(m)

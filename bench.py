@@ -10,7 +10,12 @@ bias/dark/flat calibration + 3-sigma (maxiters 5, median-centred) clipped mean a
   N > 1, --scaling weak  (default) every rank holds its own 64 x 4096 x 4096 frames: the global stack is 64*N frames
                          sharded on the N axis (parallel.stack_nshard: per-rank partial moments, one RCCL all-reduce
                          per row stripe overlapped with the reduction of the next stripes).
-  N > 1, --scaling strong  BASELINE.json configs[2] "C3": --total-frames (256) x 4096 x 4096 in total, 256/N per rank.
+  --scaling strong       BASELINE.json configs[2] "C3": --total-frames (256) x 4096 x 4096 in total, 256/N per rank, with the
+                         SAME semantics at every N: the job is --hier-shards (8) shards of 32 frames, each clipped against
+                         its own statistics, float64 moments added - a rank holding several shards reduces them chunk by
+                         chunk on the device.  At N = 1 the exact 256-frame kernel is timed beside it ("exact_ms").
+  N > 1                  the line also carries the row-shard time of the same job ("rowshard") and the time the stripes'
+                         all-reduces take on the communication stream ("exchange_ms").
   --parallelism rowshard   the exact partition: every rank reduces ALL frames of its own row block, no data-path
                          collective (weak: 4096 rows per rank, strong: 4096/N rows per rank).
 
@@ -55,7 +60,11 @@ def parse(argv=None):
                     help='c2 (default, the BASELINE metric): fused calibrate + clipped mean; c4: uint16 Bayer frames, per-channel '
                          'flat + fused calibrate + median stack (use --height 6248 --width 4176); c5: bad-pixel mask + per-frame '
                          'affine Lanczos-3 resample + 5-iteration clipped mean (use --frames 16 --height 8192 --width 8192)')
-    ap.add_argument('--stripes', type=int, default=8, help='row stripes for collective/compute overlap (N > 1)')
+    ap.add_argument('--stripes', type=int, default=0, help='row stripes for collective/compute overlap (N > 1); 0 = by payload '
+                                                            '(parallel.default_stripes: 4 for 4096 x 4096)')
+    ap.add_argument('--hier-shards', type=int, default=8, help='--scaling strong: the job is this many shards of '
+                                                               'total-frames / shards frames, whatever --gpus is')
+    ap.add_argument('--exact-moments', action='store_true', help='APGPU_STACK_EXACT_MOMENTS: float64 clip only (no float32 fast path)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-collective', action='store_true', help='run the striped all-reduce path even with one rank (testing)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU time of each cpu_baseline leg')
@@ -306,7 +315,15 @@ def main(argv=None):
         resampled = torch.empty_like(frames)
     torch.cuda.synchronize()
 
-    single_launch = (world == 1 and not args.force_collective) or rowshard
+    hier_chunk = None
+    if strong and not rowshard:
+        if args.total_frames % args.hier_shards or args.hier_shards % world:
+            print('error: --total-frames must split into --hier-shards equal shards, and the shards over the ranks', file=sys.stderr)
+            return 2
+        hier_chunk = args.total_frames // args.hier_shards
+    single_launch = (world == 1 and not args.force_collective and hier_chunk is None) or rowshard
+    n_stripes = args.stripes or parallel.default_stripes(H, W, args.exchange)
+    timings = []                                             # (start, end) events around every stripe's all-reduce
 
     def step():
         if wl == 'c4':
@@ -315,12 +332,14 @@ def main(argv=None):
             ops.resample_affine(frames, affines, mask=badmask, out=resampled, weight=False)
             if world == 1:
                 return ops.stack_sigclip(resampled, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
-            return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=args.stripes, exchange=args.exchange)
+            return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=n_stripes, exchange=args.exchange,
+                                         timings=timings)
         if single_launch:
-            return parallel.stack_rowshard(frames, calib, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
-                                           outputs=('mean',))['mean']
-        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=args.stripes,
-                                     force_collective=args.force_collective, exchange=args.exchange)
+            return ops.stack_sigclip(frames, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', calib=calib,
+                                     outputs=('mean',), exact=args.exact_moments)['mean']
+        return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=n_stripes,
+                                     force_collective=args.force_collective, exchange=args.exchange, hier_chunk=hier_chunk,
+                                     timings=timings)
 
     for _ in range(args.warmup):
         out = step()
@@ -329,6 +348,7 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
 
+    del timings[:]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -351,7 +371,68 @@ def main(argv=None):
         dist.all_gather_into_tensor(allt, mine)
         per_rank_ms = [1e3 * float(v) / args.steps for v in allt.cpu()]
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * N * P / 1e6 / (elapsed / args.steps)       # input frame pixels of ALL ranks per second
+    job_pixels = float(N) * P                                  # input frame pixels of ALL ranks (ragged blocks: summed, not
+    if world > 1:                                              # rank 0's share times the world size)
+        t = torch.tensor([job_pixels], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        job_pixels = float(t.item())
+    value = job_pixels / 1e6 / (elapsed / args.steps)
+
+    def timed_extra(fn, steps):
+        """Mean wall time per step (ms, max over ranks) of `fn`, bracketed like the main loop."""
+        fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ta = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return 1e3 * float(dt.item()) / steps
+
+    # the all-reduces of the timed steps on the communication stream (per step: summed over the stripes; max over ranks)
+    exchange_ms = None
+    if timings:
+        ex = sum(a.elapsed_time(b) for a, b in timings) / args.steps
+        t = torch.tensor([ex], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exchange_ms = float(t.item())
+
+    extra = {}
+    if wl == 'c2' and not rowshard and not single_launch:
+        # (1) strong scaling at one rank: the exact kernel on all frames beside the hierarchical reduction
+        if strong and world == 1:
+            ems = timed_extra(lambda: ops.stack_sigclip(frames, sigma=3.0, maxiters=5, calib=calib, outputs=('mean',)), min(args.steps, 5))
+            extra['exact_ms'] = ems
+            extra['exact_value'] = job_pixels / 1e6 / (ems * 1e-3)
+            extra['exact_kernel'] = ops.stack_kernel_name(N, args.dtype, calibrated=True, outputs=('mean',))
+        # (2) the row-shard form of the same job (exact at every N, no data-path collective), timed beside the N-shard one
+        if world > 1:
+            if strong:
+                r0, r1 = parallel.row_block(H, world, rank)
+                del frames
+                rmasters = {k: v[r0:r1].contiguous() for k, v in masters.items()}
+                rnflat = nflat[r0:r1].contiguous()
+                rframes = synth.make_frames(n_total, rmasters, rnflat, config_id=2, dtype=tdtype, first_frame=0)
+                rcal = dict(bias=rmasters['bias'], dark=rmasters['dark'], nflat=rnflat,
+                            exp_ratio=torch.full((n_total,), e, dtype=torch.float32, device=dev), dark_still_biased=False)
+                rpix = float(n_total) * (r1 - r0) * W
+            else:
+                rframes, rcal, rpix = frames, calib, float(N) * P
+            rms = timed_extra(lambda: parallel.stack_rowshard(rframes, rcal, sigma=3.0, maxiters=5, outputs=('mean',)), args.steps)
+            t = torch.tensor([rpix], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            extra['rowshard'] = {'ms_per_step': rms, 'value': float(t.item()) / 1e6 / (rms * 1e-3), 'unit': 'Mpixels/s',
+                                 'kernel': ops.stack_kernel_name(rframes.shape[0], args.dtype, calibrated=True, outputs=('mean',)),
+                                 'note': 'every rank: all frames of its own rows, exact clip, no data-path collective'}
+            if strong:
+                frames = rframes
 
     # dominant kernel: device time per step from HIP events on the launch stream; for a single-launch step this is
     # exactly one launch of the stack kernel, whose name the library reports for the variant it dispatched.
@@ -359,12 +440,12 @@ def main(argv=None):
     avg_kernel_ms = sum(kern_ms) / len(kern_ms)
     esize = 4 if args.dtype == 'f32' else 2
     nshard_multi = not single_launch
-    out_bytes = 4 if single_launch else (20 if args.exchange == 'f64' else 12)     # mean plane | moment planes written
+    out_bytes = 4 if single_launch else (24 if args.exchange == 'f64' else 12)     # mean plane | moment planes written
     algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
     kernel_name = ops.stack_kernel_name(N, args.dtype, calibrated=True,
-                                        outputs=('mean',) if single_launch else (('moments_f64',) if args.exchange == 'f64' else ('moments',)))
+                                        outputs=('mean',) if single_launch else (('moments_f64p',) if args.exchange == 'f64' else ('moments',)))
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
-    cfg_name = 'C2' if (world == 1 or not strong) else 'C3'
+    cfg_name = 'C3' if strong else 'C2'
     workload = '%s: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean' % (
         cfg_name, N, H, W, args.dtype)
     if wl == 'c4':
@@ -389,7 +470,7 @@ def main(argv=None):
         try:
             td = json.load(open(tfile))
             ent = td.get('workloads', {}).get(tkey)
-            if ent:
+            if ent and ent.get('kernel') == kernel_name:        # counters of ANOTHER kernel build are not this kernel's traffic
                 traffic = ent.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
@@ -419,9 +500,11 @@ def main(argv=None):
         elif rowshard:
             par = 'row-shard x%d (every rank: all %d frames of %d rows; no data-path collective)' % (world, N, H)
         else:
-            par = 'N-shard x%d (%d of %d frames per rank), %d-stripe all-reduce of %s' % (
-                world, N, n_total, args.stripes,
-                'float64 sum + int32 count (12 B/pixel)' if args.exchange == 'f64' else 'float32 sum + count (8 B/pixel)')
+            par = 'N-shard x%d (%d of %d frames per rank%s), %d stripes, ONE all-reduce per stripe of %s' % (
+                world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes,
+                'float64 sum + count (16 B/pixel)' if args.exchange == 'f64' else 'float32 sum + count (8 B/pixel)')
+        if world == 1 and hier_chunk:
+            par = 'single GPU, hierarchical: %d shards of %d frames clipped per shard, float64 moments added' % (N // hier_chunk, hier_chunk)
         line = {
             'metric': metric, 'value': value, 'unit': 'Mpixels/s',
             'n_gpus': world, 'rccl_world_size': rccl_world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -430,15 +513,21 @@ def main(argv=None):
             'config': {'workload': workload, 'frames_per_gpu': N, 'frames_total': n_total if not rowshard else N,
                        'height': H, 'width': W, 'parallelism': par},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_key': tkey,
                          'kernel': kernel_name,
                          'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes,
                          'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None},
         }
         if nshard_multi:
-            line['roofline']['note'] = ('step = %d stripe kernels + all-reduces on side streams; achieved = per-rank algorithmic '
-                                        'bytes / step time on the launch stream' % args.stripes)
+            line['roofline']['note'] = ('step = %d stripe kernels%s + all-reduces on side streams; achieved = per-rank algorithmic '
+                                        'bytes / step time on the launch stream' % (
+                                            n_stripes, ' x %d shards' % (N // hier_chunk) if hier_chunk else ''))
             line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(args.exchange)
+            line['exchange_ms'] = exchange_ms
+            line['stripes'] = n_stripes
+            if hier_chunk:
+                line['hier_shards'] = args.hier_shards
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             if args.dtype == 'f32' and wl == 'c2':
                 line['cpu_baseline'] = cpu_baseline(frames, masters, nflat, e, args.cpu_seconds)

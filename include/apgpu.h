@@ -120,7 +120,11 @@ int apgpu_calibrate_mixed(const void *raw, int raw_dtype, const void *bias, int 
  *                         mean is the float64 combine rounded once to float32 (12 bytes per pixel mean-only);
  *       moments_f64 == 2: the same layout, but the call ADDS its moments to what the buffer already holds: a stack
  *                         of more than APGPU_MAX_STACK frames is reduced chunk by chunk into one buffer (hierarchical
- *                         clipping: every chunk is clipped against its own statistics).
+ *                         clipping: every chunk is clipped against its own statistics);
+ *       moments_f64 == 3: packed float64 planes double moments[3][P] = sum, count, sum of squares: the count rides as a
+ *                         float64 (exact to 2^53), so ONE all-reduce of the contiguous [2][P] prefix (16 bytes per pixel,
+ *                         24 with the third plane for a std) combines the ranks (apgpu_moments_finalize_f64p);
+ *       moments_f64 == 4: layout 3, ADDING to what the buffer holds (a rank's share reduced in several chunks).
  * ------------------------------------------------------------------------------------------- */
 typedef struct apgpu_stack_args {
     const void *frames;          /* [N][P] APGPU_F32 or APGPU_U16 */
@@ -150,8 +154,20 @@ typedef struct apgpu_stack_args {
     double *mean_f64;            /* [P] or NULL */
     double *std_f64;             /* [P] or NULL */
     int32_t moments_f64;         /* layout of `moments`, see above */
-    int32_t reserved0;           /* must be 0 */
+    int32_t flags;               /* APGPU_STACK_* bits below; 0 = defaults (was reserved0) */
 } apgpu_stack_args;
+
+/* apgpu_stack_args.flags.  The lean kernels (mean / count / moments outputs, median centre, std deviation, full slot
+ * counts) clip on a float32 fast path: moments and bound tests in float32 with an error margin, and every wavefront in
+ * which a comparison falls inside the margin is redone on the float64 path - the survivor sets are ALWAYS those of the
+ * float64 evaluation; the mean carries the float32 rounding of its sum (a few 1e-3 ulp(float32); still the float64 mean
+ * rounded once for > 90 % of the pixels, within 1 ulp otherwise).
+ *   APGPU_STACK_EXACT_MOMENTS   force the float64 path: the mean is the float64 mean of the survivors rounded once.
+ *   APGPU_STACK_MOMENTS_MEAN    the float64-layout moments will only be used for a mean (sum, count): lets the fast path
+ *                               fill them; their sum of squares then has float32 accuracy (not good for a std).
+ *                               Without it float64-layout moments always come from the float64 path. */
+#define APGPU_STACK_EXACT_MOMENTS 1
+#define APGPU_STACK_MOMENTS_MEAN 2
 
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 
@@ -173,6 +189,11 @@ int apgpu_moments_finalize(const float *moments, float *mean, float *std, int64_
  * wanted; cnt == 0 -> NaN. */
 int apgpu_moments_finalize_f64(const double *sum, const double *sumsq, const int32_t *count, float *mean, float *std,
                                double *mean_f64, double *std_f64, int64_t n_pixels, void *stream);
+
+/* The packed float64 layout (moments_f64 == 3 / 4): the three planes as pointers (buffer, buffer + P, buffer + 2 P);
+ * sumsq may be NULL if no std is wanted; count == 0 -> NaN. */
+int apgpu_moments_finalize_f64p(const double *sum, const double *count, const double *sumsq, float *mean, float *std,
+                                double *mean_f64, double *std_f64, int64_t n_pixels, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * A3  astropy.stats.sigma_clipped_stats(data, sigma) with axis=None as called at

@@ -21,9 +21,12 @@ s = json.load(open(os.path.join(src, 'summary_%s.json' % tag)))
 line = s.get('bench_line') or s.get('bench_line_under_rocprof') or {}
 cfg = line.get('config', {})
 if 'hbm_bytes_per_launch' in s and cfg:
-    wl = cfg['workload'].split(':')[0].lower()
-    single = line.get('n_gpus', 1) == 1
-    key = '%s:%dx%dx%d:%s:%s' % (wl, cfg['frames_per_gpu'], cfg['height'], cfg['width'], line['dtype'], 'single' if single else 'nshard')
+    # the key bench.py looks its traffic up under: taken verbatim from the bench line (roofline.traffic_key)
+    key = (line.get('roofline') or {}).get('traffic_key')
+    if not key:
+        wl = cfg['workload'].split(':')[0].split(' ')[0].lower()
+        single = line.get('n_gpus', 1) == 1
+        key = '%s:%dx%dx%d:%s:%s' % (wl, cfg['frames_per_gpu'], cfg['height'], cfg['width'], line['dtype'], 'single' if single else 'f64')
     tfile = os.path.join(root, 'profiles', 'pmc_traffic.json')
     try:
         td = json.load(open(tfile))

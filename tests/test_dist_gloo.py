@@ -1,4 +1,4 @@
-"""world_size-2 gloo tests (CPU) of the multi-GPU plumbing in astrophotography_amd.parallel.
+"""world_size-2 and -4 gloo tests (CPU) of the multi-GPU plumbing in astrophotography_amd.parallel.
 
 The per-rank partial moments and the finalisation are HIP kernels in the product; here CPU stand-ins
 built on the oracle are injected so that sharding, striping, the all-reduces (both exchange payloads) and
@@ -26,7 +26,7 @@ def _free_port():
 
 
 def _oracle_local_moments(frames, calib, r0, r1, clip, exchange):
-    """Stand-in for ops.stack_sigclip(outputs=('moments' | 'moments_f64')): the same planes, computed by the oracle."""
+    """Stand-in for ops.stack_sigclip(outputs=('moments' | 'moments_f64p')): the same planes, computed by the oracle."""
     from oracle import apref
     sub = frames[:, r0:r1].numpy()
     if calib is not None:
@@ -39,8 +39,9 @@ def _oracle_local_moments(frames, calib, r0, r1, clip, exchange):
     if exchange == 'f32':
         mom = torch.from_numpy(np.stack([kept.sum(0), r['count'].astype(np.float64)]).astype(np.float32))
         return dict(sum=mom[0], count=mom[1], prefix=mom)
-    return dict(sum=torch.from_numpy(kept.sum(0)), sumsq=torch.from_numpy((kept * kept).sum(0)),
-                count=torch.from_numpy(r['count'].astype(np.int32)))
+    # the packed float64 layout: planes sum, count, sumsq in ONE buffer; a mean-only exchange sends the [2] prefix
+    buf = torch.from_numpy(np.stack([kept.sum(0), r['count'].astype(np.float64), (kept * kept).sum(0)]))
+    return dict(sum=buf[0], count=buf[1], sumsq=buf[2], buffer=buf, prefix=buf[:2])
 
 
 def _cpu_finalize(m, out_mean, out_std, exchange):
@@ -74,13 +75,29 @@ def _worker(rank, world, port, n_total, shape, out_dir):
     calib = dict(bias=torch.from_numpy(bias), dark=torch.from_numpy(dark), nflat=None, exp_ratio=0.4)
     mine = torch.from_numpy(cube[lo:hi])
     kw = dict(sigma=3.0, maxiters=5, local_moments=_oracle_local_moments, finalize=_cpu_finalize)
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append((tuple(t.shape), t.dtype))
+        return real_all_reduce(t, *a, **k)
+    parallel.dist.all_reduce = counting_all_reduce
     (mean, std), parts = parallel.stack_nshard(mine, calib, n_stripes=3, exchange='f64', want_std=True, return_moments=True, **kw)
+    # ONE all-reduce per stripe, carrying all three float64 planes
+    assert len(calls) == 3 and all(sh[0] == 3 and dt == torch.float64 for sh, dt in calls), calls
+    del calls[:]
     mean_b = parallel.stack_nshard(mine, calib, n_stripes=4, exchange='f64', **kw)          # mean-only exchange: same mean
     assert torch.equal(mean, mean_b)
+    assert len(calls) == 4 and all(sh[0] == 2 and dt == torch.float64 for sh, dt in calls), calls      # mean only: the [2] prefix
+    del calls[:]
     mean32 = parallel.stack_nshard(mine, calib, n_stripes=2, exchange='f32', **kw)
+    assert len(calls) == 2 and all(sh[0] == 2 and dt == torch.float32 for sh, dt in calls), calls
+    parallel.dist.all_reduce = real_all_reduce
+    assert parallel.exchange_bytes_per_pixel('f64') == 16 and parallel.exchange_bytes_per_pixel('f64', True) == 24
+    assert parallel.default_stripes(4096, 4096) == 4 and parallel.default_stripes(64, 64) == 1
     with pytest.raises(ValueError):
         parallel.stack_nshard(mine, calib, exchange='f32', want_std=True, **kw)
-    cnt = torch.cat([p['count'] for p in parts], 0)
+    cnt = torch.cat([p['count'] for p in parts], 0).to(torch.int64)
     np.savez(os.path.join(out_dir, f'r{rank}.npz'), mean=mean.numpy(), std=std.numpy(), mean32=mean32.numpy(), count=cnt.numpy())
 
     # row-shard: every rank reduces all frames of its own rows (stand-in for the device call), then the image is gathered
@@ -95,16 +112,18 @@ def _worker(rank, world, port, n_total, shape, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_nshard_and_rowshard_world2(tmp_path):
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,n_total', [(2, 24), (4, 50)])         # 50 frames on 4 ranks: ragged shards 13 + 13 + 12 + 12
+def test_nshard_and_rowshard_gloo(tmp_path, world, n_total):
     from oracle import apref
     from astrophotography_amd import parallel
-    world, n_total, shape = 2, 24, (11, 16)                          # 11 rows: ragged row blocks (6 + 5) and stripes
+    shape = (11, 16)                                                  # 11 rows: ragged row blocks and stripes
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_total, shape, str(tmp_path)), nprocs=world, join=True)
     res = [np.load(tmp_path / f'r{r}.npz') for r in range(world)]
     for k in ('mean', 'std', 'mean32', 'count'):
-        assert np.array_equal(res[0][k], res[1][k]), k                # every rank holds the result
+        for r in range(1, world):
+            assert np.array_equal(res[0][k], res[r][k]), k            # every rank holds the result
     # expected: hierarchical clipping = sigma-clip each rank's frames, add the float64 moments (SURVEY 8(e) option ii)
     cube, bias, dark = _data(n_total, shape)
     cal = apref.calibrate(cube, bias, dark, None, 0.4)
@@ -124,10 +143,11 @@ def test_nshard_and_rowshard_world2(tmp_path):
     assert np.array_equal(res[0]['mean'], mean64.astype(np.float32))
     std64 = np.sqrt(np.maximum(tot2 / cnt - mean64 * mean64, 0))
     np.testing.assert_allclose(res[0]['std'], std64, rtol=1e-6)
-    assert 20 < np.median(res[0]['std']) < 40                         # sigma 30 on a 50000 ADU level survives the combine
+    if n_total // world >= 12:                                        # (a 3-sigma clip cannot reject one outlier among 6 or 7
+        assert 20 < np.median(res[0]['std']) < 40                     # values) sigma 30 on a 50000 ADU level survives the combine
     # float32 exchange: per-rank rounding of the sums - close, not exact
     np.testing.assert_allclose(res[0]['mean32'], mean64, rtol=3e-7)
-    assert cnt.min() >= 16 and cnt.max() == 24 and (cnt < 24).any()   # outliers were clipped
+    assert cnt.min() >= n_total - 8 and cnt.max() == n_total and (cnt < n_total).any()   # outliers were clipped
     # row-shard + gather = the exact full-stack result on every rank
     full_ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean',))['mean'].astype(np.float32)
     for r in range(world):

@@ -46,7 +46,7 @@ def test_other_workloads_run():
     assert 'resample' in d['metric']
     for ex in ('f64', 'f32'):
         d = _run('--frames', '16', '--force-collective', '--no-cpu-baseline', '--stripes', '3', '--exchange', ex)
-        assert d['n_gpus'] == 1 and d['value'] > 0 and d['exchange_bytes_per_pixel'] == (12 if ex == 'f64' else 8)
+        assert d['n_gpus'] == 1 and d['value'] > 0 and d['exchange_bytes_per_pixel'] == (16 if ex == 'f64' else 8) and d['stripes'] == 3 and d['exchange_ms'] is not None
     d = _run('--frames', '16', '--parallelism', 'rowshard', '--no-cpu-baseline')
     assert d['n_gpus'] == 1 and d['value'] > 0
 

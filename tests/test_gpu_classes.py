@@ -273,7 +273,10 @@ def test_nshard_collective_path_on_one_gpu():
         frames = synth.make_frames(N, masters, nflat, config_id=3)
         calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
         direct = ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'std', 'count', 'moments'))
-        direct64 = ops.stack_sigclip(frames, calib=calib, outputs=('moments_f64',))['moments_f64']
+        direct64 = ops.stack_sigclip(frames, calib=calib, outputs=('moments_f64p',), moments_mean_only=True)['moments_f64p']
+        legacy = ops.stack_sigclip(frames, calib=calib, outputs=('moments_f64',))['moments_f64']     # float64 path (no flag)
+        assert torch.equal(legacy['count'], direct['count']) and torch.equal(direct64['count'].to(torch.int32), direct['count'])
+        assert float(((legacy['sum'] - direct64['sum']).abs() / legacy['sum'].abs()).max()) < 1e-7   # float32 vs float64 sums
         for exchange in ('f64', 'f32'):
             mean, parts = parallel.stack_nshard(frames, calib, n_stripes=5, force_collective=True, return_moments=True,
                                                 exchange=exchange)
@@ -283,7 +286,7 @@ def test_nshard_collective_path_on_one_gpu():
                 assert torch.equal(torch.cat([p['count'] for p in parts], 0), direct['moments'][1])
             else:
                 assert torch.equal(torch.cat([p['sum'] for p in parts], 0), direct64['sum'])
-                assert torch.equal(torch.cat([p['count'] for p in parts], 0), direct['count'])
+                assert torch.equal(torch.cat([p['count'] for p in parts], 0).to(torch.int32), direct['count'])
             # mean from the moments (sum / count) vs the kernel's float64 mean c + S/n: within 1 ulp
             assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'moments-finalised mean ' + exchange)
         mean, std = parallel.stack_nshard(frames, calib, n_stripes=3, force_collective=True, want_std=True)

@@ -467,7 +467,7 @@ def test_full_size_c2_matches_oracle(ops, apref):
         ref_mean[sl], ref_cnt[sl] = m, c
     assert np.array_equal(cnt, ref_cnt)
     exact = assert_ulp(mean, ref_mean, 1, 'C2 full size')
-    assert exact > 0.999
+    assert exact > 0.995          # float32 fast path: the sum of the deviations carries ~2e-3 ulp of float32 rounding (99.8 % measured)
     assert 40 <= cnt.min() and cnt.max() == 64 and (cnt < 64).mean() > 0.05      # the clip did real work
 
 
@@ -610,10 +610,17 @@ def test_stack_sigclip_u16_pairs_paths(ops, apref):
                                   outputs=('mean', 'count', 'moments'))
             assert np.array_equal(host(r['count']), nref), what
             assert_ulp(host(r['mean']), mref, 1, what)
+            # on the float64 path (APGPU_STACK_EXACT_MOMENTS) both kernels sum the survivors in sorted order: bit-identical;
+            # the default float32 fast path sums a pruned-sorted core, so the two agree to float32 rounding only
+            rx = ops.stack_sigclip(dev(cube, ops), sigma=3.0, maxiters=5, calib=calib, pixmask=dev(pixmask, ops),
+                                   outputs=('mean', 'count', 'moments'), exact=True)
             rf = ops.stack_sigclip(dev(cube.astype(np.float32), ops), sigma=3.0, maxiters=5, calib=calib,
-                                   pixmask=dev(pixmask, ops), outputs=('mean', 'count', 'moments'))
-            assert_biteq(host(r['mean']), host(rf['mean']), what + ' vs float32 kernel')
-            assert_biteq(host(r['moments']), host(rf['moments']), what + ' moments vs float32 kernel')
+                                   pixmask=dev(pixmask, ops), outputs=('mean', 'count', 'moments'), exact=True)
+            assert_biteq(host(rx['mean']), host(rf['mean']), what + ' vs float32 kernel')
+            assert_biteq(host(rx['moments']), host(rf['moments']), what + ' moments vs float32 kernel')
+            assert np.array_equal(host(rx['count']), nref), what
+            assert_ulp(host(rx['mean']), host(r['mean']), 1, what + ' float32 fast path vs float64 path')
+            np.testing.assert_allclose(host(r['moments'])[0], host(rx['moments'])[0], rtol=1e-6, equal_nan=True)
         # plain (no calibration), mean-centred, and an odd pixel count (ordinary kernel)
         with np.errstate(all='ignore'):
             ref = apref.stack_sigclip(cube.astype(np.float32), sigma=2.5, maxiters=None, cenfunc='mean')

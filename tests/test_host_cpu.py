@@ -163,6 +163,12 @@ def test_fitsio_long_strings_and_non_ascii(tmp_path):
     h3['NEWKEY'] = 1
     fitsio.write(str(tmp_path / 'n2.fits'), d3, h3)
     assert fitsio.read(str(tmp_path / 'n2.fits'))[1]['NOTE'] == '25?C'
+    # a long string under a HIERARCH keyword: the first piece is shorter than 67 characters, every card stays 80 bytes
+    h4 = fitsio.Header()
+    h4['LONGKEYWORD1'] = ('x' * 100 + "it's" + 'y' * 80, 'comment')
+    fitsio.write(str(tmp_path / 'h.fits'), np.zeros((2, 2), np.uint8), h4)
+    assert (tmp_path / 'h.fits').stat().st_size % 2880 == 0
+    assert fitsio.read(str(tmp_path / 'h.fits'))[1]['LONGKEYWORD1'] == 'x' * 100 + "it's" + 'y' * 80
 
 
 def test_user_badpix_yaml_semantics(tmp_path):

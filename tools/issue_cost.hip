@@ -111,6 +111,45 @@ KERNEL(k_snop, asm volatile("s_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\ns_nop 
 KERNEL(k_minmax_dep, asm volatile("v_min_f32 %0, %2, %3\nv_max_f32 %1, %2, %3" : "=&v"(a0), "=&v"(a1) : "v"(a2), "v"(a3)); asm volatile("v_min_f32 %0, %2, %3\nv_max_f32 %1, %2, %3" : "=&v"(a2), "=&v"(a3) : "v"(a0), "v"(a1));
                      asm volatile("v_min_f32 %0, %2, %3\nv_max_f32 %1, %2, %3" : "=&v"(a4), "=&v"(a5) : "v"(a6), "v"(a7)); asm volatile("v_min_f32 %0, %2, %3\nv_max_f32 %1, %2, %3" : "=&v"(a6), "=&v"(a7) : "v"(a4), "v"(a5));)
 
+
+// round 3: candidates for a cheaper compare-exchange / cheaper clip arithmetic (3-operand integer forms, carries, VOP2 fma)
+#define I3OP(ins) asm volatile(ins " %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2)); asm volatile(ins " %0, %0, %1, %2" : "+v"(a3) : "v"(a4), "v"(a5)); \
+                  asm volatile(ins " %0, %0, %1, %2" : "+v"(a6) : "v"(a7), "v"(a1)); asm volatile(ins " %0, %0, %1, %2" : "+v"(a2) : "v"(a4), "v"(a7)); \
+                  asm volatile(ins " %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2)); asm volatile(ins " %0, %0, %1, %2" : "+v"(a3) : "v"(a4), "v"(a5)); \
+                  asm volatile(ins " %0, %0, %1, %2" : "+v"(a6) : "v"(a7), "v"(a1)); asm volatile(ins " %0, %0, %1, %2" : "+v"(a2) : "v"(a4), "v"(a7));
+KERNEL(k_sad_u32, I3OP("v_sad_u32"))
+KERNEL(k_add3_u32, I3OP("v_add3_u32"))
+KERNEL(k_xad_u32, I3OP("v_xad_u32"))
+KERNEL(k_and_or, I3OP("v_and_or_b32"))
+KERNEL(k_or3, I3OP("v_or3_b32"))
+KERNEL(k_bfi, I3OP("v_bfi_b32"))
+KERNEL(k_lshl_add, I3OP("v_lshl_add_u32"))
+KERNEL(k_alignbit, I3OP("v_alignbit_b32"))
+KERNEL(k_perm, I3OP("v_perm_b32"))
+KERNEL(k_mad_u24, I3OP("v_mad_u32_u24"))
+KERNEL(k_bfe, I3OP("v_bfe_u32"))
+KERNEL(k_min3_u32, I3OP("v_min3_u32"))
+KERNEL(k_sub_u32, I32OP("v_sub_u32"))
+KERNEL(k_mul_u24, I32OP("v_mul_u32_u24"))
+KERNEL(k_lshlrev, I32OP("v_lshlrev_b32"))
+KERNEL(k_or, I32OP("v_or_b32"))
+KERNEL(k_fmac_f32, F32OP("v_fmac_f32"))
+KERNEL(k_max_u16, I32OP("v_max_u16"))
+KERNEL(k_add_f32_abs, asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a0) : "v"(a1)); asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a2) : "v"(a3));
+                      asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a4) : "v"(a5)); asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a6) : "v"(a7));
+                      asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a1) : "v"(a0)); asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a3) : "v"(a2));
+                      asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a5) : "v"(a4)); asm volatile("v_add_f32 %0, |%0|, -%1" : "+v"(a7) : "v"(a6));)
+KERNEL(k_add_co, asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a0) : "v"(a1) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a2) : "v"(a3) : "vcc");
+                 asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a4) : "v"(a5) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a6) : "v"(a7) : "vcc");
+                 asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a1) : "v"(a0) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a3) : "v"(a2) : "vcc");
+                 asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(a5) : "v"(a4) : "vcc"); asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a7) : "v"(a6) : "vcc");)
+// the candidate compare-exchange: lo = v_min_f32(a, b); hi = v_sad_u32(a, b, lo) (bit patterns of non-negative floats)
+KERNEL(k_min_sad, asm volatile("v_min_f32 %0, %2, %3\nv_sad_u32 %1, %2, %3, %0" : "=&v"(a0), "=&v"(a1) : "v"(a2), "v"(a3)); asm volatile("v_min_f32 %0, %2, %3\nv_sad_u32 %1, %2, %3, %0" : "=&v"(a2), "=&v"(a3) : "v"(a0), "v"(a1));
+                  asm volatile("v_min_f32 %0, %2, %3\nv_sad_u32 %1, %2, %3, %0" : "=&v"(a4), "=&v"(a5) : "v"(a6), "v"(a7)); asm volatile("v_min_f32 %0, %2, %3\nv_sad_u32 %1, %2, %3, %0" : "=&v"(a6), "=&v"(a7) : "v"(a4), "v"(a5));)
+// lo = v_min_f32(a, b); hi = (a + b) - lo on the bit patterns (two fast-class integer instructions)
+KERNEL(k_min_addsub, asm volatile("v_min_f32 %0, %2, %3\nv_add_u32 %1, %2, %3\nv_sub_u32 %1, %1, %0" : "=&v"(a0), "=&v"(a1) : "v"(a2), "v"(a3)); asm volatile("v_min_f32 %0, %2, %3\nv_add_u32 %1, %2, %3\nv_sub_u32 %1, %1, %0" : "=&v"(a2), "=&v"(a3) : "v"(a0), "v"(a1));
+                     asm volatile("v_min_f32 %0, %2, %3\nv_add_u32 %1, %2, %3\nv_sub_u32 %1, %1, %0" : "=&v"(a4), "=&v"(a5) : "v"(a6), "v"(a7)); asm volatile("v_min_f32 %0, %2, %3\nv_add_u32 %1, %2, %3\nv_sub_u32 %1, %1, %0" : "=&v"(a6), "=&v"(a7) : "v"(a4), "v"(a5));)
+
 struct K { const char *name; void (*fn)(unsigned long long *, float); int per_iter; };
 
 int main()
@@ -122,7 +161,12 @@ int main()
               {"v_cvt_f64_f32", k_cvt_f64_f32, 64}, {"s_nop 0", k_snop, 64}, {"v_min_i32", k_min_i32, 64}, {"v_max_i32", k_max_i32, 64}, {"v_min_u32", k_min_u32, 64}, {"v_max_u32", k_max_u32, 64},
               {"v_xor_b32", k_xor, 64}, {"v_and_b32", k_and, 64}, {"v_ashrrev_i32", k_ashr, 64}, {"v_add_u32", k_add_u32, 64}, {"v_sub_f32", k_sub_f32, 64},
               {"v_pk_min_u16", k_pk_min_u16, 64}, {"v_pk_max_i16", k_pk_max_i16, 64}, {"v_pk_min_f16", k_min_f16, 64}, {"v_mov_b32", k_mov, 64}, {"v_med3_f32", k_med3, 64},
-              {"v_cmp_gt_f32 + v_cndmask (vcc)", k_cmp_cnd, 64}, {"v_cndmask_b32 (sgpr mask)", k_cnd_sgpr, 64}, {"v_min+v_max dependent pairs", k_minmax_dep, 64}};
+              {"v_cmp_gt_f32 + v_cndmask (vcc)", k_cmp_cnd, 64}, {"v_cndmask_b32 (sgpr mask)", k_cnd_sgpr, 64}, {"v_min+v_max dependent pairs", k_minmax_dep, 64},
+              {"v_sad_u32", k_sad_u32, 64}, {"v_add3_u32", k_add3_u32, 64}, {"v_xad_u32", k_xad_u32, 64}, {"v_and_or_b32", k_and_or, 64}, {"v_or3_b32", k_or3, 64},
+              {"v_bfi_b32", k_bfi, 64}, {"v_lshl_add_u32", k_lshl_add, 64}, {"v_alignbit_b32", k_alignbit, 64}, {"v_perm_b32", k_perm, 64}, {"v_mad_u32_u24", k_mad_u24, 64},
+              {"v_bfe_u32", k_bfe, 64}, {"v_min3_u32", k_min3_u32, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_mul_u32_u24", k_mul_u24, 64}, {"v_lshlrev_b32", k_lshlrev, 64}, {"v_or_b32", k_or, 64},
+              {"v_fmac_f32", k_fmac_f32, 64}, {"v_max_u16", k_max_u16, 64}, {"v_add_f32 |a|, -b (VOP3)", k_add_f32_abs, 64}, {"v_add_co + v_addc_co (per instr)", k_add_co, 64},
+              {"v_min_f32 + v_sad_u32 (per instr)", k_min_sad, 64}, {"v_min_f32+v_add_u32+v_sub_u32 (per instr)", k_min_addsub, 96}};
     unsigned long long *d;
     hipMalloc(&d, sizeof(unsigned long long) * 4096);
     std::vector<unsigned long long> h(4096);
