@@ -102,16 +102,23 @@ __device__ __forceinline__ void lds_bitonic_sort(float *col, int lo, int len)
     }
 }
 
+// redo == nullptr: workgroup b reduces the 64 pixels [64 b, 64 b + 64).  redo != nullptr: the wavefronts the chunked fast
+// kernel (stack_chunks.hip) was not sure about - redo[0] entries redo[1 ..], each a 64-pixel block index - are shared out
+// over the grid.
 template <int NP, typename RawT, bool CALIB, bool MEDIAN>
-__global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm)
+__global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm, const int32_t *redo)
 {
     extern __shared__ float col_all[];                      // [NP][64]
     __shared__ FrameScalars<128> fs;
     const int lane = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * kBigLanes;
+    float *const col = col_all + lane;
+    const int64_t nitems = redo ? redo[0] : (int64_t)gridDim.x;
+#pragma unroll 1
+    for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int64_t base = (redo ? (int64_t)redo[1 + item] : item) * kBigLanes;
     const int64_t p = base + lane;
     const bool live = p < prm.P;                            // dead lanes of the last workgroup still stage and vote
-    float *const col = col_all + lane;
+    __syncthreads();                                        // (redo loop) the previous item is done with LDS
     int n = 0;
 #pragma unroll 1
     for (int c0 = 0; c0 < NP; c0 += 128) {
@@ -142,51 +149,65 @@ __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackPara
             lds_bitonic_sort(col, lo, len / 2);
             lds_bitonic_sort(col, lo + len / 2, len / 2);
         }
-    if (!live) return;
-    if constexpr (MEDIAN) {
-        const float m1 = col_read<NP, kBigLanes>(col, (n - 1) >> 1);
-        const float m2 = col_read<NP, kBigLanes>(col, n >> 1);
-        const double med = ((double)m1 + (double)m2) / 2.0;
-        if (prm.median) prm.median[p] = n > 0 ? (float)med : __builtin_nanf("");
-        if (prm.count) prm.count[p] = n;
-    } else {
-        float dummy[1] = {0.f};
-        reduce_and_store_rich<NP, kBigLanes, false, 1>(prm, dummy, n, p, col);
+    if (live) {
+        if constexpr (MEDIAN) {
+            const float m1 = col_read<NP, kBigLanes>(col, (n - 1) >> 1);
+            const float m2 = col_read<NP, kBigLanes>(col, n >> 1);
+            const double med = ((double)m1 + (double)m2) / 2.0;
+            if (prm.median) prm.median[p] = n > 0 ? (float)med : __builtin_nanf("");
+            if (prm.count) prm.count[p] = n;
+        } else {
+            float dummy[1] = {0.f};
+            reduce_and_store_rich<NP, kBigLanes, false, 1>(prm, dummy, n, p, col);
+        }
+    }
     }
 }
 
 template <int NP, typename RawT, bool CALIB, bool MEDIAN>
-static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe)
+static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe, const int32_t *redo)
 {
     if (describe) {
         snprintf(describe, 256, "stack_big_kernel<%d, %s, %s, %s>", NP, sizeof(RawT) == 2 ? "unsigned short" : "float",
                  CALIB ? "true" : "false", MEDIAN ? "true" : "false");
         return APGPU_OK;
     }
-    const int64_t grid = (prm.P + kBigLanes - 1) / kBigLanes;
+    int64_t grid = (prm.P + kBigLanes - 1) / kBigLanes;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    if (redo && grid > 2048) grid = 2048;                    // the redo list is short: a fixed grid walks it
     const size_t lds = (size_t)NP * kBigLanes * sizeof(float);
     auto kern = stack_big_kernel<NP, RawT, CALIB, MEDIAN>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (big): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBigLanes), lds, st, prm);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBigLanes), lds, st, prm, redo);
     return check_launch("stack kernel (129..512 frames)");
 }
 
 template <typename RawT, bool CALIB>
-static int launch_big_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe)
+static int launch_big_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe, const int32_t *redo)
 {
     if (prm.N <= 256)
-        return median_only ? launch_big_one<256, RawT, CALIB, true>(prm, st, describe) : launch_big_one<256, RawT, CALIB, false>(prm, st, describe);
-    return median_only ? launch_big_one<512, RawT, CALIB, true>(prm, st, describe) : launch_big_one<512, RawT, CALIB, false>(prm, st, describe);
+        return median_only ? launch_big_one<256, RawT, CALIB, true>(prm, st, describe, redo) : launch_big_one<256, RawT, CALIB, false>(prm, st, describe, redo);
+    return median_only ? launch_big_one<512, RawT, CALIB, true>(prm, st, describe, redo) : launch_big_one<512, RawT, CALIB, false>(prm, st, describe, redo);
 }
 
+// The exact LDS-resident kernel, on every pixel (redo == nullptr) or on the wavefronts of a redo list.
+int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, const int32_t *redo)
+{
+    if (u16) return calib ? launch_big_np<uint16_t, true>(prm, median_only, st, describe, redo) : launch_big_np<uint16_t, false>(prm, median_only, st, describe, redo);
+    return calib ? launch_big_np<float, true>(prm, median_only, st, describe, redo) : launch_big_np<float, false>(prm, median_only, st, describe, redo);
+}
+
+bool chunks_eligible(const StackParams &prm, bool median_only);                                        // stack_chunks.hip
+int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe);
+
+// 129 .. 512 frames: the chunked float32 fast path where it applies (129 .. 256 frames, lean outputs), else the exact kernel.
 int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
-    if (u16) return calib ? launch_big_np<uint16_t, true>(prm, median_only, st, describe) : launch_big_np<uint16_t, false>(prm, median_only, st, describe);
-    return calib ? launch_big_np<float, true>(prm, median_only, st, describe) : launch_big_np<float, false>(prm, median_only, st, describe);
+    if (chunks_eligible(prm, median_only)) return launch_chunks(prm, u16, calib, st, describe);
+    return launch_big_exact(prm, u16, calib, median_only, st, describe, nullptr);
 }
 
 }  // namespace apgpu_stack

@@ -271,13 +271,16 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
 // FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
 // wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes), and the range guards of the
 // reciprocal division are deferred to the sorted column (cx.range_pending, see load_sorted_column).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL)>
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), bool FORCE_HALVES = false>
 __device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
                                            float (&v)[NP], ColumnCtx &cx)
 {
     const int N = prm.N;
     const int64_t p = base + lane;
-    constexpr bool HALVES = CALIB && NP >= 104;           // 104 .. 128 slots: two half columns (register budget: 2 waves/SIMD)
+#ifndef APGPU_HALVES_MIN
+#define APGPU_HALVES_MIN 104
+#endif
+    constexpr bool HALVES = CALIB && (NP >= APGPU_HALVES_MIN || FORCE_HALVES);  // 104 .. 128 slots: two half columns (register budget: 2 waves/SIMD)
     // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
     // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
     constexpr bool GUARD = NP >= 104;
@@ -348,12 +351,13 @@ __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)
 // PRUNE_T > 0 and *pruned on entry (wave-uniform: the caller wants the fast path): a column without sentinels in the whole
 // wave is sorted with the pruned network (its ends and middle window only, make_pruned_net) and *pruned stays true;
 // otherwise the sort is complete and *pruned is cleared.
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0>
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0,
+          bool FORCE_HALVES = false>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
                                                   int lane, float (&v)[NP], bool *pruned = nullptr)
 {
     ColumnCtx cx;
-    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN>(prm, fs, base, lane, v, cx);
+    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES>(prm, fs, base, lane, v, cx);
     bool prune = false;
     if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == NP);
     if constexpr (PRUNE_T > 0) {

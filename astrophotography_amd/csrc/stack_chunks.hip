@@ -1,0 +1,550 @@
+// stack_chunks.hip - 129 .. 256 frames on the float32 fast path (round 3): the column never exists as a whole.
+//
+// Same semantics and outputs as the lean register kernels (stack_kernels.h / stack_reduce.h): the sigma-clipped mean /
+// count / partial moments of astropy.stats.sigma_clipped_stats(cube, axis=0) (sigma_clipping.py:298-383, 924-937) with the
+// median as centre and the std as deviation, optionally fused with ApCalibrate's arithmetic (core/ApCalibrate.py:439-464).
+// scripts/ap_combine_darks.py:411-420 (ccdproc.combine) takes any N; BASELINE's C3 needs 256 frames on one GPU.
+//
+// What the clip of a sorted column needs (clip_fast32): the few lowest and highest values in order, the few order
+// statistics around the middle, and SUMS over everything in between.  None of that needs the whole column sorted, or
+// resident.  One lane owns one pixel and walks K = ceil(N / 64) chunks of c_k <= 64 frames; every chunk is loaded,
+// calibrated and sorted in registers by the ordinary 64-slot path (load_sorted_column: same fused calibration, guards and
+// network), and only three things survive it:
+//   * its 8 lowest / 8 highest values, merged into the running global tails GL / GH (bitonic 8 + 8 -> 8; the values
+//     pushed out of a tail are ADDED to the running sums - sums only ever grow by what belongs to them, clip_fast32's
+//     rule against subtracting an outlier from a total it dominates);
+//   * a window of 32 values around ITS middle.  A chunk is a random subset of the column, so the column's middle order
+//     statistics have local rank c_k / 2 +- 4 (one sigma) in it: the 4-sigma window holds them.  After the last chunk the
+//     K windows are merged (two levels of Batcher's odd-even merge, pruned to the 16 middle outputs) and the element of
+//     global rank r is merged element r - (number of values below the windows) - PROVIDED it lies in the zone
+//     [max_k W_k[0], min_k W_k[31]] in which every value below a window is known to be smaller and every value above
+//     one larger.  A median outside that zone (probability ~1e-4 per wave) sends the wave to the exact kernel;
+//   * S = sum(x - c0), Q = sum((x - c0)^2) of its other values, c0 = the first chunk's median (float32, per-chunk
+//     partial sums added to running totals: the error budget of clip_fast32 holds with the same rho, see below).
+// The clip then runs exactly as clip_fast32 does, with tails of 8 (7 usable: the value after the tail is not known) and
+// the median picked from the merged window.  Lanes that are not sure - a comparison inside the error margin, a tail used
+// up, non-finite values, a masked pixel, a median outside the zone - put their wave on a redo list, and
+// stack_big_kernel (the exact LDS-resident kernel, stack_big.hip) recomputes exactly those waves afterwards.
+// Survivor sets are therefore those of the exact path; the mean carries the float32 rounding of its sum like the
+// 64-frame kernel's.
+//
+// Error budget: per chunk 4 chains of <= 12 terms + 2 (+ <= 16 pushed-out values in 4 chains + 2), K <= 4 chunk totals
+// + 3, tails 8 + 2: every partial sum at most ~24 roundings deep -> |dQ| <= 26u Q, |dS| <= 25u sqrt(n Q), |dV| <=
+// (27 + 50 + 1)u nQ <= 312u V under the guard V >= nQ / 4, + 10u for the test itself: rho = 2^-15 = 512u covers it.
+//
+// Registers / LDS: 64 (chunk) + 32 (half of its raw values) + the last two windows + 16 (tails) + sums in registers; the
+// windows of the first K - 2 chunks are parked in LDS (64 KB per 256-pixel workgroup for K = 4): two workgroups = eight
+// wavefronts per CU.
+#include "stack_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+namespace apgpu_stack {
+
+using namespace apgpu;
+
+constexpr int kChunkSlots = 64;
+constexpr int kChunkTail = 8;
+constexpr int kChunkWin = 32;
+constexpr int kChunkMinFrames = 33;                          // a chunk holds its whole window: c_k >= 33
+#ifndef APGPU_CHUNKS_HALVES
+#define APGPU_CHUNKS_HALVES 1
+#endif
+#ifndef APGPU_CHUNKS_MINBLOCKS
+#define APGPU_CHUNKS_MINBLOCKS 2
+#endif
+
+// out[j] = v[BASE + s + j], j < LEN, for a WAVE-UNIFORM s in [0, MAXS]: logarithmic shifter over a working copy, every
+// register index static, one scalar branch per bit of s.
+template <int LEN, int MAXS, int BASE, int NV>
+__device__ __forceinline__ void uniform_slice(const float (&v)[NV], int s, float (&out)[LEN])
+{
+    constexpr int WN = LEN + MAXS;
+    static_assert(BASE + WN <= NV, "slice leaves the array");
+    float w[WN];
+#pragma unroll
+    for (int i = 0; i < WN; i++) w[i] = v[BASE + i];
+#pragma unroll
+    for (int bit = 16; bit >= 1; bit >>= 1) {
+        if (bit <= MAXS && (s & bit)) {
+#pragma unroll
+            for (int i = 0; i + bit < WN; i++) w[i] = w[i + bit];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LEN; j++) out[j] = w[j];
+}
+
+// Sorts a bitonic sequence of 8 ascending (3 layers of 4 compare-exchanges).
+__device__ __forceinline__ void bitonic8(float (&t)[8])
+{
+    cmpx(t[0], t[4]); cmpx(t[1], t[5]); cmpx(t[2], t[6]); cmpx(t[3], t[7]);
+    cmpx(t[0], t[2]); cmpx(t[1], t[3]); cmpx(t[4], t[6]); cmpx(t[5], t[7]);
+    cmpx(t[0], t[1]); cmpx(t[2], t[3]); cmpx(t[4], t[5]); cmpx(t[6], t[7]);
+}
+
+struct ChunkSums {
+    float S[4], Q[4];
+};
+
+__device__ __forceinline__ void add_value(ChunkSums &cs, int k, float x, float c0)
+{
+    const float d = x - c0;
+    cs.S[k & 3] += d;
+    cs.Q[k & 3] = __builtin_fmaf(d, d, cs.Q[k & 3]);
+}
+
+// The chunk's column, calibrated on the fast path and sorted (sentinels of a ragged chunk last).  No exact fallback in this
+// kernel: a lane whose fast calibration does not vouch for its values (non-finite value, operand or quotient outside the
+// guarded ranges - calibrate_fast, range_ok_sorted) returns false and its wave is redone by the exact kernel.  (With the
+// exact reload path and its second sort inlined four times the kernel needed 256 VGPRs + 134 spilled ones, and the spill
+// traffic - as many memory operations as the frame loads - halved its throughput.)
+template <typename RawT, bool CALIB, bool FULLCH>
+__device__ __forceinline__ bool load_chunk(const StackParams &q, const FrameScalars<kChunkSlots> &fs, int64_t base, int lane,
+                                           float (&v)[kChunkSlots])
+{
+    constexpr int NP = kChunkSlots, MINN = FULLCH ? NP : kChunkMinFrames - 1;
+    const int N = q.N;
+    const int64_t p = base + lane;
+    bool good = true;
+    if constexpr (CALIB) {
+        const float b = q.bias[p];
+        const float d = q.dark[p];
+        const float D = q.still_biased ? d - b : d;          // ApCalibrate.py:440-445
+        float nf = 1.f;
+        bool dodiv = false;
+        if (q.nflat) {
+            nf = q.nflat[p];
+            dodiv = (nf != 0.f);                             // ApCalibrate.py:462 (NaN != 0 is True)
+        }
+#if APGPU_CHUNKS_HALVES
+        constexpr int HN = NP / 2;
+        RawT half[HN];
+        load_raw<NP, RawT, FULLCH, 0, HN, MINN>(q, base, lane, half);
+        good = q.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N)
+                          : calibrate_fast<NP, RawT, false, 0, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N);
+        load_raw<NP, RawT, FULLCH, HN, HN, MINN>(q, base, lane, half);
+        const bool good2 = q.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N)
+                                      : calibrate_fast<NP, RawT, false, HN, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N);
+        good = good && good2;
+#else
+        RawT raw[NP];
+        load_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
+        good = q.pedestal ? calibrate_fast<NP, RawT, true, 0, NP, false, MINN>(fs, raw, b, D, nf, dodiv, v, N)
+                          : calibrate_fast<NP, RawT, false, 0, NP, false, MINN>(fs, raw, b, D, nf, dodiv, v, N);
+#endif
+        sort_column<NP>(v);
+        good = good && range_ok_sorted<NP, MINN>(v, dodiv, N);
+    } else {
+        RawT raw[NP];
+        load_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
+        int nframes = N;
+        asm volatile("" : "+s"(nframes));
+        float acc = 0.f;                                    // NaN iff some value is not finite (x * 0 is NaN for NaN and inf)
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            if (f >= MINN && f >= nframes) {
+                v[f] = __builtin_inff();                    // padding slot of a ragged chunk (wave-uniform test)
+            } else {
+                v[f] = to_f32(raw[f]);
+                acc = __builtin_fmaf(v[f], 0.f, acc);
+            }
+        }
+        good = acc == 0.f;
+        asm volatile("" : "+v"(acc));                       // (evaluated here, not sunk to where the flag is read)
+        sort_column<NP>(v);
+    }
+    return good;
+}
+
+// One chunk: frames [f0, f0 + c) of the stack -> tails merged, window kept, sums accumulated.  Returns false for a lane
+// whose chunk holds a non-finite value (or whose pixel is masked): its wave goes to the exact kernel.
+template <typename RawT, bool CALIB, bool FULLCH, int KIDX>
+__device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameScalars<kChunkSlots> &fs, int f0, int c, int64_t base,
+                                           int lane, float (&GL)[kChunkTail], float (&GH)[kChunkTail], float (&win)[kChunkWin],
+                                           float &c0, float &Stot, float &Qtot, float &Lmax, float &Umin)
+{
+    constexpr int NP = kChunkSlots, T = kChunkTail;
+    __builtin_amdgcn_sched_barrier(0);                      // chunks do not overlap: the scheduler otherwise stretches live ranges across them
+    StackParams q = prm;                                    // the chunk as a stack of its own
+    q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)f0 * prm.stride;
+    q.N = c;
+    if (prm.exp_ratio) q.exp_ratio = prm.exp_ratio + f0;
+    if (prm.pedestal) q.pedestal = prm.pedestal + f0;
+    float v[NP];
+    const bool ok = load_chunk<RawT, CALIB, FULLCH>(q, fs, base, lane, v);     // v[0 .. c) are the chunk, sorted; false: redo
+    float lo[T], hi[T];
+#pragma unroll
+    for (int j = 0; j < T; j++) lo[j] = v[j];
+    if constexpr (FULLCH) {
+#pragma unroll
+        for (int j = 0; j < T; j++) hi[j] = v[NP - T + j];
+#pragma unroll
+        for (int j = 0; j < kChunkWin; j++) win[j] = v[(NP - kChunkWin) / 2 + j];
+    } else {
+        uniform_slice<T, NP - kChunkMinFrames, kChunkMinFrames - T, NP>(v, c - kChunkMinFrames, hi);          // v[c - 8 .. c)
+        uniform_slice<kChunkWin, (NP - kChunkWin) / 2, 0, NP>(v, c / 2 - kChunkWin / 2, win);                  // v[c/2 - 16 .. c/2 + 16)
+    }
+    if constexpr (KIDX == 0) c0 = win[kChunkWin / 2];       // the first chunk's (upper) median: the pivot of every sum
+    Lmax = KIDX == 0 ? win[0] : fmaxf(Lmax, win[0]);
+    Umin = KIDX == 0 ? win[kChunkWin - 1] : fminf(Umin, win[kChunkWin - 1]);
+    // the chunk's own sums: everything between its tails, in mirror pairs (clip_fast32)
+    ChunkSums cs = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if constexpr (FULLCH) {
+#pragma unroll
+        for (int i = T; i < NP / 2; i++) {
+            const float d1 = v[i] - c0, d2 = v[NP - 1 - i] - c0;
+            cs.S[i & 3] += d1 + d2;
+            cs.Q[i & 3] = __builtin_fmaf(d1, d1, cs.Q[i & 3]);
+            cs.Q[(i + 2) & 3] = __builtin_fmaf(d2, d2, cs.Q[(i + 2) & 3]);
+        }
+    } else {
+        int cend = c - T;                                   // wave-uniform: slots [8, c - 8)
+        asm volatile("" : "+s"(cend));
+#pragma unroll
+        for (int i = T; i < NP - T; i++) {
+            if (i >= kChunkMinFrames - T && i >= cend) continue;
+            add_value(cs, i, v[i], c0);
+        }
+    }
+    // tails: 8 + 8 -> 8 (bitonic), the values pushed out join the sums
+    if constexpr (KIDX == 0) {
+#pragma unroll
+        for (int j = 0; j < T; j++) { GL[j] = lo[j]; GH[j] = hi[j]; }
+    } else {
+        float out[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            float a = GL[j], b = lo[T - 1 - j];
+            cmpx(a, b);                                     // a = min stays in the tail, b = max leaves it
+            GL[j] = a;
+            out[j] = b;
+        }
+        bitonic8(GL);
+#pragma unroll
+        for (int j = 0; j < T; j++) add_value(cs, j, out[j], c0);
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+            float a = GH[j], b = hi[T - 1 - j];
+            cmpx(a, b);                                     // b = max stays
+            GH[j] = b;
+            out[j] = a;
+        }
+        bitonic8(GH);
+#pragma unroll
+        for (int j = 0; j < T; j++) add_value(cs, j + 2, out[j], c0);
+    }
+    const float Sk = (cs.S[0] + cs.S[1]) + (cs.S[2] + cs.S[3]);
+    const float Qk = (cs.Q[0] + cs.Q[1]) + (cs.Q[2] + cs.Q[3]);
+    Stot = KIDX == 0 ? Sk : Stot + Sk;
+    Qtot = KIDX == 0 ? Qk : Qtot + Qk;
+    // pin the sums HERE: their only use is the clip at the end, inside the region the `ok` flags guard, and LLVM sinks the
+    // whole summation down there - keeping every chunk's values alive (132 spilled registers, measured)
+    asm volatile("" : "+v"(Stot), "+v"(Qtot));
+    __builtin_amdgcn_sched_barrier(0);
+    return ok;
+}
+
+struct FastT {
+    float m1, m2, nf;
+    float tl_hi, tl_lo, th_hi, th_lo;
+    float Slo, Qlo, Shi, Qhi;
+    int ta, tb;                                             // values trimmed from the low / high end
+    bool unsure;
+};
+
+__device__ __forceinline__ float fast_t(const FastT &f, float x)
+{
+    const float w = f.nf * ((x - f.m1) + (x - f.m2));
+    return w * w;
+}
+
+template <int I>
+__device__ __forceinline__ void trim_low_t(const float (&GL)[kChunkTail], FastT &f, const float (&SL)[kChunkTail + 1], const float (&QL)[kChunkTail + 1])
+{
+    if constexpr (I < kChunkTail) {
+        const float t = fast_t(f, GL[I]);
+        const bool at = f.ta == I;
+        const bool rej = at && (t > f.tl_hi);
+        const bool maybe = at && (t > f.tl_lo);
+        f.unsure = f.unsure || (maybe != rej);
+        if (rej) {
+            f.ta = I + 1;
+            f.Slo = SL[I + 1];
+            f.Qlo = QL[I + 1];
+        }
+        if (wave_any(f.ta > I)) trim_low_t<I + 1>(GL, f, SL, QL);
+    } else {
+        f.unsure = f.unsure || (f.ta == kChunkTail);        // the tail is used up: the next value is not known here
+    }
+}
+
+template <int I>                                             // GH ascending: GH[7] is the column's maximum; I counts from the top
+__device__ __forceinline__ void trim_high_t(const float (&GH)[kChunkTail], FastT &f, const float (&SH)[kChunkTail + 1], const float (&QH)[kChunkTail + 1])
+{
+    if constexpr (I < kChunkTail) {
+        const float t = fast_t(f, GH[kChunkTail - 1 - I]);
+        const bool at = f.tb == I;
+        const bool rej = at && (t > f.th_hi);
+        const bool maybe = at && (t > f.th_lo);
+        f.unsure = f.unsure || (maybe != rej);
+        if (rej) {
+            f.tb = I + 1;
+            f.Shi = SH[kChunkTail - 1 - I];
+            f.Qhi = QH[kChunkTail - 1 - I];
+        }
+        if (wave_any(f.tb > I)) trim_high_t<I + 1>(GH, f, SH, QH);
+    } else {
+        f.unsure = f.unsure || (f.tb == kChunkTail);
+    }
+}
+
+template <int K, typename RawT, bool CALIB, bool FULLCH>
+__global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo)
+{
+    constexpr int T = kChunkTail, W = kChunkWin;
+    __shared__ FrameScalars<kChunkSlots> fs[K];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t p = base + lane;
+    const int N = prm.N;
+    // chunk sizes: N / K, the first N % K chunks one more (all in [33, 64])
+    const int cbase = N / K, cextra = N % K;
+    for (int k = 0; k < K; k++) {
+        const int c = cbase + (k < cextra ? 1 : 0);
+        const int f0 = k * cbase + (k < cextra ? k : cextra);
+        for (int t = threadIdx.x; t < kChunkSlots; t += blockDim.x) {
+            const int ff = f0 + (t < c ? t : c - 1);
+            fs[k].e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
+            fs[k].ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
+            fs[k].pad[t] = t < c ? -__builtin_inff() : __builtin_inff();
+        }
+    }
+    __syncthreads();
+    if (p >= prm.P) return;
+
+    // the windows of the first K - 2 chunks wait in LDS ([slot][lane]: bank = lane), the last two stay in registers: with all
+    // four in registers next to a 64-slot chunk the kernel spills (256 VGPRs, 142 spilled); 64 KB of LDS per workgroup still
+    // leaves two workgroups (8 wavefronts) per CU
+    extern __shared__ float parked[];                       // [(K - 2) * W][256]
+    float R0[W], R1[W];
+    float GL[T], GH[T];
+    float c0 = 0.f, Stot = 0.f, Qtot = 0.f, Lmax = 0.f, Umin = 0.f;
+    bool ok = !(prm.pixmask && prm.pixmask[p]);
+    int below = 0;                                          // values below the windows (wave-uniform)
+    {
+        float win[W];
+        const int c = cbase + (0 < cextra ? 1 : 0);
+        ok = chunk_step<RawT, CALIB, FULLCH, 0>(prm, fs[0], 0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
+        below += c / 2 - W / 2;
+#pragma unroll
+        for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
+    }
+    if constexpr (K == 4) {
+        float win[W];
+        const int c = cbase + (1 < cextra ? 1 : 0);
+        const int f0 = cbase + (1 < cextra ? 1 : cextra);
+        ok = chunk_step<RawT, CALIB, FULLCH, 1>(prm, fs[1], f0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
+        below += c / 2 - W / 2;
+#pragma unroll
+        for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
+    }
+    {
+        constexpr int k = K - 2;
+        const int c = cbase + (k < cextra ? 1 : 0);
+        const int f0 = k * cbase + (k < cextra ? k : cextra);
+        ok = chunk_step<RawT, CALIB, FULLCH, 2>(prm, fs[k], f0, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
+        below += c / 2 - W / 2;
+    }
+    {
+        constexpr int k = K - 1;
+        const int c = cbase;                                // the last chunk never gets an extra frame
+        const int f0 = k * cbase + cextra;
+        ok = chunk_step<RawT, CALIB, FULLCH, 3>(prm, fs[k], f0, c, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin) && ok;
+        below += c / 2 - W / 2;
+    }
+    float X[4 * W];                                         // the K windows side by side (K = 3: the last quarter is +inf)
+    {
+        int slot = lane;
+        asm volatile("" : "+v"(slot) : : "memory");         // opaque index: no store-to-load forwarding through registers
+#pragma unroll
+        for (int j = 0; j < (K - 2) * W; j++) X[j] = parked[j * 256 + slot];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            X[(K - 2) * W + j] = R0[j];
+            X[(K - 1) * W + j] = R1[j];
+        }
+        if constexpr (K == 3) {
+#pragma unroll
+            for (int j = 0; j < W; j++) X[3 * W + j] = __builtin_inff();
+        }
+    }
+    APGPU_MARK("chunks_merge");
+    // merge the windows: [0,32)+[32,64) and [64,96)+[96,128), then the two halves - only the 16 middle outputs are read
+    constexpr int MLO = 16 * K - 8;
+#ifndef APGPU_EXP_NOMERGE
+    window_net_from<4 * W, W, MLO, MLO + 16>(X);
+#endif
+    float M[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) M[j] = X[MLO + j];
+
+    APGPU_MARK("chunks_clip");
+    const float sl2f = (float)prm.sl2, su2f = (float)prm.su2;
+    const int maxiters = prm.maxiters;
+    // tail tables, from the inside out (clip_fast32): SL[k] = sum of d(GL[k .. 8)), SH[k] = sum of d(GH[0 .. k))
+    float SL[T + 1], QL[T + 1], SH[T + 1], QH[T + 1];
+    SL[T] = 0.f; QL[T] = 0.f; SH[0] = 0.f; QH[0] = 0.f;
+#pragma unroll
+    for (int k = T - 1; k >= 0; k--) {
+        const float d = GL[k] - c0;
+        SL[k] = SL[k + 1] + d;
+        QL[k] = __builtin_fmaf(d, d, QL[k + 1]);
+    }
+#pragma unroll
+    for (int k = 1; k <= T; k++) {
+        const float d = GH[k - 1] - c0;
+        SH[k] = SH[k - 1] + d;
+        QH[k] = __builtin_fmaf(d, d, QH[k - 1]);
+    }
+    FastT f;
+    f.ta = 0;
+    f.tb = 0;
+    f.Slo = SL[0]; f.Qlo = QL[0]; f.Shi = SH[T]; f.Qhi = QH[T];
+    const float dmax = fmaxf(c0 - GL[0], GH[T - 1] - c0);
+    f.unsure = !ok || !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
+    const float rho = APGPU_FAST32_RHO;
+    const float sl4 = 4.f * sl2f, su4 = 4.f * su2f;
+    const int mbase = below + MLO;                          // merged-window index of global rank r: r - below; M index: r - mbase
+    float S, Q;
+    int it = 0;
+    for (;;) {
+        // the middle pair of the current range [ta, N - tb): ranks (ta + N - tb - 1) >> 1 and (ta + N - tb) >> 1
+        const int i1 = ((f.ta + N - f.tb - 1) >> 1) - mbase, i2 = ((f.ta + N - f.tb) >> 1) - mbase;
+        f.unsure = f.unsure || i1 < 0 || i2 > 15;
+        f.m1 = pick_rel<0, 16, 16>(M, i1 & 15);
+        f.m2 = pick_rel<0, 16, 16>(M, i2 & 15);
+        f.unsure = f.unsure || !(f.m1 >= Lmax && f.m2 <= Umin);          // outside the zone the windows vouch for
+        const int ta0 = f.ta, tb0 = f.tb;
+        f.nf = (float)(N - f.ta - f.tb);
+        S = (Stot + f.Slo) + f.Shi;
+        Q = (Qtot + f.Qlo) + f.Qhi;
+        const float nQ = f.nf * Q;
+        const float V = __builtin_fmaf(-S, S, nQ);
+        f.unsure = f.unsure || !(V >= 0.25f * nQ);
+        const float tl = sl4 * V, th = su4 * V;
+        f.tl_hi = __builtin_fmaf(tl, rho, tl);
+        f.tl_lo = __builtin_fmaf(tl, -rho, tl);
+        f.th_hi = __builtin_fmaf(th, rho, th);
+        f.th_lo = __builtin_fmaf(th, -rho, th);
+#ifndef APGPU_EXP_NOTRIM
+        trim_low_t<0>(GL, f, SL, QL);
+        trim_high_t<0>(GH, f, SH, QH);
+#endif
+        it++;
+        const bool changed = (f.ta != ta0) || (f.tb != tb0);
+        if (!(wave_any(changed) && (maxiters < 0 || it < maxiters))) break;
+    }
+    // re-admission (astropy applies the final bounds to all values): the innermost trimmed value of either side must be
+    // surely outside them
+    if (wave_any(f.ta > 0)) {
+        const float t = fast_t(f, pick_rel<0, T, T>(GL, (f.ta - 1) & (T - 1)));
+        f.unsure = f.unsure || (f.ta > 0 && !(t > f.tl_hi));
+    }
+    if (wave_any(f.tb > 0)) {
+        const float t = fast_t(f, pick_rel<0, T, T>(GH, (T - f.tb) & (T - 1)));
+        f.unsure = f.unsure || (f.tb > 0 && !(t > f.th_hi));
+    }
+    S = (Stot + f.Slo) + f.Shi;
+    Q = (Qtot + f.Qlo) + f.Qhi;
+    const int cnt = N - f.ta - f.tb;
+    f.unsure = f.unsure || !(4.f * Q <= (float)cnt * (c0 * c0));           // mean-accuracy guard, see clip_fast32
+    if (wave_any(f.unsure)) {
+        // the whole wave is redone by the exact kernel (stack_big_kernel over the redo list); nothing is written here
+        if (__builtin_amdgcn_readfirstlane(lane) == lane) {
+            const int slot = atomicAdd(&redo[0], 1);
+            redo[1 + slot] = (int32_t)(p >> 6);
+        }
+        return;
+    }
+    const float nf32 = (float)cnt;
+    const float y = __builtin_amdgcn_rcpf(nf32);
+    const float q0 = S * y;
+    const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, S), y, q0);
+    if (prm.mean) prm.mean[p] = c0 + ms32;
+    if (prm.count) prm.count[p] = cnt;
+    if (prm.moments) store_moments(prm.moments, prm.moments64, prm.P, p, cnt, (double)c0, (double)S, (double)Q);
+}
+
+// ---- dispatch -----------------------------------------------------------------------------------------------------
+int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, const int32_t *redo);   // stack_big.hip
+
+// Whether a stack of 129 .. 256 frames can take the chunked fast path: lean outputs, median centre / std deviation, the
+// float32 path not switched off, float64-layout moments only when they are for a mean.
+bool chunks_eligible(const StackParams &prm, bool median_only)
+{
+    if (median_only || prm.N <= 128 || prm.N > 4 * kChunkSlots) return false;
+    if (prm.median || prm.std || prm.mean64 || prm.std64) return false;
+    if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
+    if (prm.fast32 == 0) return false;
+    if (prm.moments && !(prm.moments64 == 0 || prm.moments64 == 3 || prm.moments64 == 4) ) return false;
+    if (prm.moments && prm.moments64 != 0 && prm.fast32 != 2) return false;
+    return true;
+}
+
+template <int K, typename RawT, bool CALIB>
+static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, char *describe)
+{
+    const bool fullch = prm.N == K * kChunkSlots;
+    if (describe) {
+        snprintf(describe, 256, "stack_chunks_kernel<%d, %s, %s, %s>", K, sizeof(RawT) == 2 ? "unsigned short" : "float",
+                 CALIB ? "true" : "false", fullch ? "true" : "false");
+        return APGPU_OK;
+    }
+    const int64_t grid = (prm.P + 255) / 256;
+    if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    // redo list: count + one entry per wavefront, a stream-ordered temporary (nothing persistent is allocated)
+    const int64_t nwaves = (prm.P + 63) / 64;
+    int32_t *redo = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), (size_t)(nwaves + 1) * sizeof(int32_t), st);
+    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot allocate the redo list: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): memset: %s", hipGetErrorString(e));
+    const size_t lds = (size_t)(K - 2) * kChunkWin * 256 * sizeof(float);
+    if (lds > 48 * 1024) {
+        const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, true>)
+                                  : reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, false>);
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+    }
+    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);
+    else hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);
+    int rc = check_launch("stack kernel (chunked, 129..256 frames)");
+#ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
+    if (getenv("APGPU_DEBUG_REDO")) {
+        int32_t cnt = -1;
+        (void)hipMemcpyAsync(&cnt, redo, sizeof(cnt), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "stack_chunks: %d of %lld wavefronts on the redo list\n", cnt, (long long)nwaves);
+    }
+#endif
+    if (rc == APGPU_OK) rc = launch_big_exact(prm, u16, CALIB, false, st, nullptr, redo);
+    const hipError_t ef = hipFreeAsync(redo, st);
+    if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
+    return rc;
+}
+
+int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
+{
+    const int K = (prm.N + kChunkSlots - 1) / kChunkSlots;  // 3 or 4
+    if (K == 3) {
+        if (u16) return calib ? launch_chunks_k<3, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<3, uint16_t, false>(prm, u16, st, describe);
+        return calib ? launch_chunks_k<3, float, true>(prm, u16, st, describe) : launch_chunks_k<3, float, false>(prm, u16, st, describe);
+    }
+    if (u16) return calib ? launch_chunks_k<4, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<4, uint16_t, false>(prm, u16, st, describe);
+    return calib ? launch_chunks_k<4, float, true>(prm, u16, st, describe) : launch_chunks_k<4, float, false>(prm, u16, st, describe);
+}
+
+}  // namespace apgpu_stack

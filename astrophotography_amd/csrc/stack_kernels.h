@@ -34,8 +34,11 @@ using namespace apgpu;
 
 // EXTRA: the rich kernels (sorted column parked in LDS: mad_std, float64 planes).  PLUS (lean only): median and std planes
 // straight from the register-resident column - the same kernel as the benchmarked one with a longer epilogue.
+#ifndef APGPU_LEAN_MIN_BLOCKS
+#define APGPU_LEAN_MIN_BLOCKS 2
+#endif
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
-__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? 2 : 1) void stack_sigclip_kernel(const StackParams prm)
+__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA || PLUS ? 2 : APGPU_LEAN_MIN_BLOCKS) : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;

@@ -95,6 +95,30 @@ constexpr Net<NP> make_pruned_net()
     return net;
 }
 
+// The network pruned to the outputs [LO, HI) (same backward liveness): the merge levels of stack_chunks.hip, where only the
+// middle of the merged list is ever read.
+template <int NP, int P0, int LO, int HI>
+constexpr Net<NP> make_window_net()
+{
+    constexpr Net<NP> full = make_net<NP, P0>();
+    bool live[NP] = {};
+    for (int i = LO; i < HI; i++) live[i] = true;
+    bool keep[NP * 12 + 1] = {};
+    for (int c = full.n - 1; c >= 0; c--) {
+        const int a = full.ce[c].a, b = full.ce[c].b;
+        if (live[a] || live[b]) {
+            keep[c] = true;
+            live[a] = live[b] = true;
+        }
+    }
+    Net<NP> net{};
+    int n = 0;
+    for (int c = 0; c < full.n; c++)
+        if (keep[c]) net.ce[n++] = full.ce[c];
+    net.n = n;
+    return net;
+}
+
 // Compare-exchange.  Written as the two machine instructions: through fminf/fmaxf the compiler has to
 // quiet possible signalling NaNs first (IEEE mode) and adds a v_max_f32 x, x, x canonicalisation per
 // network input (~120 instructions per column); the columns are NaN-free by construction here.
@@ -142,6 +166,26 @@ __device__ __forceinline__ void net_from(float (&v)[NP])
         constexpr int len = (total - BASE < CH) ? total - BASE : CH;
         net_chunk<NP, P0, T, BASE>(v, std::make_integer_sequence<int, len>{});
         net_from<NP, P0, T, BASE + len>(v);
+    }
+}
+
+template <int NP, int P0, int LO, int HI, int BASE, int... I>
+__device__ __forceinline__ void window_net_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_window_net<NP, P0, LO, HI>();
+    (cmpx(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+// Runs the merge levels p = P0, 2 P0, .. of the Batcher network on v, pruned to the outputs [LO, HI).
+template <int NP, int P0, int LO, int HI, int BASE = 0>
+__device__ __forceinline__ void window_net_from(float (&v)[NP])
+{
+    constexpr int total = make_window_net<NP, P0, LO, HI>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        window_net_chunk<NP, P0, LO, HI, BASE>(v, std::make_integer_sequence<int, len>{});
+        window_net_from<NP, P0, LO, HI, BASE + len>(v);
     }
 }
 

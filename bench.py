@@ -442,7 +442,7 @@ def main(argv=None):
     nshard_multi = not single_launch
     out_bytes = 4 if single_launch else (24 if args.exchange == 'f64' else 12)     # mean plane | moment planes written
     algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
-    kernel_name = ops.stack_kernel_name(N, args.dtype, calibrated=True,
+    kernel_name = ops.stack_kernel_name(min(N, hier_chunk) if hier_chunk else N, args.dtype, calibrated=True,
                                         outputs=('mean',) if single_launch else (('moments_f64p',) if args.exchange == 'f64' else ('moments',)))
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
     cfg_name = 'C3' if strong else 'C2'
@@ -521,7 +521,8 @@ def main(argv=None):
         if nshard_multi:
             line['roofline']['note'] = ('step = %d stripe kernels%s + all-reduces on side streams; achieved = per-rank algorithmic '
                                         'bytes / step time on the launch stream' % (
-                                            n_stripes, ' x %d shards' % (N // hier_chunk) if hier_chunk else ''))
+                                            n_stripes if world > 1 or args.force_collective else 1,
+                                            ' x %d shards' % (N // hier_chunk) if hier_chunk and N > hier_chunk else ''))
             line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(args.exchange)
             line['exchange_ms'] = exchange_ms
             line['stripes'] = n_stripes
