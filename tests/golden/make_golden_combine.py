@@ -1,0 +1,104 @@
+#!/opt/conda/bin/python3.9 -B
+"""Golden group G12: the arithmetic ccdproc.combine performs for scripts/ap_combine_darks.py:394-420, rebuilt from the
+pieces of it that ARE installed in the build container.
+
+RUN ONLY IN THE BUILD CONTAINER:   /opt/conda/bin/python3.9 -B tests/golden/make_golden_combine.py
+
+ccdproc (>= 2.1.0, requirements.txt:18) is absent, so ccdproc itself cannot be run.  What ApMasterCal asks of it
+(method='average', sigma_clip=True, sigma_clip_low_thresh = sigma_clip_high_thresh = 5, sigma_clip_func=np.ma.median,
+sigma_clip_dev_func=astropy.stats.mad_std) is, per ccdproc's published Combiner:
+    data_arr = float64 masked cube [N, H, W] of the frames                              (Combiner.__init__, dtype float64)
+    baseline = np.ma.median(data_arr, axis=0);  dev = astropy.stats.mad_std(data_arr, axis=0)
+    mask |= (data_arr - baseline < -5 * dev);   mask |= (data_arr - baseline > 5 * dev)    (Combiner.sigma_clipping: strict)
+    mean = masked mean along N, float64;  pixels masked in all frames are flagged          (Combiner.average_combine)
+This script runs exactly those NumPy / astropy calls (numpy.ma.median, astropy.stats.mad_std on masked arrays,
+numpy.ma.average) on float64 masked cubes built from uint16 and float32 frames - the third-party code paths ccdproc would
+call - and records inputs and outputs.  tests/test_oracle_golden.py holds oracle/apref.c's apref_combine_ccdproc() to them,
+including columns that sit EXACTLY on a +-5 dev bound (kept: the inequalities are strict).
+"""
+import json
+import os
+import sys
+import warnings
+
+warnings.filterwarnings('ignore')
+import numpy as np
+
+for nm, fn in [('asscalar', lambda a: a.item()), ('alen', len), ('msort', lambda a: np.sort(a, axis=0)),
+               ('product', np.prod), ('cumproduct', np.cumprod), ('sometrue', np.any), ('alltrue', np.all),
+               ('float', float), ('int', int), ('bool', bool), ('object', object), ('complex', complex), ('str', str)]:
+    if not hasattr(np, nm):
+        setattr(np, nm, fn)
+import astropy
+import astropy.stats.sigma_clipping as sc
+sc.HAS_BOTTLENECK = False
+from astropy.stats import mad_std
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def combiner(frames, low=5.0, high=5.0):
+    """The Combiner steps on a float64 masked cube (non-finite values masked, as ccdproc's CCDData masks would be)."""
+    data_arr = np.ma.masked_invalid(np.asarray(frames, dtype=np.float64))
+    baseline = np.ma.median(data_arr, axis=0)
+    dev = mad_std(data_arr, axis=0)
+    mask = np.ma.getmaskarray(data_arr).copy()
+    mask |= (data_arr - baseline < -low * dev).filled(False)
+    mask |= (data_arr - baseline > high * dev).filled(False)
+    clipped = np.ma.array(data_arr.data, mask=mask)
+    mean = np.ma.average(clipped, axis=0)
+    count = (~mask).sum(axis=0).astype(np.int32)
+    std = np.ma.std(clipped, axis=0)
+    return (np.ma.filled(mean.astype(np.float64), np.nan), count, np.ma.filled(std.astype(np.float64), np.nan),
+            np.ma.filled(baseline, np.nan), np.ma.filled(dev, np.nan))
+
+
+def main():
+    rng = np.random.default_rng(1212)
+    out = {}
+    meta = []
+    k = 0
+    for N in (3, 8, 9, 16, 33, 64):
+        for kind in ('f32', 'u16', 'f64ties'):
+            shape = (6, 9)
+            cube = rng.normal(1000, 8, (N,) + shape)
+            hits = rng.random(cube.shape) < 0.06
+            cube[hits] += rng.uniform(60, 4000, hits.sum())
+            lows = rng.random(cube.shape) < 0.02
+            cube[lows] -= rng.uniform(60, 400, lows.sum())
+            if kind == 'u16':
+                frames = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
+            elif kind == 'f32':
+                frames = cube.astype(np.float32)
+                frames[0, 0, 0] = np.nan                    # a masked-invalid value
+                frames[:, 1, 1] = 1234.5                    # constant column: dev = 0, nothing beyond +-0
+                if N > 3:
+                    frames[1, 2, 2] = np.inf
+            else:
+                # float64 columns built so that one value sits EXACTLY on the +5 dev bound and one on the -5 dev bound:
+                # integers around 0 with median 0 and MAD 1 (dev = 1.482602218505602), then x = +-5 dev as float64
+                frames = cube.astype(np.float64)
+                if N >= 8:
+                    half = (N - 2) // 2
+                    col = np.concatenate([-np.ones(half), np.ones(half), np.zeros(N - 2 - 2 * half)])
+                    d = 1.482602218505602                    # mad_std of the finished column: median 0, MAD 1
+                    frames[:, 0, 0] = np.concatenate([col, [5.0 * d, -5.0 * d]])      # exactly ON the +-5 dev bounds
+            mean, count, std, baseline, dev = combiner(frames)
+            out[f'c{k}_frames'] = frames
+            out[f'c{k}_mean'] = mean
+            out[f'c{k}_count'] = count
+            out[f'c{k}_std'] = std
+            out[f'c{k}_baseline'] = baseline
+            out[f'c{k}_dev'] = dev
+            meta.append(dict(case=k, N=N, kind=kind))
+            k += 1
+    out['_meta'] = np.array(json.dumps(meta))
+    out['_versions'] = np.array(json.dumps(dict(astropy=astropy.__version__, numpy=np.__version__, python=sys.version.split()[0],
+                                                 bottleneck='disabled', ccdproc='absent: Combiner steps restated with its own '
+                                                 'third-party calls (np.ma.median, astropy.stats.mad_std, np.ma.average)')))
+    np.savez_compressed(os.path.join(HERE, 'g12_combine.npz'), **out)
+    print('wrote g12_combine.npz', k, 'cases')
+
+
+if __name__ == '__main__':
+    main()

@@ -208,6 +208,28 @@ def test_big_stacks_other_paths(ops, apref):
     assert_ulp(host(r['mean']), (tot / cnt).astype(np.float32), 1, 'chunked clip = oracle per chunk, moments added')
 
 
+def test_combine_ccdproc_config_golden(ops):
+    """A6: the ccdproc.combine configuration of scripts/ap_combine_darks.py:394-420 (one pass, np.ma.median / mad_std,
+    strict 5-sigma bounds, masked mean in float64) against golden group G12 - numpy.ma + astropy run on float64 masked
+    cubes, what ccdproc's Combiner calls (tests/golden/make_golden_combine.py)."""
+    g = load_golden('g12_combine.npz')
+    ncase = 0
+    for m in json.loads(str(g['_meta'])):
+        if m['kind'] == 'f64ties':
+            continue                                         # float64 frames: the kernels take uint16 / float32 slabs
+        k = m['case']
+        fr = g[f'c{k}_frames']
+        r = ops.stack_sigclip(dev(fr, ops), sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
+                              outputs=('mean', 'count', 'mean_f64', 'std_f64'))
+        assert np.array_equal(host(r['count']), g[f'c{k}_count']), m
+        ref = g[f'c{k}_mean']
+        np.testing.assert_allclose(host(r['mean_f64']), ref, rtol=4e-16, atol=0, equal_nan=True, err_msg=str(m))
+        assert_ulp(host(r['mean']), ref.astype(np.float32), 1, str(m))
+        np.testing.assert_allclose(host(r['std_f64']), g[f'c{k}_std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=str(m))
+        ncase += 1
+    assert ncase == 12
+
+
 def test_stack_u16_and_pixmask(ops, apref):
     rng = np.random.default_rng(7)
     cube = synth_cube(rng, 16, (19, 40), dtype=np.uint16)

@@ -194,6 +194,30 @@ def test_g6_madstd_blocks(golden_dir):
         assert np.array_equal(c['count'], keep.sum(0))
 
 
+# ---- G12: the Combiner steps of ccdproc.combine, run with the third-party calls it makes ------------------
+def test_g12_combine_ccdproc(golden_dir):
+    """apref_combine_ccdproc against np.ma.median + astropy.stats.mad_std + np.ma.average on float64 masked cubes
+    (tests/golden/make_golden_combine.py): means, survivor counts and stds bit for bit, values exactly on a +-5 dev
+    bound kept (strict inequalities, scripts/ap_combine_darks.py:394-420 -> ccdproc Combiner.sigma_clipping)."""
+    import json
+    g = load(golden_dir, 'g12_combine.npz')
+    ties = 0
+    for m in json.loads(str(g['_meta'])):
+        k = m['case']
+        fr = g[f'c{k}_frames']
+        cube = fr.astype(np.float32) if fr.dtype == np.uint16 else fr          # uint16 -> float32 -> float64 is exact
+        r = apref.combine_ccdproc(cube, 5.0, 5.0)
+        assert np.array_equal(r['count'], g[f'c{k}_count']), m
+        assert_biteq(r['mean'], g[f'c{k}_mean'])
+        assert_biteq(r['std'], g[f'c{k}_std'])
+        if m['kind'] == 'f64ties' and m['N'] >= 8:
+            col, base, dev = fr[:, 0, 0], g[f'c{k}_baseline'][0, 0], g[f'c{k}_dev'][0, 0]
+            assert col[-2] - base == 5.0 * dev and col[-1] - base == -5.0 * dev      # exactly ON the bounds ...
+            assert g[f'c{k}_count'][0, 0] == m['N']                                 # ... and kept
+            ties += 1
+    assert ties == 5
+
+
 # ---- G8: ApImageDifference / ApCalcReadNoise -------------------------------------------------------
 def test_g8_read_noise(golden_dir):
     import math
