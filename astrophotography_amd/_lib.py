@@ -58,6 +58,9 @@ SIGNATURES = {
                                              C.c_int64, C.c_void_p]),
     'apgpu_moments_finalize_f64p': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p]),
+    'apgpu_combine_ccdproc_f64_ws_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
+    'apgpu_combine_ccdproc_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
     'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),

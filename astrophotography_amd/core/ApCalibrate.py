@@ -238,26 +238,26 @@ class ApCalibrate:
                     dark_still_biased=self._dark_still_biased)
 
     def load_slab(self, raw_images):
-        """Reads N raw frames into one contiguous [N,H,W] device slab.
+        """Reads N raw frames into one contiguous [N,H,W] device slab (fitsio.read_slab_device: pinned double-buffered
+        staging, payload decoded on the device straight into the slab).
 
         Returns (slab, headers, exp_ratio[N], pedestal[N] or None)."""
         import torch
-        tensors, hdrs, ratios, peds = [], [], [], []
-        for f in raw_images:
-            t, hdr, ped = self._read_raw(f)
-            tensors.append(t)
-            hdrs.append(hdr)
-            ratios.append(self._find_exptime_ratio(hdr, self._dark_hdr))
-            peds.append(ped)
-        kinds = {t.dtype for t in tensors}
-        if len(kinds) != 1:
-            if torch.float64 in kinds:
-                raise TypeError('raw frames mix float64 with other types: their results have different dtypes, calibrate '
-                                'them one at a time')
-            # mixed uint16 / float32 inputs: widen exactly (uint16 becomes float32 at read time anyway)
-            tensors = [t if t.dtype == torch.float32
-                       else (t.view(torch.int16).to(torch.int32) & 0xFFFF).to(torch.float32) for t in tensors]
-        slab = torch.stack(tensors, 0)
+        files = [str(_common.check_file_exists(self._logger, f)) for f in raw_images]
+        hdrs0 = [fitsio.read(f, want_data=False)[1] for f in files]
+        wide = [int(h['BITPIX']) == -64 for h in hdrs0]
+        if any(wide) and not all(wide):
+            raise TypeError('raw frames mix float64 with other types: their results have different dtypes, calibrate '
+                            'them one at a time')
+        for f, h in zip(files, hdrs0):
+            if h['NAXIS'] == 3:
+                self._logger.error('Error, 3-D handling has not been implemented yet.')
+                raise SystemExit(1)
+        slab, hdrs = fitsio.read_slab_device(files)          # uint16 if all are, else float32 (exact widening) / float64
+        if tuple(slab.shape[1:]) != tuple(self._bias_data.shape):
+            raise RuntimeError(f'{Path(files[0]).name} has shape {tuple(slab.shape[1:])}, the masters have {tuple(self._bias_data.shape)}.')
+        ratios = [self._find_exptime_ratio(h, self._dark_hdr) for h in hdrs]
+        peds = [float(h['PEDESTAL']) if 'PEDESTAL' in h else 0.0 for h in hdrs]
         return slab, hdrs, ratios, (peds if any(p != 0 for p in peds) else None)
 
     def calibrate_slab(self, slab, exp_ratio, pedestal=None):

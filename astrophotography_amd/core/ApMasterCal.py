@@ -148,17 +148,16 @@ class ApMasterCal:
         files = [self._data_dir / n for n in self._values('file')]
         self._logger.debug(f'About to combine {len(files)} {kw_dict["IMAGETYP"][0]} files, method=average sigma_clip=True '
                            'sig_clip_lothresh=5 sig_clip_hithresh=5 (median / mad_std, one pass).')
-        arrs, hdrs = [], []
-        for f in files:
-            data, hdr = fitsio.read(str(f))
-            arrs.append(data)
-            hdrs.append(hdr)
-        if all(a.dtype == np.uint16 for a in arrs):
-            slab = ops.to_device_u16(np.stack(arrs, 0))
+        # one slab in HBM, filled file by file through pinned staging + on-device decode (fitsio.read_slab_device)
+        slab, hdrs = fitsio.read_slab_device([str(f) for f in files])
+        if slab.dtype == torch.float64:
+            # float64 frames (BITPIX -64): ccdproc combines in float64 anyway; here the float64 combine kernel
+            res = ops.combine_f64(slab, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std')
         else:
-            slab = torch.from_numpy(np.stack([a.astype(np.float32) for a in arrs], 0)).cuda()
-        res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
-                                outputs=('mean_f64', 'count', 'std_f64'))
+            res = None
+        if res is None:
+            res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
+                                    outputs=('mean_f64', 'count', 'std_f64'))
         # ccdproc's CCDData product (ap_combine_darks.py:411-439): float64 primary, MASK = pixels with every
         # input rejected, UNCERT = std of the surviving values / sqrt(their number) - all in float64
         master = res['mean_f64'].cpu().numpy()

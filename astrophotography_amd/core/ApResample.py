@@ -79,23 +79,26 @@ class ApResample:
             affines = np.asarray(affines, dtype=np.float64).reshape(-1, 6)
             if len(affines) != len(input_files):
                 raise RuntimeError(f'Error, {len(affines)} transforms given for {len(input_files)} files.')
-        arrs, hdrs, fscale, texp, gains = [], [], [], 0.0, []
+        from .ApStack import _apply_pedestals
+        from .. import fitsio
         for f in input_files:
-            data, hdr, _ = _common.read_fits(self._logger, f)
+            _common.check_file_exists(self._logger, f)
+        # one float32 slab in HBM, filled through pinned staging + on-device decode (fitsio.read_slab_device)
+        slab, hdrs = fitsio.read_slab_device(input_files, dtype=torch.float32)
+        slab = _apply_pedestals(slab, hdrs)
+        fscale, texp, gains = [], 0.0, []
+        for f, hdr in zip(input_files, hdrs):
             exp = self._exposure(hdr, f)
             texp += exp
             gains.append(float(hdr[self.gain_keyword]) if self.gain_keyword and self.gain_keyword in hdr else None)
             fscale.append(1.0 if self.combine == 'SUM' else 1.0 / exp)
-            arrs.append(np.asarray(data, dtype=np.float32))
-            hdrs.append(hdr)
             self._logger.info(f'  File {Path(f).name:40s} EXPOSURE {exp:8.3f} FSCALE {fscale[-1]:8.6f}')
-        if len({a.shape for a in arrs}) != 1:
-            raise RuntimeError(f'Error, input images differ in shape: {sorted({a.shape for a in arrs})}')
+        in_shape = tuple(slab.shape[1:])
         mask = None
         if mask_file is not None:
             m, _, _ = _common.read_fits(self._logger, mask_file)
-            if m.shape != arrs[0].shape:
-                raise RuntimeError(f'Error, mask shape {m.shape} differs from the image shape {arrs[0].shape}.')
+            if m.shape != in_shape:
+                raise RuntimeError(f'Error, mask shape {m.shape} differs from the image shape {in_shape}.')
             mask = torch.from_numpy((np.asarray(m) != 0).astype(np.uint8)).cuda()
         out_wcs = None
         if use_wcs:
@@ -107,7 +110,7 @@ class ApResample:
                 out_wcs = apwcs.TanWcs.from_center(float(center[0]), float(center[1]), float(pixscale), out_shape)
             else:
                 out_wcs = in_wcs[0]
-                out_shape = out_shape or arrs[0].shape
+                out_shape = out_shape or in_shape
             fine_affines = None
             if self.oversampling > 1:
                 n = self.oversampling
@@ -119,7 +122,6 @@ class ApResample:
             self._logger.info(f'Registered {len(in_wcs)} files through their TAN WCS onto a {out_shape[1]}x{out_shape[0]} grid.')
         else:
             fine_affines = None
-        slab = torch.from_numpy(np.stack(arrs, 0)).cuda()
         weights = None
         if self.combine == 'WEIGHTED':
             from .. import ops

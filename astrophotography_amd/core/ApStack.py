@@ -18,6 +18,19 @@ from . import _common
 METHODS = ('sigclip', 'median', 'mean')
 
 
+def _apply_pedestals(slab, hdrs):
+    """PEDESTAL (if present and non-zero) is ADDED to the data at read time (core/ApCalibrate.py:318-326); integer data with
+    a pedestal is refused like numpy refuses `uint16 += float`."""
+    import torch
+    for k, h in enumerate(hdrs):
+        ped = float(h['PEDESTAL']) if 'PEDESTAL' in h else 0.0
+        if ped != 0:
+            if not slab.dtype.is_floating_point:
+                raise TypeError(f'Cannot add PEDESTAL={ped} to integer data of type {slab.dtype}.')
+            slab[k] += ped
+    return slab
+
+
 class ApStack:
     def __init__(self, loglevel='INFO', sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
                  stdfunc='std'):
@@ -82,17 +95,13 @@ class ApStack:
             else:
                 calib = dict(masters, exp_ratio=ratios, pedestal=peds)
         else:
-            arrs, hdrs = [], []
             for f in input_files:
-                data, hdr, _ = _common.read_fits(self._logger, f)
-                arrs.append(data)
-                hdrs.append(hdr)
-            if len({a.shape for a in arrs}) != 1:
-                raise RuntimeError(f'Error, input images differ in shape: {sorted({a.shape for a in arrs})}')
-            if all(a.dtype == np.uint16 for a in arrs):
-                slab = ops.to_device_u16(np.stack(arrs, 0))
-            else:
-                slab = torch.from_numpy(np.stack([a.astype(np.float32) for a in arrs], 0)).cuda()
+                _common.check_file_exists(self._logger, f)
+            slab, hdrs = fitsio.read_slab_device(input_files)            # pinned staging + on-device decode, one slab
+            slab = _apply_pedestals(slab, hdrs)
+            if slab.dtype == torch.float64:
+                self._logger.warning('float64 frames are rounded to float32 for the stack kernel.')
+                slab = slab.to(torch.float32)
         key = 'median' if method == 'median' else 'mean'
         res = self.stack(slab, method=method, calib=calib, outputs=('mean', 'count') if method != 'median' else ())
         out = res[key].cpu().numpy()

@@ -315,6 +315,31 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, fina
     return res
 
 
+def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std'):
+    """The ccdproc.combine configuration (scripts/ap_combine_darks.py:394-420) on a FLOAT64 slab [N, ...]: one strict
+    pass about the median with mad_std, float64 mean / std / count -> dict(mean_f64, std_f64, count).  float64 frames are
+    never narrowed to float32 (apgpu_combine_ccdproc_f64: a correctness path, bit-identical to the oracle)."""
+    _need_cuda(frames)
+    if frames.dtype != torch.float64:
+        raise TypeError('combine_f64 takes a float64 slab, got %s' % frames.dtype)
+    if maxiters != 1 or cenfunc != 'median' or stdfunc != 'mad_std':
+        raise ValueError('combine_f64 implements the ccdproc.combine configuration only: maxiters=1, median, mad_std')
+    lib = _lib.load()
+    N = frames.shape[0]
+    shp = tuple(frames.shape[1:])
+    P = frames[0].numel()
+    if not (frames[0].is_contiguous() and (N == 1 or frames.stride(0) >= P)):
+        frames = frames.contiguous()
+    dev = frames.device
+    res = dict(mean_f64=torch.empty(shp, dtype=torch.float64, device=dev), std_f64=torch.empty(shp, dtype=torch.float64, device=dev),
+               count=torch.empty(shp, dtype=torch.int32, device=dev))
+    nb = lib.apgpu_combine_ccdproc_f64_ws_bytes(N, P)
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    check(lib.apgpu_combine_ccdproc_f64(_ptr(frames), N, P, frames.stride(0) if N > 1 else P, float(sigma_lower), float(sigma_upper),
+                                        _ptr(res['mean_f64']), _ptr(res['count']), _ptr(res['std_f64']), _ptr(ws), nb, _stream()))
+    return res
+
+
 def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std'):
     """Name of the kernel variant the library dispatches for such a stack call (apgpu_stack_kernel_name): what the
     bench line and the profiles call the dominant kernel.  Needs no device."""

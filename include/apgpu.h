@@ -171,6 +171,17 @@ typedef struct apgpu_stack_args {
 
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 
+/* A6 on FLOAT64 frames (BITPIX -64 inputs of ApMasterCal: ccdproc's Combiner is float64 throughout, so such frames must
+ * not pass through the float32 stack kernels): base = median, dev = mad_std, ONE strict pass (x - base < -low dev or
+ * > high dev is rejected), float64 mean in frame order, std of the kept values, survivor count.  frames: double [N][P]
+ * with frame_stride elements between frames (0 = n_pixels); outputs may be NULL; workspace: double[2][N][P]
+ * (apgpu_combine_ccdproc_f64_ws_bytes).  A correctness path (insertion sort per pixel), bit-identical to
+ * oracle/apref.c apref_combine_ccdproc and golden group G12. */
+size_t apgpu_combine_ccdproc_f64_ws_bytes(int32_t n_frames, int64_t n_pixels);
+int apgpu_combine_ccdproc_f64(const double *frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, double low,
+                              double high, double *mean, int32_t *count, double *std, void *workspace, size_t workspace_bytes,
+                              void *stream);
+
 /* Plain median along N (np.nanmedian(axis=0)); config 4.  Optional fused calibration as above. */
 int apgpu_stack_median(const apgpu_stack_args *args, void *stream);
 

@@ -413,3 +413,90 @@ def test_apresample_files_and_script(tmp_path):
         rs.coadd_files(names, A[:-1], str(tmp_path / 'x.fits'))
     with pytest.raises(ValueError):
         ap.ApResample('CRITICAL', combine='MODE')
+
+
+def test_read_slab_device_and_float64_masters(tmp_path):
+    """F1 for the stackers: fitsio.read_slab_device (pinned double-buffered staging, payload decoded on the device straight
+    into the slab) against the host reader for every layout; ApMasterCal on FLOAT64 frames = the oracle's float64 combine
+    bit for bit (golden group G12, nothing narrowed to float32); ApStack.stack_files with a calibrator built from the
+    float64 masters ApMasterCal writes."""
+    import json
+    import astrophotography_amd as ap
+    from astrophotography_amd import fitsio, ops
+    from oracle import apref
+    from tests.util import load_golden
+    rng = np.random.default_rng(77)
+    shape = (37, 53)
+    u16 = rng.integers(0, 65535, (5,) + shape).astype(np.uint16)
+    f32 = rng.normal(500, 30, (5,) + shape).astype(np.float32)
+    f64 = rng.normal(500, 30, (3,) + shape)
+    i16 = rng.integers(-3000, 3000, (2,) + shape).astype(np.int16)
+    names = {}
+    for tag, cube in (('u16', u16), ('f32', f32), ('f64', f64), ('i16', i16)):
+        names[tag] = []
+        for i in range(cube.shape[0]):
+            p = tmp_path / f'{tag}_{i}.fits'
+            _wf(p, cube[i], EXPTIME=10.0 + i)
+            names[tag].append(str(p))
+    tm = {}
+    slab, hdrs = fitsio.read_slab_device(names['u16'], timings=tm)
+    assert slab.dtype == torch.uint16 and np.array_equal(slab.view(torch.int16).cpu().numpy().view(np.uint16), u16)
+    assert [h['EXPTIME'] for h in hdrs] == [10.0 + i for i in range(5)] and tm['total'] >= tm['read'] >= 0
+    slab, _ = fitsio.read_slab_device(names['f32'])
+    assert slab.dtype == torch.float32 and np.array_equal(slab.cpu().numpy(), f32)
+    slab, _ = fitsio.read_slab_device(names['f64'])
+    assert slab.dtype == torch.float64 and np.array_equal(slab.cpu().numpy(), f64)
+    slab, _ = fitsio.read_slab_device(names['i16'] + names['u16'][:2])                 # mixed integers widen exactly
+    assert slab.dtype == torch.float32 and np.array_equal(slab.cpu().numpy(), np.concatenate([i16, u16[:2]]).astype(np.float32))
+    slab, _ = fitsio.read_slab_device(names['f32'][:2] + names['f64'][:1])             # any float64 file: nothing is narrowed
+    assert slab.dtype == torch.float64 and np.array_equal(slab.cpu().numpy()[2], f64[0])
+    slab, _ = fitsio.read_slab_device(names['u16'], dtype=torch.float32)
+    assert np.array_equal(slab.cpu().numpy(), u16.astype(np.float32))
+    with pytest.raises(RuntimeError):
+        _wf(tmp_path / 'odd.fits', np.zeros((5, 5), np.float32))
+        fitsio.read_slab_device(names['f32'][:1] + [str(tmp_path / 'odd.fits')])
+
+    # ApMasterCal on float64 frames: the float64 combine kernel, bit for bit the oracle / G12
+    g = load_golden('g12_combine.npz')
+    case = [m for m in json.loads(str(g['_meta'])) if m['kind'] == 'f64ties' and m['N'] == 16][0]['case']
+    frames = g[f'c{case}_frames']
+    d = tmp_path / 'd64'
+    d.mkdir()
+    for i in range(frames.shape[0]):
+        _wf(d / f'dark{i:02d}.fits', frames[i], TELESCOP='T05', IMAGETYP='Dark Frame', EXPTIME=300.0, SET_TEMP=-20.0,
+            CCD_TEMP=-20.0, DATE_OBS='2020-01-01', FILTER='none')
+    ap.ApMasterCal(str(d), 'master*', 'UNKNOWN', 0.5, 'CRITICAL').make_master(str(d / 'master_dark.fits'))
+    m, h = fitsio.read(str(d / 'master_dark.fits'))
+    assert m.dtype == np.float64
+    assert_biteq(m, g[f'c{case}_mean'])
+    unc, _ = fitsio.read_extension(str(d / 'master_dark.fits'), 'UNCERT')
+    assert_biteq(unc, g[f'c{case}_std'] / np.sqrt(g[f'c{case}_count'].astype(np.float64)))
+    r = ops.combine_f64(torch.from_numpy(frames).cuda())
+    assert np.array_equal(r['count'].cpu().numpy(), g[f'c{case}_count'])                # the values ON the +-5 dev bounds are kept
+    ref = apref.combine_ccdproc(frames, 5.0, 5.0)
+    assert_biteq(r['mean_f64'].cpu().numpy(), ref['mean'])
+    assert_biteq(r['std_f64'].cpu().numpy(), ref['std'])
+
+    # float64 masters (what ApMasterCal writes) -> ApCalibrate -> ApStack.stack_files(calibrator=...)
+    N = 8
+    raw = np.clip(rng.normal(1500, 40, (N,) + shape), 0, 65535).astype(np.uint16)
+    bias, dark = rng.normal(100, 2, shape), rng.normal(10, 1, shape)                   # float64
+    flat = rng.normal(30000, 300, shape)
+    _wf(tmp_path / 'mb.fits', bias)
+    _wf(tmp_path / 'md.fits', dark, EXPTIME=300.0)
+    _wf(tmp_path / 'mf.fits', flat)
+    files = []
+    for i in range(N):
+        _wf(tmp_path / f'light{i}.fits', raw[i], EXPTIME=120.0)
+        files.append(str(tmp_path / f'light{i}.fits'))
+    cal = ap.ApCalibrate(str(tmp_path / 'mb.fits'), str(tmp_path / 'md.fits'), str(tmp_path / 'mf.fits'), None, 'CRITICAL',
+                         dark_still_biased=False)
+    res = ap.ApStack('CRITICAL').stack_files(files, str(tmp_path / 'stk.fits'), calibrator=cal)
+    # reference semantics: NumPy calibrates in float64 when a master is float64 (ApCalibrate.py:439-464); the calibrated
+    # frames are then stacked (float32 stack kernel: values rounded to float32)
+    nflat = flat / np.nanmean(flat)
+    calf = ((raw.astype(np.float32) - bias) - (120.0 / 300.0) * dark) / nflat
+    ref = apref.stack_sigclip(calf.astype(np.float32), sigma=3.0, maxiters=5)
+    s, _ = fitsio.read(str(tmp_path / 'stk.fits'))
+    assert np.array_equal(res['count'].cpu().numpy(), ref['count'])
+    assert_ulp(s, ref['mean'].astype(np.float32), 1, 'stack_files with float64 masters')
