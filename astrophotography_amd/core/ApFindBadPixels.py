@@ -59,18 +59,22 @@ class ApFindBadPixels:
             cast = np.float64
             # the threshold comparison runs in float32 (numpy promotes uint16 vs a float scalar to float32)
             d = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).cuda()
-        s = stats.cpu().numpy()
-        mean, med, std = cast(s[0]), cast(s[1]), cast(s[2])
-        self._logger.debug(f'Sigma-clipped mean={mean:.2f}, median={med:.2f}, and madstddev={std:.2f} values (ADU).')
-        # ApFindBadPixels.py:194-195: np.float32 scalar -/+ python float * np.float32 -> float64 (numpy 1.x)
-        lothresh = float(med) - (sigma * float(std))
-        hithresh = float(med) + (sigma * float(std))
-        self._logger.info(f'Good pixels have values between {lothresh:.2f} and {hithresh:.2f} ADU.')
-        mask, nbad = ops.threshold_mask(d, lothresh, hithresh)
-        self._stats = dict(mean=mean, median=med, std=std, lothresh=lothresh, hithresh=hithresh, niter=int(s[5]))
+        # One device pipeline, no host read in between: statistics -> thresholds -> mask.  ApFindBadPixels.py:194-195 forms
+        # median -/+ sigma * std from np.float32 scalars and a python float, i.e. in float64 (numpy 1.x promotion); the
+        # statistics vector holds the float32 (or float64) statistics exactly, so the same float64 expression is
+        # evaluated on the device and handed to the mask kernel as a tensor.
+        thr = torch.stack((stats[1] - sigma * stats[2], stats[1] + sigma * stats[2]))
+        mask, nbad = ops.threshold_mask(d, thresholds=thr)
         self._badpixmask_dev = mask
         self._mask_host = None
-        nbad = int(nbad.item())
+        # the only synchronisation: everything the log lines and get_stats() report, in one read
+        s = torch.cat((stats, thr, nbad.to(torch.float64))).cpu().numpy()
+        mean, med, std = cast(s[0]), cast(s[1]), cast(s[2])
+        lothresh, hithresh = float(s[10]), float(s[11])
+        self._logger.debug(f'Sigma-clipped mean={mean:.2f}, median={med:.2f}, and madstddev={std:.2f} values (ADU).')
+        self._logger.info(f'Good pixels have values between {lothresh:.2f} and {hithresh:.2f} ADU.')
+        self._stats = dict(mean=mean, median=med, std=std, lothresh=lothresh, hithresh=hithresh, niter=int(s[5]))
+        nbad = int(s[12])
         self._logger.info(f'Out of {npix} pixels, {nbad} are bad ({100 * (nbad / npix):.4f}%).')
         self._nbad_auto = nbad
 
