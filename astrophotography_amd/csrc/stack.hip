@@ -7,6 +7,7 @@
 
 namespace apgpu_stack {
 int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe);   // stack_big.hip
+bool chunks_eligible(const StackParams &prm, bool median_only);                                                  // stack_chunks.hip
 }
 
 namespace {
@@ -130,7 +131,8 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     if (getenv("APGPU_DEBUG_EXACT")) prm.fast32 = 0;
 #endif
     hipStream_t st = as_stream(stream);
-    if (prm.N > 128)                                        // the column does not fit the registers: LDS-resident path
+    // beyond 128 frames the column does not fit the registers: chunked fast path / LDS-resident exact kernel (stack_big.hip)
+    if (prm.N > 128)
         return launch_big(prm, args->dtype == APGPU_U16, calib, median_only, st, describe);
     if (args->dtype == APGPU_F32)
         return calib ? launch_np<float, true>(prm, median_only, st, describe) : launch_np<float, false>(prm, median_only, st, describe);

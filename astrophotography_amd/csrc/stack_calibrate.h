@@ -335,7 +335,9 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 
 // Slot counts / padding schemes for which the float32 fast path exists: full columns with a core between two tails.
 constexpr int kFastTail = 4;
-constexpr bool fast32_possible(int np, int minn) { return np >= 16 && np % 4 == 0 && minn >= np; }
+// (up to 96 slots: with the fast path next to the exact one the 104 .. 128-slot kernels need more than 256 VGPRs, i.e. one
+// wavefront per SIMD - 128 frames 2.7 -> 3.9 ms; such stacks take the chunked kernel, stack_chunks.hip, when they qualify)
+constexpr bool fast32_possible(int np, int minn) { return np >= 16 && np <= 96 && np % 4 == 0 && minn >= np; }
 
 // Whether the lean reduction will try its float32 fast path (stack_reduce.h, clip_fast32) - wave-uniform, from the arguments.
 __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)

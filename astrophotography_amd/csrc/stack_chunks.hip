@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     float c0 = 0.f, Stot = 0.f, Qtot = 0.f, Lmax = 0.f, Umin = 0.f;
     bool ok = !(prm.pixmask && prm.pixmask[p]);
     int below = 0;                                          // values below the windows (wave-uniform)
-    {
+    if constexpr (K >= 3) {
         float win[W];
         const int c = cbase + (0 < cextra ? 1 : 0);
         ok = chunk_step<RawT, CALIB, FULLCH, 0>(prm, fs[0], 0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
     }
     {
-        constexpr int k = K - 2;
+        constexpr int k = K - 2;                            // (K = 2: this is the first chunk)
         const int c = cbase + (k < cextra ? 1 : 0);
         const int f0 = k * cbase + (k < cextra ? k : cextra);
-        ok = chunk_step<RawT, CALIB, FULLCH, 2>(prm, fs[k], f0, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
+        ok = chunk_step<RawT, CALIB, FULLCH, (k == 0 ? 0 : 2)>(prm, fs[k], f0, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
     }
     {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
         ok = chunk_step<RawT, CALIB, FULLCH, 3>(prm, fs[k], f0, c, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
     }
-    float X[4 * W];                                         // the K windows side by side (K = 3: the last quarter is +inf)
+    float X[4 * W];                                         // the K windows side by side, +inf beyond them
     {
         int slot = lane;
         asm volatile("" : "+v"(slot) : : "memory");         // opaque index: no store-to-load forwarding through registers
@@ -376,10 +376,8 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
             X[(K - 2) * W + j] = R0[j];
             X[(K - 1) * W + j] = R1[j];
         }
-        if constexpr (K == 3) {
 #pragma unroll
-            for (int j = 0; j < W; j++) X[3 * W + j] = __builtin_inff();
-        }
+        for (int j = K * W; j < 4 * W; j++) X[j] = __builtin_inff();
     }
     APGPU_MARK("chunks_merge");
     // merge the windows: [0,32)+[32,64) and [64,96)+[96,128), then the two halves - only the 16 middle outputs are read
@@ -485,6 +483,8 @@ int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_o
 // float32 path not switched off, float64-layout moments only when they are for a mean.
 bool chunks_eligible(const StackParams &prm, bool median_only)
 {
+    // (97 .. 128 frames as two chunks were measured too: 2.8 - 3.1 ms for 128 frames against 2.7 ms for the 128-slot
+    // register kernel - a chunk costs what the whole 64-frame kernel costs - so the register kernels keep that range)
     if (median_only || prm.N <= 128 || prm.N > 4 * kChunkSlots) return false;
     if (prm.median || prm.std || prm.mean64 || prm.std64) return false;
     if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
@@ -538,7 +538,7 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
 
 int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
 {
-    const int K = (prm.N + kChunkSlots - 1) / kChunkSlots;  // 3 or 4
+    const int K = (prm.N + kChunkSlots - 1) / kChunkSlots;  // 3 or 4 (the kernel template also takes K = 2)
     if (K == 3) {
         if (u16) return calib ? launch_chunks_k<3, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<3, uint16_t, false>(prm, u16, st, describe);
         return calib ? launch_chunks_k<3, float, true>(prm, u16, st, describe) : launch_chunks_k<3, float, false>(prm, u16, st, describe);

@@ -200,10 +200,11 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
 }
 
 // One pixel of the uint16 pair kernel: its sorted raw column arrives packed two values per register.
+// pruned (wave-uniform): the raw columns came out of the pruned network (the caller wants the float32 fast path).
 template <int NP, bool CALIB, bool FULL>
 __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm, const FrameScalars<NP> &fs,
                                                          const uint32_t (&cur)[NP >= 2 ? NP / 2 : 1], float b, float D, float nf,
-                                                         bool dv, int64_t p)
+                                                         bool dv, int64_t p, bool pruned = false)
 {
     constexpr int HP = NP >= 2 ? NP / 2 : 1;
     const int N = prm.N;
@@ -238,6 +239,7 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
             for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
         }
     } else {
+        pruned = false;                                     // (the column below is sorted completely)
         // rare: exact IEEE calibration of every value (frame order is irrelevant: the per-frame scalars are
         // uniform), non-finite results and padding become sentinels, and the column is sorted the ordinary way.
         // The raw values are re-read from memory: the sorted copy has left the registers.
@@ -254,7 +256,7 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
         }
         sort_column<NP>(v);
     }
-    reduce_and_store<NP>(prm, v, n, p);
+    reduce_and_store<NP>(prm, v, n, p, pruned);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -317,7 +319,18 @@ __global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs
             for (int f = 0; f < NP; f++) w[f] |= (uint32_t)((N - 1 - f) >> 31);  // f >= N: all ones, sorts to the top
         }
     }
-    if constexpr (NP > 1) net_from_pk16<NP, 0>(w);
+    // full stacks headed for the float32 fast path only sort what it reads (both pixels at once); a wave that falls back to
+    // the exact path completes the sort of its calibrated column there (reduce_and_store)
+    bool pruned = false;
+    if constexpr (FULL && fast32_possible(NP, NP)) pruned = fast32_wanted(prm);
+    if constexpr (NP > 1) {
+        if constexpr (FULL && fast32_possible(NP, NP)) {
+            if (pruned) pruned_net_pk16<NP, kFastTail>(w);
+            else net_from_pk16<NP, 0>(w);
+        } else {
+            net_from_pk16<NP, 0>(w);
+        }
+    }
 
     // Re-pack the two sorted columns: cur[k] = (raw[2k], raw[2k+1]) of the first pixel stays in registers, the
     // second pixel's column is parked in LDS (NP/2 dwords per lane, bank = lane) while the first is reduced, so
@@ -351,14 +364,14 @@ __global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs
             dodiv[1] = n2.y != 0.f;
         }
     }
-    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[0], dd[0], nn[0], dodiv[0], p2);
+    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[0], dd[0], nn[0], dodiv[0], p2, pruned);
     // the parked column takes over the registers (through an opaque pointer: otherwise the compiler forwards the
     // stored values to these loads, i.e. keeps the column in NP/2 registers across the whole first reduction)
     int slot = lane;
     asm volatile("" : "+v"(slot) : : "memory");             // opaque index: no store-to-load forwarding in registers
 #pragma unroll
     for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
-    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1);
+    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1, pruned);
 }
 
 // `describe` != nullptr: write the name of the kernel variant this call would launch (as rocprofv3 prints it, without

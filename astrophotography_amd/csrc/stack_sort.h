@@ -302,6 +302,26 @@ __device__ __forceinline__ void net_from_pk16(uint32_t (&v)[NP])
     }
 }
 
+// The packed network pruned to what clip_fast32 reads (make_pruned_net), both columns at once.
+template <int NP, int T, int BASE, int... I>
+__device__ __forceinline__ void pruned_chunk_pk16(uint32_t (&v)[NP], std::integer_sequence<int, I...>)
+{
+    constexpr Net<NP> net = make_pruned_net<NP, 1, T>();
+    (cmpx_pk16(v[net.ce[BASE + I].a], v[net.ce[BASE + I].b]), ...);
+}
+
+template <int NP, int T, int BASE = 0>
+__device__ __forceinline__ void pruned_net_pk16(uint32_t (&v)[NP])
+{
+    constexpr int total = make_pruned_net<NP, 1, T>().n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        pruned_chunk_pk16<NP, T, BASE>(v, std::make_integer_sequence<int, len>{});
+        pruned_net_pk16<NP, T, BASE + len>(v);
+    }
+}
+
 // v[LO + rel] for rel in [0, LEN): select tree with static register indices (a branchy binary search over the
 // registers gets turned into a run-time indexed array by the compiler, i.e. the column is demoted to scratch).
 template <int LO, int LEN, int NP>
