@@ -3,10 +3,16 @@
 // :330-342 the swarp call).  There is no in-tree arithmetic to match; the definition is this build's own and
 // is restated on the CPU in oracle/apref.c (apref_resample_affine_f32) - the two agree bit for bit.
 //
-//   xin = fma(A0, x, fma(A1, y, A2)), yin = fma(A3, x, fma(A4, y, A5))           (float64, output -> input)
-//   ix = floor(xin), phase px = (int)((xin - ix) * n_phases + 0.5); taps ix-2 .. ix+3 weighted by lut[px][0..5]
+//   F[k] = llrint(A[k] * 2^32); xin = F0 x + F1 y + F2, yin = F3 x + F4 y + F5   (32.32 fixed point, output -> input: exactly
+//   reproducible, and a 64-bit add per row where the float64 evaluation of round 2 cost ~25 four-cycle instructions per pixel)
+//   ix = xin >> 32, phase px = top log2(n_phases) bits of the fraction, rounded; taps ix-2 .. ix+3 weighted by lut[px][0..5]
 //   (a host-built table of normalised Lanczos-3 weights), rows combined by lut[py]; even / odd fmaf chains in a
 //   fixed order (= packed float32 arithmetic); result * fscale[f].  Any tap outside the frame, masked or non-finite -> NaN, weight 0.
+//
+// (Round 3 also built a variant in which a lane produces four CONSECUTIVE rows and keeps its 6 x 6 window in registers between
+// them - one new window row per pixel, 10 instead of 18 LDS reads - behind a wave vote on "same columns, next row": the
+// register shuffling around the vote cost more VALU work (151 against 133 instructions per pixel) than the LDS reads it
+// saved: 6.2 ms against 5.2 ms per 64 x 4096^2, not kept.  The kernel is VALU-bound: 133 instructions per pixel.)
 //
 // A workgroup produces a 64 x 16 output tile.  For registration-sized transforms (small rotation / shift /
 // scale near 1) the tile's input footprint is ~70 x 22 pixels: it is staged in LDS once (coalesced runs,
@@ -79,10 +85,11 @@ template <bool HAS_MASK>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const double *__restrict__ affines, int per_tile, int conserve_flux,
                                                              const float *__restrict__ fscale, const float *__restrict__ lut,
-                                                             int n_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
+                                                             int log2_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out)
 {
     __shared__ float tile[kLdsFloats];
+    __shared__ long long Fs[6];
     const int64_t f = blockIdx.z;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     // one transform per frame, or one per output tile (= per workgroup)
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
 
     // input footprint of the tile: an affine map takes its extremes at the tile corners
     int bx0 = 0, by0 = 0, fw = 0;
-    bool staged = false;
+    bool staged = false, sane = false;
     {
         const double xa = (double)x0, xb = (double)(x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1);
         const double ya = (double)y0, yb = (double)(y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1);
@@ -111,12 +118,18 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
             mny = fmin(mny, yi); mxy = fmax(mxy, yi);
         }
-        // clip to the band of coordinates that can produce a defined pixel at all; false for NaN coefficients
-        const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9);
+        // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
+        // fixed-point evaluation below is then exact: the true sums fit 64 bits); false for NaN coefficients
+        const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
+        sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
+               (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
+        if (threadIdx.x < 6) Fs[threadIdx.x] = sane ? __double2ll_rn(A[threadIdx.x] * 4294967296.0) : 0;
         if (sane) {
-            bx0 = (int)floor(mnx) - 2;
-            by0 = (int)floor(mny) - 2;
-            const int w = (int)floor(mxx) + 3 - bx0 + 1, h = (int)floor(mxy) + 3 - by0 + 1;
+            // (one pixel of slack on every side: the corners are evaluated in float64, the pixels in fixed point, and the two
+            // can fall on different sides of an integer)
+            bx0 = (int)floor(mnx) - 3;
+            by0 = (int)floor(mny) - 3;
+            const int w = (int)floor(mxx) + 4 - bx0 + 1, h = (int)floor(mxy) + 4 - by0 + 1;
             if (w > 0 && h > 0 && w <= kLdsFloats && h <= kLdsFloats && w * h <= kLdsFloats) {
                 staged = true;
                 fw = w;
@@ -169,41 +182,38 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
     const int x = x0 + lx;
     if (x >= w_out) return;
-    // One pixel per trip (not unrolled): 78 VGPRs = 6 wavefronts per SIMD.  Fetching the table rows of all four
-    // pixels first (110 VGPRs, 4 wavefronts) measured 5 % slower: residency hides latency better than batching.
-    constexpr int NPX = 1;
+    const long long F0 = Fs[0], F1 = Fs[1], F2 = Fs[2], F3 = Fs[3], F4 = Fs[4], F5 = Fs[5];
+    const int sh = 32 - log2_phases;
+    // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12
+    const int yb0 = y0 + ly;
+    constexpr int YSTEP = 4;
+    // 64-bit two's-complement sums: exact, because the true coordinates fit (sane), whatever the partial products do
+    unsigned long long X = (unsigned long long)F0 * (unsigned long long)(long long)x + (unsigned long long)F1 * (unsigned long long)(long long)yb0 + (unsigned long long)F2;
+    unsigned long long Y = (unsigned long long)F3 * (unsigned long long)(long long)x + (unsigned long long)F4 * (unsigned long long)(long long)yb0 + (unsigned long long)F5;
+    const unsigned long long dX = (unsigned long long)F1 * YSTEP, dY = (unsigned long long)F4 * YSTEP;
+    // One pixel per trip (not unrolled): residency hides latency better than batching (round 1 measurement).
 #pragma unroll 1
-    for (int kb = 0; kb < kTileH / 4; kb += NPX) {
-    bool inside[NPX];
-    int ixs[NPX], iys[NPX];
-    Weights wts[NPX];
-#pragma unroll
-    for (int k = 0; k < NPX; k++) {
-        const int y = y0 + ly + 4 * (kb + k);
-        const double xin = fma(a0, (double)x, fma(a1, (double)y, a2));
-        const double yin = fma(a3, (double)x, fma(a4, (double)y, a5));
-        const double fx0 = floor(xin), fy0 = floor(yin);
-        // 2 <= xin < w_in - 3  <=>  2 <= floor(xin) <= w_in - 4 (integer bounds).  The clamp keeps the conversion
-        // defined for huge or NaN coordinates (fmax / fmin return the finite operand), which then fail the test.
-        const int jx = (int)fmin(fmax(fx0, -4.0), 2147483000.0), jy = (int)fmin(fmax(fy0, -4.0), 2147483000.0);
-        inside[k] = (y < h_out) && (unsigned)(jx - 2) < (unsigned)(w_in - 5) && (unsigned)(jy - 2) < (unsigned)(h_in - 5);
-        const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
-        const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
-        ixs[k] = inside[k] ? jx : 0;
-        iys[k] = inside[k] ? jy : 0;
-        wts[k] = load_weights(lut, inside[k] ? px : 0, inside[k] ? py : 0);
-    }
-#pragma unroll
-    for (int k = 0; k < NPX; k++) {
-        const int y = y0 + ly + 4 * (kb + k);
+    for (int k = 0; k < kTileH / 4; k++) {
+        const int y = yb0 + YSTEP * k;
+        const long long xin = (long long)X, yin = (long long)Y;
+        X += dX;
+        Y += dY;
+        // a sane tile keeps the coordinates within +-1e9: the integer part IS the high dword (no 64-bit compares or selects)
+        const int jx = (int)(xin >> 32), jy = (int)(yin >> 32);
+        // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
+        const bool inside = sane && (y < h_out) && (unsigned)(jx - 2) < (unsigned)(w_in - 5) && (unsigned)(jy - 2) < (unsigned)(h_in - 5);
+        const unsigned frx = (unsigned)(unsigned long long)xin, fry = (unsigned)(unsigned long long)yin;
+        const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
+        const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
+        const int ix = inside ? jx : 0, iy = inside ? jy : 0;
+        const Weights wts = load_weights(lut, inside ? px : 0, inside ? py : 0);
         if (y >= h_out) break;
-        const int ix = ixs[k], iy = iys[k];
         float v;
         if (staged) {
             // pixels outside the frame read (and discard) the tile origin
-            const int off = inside[k] ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
+            const int off = inside ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
+            const int stride = inside ? fw : 0;
             const float *t = tile + off;
-            const int stride = inside[k] ? fw : 0;
             // all 18 ds_read2_b32 of the window are issued before the first product
             v2f smp[6][3];
 #pragma unroll
@@ -213,24 +223,23 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                 smp[j][1] = v2f{r[2], r[3]};
                 smp[j][2] = v2f{r[4], r[5]};
             }
-            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+            v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
                 s01 = smp[j][0];
                 s23 = smp[j][1];
                 s45 = smp[j][2];
             });
         } else {
-            v = window_sum(wts[k], [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+            v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
                 s01 = v2f{fetch_global(fv, iy - 2 + j, ix - 2), fetch_global(fv, iy - 2 + j, ix - 1)};
                 s23 = v2f{fetch_global(fv, iy - 2 + j, ix), fetch_global(fv, iy - 2 + j, ix + 1)};
                 s45 = v2f{fetch_global(fv, iy - 2 + j, ix + 2), fetch_global(fv, iy - 2 + j, ix + 3)};
             });
         }
         // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
-        const float res = (inside[k] && v == v) ? v * fs : __builtin_nanf("");
+        const float res = (inside && v == v) ? v * fs : __builtin_nanf("");
         const int64_t o = (f * h_out + y) * (int64_t)w_out + x;
         out[o] = res;
         if (wout) wout[o] = (res == res) ? 1 : 0;
-    }
     }
 }
 
@@ -246,17 +255,20 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
     if (h_in < 6 || w_in < 6 || h_out <= 0 || w_out <= 0) return fail(APGPU_EINVAL, "resample_affine: bad shape");
     if (h_in > 0x3fffffff || w_in > 0x3fffffff || h_out > 0x3fffffff || w_out > 0x3fffffff)
         return fail(APGPU_EUNSUPPORTED, "resample_affine: image sides are limited to 2^30 pixels");
-    if (n_phases < 1 || n_phases > (1 << 20)) return fail(APGPU_EINVAL, "resample_affine: n_phases = %d", n_phases);
+    if (n_phases < 2 || n_phases > (1 << 20) || (n_phases & (n_phases - 1)))
+        return fail(APGPU_EINVAL, "resample_affine: n_phases = %d (a power of two, 2 .. 2^20: the phase is the top bits of a 32-bit fraction)", n_phases);
+    int log2_phases = 0;
+    while ((1 << log2_phases) < n_phases) log2_phases++;
     if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "resample_affine: lut must be 8-byte aligned");
     const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
     if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "resample_affine: output too large");
     hipStream_t st = as_stream(stream);
     const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
     if (mask)
-        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, n_phases, out,
+        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, log2_phases, out,
                            weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     else
-        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, n_phases, out,
+        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, log2_phases, out,
                            weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
     return check_launch("resample_affine");
 }

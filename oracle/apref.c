@@ -890,8 +890,9 @@ void apref_set_num_threads(int n)
  *     (parity with SWarp unpinned); the HIP kernel must match it bit for bit.
  *
  *     For output pixel (x, y) (0-based column, row) of frame f with affine A = affines[f][0..5]:
- *         xin = fma(A0, x, fma(A1, y, A2));  yin = fma(A3, x, fma(A4, y, A5))          (float64)
- *         ix = floor(xin), px = (int)((xin - ix) * n_phases + 0.5)   (0 .. n_phases), same for y
+ *         F[k] = llrint(A[k] * 2^32);  xin = F0 x + F1 y + F2,  yin = F3 x + F4 y + F5      (32.32 fixed point, int64)
+ *         ix = xin >> 32, px = the top log2(n_phases) bits of the fraction, rounded   (0 .. n_phases), same for y
+ *         (n_phases a power of two; round 2 evaluated the transform in float64 - see resample_tile_fx below)
  *         wx = lut[px][0..5], wy = lut[py][0..5]      (row p holds the normalised Lanczos-3 weights of the
  *                                                       taps ix-2 .. ix+3 for a fractional offset p/n_phases)
  *         e_j = fmaf(wx4, s4, fmaf(wx2, s2, wx0 * s0)), o_j = fmaf(wx5, s5, fmaf(wx3, s3, wx1 * s1)),
@@ -901,12 +902,37 @@ void apref_set_num_threads(int n)
  *     If any of the 36 taps lies outside the frame, on a masked pixel (mask != 0) or on a non-finite value,
  *     out = NaN.  weight = 1 where out is not NaN, else 0.
  * --------------------------------------------------------------------------------------------------- */
+/* 32.32 fixed-point statement of the transform (round 3): F[k] = llrint(A[k] * 2^32); an output pixel (x, y) maps to
+ * xin = F0 x + F1 y + F2, yin = F3 x + F4 y + F5 in 64-bit two's-complement arithmetic (exactly reproducible on CPU and GPU,
+ * 4 integer instructions where the float64 evaluation needed ~25); floor = xin >> 32, sub-pixel phase = the top log2(n_phases)
+ * bits of the fraction, rounded to nearest.  A 64 x 16 output tile whose corner coordinates (float64, fma order below) leave
+ * +-1e9 pixels, or whose coefficients are not below 2^30 in magnitude, is undefined (NaN) as a whole. */
+static int resample_tile_fx(const double *A, long x0, long y0, long w_out, long h_out, int64_t *F)
+{
+    const double xa = (double)x0, xb = (double)(x0 + 63 < w_out - 1 ? x0 + 63 : w_out - 1);
+    const double ya = (double)y0, yb = (double)(y0 + 15 < h_out - 1 ? y0 + 15 : h_out - 1);
+    const double cx[4] = {xa, xb, xa, xb}, cy[4] = {ya, ya, yb, yb};
+    for (int k = 0; k < 4; k++) {
+        const double xi = fma(A[0], cx[k], fma(A[1], cy[k], A[2]));
+        const double yi = fma(A[3], cx[k], fma(A[4], cy[k], A[5]));
+        if (!(xi > -1e9 && xi < 1e9 && yi > -1e9 && yi < 1e9)) return 0;
+    }
+    for (int k = 0; k < 6; k++) {
+        if (!(fabs(A[k]) < 1073741824.0)) return 0;
+        F[k] = (int64_t)llrint(A[k] * 4294967296.0);
+    }
+    return 1;
+}
+
 int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
                               const double *affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
                               int n_phases,
                               float *out, uint8_t *weight_out, long h_out, long w_out)
 {
-    if (!frames || !affines || !lut || !out || n_phases < 1) return -1;
+    if (!frames || !affines || !lut || !out || n_phases < 2 || (n_phases & (n_phases - 1))) return -1;
+    int log2p = 0;
+    while ((1 << log2p) < n_phases) log2p++;
+    const int sh = 32 - log2p;
 #pragma omp parallel for collapse(2) schedule(static)
     for (long f = 0; f < n_frames; f++)
         for (long y = 0; y < h_out; y++) {
@@ -918,32 +944,35 @@ int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, lon
                 const double *A = affines + 6 * (per_tile ? (f * tiles_y + y / 16) * tiles_x + x / 64 : f);
                 /* FSCALASTRO_TYPE VARIABLE: output pixel area in input pixels */
                 const float fs = conserve_flux ? (float)((double)fs0 * fabs(fma(A[0], A[4], -(A[1] * A[3])))) : fs0;
-                const double xin = fma(A[0], (double)x, fma(A[1], (double)y, A[2]));
-                const double yin = fma(A[3], (double)x, fma(A[4], (double)y, A[5]));
+                int64_t F[6];
                 float res = NAN;
                 uint8_t wt = 0;
-                /* the 6x6 window must lie inside the frame (also rejects NaN / huge coordinates) */
-                if (xin >= 2.0 && yin >= 2.0 && xin < (double)(w_in - 3) && yin < (double)(h_in - 3)) {
-                    const double fx0 = floor(xin), fy0 = floor(yin);
-                    const long ix = (long)fx0, iy = (long)fy0;
-                    const int px = (int)((xin - fx0) * (double)n_phases + 0.5);
-                    const int py = (int)((yin - fy0) * (double)n_phases + 0.5);
-                    const float *wx = lut + 6 * px, *wy = lut + 6 * py;
-                    int ok = 1;
-                    float ve = 0.f, vo = 0.f;
-                    for (int j = 0; j < 6; j++) {
-                        const long row = iy - 2 + j;
-                        const float *s = src + row * w_in + (ix - 2);
-                        for (int i = 0; i < 6; i++)
-                            if (!isfinite(s[i]) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
-                        const float e = fmaf(wx[4], s[4], fmaf(wx[2], s[2], wx[0] * s[0]));   /* even taps */
-                        const float o = fmaf(wx[5], s[5], fmaf(wx[3], s[3], wx[1] * s[1]));   /* odd taps  */
-                        ve = (j == 0) ? wy[0] * e : fmaf(wy[j], e, ve);
-                        vo = (j == 0) ? wy[0] * o : fmaf(wy[j], o, vo);
+                if (resample_tile_fx(A, (x / 64) * 64, (y / 16) * 16, w_out, h_out, F)) {
+                    const int64_t xin = (int64_t)((uint64_t)F[0] * (uint64_t)x + (uint64_t)F[1] * (uint64_t)y + (uint64_t)F[2]);
+                    const int64_t yin = (int64_t)((uint64_t)F[3] * (uint64_t)x + (uint64_t)F[4] * (uint64_t)y + (uint64_t)F[5]);
+                    const int64_t ix = xin >> 32, iy = yin >> 32;
+                    /* the 6x6 window must lie inside the frame */
+                    if (ix >= 2 && iy >= 2 && ix <= w_in - 4 && iy <= h_in - 4) {
+                        const uint32_t frx = (uint32_t)xin, fry = (uint32_t)yin;
+                        const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
+                        const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
+                        const float *wx = lut + 6 * px, *wy = lut + 6 * py;
+                        int ok = 1;
+                        float ve = 0.f, vo = 0.f;
+                        for (int j = 0; j < 6; j++) {
+                            const long row = iy - 2 + j;
+                            const float *s = src + row * w_in + (ix - 2);
+                            for (int i = 0; i < 6; i++)
+                                if (!isfinite(s[i]) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
+                            const float e = fmaf(wx[4], s[4], fmaf(wx[2], s[2], wx[0] * s[0]));   /* even taps */
+                            const float o = fmaf(wx[5], s[5], fmaf(wx[3], s[3], wx[1] * s[1]));   /* odd taps  */
+                            ve = (j == 0) ? wy[0] * e : fmaf(wy[j], e, ve);
+                            vo = (j == 0) ? wy[0] * o : fmaf(wy[j], o, vo);
+                        }
+                        const float v = ve + vo;
+                        if (ok && v == v) res = v * fs;
+                        wt = (res == res) ? 1 : 0;       /* weight plane: out is defined */
                     }
-                    const float v = ve + vo;
-                    if (ok && v == v) res = v * fs;
-                    wt = (res == res) ? 1 : 0;       /* weight plane: out is defined */
                 }
                 out[(f * h_out + y) * w_out + x] = res;
                 if (weight_out) weight_out[(f * h_out + y) * w_out + x] = wt;

@@ -89,12 +89,11 @@ def test_c5_share_full_size_resample_clip(ops, apref):
     #     whole input frame because the window rows come from neighbouring input rows)
     for f in (2, N - 1):
         for r0 in (0, 4097, H - 16):
-            Ab = A[f].copy()
-            Ab[2] += Ab[1] * r0                              # shift the output origin to row r0
-            Ab[5] += Ab[4] * r0
-            ref, wref = apref.resample_affine(frames[f].cpu().numpy(), [Ab], mask=mask.cpu().numpy(), out_shape=(16, W))
-            assert_biteq(res[f, r0:r0 + 16].cpu().numpy(), ref[0], f'C5 frame {f} rows {r0}..')
-            assert np.array_equal(wt[f, r0:r0 + 16].cpu().numpy(), wref[0])
+            # (the oracle computes the rows 0 .. r0 + 16 with the SAME transform: shifting the origin into the coefficients
+            # would round them differently in the 32.32 fixed-point definition)
+            ref, wref = apref.resample_affine(frames[f].cpu().numpy(), [A[f]], mask=mask.cpu().numpy(), out_shape=(r0 + 16, W))
+            assert_biteq(res[f, r0:r0 + 16].cpu().numpy(), ref[0][r0:], f'C5 frame {f} rows {r0}..')
+            assert np.array_equal(wt[f, r0:r0 + 16].cpu().numpy(), wref[0][r0:])
     # (3) homogeneity: scaling the input by a power of two scales the output exactly
     res2, _ = ops.resample_affine(frames[2:3] * 4.0, A[2:3], mask=mask, weight=False)
     assert torch.equal(torch.nan_to_num(res2[0], nan=-1.0), torch.nan_to_num(res[2] * 4.0, nan=-1.0))
