@@ -246,7 +246,14 @@ def main(argv=None):
         os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('APGPU_BENCH_ONE_GPU_TEST'):
+            # test hook (tests/test_gpu_bench_contract.py): every rank uses GPU 0 and the ranks talk over gloo, so that the
+            # whole N > 1 code path - sharding, striped exchange, hierarchical shards, the row-shard leg, the reporting -
+            # runs with real kernels on a one-GPU box.  The numbers of such a run mean nothing and the line says so.
+            local_rank = 0
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     rccl_world = dist.get_world_size() if dist.is_initialized() else 1
     if rccl_world != args.gpus:
         print('error: process group has %d ranks, --gpus %d' % (rccl_world, args.gpus), file=sys.stderr)
@@ -367,9 +374,9 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         mine = torch.tensor([local_elapsed], dtype=torch.float64, device=dev)
-        allt = torch.empty(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allt, mine)
-        per_rank_ms = [1e3 * float(v) / args.steps for v in allt.cpu()]
+        allt = [torch.empty(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank_ms = [1e3 * float(v.item()) / args.steps for v in allt]
     ms_per_step = 1e3 * elapsed / args.steps
     job_pixels = float(N) * P                                  # input frame pixels of ALL ranks (ragged blocks: summed, not
     if world > 1:                                              # rank 0's share times the world size)
@@ -509,6 +516,7 @@ def main(argv=None):
             'metric': metric, 'value': value, 'unit': 'Mpixels/s',
             'n_gpus': world, 'rccl_world_size': rccl_world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'per_rank_ms': per_rank_ms,
+            **({'one_gpu_test': True} if os.environ.get('APGPU_BENCH_ONE_GPU_TEST') else {}),
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload, 'frames_per_gpu': N, 'frames_total': n_total if not rowshard else N,
                        'height': H, 'width': W, 'parallelism': par},

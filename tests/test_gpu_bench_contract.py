@@ -56,3 +56,28 @@ def test_gpus_flag_must_match_the_world():
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode != 0 and not r.stdout.strip()
+
+
+def test_multi_rank_paths_on_one_gpu():
+    """The N > 1 code of bench.py with REAL kernels on a one-GPU box: APGPU_BENCH_ONE_GPU_TEST puts every rank on GPU 0 and the
+    ranks on gloo, so the built-in launcher, N-sharding, the striped one-all-reduce-per-stripe exchange, the hierarchical
+    shards of --scaling strong, the row-shard leg and every reported field run end to end (the numbers mean nothing)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['APGPU_BENCH_ONE_GPU_TEST'] = '1'
+    base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '128',
+            '--width', '512', '--frames', '16', '--no-cpu-baseline']
+    for extra in ([], ['--exchange', 'f32'], ['--scaling', 'strong', '--total-frames', '64', '--hier-shards', '4'],
+                  ['--parallelism', 'rowshard'], ['--scaling', 'strong', '--total-frames', '64', '--parallelism', 'rowshard']):
+        r = subprocess.run(base + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, (extra, r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['rccl_world_size'] == 2 and len(d['per_rank_ms']) == 2 and d['value'] > 0 and d['one_gpu_test']
+        if '--parallelism' not in extra:
+            assert d['exchange_ms'] is not None and d['exchange_ms'] >= 0 and d['stripes'] >= 1
+            assert d['rowshard']['value'] > 0 and d['rowshard']['ms_per_step'] > 0
+            assert d['exchange_bytes_per_pixel'] == (8 if 'f32' in extra else 16)
+        if '--scaling' in extra and '--parallelism' not in extra:
+            assert d['hier_shards'] == 4 and d['config']['frames_per_gpu'] == 32 and d['config']['frames_total'] == 64
+            assert d['roofline']['kernel'].startswith('stack_sigclip_kernel<16,')        # shards of 16 frames
