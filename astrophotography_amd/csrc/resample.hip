@@ -81,138 +81,51 @@ __device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
     return V.x + V.y;
 }
 
-template <bool HAS_MASK>
-__global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
-                                                             const double *__restrict__ affines, int per_tile, int conserve_flux,
-                                                             const float *__restrict__ fscale, const float *__restrict__ lut,
-                                                             int log2_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
-                                                             int h_in, int w_in, int h_out, int w_out)
+// What thread 0 works out once per workgroup (everything here is tile-uniform): round 2 had every lane redo the float64
+// corner arithmetic - ~60 four-cycle instructions per lane for four output pixels each.
+struct TileInfo {
+    long long F[6];             // the transform in 32.32 fixed point
+    int bx0, by0, fw, fh;       // input footprint staged in LDS
+    int staged, sane, interior; // interior: the footprint lies inside the frame and the tile inside the output rows
+    float fs;                   // flux scale
+};
+
+// The pixels of one lane: column x, rows yb0, yb0 + 4, ...  INTERIOR: every window of the tile lies inside the frame (decided
+// once per workgroup), so the per-pixel frame tests and the selects they feed disappear.
+template <bool INTERIOR>
+__device__ __forceinline__ void resample_pixels(const TileInfo &ti, const FrameView &fv, const float *tile, const float *__restrict__ lut,
+                                                int sh, int x, int yb0, int h_out, int64_t row_stride, float *op, uint8_t *wp)
 {
-    __shared__ float tile[kLdsFloats];
-    __shared__ long long Fs[6];
-    const int64_t f = blockIdx.z;
-    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
-    // one transform per frame, or one per output tile (= per workgroup)
-    const double *A = affines + 6 * (per_tile ? (f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x : f);
-    const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
-    float fs = fscale ? fscale[f] : 1.0f;
-    if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // output pixel area in input pixels
-    FrameView fv;
-    fv.src = frames + f * (int64_t)h_in * w_in;
-    fv.mask = HAS_MASK ? mask : nullptr;
-    fv.h_in = h_in;
-    fv.w_in = w_in;
-
-    // input footprint of the tile: an affine map takes its extremes at the tile corners
-    int bx0 = 0, by0 = 0, fw = 0;
-    bool staged = false, sane = false;
-    {
-        const double xa = (double)x0, xb = (double)(x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1);
-        const double ya = (double)y0, yb = (double)(y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1);
-        double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
-        const double cx[4] = {xa, xb, xa, xb}, cy[4] = {ya, ya, yb, yb};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double xi = fma(a0, cx[k], fma(a1, cy[k], a2));
-            const double yi = fma(a3, cx[k], fma(a4, cy[k], a5));
-            mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
-            mny = fmin(mny, yi); mxy = fmax(mxy, yi);
-        }
-        // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
-        // fixed-point evaluation below is then exact: the true sums fit 64 bits); false for NaN coefficients
-        const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
-        sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
-               (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
-        if (threadIdx.x < 6) Fs[threadIdx.x] = sane ? __double2ll_rn(A[threadIdx.x] * 4294967296.0) : 0;
-        if (sane) {
-            // (one pixel of slack on every side: the corners are evaluated in float64, the pixels in fixed point, and the two
-            // can fall on different sides of an integer)
-            bx0 = (int)floor(mnx) - 3;
-            by0 = (int)floor(mny) - 3;
-            const int w = (int)floor(mxx) + 4 - bx0 + 1, h = (int)floor(mxy) + 4 - by0 + 1;
-            if (w > 0 && h > 0 && w <= kLdsFloats && h <= kLdsFloats && w * h <= kLdsFloats) {
-                staged = true;
-                fw = w;
-                // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
-                // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
-                // a trip are in flight together; validity is applied afterwards
-                const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-                // HAS_MASK is a template flag: as a run-time test every mask load became a branch followed by a
-                // full wait, which serialised the whole batch of loads
-                constexpr int RU = 3;
-                for (int r0 = wave; r0 < h; r0 += 4 * RU) {
-                    for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
-                        float val[RU][2];
-                        uint8_t mk[RU][2];
-#pragma unroll
-                        for (int u = 0; u < RU; u++) {
-                            const int row = by0 + r0 + 4 * u;
-                            const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
-                            const float *rp = fv.src + (int64_t)rc * w_in;
-                            const uint8_t *mp = HAS_MASK ? mask + (int64_t)rc * w_in : nullptr;
-#pragma unroll
-                            for (int q = 0; q < 2; q++) {
-                                const int col = bx0 + c0 + q * kWave + lane;
-                                const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
-                                val[u][q] = rp[cc];
-                                if constexpr (HAS_MASK) mk[u][q] = mp[cc];
-                                else mk[u][q] = 0;
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < RU; u++) {
-                            const int r = r0 + 4 * u;
-                            const int row = by0 + r;
-                            const bool row_ok = row >= 0 && row < h_in;
-#pragma unroll
-                            for (int q = 0; q < 2; q++) {
-                                const int c = c0 + q * kWave + lane;
-                                const int col = bx0 + c;
-                                const bool good = row_ok && col >= 0 && col < w_in && (fabsf(val[u][q]) < __builtin_inff()) && mk[u][q] == 0;
-                                if (r < h && c < fw) tile[r * fw + c] = good ? val[u][q] : __builtin_nanf("");
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
-    const int x = x0 + lx;
-    if (x >= w_out) return;
-    const long long F0 = Fs[0], F1 = Fs[1], F2 = Fs[2], F3 = Fs[3], F4 = Fs[4], F5 = Fs[5];
-    const int sh = 32 - log2_phases;
-    // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12
-    const int yb0 = y0 + ly;
-    constexpr int YSTEP = 4;
+    const long long F0 = ti.F[0], F1 = ti.F[1], F2 = ti.F[2], F3 = ti.F[3], F4 = ti.F[4], F5 = ti.F[5];
+    const int bx0 = ti.bx0, by0 = ti.by0, fw = ti.fw;
+    const bool staged = ti.staged != 0, sane = ti.sane != 0;
+    const float fs = ti.fs;
     // 64-bit two's-complement sums: exact, because the true coordinates fit (sane), whatever the partial products do
     unsigned long long X = (unsigned long long)F0 * (unsigned long long)(long long)x + (unsigned long long)F1 * (unsigned long long)(long long)yb0 + (unsigned long long)F2;
     unsigned long long Y = (unsigned long long)F3 * (unsigned long long)(long long)x + (unsigned long long)F4 * (unsigned long long)(long long)yb0 + (unsigned long long)F5;
-    const unsigned long long dX = (unsigned long long)F1 * YSTEP, dY = (unsigned long long)F4 * YSTEP;
+    const unsigned long long dX = (unsigned long long)F1 * 4ull, dY = (unsigned long long)F4 * 4ull;
     // One pixel per trip (not unrolled): residency hides latency better than batching (round 1 measurement).
 #pragma unroll 1
     for (int k = 0; k < kTileH / 4; k++) {
-        const int y = yb0 + YSTEP * k;
+        const int y = yb0 + 4 * k;
         const long long xin = (long long)X, yin = (long long)Y;
         X += dX;
         Y += dY;
         // a sane tile keeps the coordinates within +-1e9: the integer part IS the high dword (no 64-bit compares or selects)
         const int jx = (int)(xin >> 32), jy = (int)(yin >> 32);
-        // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
-        const bool inside = sane && (y < h_out) && (unsigned)(jx - 2) < (unsigned)(w_in - 5) && (unsigned)(jy - 2) < (unsigned)(h_in - 5);
         const unsigned frx = (unsigned)(unsigned long long)xin, fry = (unsigned)(unsigned long long)yin;
         const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
         const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
-        const int ix = inside ? jx : 0, iy = inside ? jy : 0;
-        const Weights wts = load_weights(lut, inside ? px : 0, inside ? py : 0);
-        if (y >= h_out) break;
+        // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
+        const bool inside = INTERIOR || (sane && (y < h_out) && (unsigned)(jx - 2) < (unsigned)(fv.w_in - 5) && (unsigned)(jy - 2) < (unsigned)(fv.h_in - 5));
+        const int ix = (INTERIOR || inside) ? jx : 0, iy = (INTERIOR || inside) ? jy : 0;
+        const Weights wts = load_weights(lut, (INTERIOR || inside) ? px : 0, (INTERIOR || inside) ? py : 0);
+        if (!INTERIOR && y >= h_out) break;
         float v;
-        if (staged) {
+        if (INTERIOR || staged) {
             // pixels outside the frame read (and discard) the tile origin
-            const int off = inside ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
-            const int stride = inside ? fw : 0;
+            const int off = (INTERIOR || inside) ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
+            const int stride = (INTERIOR || inside) ? fw : 0;
             const float *t = tile + off;
             // all 18 ds_read2_b32 of the window are issued before the first product
             v2f smp[6][3];
@@ -236,11 +149,134 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             });
         }
         // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
-        const float res = (inside && v == v) ? v * fs : __builtin_nanf("");
-        const int64_t o = (f * h_out + y) * (int64_t)w_out + x;
-        out[o] = res;
-        if (wout) wout[o] = (res == res) ? 1 : 0;
+        const float res = ((INTERIOR || inside) && v == v) ? v * fs : __builtin_nanf("");
+        *op = res;
+        op += row_stride;
+        if (wp) {
+            *wp = (res == res) ? 1 : 0;
+            wp += row_stride;
+        }
     }
+}
+
+template <bool HAS_MASK>
+__global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
+                                                             const double *__restrict__ affines, int per_tile, int conserve_flux,
+                                                             const float *__restrict__ fscale, const float *__restrict__ lut,
+                                                             int log2_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
+                                                             int h_in, int w_in, int h_out, int w_out)
+{
+    __shared__ float tile[kLdsFloats];
+    __shared__ TileInfo ti;
+    const int64_t f = blockIdx.z;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    FrameView fv;
+    fv.src = frames + f * (int64_t)h_in * w_in;
+    fv.mask = HAS_MASK ? mask : nullptr;
+    fv.h_in = h_in;
+    fv.w_in = w_in;
+    if (threadIdx.x == 0) {
+        // one transform per frame, or one per output tile (= per workgroup)
+        const double *A = affines + 6 * (per_tile ? (f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x : f);
+        const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
+        float fs = fscale ? fscale[f] : 1.0f;
+        if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // output pixel area in input pixels
+        ti.fs = fs;
+        // input footprint of the tile: an affine map takes its extremes at the tile corners
+        const double xa = (double)x0, xb = (double)(x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1);
+        const double ya = (double)y0, yb = (double)(y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1);
+        double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
+        const double cx[4] = {xa, xb, xa, xb}, cy[4] = {ya, ya, yb, yb};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double xi = fma(a0, cx[k], fma(a1, cy[k], a2));
+            const double yi = fma(a3, cx[k], fma(a4, cy[k], a5));
+            mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
+            mny = fmin(mny, yi); mxy = fmax(mxy, yi);
+        }
+        // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
+        // fixed-point evaluation is then exact: the true sums fit 64 bits); false for NaN coefficients
+        const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
+        const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
+                          (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
+#pragma unroll
+        for (int k = 0; k < 6; k++) ti.F[k] = sane ? __double2ll_rn(A[k] * 4294967296.0) : 0;
+        int bx0 = 0, by0 = 0, w = 0, h = 0;
+        bool staged = false;
+        if (sane) {
+            // (one pixel of slack on every side: the corners are evaluated in float64, the pixels in fixed point, and the two
+            // can fall on different sides of an integer)
+            bx0 = (int)floor(mnx) - 3;
+            by0 = (int)floor(mny) - 3;
+            w = (int)floor(mxx) + 4 - bx0 + 1;
+            h = (int)floor(mxy) + 4 - by0 + 1;
+            staged = w > 0 && h > 0 && w <= kLdsFloats && h <= kLdsFloats && w * h <= kLdsFloats;
+        }
+        ti.bx0 = bx0; ti.by0 = by0; ti.fw = w; ti.fh = h;
+        ti.staged = staged;
+        ti.sane = sane;
+        ti.interior = staged && bx0 >= 0 && by0 >= 0 && bx0 + w <= w_in && by0 + h <= h_in && y0 + kTileH <= h_out;
+    }
+    __syncthreads();
+    const bool staged = ti.staged != 0, interior = ti.interior != 0;
+    if (staged) {
+        const int bx0 = ti.bx0, by0 = ti.by0, fw = ti.fw, h = ti.fh;
+        // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
+        // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
+        // a trip are in flight together; validity is applied afterwards
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
+        // HAS_MASK is a template flag: as a run-time test every mask load became a branch followed by a
+        // full wait, which serialised the whole batch of loads
+        constexpr int RU = 3;
+        for (int r0 = wave; r0 < h; r0 += 4 * RU) {
+            for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
+                float val[RU][2];
+                uint8_t mk[RU][2];
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int row = by0 + r0 + 4 * u;
+                    const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
+                    const float *rp = fv.src + (int64_t)rc * w_in;
+                    const uint8_t *mp = HAS_MASK ? mask + (int64_t)rc * w_in : nullptr;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int col = bx0 + c0 + q * kWave + lane;
+                        const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
+                        val[u][q] = rp[cc];
+                        if constexpr (HAS_MASK) mk[u][q] = mp[cc];
+                        else mk[u][q] = 0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; u++) {
+                    const int r = r0 + 4 * u;
+                    const int row = by0 + r;
+                    const bool row_ok = row >= 0 && row < h_in;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int c = c0 + q * kWave + lane;
+                        const int col = bx0 + c;
+                        const bool good = row_ok && col >= 0 && col < w_in && (fabsf(val[u][q]) < __builtin_inff()) && mk[u][q] == 0;
+                        if (r < h && c < fw) tile[r * fw + c] = good ? val[u][q] : __builtin_nanf("");
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12
+    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int x = x0 + lx;
+    if (x >= w_out) return;
+    const int yb0 = y0 + ly;
+    const int sh = 32 - log2_phases;
+    const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;
+    float *op = out + o0;
+    uint8_t *wp = wout ? wout + o0 : nullptr;
+    const int64_t row_stride = 4 * (int64_t)w_out;
+    if (interior) resample_pixels<true>(ti, fv, tile, lut, sh, x, yb0, h_out, row_stride, op, wp);
+    else resample_pixels<false>(ti, fv, tile, lut, sh, x, yb0, h_out, row_stride, op, wp);
 }
 
 }  // namespace
