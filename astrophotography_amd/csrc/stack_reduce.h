@@ -475,17 +475,20 @@ __device__ __forceinline__ void clip_exact(const float (&v)[NP], const int n, co
     // the keep / reject decisions need, and the moments are summed afresh about a pivot inside the survivors.
     double refresh_below = ldexp((double)n * Q0, -22);
 
-    while (wave_any(active)) {
+    // The LAST pass may itself have trimmed a value that dominated the sums (maxiters reached while huge outliers were still
+    // being peeled off: five outliers of 1e16 .. 1e29 times the spread with maxiters = 5 - round 3's adversarial test): what
+    // the subtraction leaves of S is then rounding noise of the removed value.  So once no lane is active any more the loop
+    // makes one more visit (fin) that only repeats the refresh test, on every lane's final range.
+    for (;;) {
+        const bool fin = !wave_any(active);
         const int a0 = st.a, b0 = st.b;
-        double V = 0.0;
-        if (active) {
-            st.nn = (double)(st.b - st.a);
-            V = fma(st.nn, st.Q, -(st.S * st.S));            // n^2 * variance
-        }
+        const double nn = (double)(st.b - st.a);
+        double V = fma(nn, st.Q, -(st.S * st.S));            // n^2 * variance
+        if (active) st.nn = nn;
 #ifdef APGPU_VARIANT_NO_REFRESH
         const bool refresh = false;
 #else
-        const bool refresh = active && (st.b > st.a) && (V < refresh_below);
+        const bool refresh = (active || fin) && (st.b > st.a) && (V < refresh_below);
 #endif
         if (wave_any(refresh)) {                             // rare: see above
             float p1, p2;
@@ -510,10 +513,11 @@ __device__ __forceinline__ void clip_exact(const float (&v)[NP], const int n, co
                 st.c = cn;
                 c = cn;
                 cf = p1;
-                V = fma(st.nn, Qn, -(Sn * Sn));
-                refresh_below = ldexp(st.nn * Qn, -22);
+                V = fma(nn, Qn, -(Sn * Sn));
+                refresh_below = ldexp(nn * Qn, -22);
             }
         }
+        if (fin) break;
         if (active) {
             const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
             st.cen = use_median ? med : c;
@@ -725,19 +729,18 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     int it = 0;
     double refresh_below = ldexp((double)n * st.Q, -22);     // see the lean kernel: when to sum the moments afresh
 
-    while (wave_any(active)) {
+    for (;;) {
+        const bool fin = !wave_any(active);                  // one last visit for the refresh test alone (see clip_exact)
         const int a0 = st.a, b0 = st.b;
         const float m1 = col_read<NP, B>(col, (st.a + st.b - 1) >> 1);
         const float m2 = col_read<NP, B>(col, (st.a + st.b) >> 1);
         const double med = 0.5 * ((double)m1 + (double)m2);  // wirth_median (even: mean of the two)
         double mad = 0.0;
-        if (use_mad) mad = mad_std_window<NP, B>(col, active, st.a, st.b, med);
-        double V = 0.0;
-        if (active) {
-            st.nn = (double)(st.b - st.a);
-            V = fma(st.nn, st.Q, -(st.S * st.S));            // n^2 * variance
-        }
-        const bool refresh = active && (st.b > st.a) && (V < refresh_below);
+        if (use_mad && !fin) mad = mad_std_window<NP, B>(col, active, st.a, st.b, med);
+        const double nn = (double)(st.b - st.a);
+        double V = fma(nn, st.Q, -(st.S * st.S));            // n^2 * variance
+        if (active) st.nn = nn;
+        const bool refresh = (active || fin) && (st.b > st.a) && (V < refresh_below);
         if (wave_any(refresh)) {
             const double cn = refresh ? (double)m1 : st.c;
             double Sn = 0.0, Qn = 0.0;
@@ -761,10 +764,11 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
                 st.c = cn;
                 c = cn;
                 cf = m1;
-                V = fma(st.nn, Qn, -(Sn * Sn));
-                refresh_below = ldexp(st.nn * Qn, -22);
+                V = fma(nn, Qn, -(Sn * Sn));
+                refresh_below = ldexp(nn * Qn, -22);
             }
         }
+        if (fin) break;
         if (active) {
             st.cen = use_median ? med : c;
             if (use_mad) {

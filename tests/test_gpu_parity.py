@@ -726,3 +726,46 @@ def test_sigclip_global_median_neighbours(ops, apref):
             # negative / mixed-sign medians and constant data
             check(rng.permutation(np.concatenate([rng.uniform(-3, -1, half), rng.uniform(-1, 4, n - half)]).astype(dt)), (dt.__name__, n, 'mixed'))
             check(np.full(n, -2.75, dt), (dt.__name__, n, 'constant'))
+
+
+def test_fast32_path_guards_on_adversarial_columns(ops, apref):
+    """The float32 fast path of the lean stack kernels (clip_fast32 / stack_chunks_kernel) against the float64 path
+    (exact=True) and the oracle on columns built to hit its guards: means near zero against the spread (the mean-accuracy
+    guard), outliers of 1e4..1e30 times the spread, constant and two-level columns, spreads of a few ulp, negative and
+    mixed-sign values, values needing more than four trims per side, columns sitting next to a clip bound.  Survivor
+    counts must be identical everywhere, means within 1 ulp."""
+    rng = np.random.default_rng(2025)
+    H, W = 16, 256
+    for N in (16, 32, 64, 96, 160, 256):
+        cols = []
+        base = rng.normal(0.0, 1.0, (N, H, W))
+        level = np.array([0.0, 1e-3, 1.0, 50.0, 500.0, 5e4, -300.0, 1e-20])[rng.integers(0, 8, (H, W))]
+        spread = np.array([1e-6, 1e-3, 1.0, 30.0, 300.0])[rng.integers(0, 5, (H, W))]
+        cube = level[None] + spread[None] * base
+        kind = rng.integers(0, 8, (H, W))
+        k = min(N // 3, 9)
+        for f in range(k):                                                          # up to nine outliers on one side
+            m = (kind == 1) & (rng.random((H, W)) < 0.7)
+            cube[f][m] += (10.0 ** rng.uniform(1, 30, m.sum())) * spread[m]
+        m = kind == 2
+        cube[:, m] = level[m]                                                       # constant columns
+        m = kind == 3
+        two = rng.random((N, H, W)) < 0.5
+        cube[:, m] = np.where(two[:, m], level[m], level[m] + spread[m])            # two discrete levels
+        m = kind == 4
+        cube[:, m] = np.float32(level[m]) * (1 + np.float32(2.0 ** -22) * rng.integers(-3, 4, (N, m.sum())))   # a few ulp of spread
+        m = kind == 5
+        cube[:5, m] -= 4.0 * spread[m] * rng.uniform(0.9, 1.6, (5, m.sum()))         # several values near the lower 3-sigma bound
+        cube[5:9, m] += 4.0 * spread[m] * rng.uniform(0.9, 1.6, (4, m.sum()))
+        cube = cube.astype(np.float32)
+        d = dev(cube, ops)
+        for sigma, maxiters in ((3.0, 5), (2.0, None), (4.5, 2)):
+            with np.errstate(all='ignore'):
+                ref = apref.stack_sigclip(cube, sigma=sigma, maxiters=maxiters)
+            fast = ops.stack_sigclip(d, sigma=sigma, maxiters=maxiters, outputs=('mean', 'count'))
+            exact = ops.stack_sigclip(d, sigma=sigma, maxiters=maxiters, outputs=('mean', 'count'), exact=True)
+            what = f'N={N} sigma={sigma} maxiters={maxiters}'
+            assert np.array_equal(host(fast['count']), ref['count']), what
+            assert np.array_equal(host(exact['count']), ref['count']), what
+            assert_ulp(host(exact['mean']), ref['mean'].astype(np.float32), 1, what + ' float64 path')
+            assert_ulp(host(fast['mean']), ref['mean'].astype(np.float32), 1, what + ' float32 fast path')
