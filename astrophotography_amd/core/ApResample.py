@@ -115,7 +115,7 @@ class ApResample:
             if self.oversampling > 1:
                 n = self.oversampling
                 fine_wcs, fine_shape = out_wcs.oversampled(n), (out_shape[0] * n, out_shape[1] * n)
-                fine_affines = np.stack([apwcs.tile_affines(fine_wcs, w, fine_shape) for w in in_wcs], 0)
+                fine_affines = np.stack([apwcs.tile_affines(fine_wcs, w, fine_shape, tile_scale=n) for w in in_wcs], 0)
                 affines = np.zeros((len(in_wcs), 6))
             else:
                 affines = np.stack([apwcs.tile_affines(out_wcs, w, out_shape) for w in in_wcs], 0)

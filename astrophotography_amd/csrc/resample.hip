@@ -1,32 +1,88 @@
 // resample.hip - F3: affine Lanczos-3 resample of registered frames on gfx950 (the step the reference
 // delegates to SWarp: scripts/resample_all.sh:123-131 RESAMPLING_TYPE LANCZOS3, :298 FSCALE = 1/EXPTIME,
-// :330-342 the swarp call).  There is no in-tree arithmetic to match; the definition is this build's own and
-// is restated on the CPU in oracle/apref.c (apref_resample_affine_f32) - the two agree bit for bit.
+// :112 / :339 OVERSAMPLING 4, :330-342 the swarp call).  There is no in-tree arithmetic to match; the definition is this
+// build's own and is restated on the CPU in oracle/apref.c (apref_resample_affine_f32, apref_resample_oversampled_f32) -
+// the two agree bit for bit.
 //
 //   F[k] = llrint(A[k] * 2^32); xin = F0 x + F1 y + F2, yin = F3 x + F4 y + F5   (32.32 fixed point, output -> input: exactly
-//   reproducible, and a 64-bit add per row where the float64 evaluation of round 2 cost ~25 four-cycle instructions per pixel)
+//   reproducible, a 64-bit add per row)
 //   ix = xin >> 32, phase px = top log2(n_phases) bits of the fraction, rounded; taps ix-2 .. ix+3 weighted by lut[px][0..5]
 //   (a host-built table of normalised Lanczos-3 weights), rows combined by lut[py]; even / odd fmaf chains in a
 //   fixed order (= packed float32 arithmetic); result * fscale[f].  Any tap outside the frame, masked or non-finite -> NaN, weight 0.
+//   OVERSAMPLING n: the transform is that of the n-times finer grid, every output pixel the float64 mean of its n x n
+//   sub-samples in row-major order (= apgpu_block_mean_f32 of the fine resample, without the fine image ever existing).
 //
-// (Round 3 also built a variant in which a lane produces four CONSECUTIVE rows and keeps its 6 x 6 window in registers between
-// them - one new window row per pixel, 10 instead of 18 LDS reads - behind a wave vote on "same columns, next row": the
-// register shuffling around the vote cost more VALU work (151 against 133 instructions per pixel) than the LDS reads it
-// saved: 6.2 ms against 5.2 ms per 64 x 4096^2, not kept.  The kernel is VALU-bound: 133 instructions per pixel.)
-//
-// A workgroup produces a 64 x 16 output tile.  For registration-sized transforms (small rotation / shift /
-// scale near 1) the tile's input footprint is ~70 x 22 pixels: it is staged in LDS once (coalesced runs,
-// invalid pixels stored as NaN) and the 36 taps of every output pixel are LDS reads, so HBM traffic is one
-// read of the input (+ ~40 % halo, mostly L2 hits) and one write of the output: 8 B per pixel.  A footprint
-// that does not fit (strong shear / large scale) takes the direct-gather path, same arithmetic.
+// Two launches.  resample_tiles_kernel works out, once per 64 x 16 output tile, what every lane of that tile's workgroup
+// needs: the fixed-point coefficients, the flux scale, the input footprint (exact: the integer corner coordinates) and which
+// path the tile takes - 64 bytes per tile that the main kernel reads with ONE scalar load (rounds 1-2 did the float64 corner
+// arithmetic in every lane, round 3 first in thread 0 behind an LDS broadcast and a barrier).
+// The main kernel stages the footprint in LDS and evaluates the taps from there:
+//   FAST tiles (the window of every pixel inside the frame, footprint at most 80 x 32: registration-sized rotations up to
+//   ~8 degrees, frames below 2^30 pixels): fixed LDS pitch of 80 floats and TWO copies of the footprint, the second shifted
+//   by one float, so that every lane reads its six taps of a row as three ALIGNED ds_read_b64 from the copy that matches the
+//   parity of its first column - 256 B/clk where ds_read2_b32 gets 128 (MI355X guide, LDS table) - with all 18 reads of a
+//   window off one address register (row j at the immediate offset 320 j).  The second copy starts 32 banks after the first
+//   (offset = 32 mod 64 dwords): an even-start lane and its odd-start neighbour read the same dword offsets of different
+//   copies, and land on disjoint banks.  Footprint rows are fetched through a bounds-checked buffer resource (no clamps),
+//   table rows and output stores go through buffer instructions with 32-bit offsets.
+//   Other tiles (frame border, strong shear / minification, giant frames): the general path - footprint at its own pitch up
+//   to 16 KB with validity applied at the fill, or a direct gather from global memory - same arithmetic.
+// HBM traffic is one read of the input (+ halo, mostly L2 hits) and one write of the output: 8 B per pixel.
 #include "common.h"
 
 namespace {
 using namespace apgpu;
 
 constexpr int kTileW = APGPU_RESAMPLE_TILE_W, kTileH = APGPU_RESAMPLE_TILE_H;
-constexpr int kLdsFloats = 4096;               // 16 KB footprint buffer: eight workgroups (all 32 wave slots) per CU
+constexpr int kGenericFloats = 4096;                 // general path: footprint up to 16 KB at its own pitch
+constexpr int kFastPitch = 80, kFastRows = 32;       // fast path: fixed pitch (320 B: row j of a window = immediate offset)
+constexpr int kFastCopy = kFastPitch * kFastRows;    // 2560 floats per copy
+constexpr int kFastOffB = kFastCopy + 32;            // copy B (shifted by one float) starts 32 banks after copy A
+constexpr int kLdsFloats = kFastOffB + kFastCopy;    // 20.1 KB: seven workgroups per CU
+static_assert(kFastOffB % 64 == 32 && kFastPitch % 2 == 0 && kLdsFloats >= kGenericFloats, "LDS layout");
+constexpr unsigned kRsrcFlags = 0x00020000;          // raw buffer, 32-bit elements (gfx9 family word 3)
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// Raw buffer instructions by their LLVM names (this clang's __builtin_amdgcn_raw_buffer_load_b128 / _b64 emit a ONE-dword
+// load): resource in four SGPRs, 32-bit byte offset per lane, bounds-checked against the resource's size.
+__device__ float buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ v2f buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ v4f buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ char buffer_load_i8(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i8");
+__device__ void buffer_store_f32(float v, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void buffer_store_i8(char v, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
+
+// p and bytes are wave-uniform
+__device__ __forceinline__ v4i make_rsrc(const void *p, unsigned bytes)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));     // stride 0
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = (int)kRsrcFlags;
+    return r;
+}
+#ifdef APGPU_VARIANT_RESAMPLE_READ2
+typedef __attribute__((address_space(3))) const v2f *lds_pair_p;            // the compiler pairs them into ds_read2_b64
+#else
+typedef __attribute__((address_space(3))) const volatile v2f *lds_pair_p;   // volatile: one ds_read_b64 each (256 B/clk)
+#endif
+#ifndef APGPU_RESAMPLE_UNROLL
+#define APGPU_RESAMPLE_UNROLL 1
+#endif
+
+enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8 };
+
+// What the tile pass works out per output tile (everything tile-uniform), 64 bytes.
+struct alignas(64) TileRec {
+    long long F[6];             // the transform in 32.32 fixed point (of the fine grid when oversampling)
+    int bx0, by0;               // first input column / row of the footprint
+    unsigned dims;              // footprint width | height << 13 | flags << 26
+    float fs;                   // flux scale
+};
 
 struct FrameView {
     const float *src;
@@ -63,6 +119,24 @@ __device__ __forceinline__ Weights load_weights(const float *__restrict__ lut, i
     return w;
 }
 
+// the same rows through a buffer resource: one 32-bit offset per row, 16 + 8 bytes
+__device__ __forceinline__ Weights load_weights(v4i lut, int px, int py)
+{
+    const int ox = (int)__umul24((unsigned)px, 24u), oy = (int)__umul24((unsigned)py, 24u);
+    const v4f a = buffer_load_v4f32(lut, ox, 0, 0);
+    const v2f b = buffer_load_v2f32(lut, ox + 16, 0, 0);
+    const v4f c = buffer_load_v4f32(lut, oy, 0, 0);
+    const v2f d = buffer_load_v2f32(lut, oy + 16, 0, 0);
+    Weights w;
+    w.wx01 = v2f{a.x, a.y};
+    w.wx23 = v2f{a.z, a.w};
+    w.wx45 = b;
+    w.wy01 = v2f{c.x, c.y};
+    w.wy23 = v2f{c.z, c.w};
+    w.wy45 = d;
+    return w;
+}
+
 template <typename RowFn>
 __device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
 {
@@ -81,75 +155,204 @@ __device__ __forceinline__ float window_sum(const Weights &w, RowFn row)
     return V.x + V.y;
 }
 
-// What thread 0 works out once per workgroup (everything here is tile-uniform): round 2 had every lane redo the float64
-// corner arithmetic - ~60 four-cycle instructions per lane for four output pixels each.
-struct TileInfo {
-    long long F[6];             // the transform in 32.32 fixed point
-    int bx0, by0, fw, fh;       // input footprint staged in LDS
-    int staged, sane, interior; // interior: the footprint lies inside the frame and the tile inside the output rows
-    float fs;                   // flux scale
+__device__ __forceinline__ void phases(unsigned long long X, unsigned long long Y, int sh, int &jx, int &jy, int &px, int &py)
+{
+    // a sane tile keeps the coordinates within +-1e9: the integer part IS the high dword (no 64-bit compares or selects)
+    jx = (int)((long long)X >> 32);
+    jy = (int)((long long)Y >> 32);
+    const unsigned frx = (unsigned)X, fry = (unsigned)Y;
+    px = (int)(((frx >> (sh - 1)) + 1u) >> 1);              // = (frx >> sh) + ((frx >> (sh - 1)) & 1)
+    py = (int)(((fry >> (sh - 1)) + 1u) >> 1);
+}
+
+struct TileCtx {
+    long long F[6];
+    int bx0, by0, fw, fh;
+    bool staged, sane;
+    float fs;
 };
 
-// The pixels of one lane: column x, rows yb0, yb0 + 4, ...  INTERIOR: every window of the tile lies inside the frame (decided
-// once per workgroup), so the per-pixel frame tests and the selects they feed disappear.
-template <bool INTERIOR>
-__device__ __forceinline__ void resample_pixels(const TileInfo &ti, const FrameView &fv, const float *tile, const float *__restrict__ lut,
-                                                int sh, int x, int yb0, int h_out, int64_t row_stride, float *op, uint8_t *wp)
+// ---- FAST tiles ------------------------------------------------------------------------------------------------------
+// One sample in two steps, so that the table rows of the NEXT sample are on their way while this one is evaluated:
+// prep: phases, the two table rows (buffer loads), the LDS address; eval: 18 aligned LDS reads, 20 packed multiply-adds.
+// cxo / cyo: input column / row of the footprint's origin + 2 (the window starts two taps before floor()).
+struct FastPrep {
+    Weights w;
+    int idx;                    // float index of the window's first pair (even)
+};
+
+__device__ __forceinline__ FastPrep prep_fast(unsigned long long X, unsigned long long Y, int sh, int cxo, int cyo, v4i lut)
 {
-    const long long F0 = ti.F[0], F1 = ti.F[1], F2 = ti.F[2], F3 = ti.F[3], F4 = ti.F[4], F5 = ti.F[5];
-    const int bx0 = ti.bx0, by0 = ti.by0, fw = ti.fw;
-    const bool staged = ti.staged != 0, sane = ti.sane != 0;
-    const float fs = ti.fs;
+    int jx, jy, px, py;
+    phases(X, Y, sh, jx, jy, px, py);
+    FastPrep p;
+    p.w = load_weights(lut, px, py);
+    const unsigned s = (unsigned)(jx - cxo), r = (unsigned)(jy - cyo);   // first column / row of the window inside the footprint
+    // an odd first column reads copy B, where element k holds the footprint's k + 1: the same six taps from the even k = s - 1
+    p.idx = (int)(__umul24(r, (unsigned)kFastPitch) + s + __umul24(s & 1u, (unsigned)(kFastOffB - 1)));
+    return p;
+}
+
+// the value before the flux scale
+__device__ __forceinline__ float eval_fast(const FastPrep &p, const float *tile)
+{
+    lds_pair_p t = (lds_pair_p)(tile + p.idx);
+    v2f smp[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        smp[j][0] = t[j * (kFastPitch / 2) + 0];
+        smp[j][1] = t[j * (kFastPitch / 2) + 1];
+        smp[j][2] = t[j * (kFastPitch / 2) + 2];
+    }
+    return window_sum(p.w, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+        s01 = smp[j][0];
+        s23 = smp[j][1];
+        s45 = smp[j][2];
+    });
+}
+
+template <bool OVERSAMPLED>
+__device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, v4i lut, int sh, int os, int x, int yb0,
+                                            v4i orsrc, v4i wrsrc, bool want_w, int ooff, int ostep)
+{
+    const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
+    const int cxo = tc.bx0 + 2, cyo = tc.by0 + 2;
+    const float fs = tc.fs;
+    const unsigned long long n = OVERSAMPLED ? (unsigned long long)os : 1ull;
+    const unsigned long long u0 = (unsigned long long)(long long)x * n, v0 = (unsigned long long)(long long)yb0 * n;
     // 64-bit two's-complement sums: exact, because the true coordinates fit (sane), whatever the partial products do
-    unsigned long long X = (unsigned long long)F0 * (unsigned long long)(long long)x + (unsigned long long)F1 * (unsigned long long)(long long)yb0 + (unsigned long long)F2;
-    unsigned long long Y = (unsigned long long)F3 * (unsigned long long)(long long)x + (unsigned long long)F4 * (unsigned long long)(long long)yb0 + (unsigned long long)F5;
-    const unsigned long long dX = (unsigned long long)F1 * 4ull, dY = (unsigned long long)F4 * 4ull;
+    unsigned long long X = F0 * u0 + F1 * v0 + F2;
+    unsigned long long Y = F3 * u0 + F4 * v0 + F5;
+    const unsigned long long dX = F1 * (4ull * n), dY = F4 * (4ull * n);
+    if constexpr (!OVERSAMPLED) {
+        FastPrep nxt = prep_fast(X, Y, sh, cxo, cyo, lut);
+#pragma unroll
+        for (int k = 0; k < kTileH / 4; k++) {
+            const FastPrep cur = nxt;
+            if (k + 1 < kTileH / 4) {
+                X += dX;
+                Y += dY;
+                nxt = prep_fast(X, Y, sh, cxo, cyo, lut);
+            }
+            const float v = eval_fast(cur, tile);
+            const float res = (v == v) ? v * fs : __builtin_nanf("");
+            buffer_store_f32(res, orsrc, ooff, 0, 0);
+            if (want_w) buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
+            ooff += ostep;
+        }
+    } else {
+        const double inv = 1.0 / (double)(os * os);
+#pragma unroll 1
+        for (int k = 0; k < kTileH / 4; k++) {
+            double acc = 0.0;                                     // a NaN sub-sample makes the sum, and the pixel, NaN
+            unsigned long long Xa = X, Ya = Y;
+#pragma unroll 1
+            for (int a = 0; a < os; a++) {
+                unsigned long long Xb = Xa, Yb = Ya;
+#pragma unroll 1
+                for (int b = 0; b < os; b++) {
+                    const FastPrep cur = prep_fast(Xb, Yb, sh, cxo, cyo, lut);
+                    const float v = eval_fast(cur, tile);
+                    acc += (double)((v == v) ? v * fs : __builtin_nanf(""));
+                    Xb += F0;
+                    Yb += F3;
+                }
+                Xa += F1;
+                Ya += F4;
+            }
+            const float res = (float)(acc * inv);
+            X += dX;
+            Y += dY;
+            buffer_store_f32(res, orsrc, ooff, 0, 0);
+            if (want_w) buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
+            ooff += ostep;
+        }
+    }
+}
+
+// ---- general tiles ---------------------------------------------------------------------------------------------------
+// INTERIOR: every window of the tile lies inside the frame (decided once per tile), so the per-sample frame tests and the
+// selects they feed disappear.  y_ok: the pixel's row is inside the output.
+template <bool INTERIOR>
+__device__ __forceinline__ float sample_general(const TileCtx &tc, const FrameView &fv, const float *tile, const float *__restrict__ lut,
+                                                unsigned long long X, unsigned long long Y, int sh)
+{
+    int jx, jy, px, py;
+    phases(X, Y, sh, jx, jy, px, py);
+    // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
+    const bool inside = INTERIOR || (tc.sane && (unsigned)(jx - 2) < (unsigned)(fv.w_in - 5) && (unsigned)(jy - 2) < (unsigned)(fv.h_in - 5));
+    const int ix = inside ? jx : 0, iy = inside ? jy : 0;
+    const Weights wts = load_weights(lut, inside ? px : 0, inside ? py : 0);
+    float v;
+    if (INTERIOR || tc.staged) {
+        // pixels outside the frame read (and discard) the tile origin
+        const int off = inside ? (iy - 2 - tc.by0) * tc.fw + (ix - 2 - tc.bx0) : 0;
+        const int stride = inside ? tc.fw : 0;
+        const float *t = tile + off;
+        // all 18 ds_read2_b32 of the window are issued before the first product
+        v2f smp[6][3];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const float *r = t + j * stride;
+            smp[j][0] = v2f{r[0], r[1]};
+            smp[j][1] = v2f{r[2], r[3]};
+            smp[j][2] = v2f{r[4], r[5]};
+        }
+        v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+            s01 = smp[j][0];
+            s23 = smp[j][1];
+            s45 = smp[j][2];
+        });
+    } else {
+        v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
+            s01 = v2f{fetch_global(fv, iy - 2 + j, ix - 2), fetch_global(fv, iy - 2 + j, ix - 1)};
+            s23 = v2f{fetch_global(fv, iy - 2 + j, ix), fetch_global(fv, iy - 2 + j, ix + 1)};
+            s45 = v2f{fetch_global(fv, iy - 2 + j, ix + 2), fetch_global(fv, iy - 2 + j, ix + 3)};
+        });
+    }
+    // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
+    return (inside && v == v) ? v * tc.fs : __builtin_nanf("");
+}
+
+// The pixels of one lane: column x, rows yb0, yb0 + 4, ...
+template <bool INTERIOR, bool OVERSAMPLED>
+__device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameView &fv, const float *tile, const float *__restrict__ lut,
+                                               int sh, int os, int x, int yb0, int h_out, int64_t row_stride, float *op, uint8_t *wp)
+{
+    const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
+    const unsigned long long n = OVERSAMPLED ? (unsigned long long)os : 1ull;
+    const unsigned long long u0 = (unsigned long long)(long long)x * n, v0 = (unsigned long long)(long long)yb0 * n;
+    unsigned long long X = F0 * u0 + F1 * v0 + F2;
+    unsigned long long Y = F3 * u0 + F4 * v0 + F5;
+    const unsigned long long dX = F1 * (4ull * n), dY = F4 * (4ull * n);
+    const double inv = 1.0 / (double)(os * os);
     // One pixel per trip (not unrolled): residency hides latency better than batching (round 1 measurement).
 #pragma unroll 1
     for (int k = 0; k < kTileH / 4; k++) {
         const int y = yb0 + 4 * k;
-        const long long xin = (long long)X, yin = (long long)Y;
+        if (!INTERIOR && y >= h_out) break;
+        float res;
+        if constexpr (!OVERSAMPLED) {
+            res = sample_general<INTERIOR>(tc, fv, tile, lut, X, Y, sh);
+        } else {
+            double acc = 0.0;
+            unsigned long long Xa = X, Ya = Y;
+#pragma unroll 1
+            for (int a = 0; a < os; a++) {
+                unsigned long long Xb = Xa, Yb = Ya;
+#pragma unroll 1
+                for (int b = 0; b < os; b++) {
+                    acc += (double)sample_general<INTERIOR>(tc, fv, tile, lut, Xb, Yb, sh);
+                    Xb += F0;
+                    Yb += F3;
+                }
+                Xa += F1;
+                Ya += F4;
+            }
+            res = (float)(acc * inv);
+        }
         X += dX;
         Y += dY;
-        // a sane tile keeps the coordinates within +-1e9: the integer part IS the high dword (no 64-bit compares or selects)
-        const int jx = (int)(xin >> 32), jy = (int)(yin >> 32);
-        const unsigned frx = (unsigned)(unsigned long long)xin, fry = (unsigned)(unsigned long long)yin;
-        const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
-        const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
-        // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
-        const bool inside = INTERIOR || (sane && (y < h_out) && (unsigned)(jx - 2) < (unsigned)(fv.w_in - 5) && (unsigned)(jy - 2) < (unsigned)(fv.h_in - 5));
-        const int ix = (INTERIOR || inside) ? jx : 0, iy = (INTERIOR || inside) ? jy : 0;
-        const Weights wts = load_weights(lut, (INTERIOR || inside) ? px : 0, (INTERIOR || inside) ? py : 0);
-        if (!INTERIOR && y >= h_out) break;
-        float v;
-        if (INTERIOR || staged) {
-            // pixels outside the frame read (and discard) the tile origin
-            const int off = (INTERIOR || inside) ? (iy - 2 - by0) * fw + (ix - 2 - bx0) : 0;
-            const int stride = (INTERIOR || inside) ? fw : 0;
-            const float *t = tile + off;
-            // all 18 ds_read2_b32 of the window are issued before the first product
-            v2f smp[6][3];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const float *r = t + j * stride;
-                smp[j][0] = v2f{r[0], r[1]};
-                smp[j][1] = v2f{r[2], r[3]};
-                smp[j][2] = v2f{r[4], r[5]};
-            }
-            v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
-                s01 = smp[j][0];
-                s23 = smp[j][1];
-                s45 = smp[j][2];
-            });
-        } else {
-            v = window_sum(wts, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
-                s01 = v2f{fetch_global(fv, iy - 2 + j, ix - 2), fetch_global(fv, iy - 2 + j, ix - 1)};
-                s23 = v2f{fetch_global(fv, iy - 2 + j, ix), fetch_global(fv, iy - 2 + j, ix + 1)};
-                s45 = v2f{fetch_global(fv, iy - 2 + j, ix + 2), fetch_global(fv, iy - 2 + j, ix + 3)};
-            });
-        }
-        // invalid taps arrive as NaN and poison v; the weight plane is "out is not NaN" in the oracle too
-        const float res = ((INTERIOR || inside) && v == v) ? v * fs : __builtin_nanf("");
         *op = res;
         op += row_stride;
         if (wp) {
@@ -159,15 +362,88 @@ __device__ __forceinline__ void resample_pixels(const TileInfo &ti, const FrameV
     }
 }
 
-template <bool HAS_MASK>
+// ---- the tile pass ---------------------------------------------------------------------------------------------------
+// One thread per (frame, tile).  os = 1, or the oversampling factor: the transform then belongs to the os-times finer grid
+// and the tile covers the fine pixels of its 64 x 16 output pixels.
+__global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__restrict__ affines, int per_tile, int conserve_flux,
+                                                            const float *__restrict__ fscale, int os, int gx, int gy, int64_t ntiles,
+                                                            int h_in, int w_in, int h_out, int w_out, int fast_ok, TileRec *__restrict__ recs)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ntiles) return;
+    const int tx = (int)(idx % gx), ty = (int)((idx / gx) % gy);
+    const int64_t f = idx / ((int64_t)gx * gy);
+    const int x0 = tx * kTileW, y0 = ty * kTileH;
+    // one transform per frame, or one per output tile
+    const double *A = affines + 6 * (per_tile ? idx : f);
+    const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
+    float fs = fscale ? fscale[f] : 1.0f;
+    if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // (fine) output pixel area in input pixels
+    // corner pixels of the tile on the (fine) output grid: an affine map takes its extremes there
+    const int xl = x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1;
+    const int yl = y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1;
+    const long long ua = (long long)x0 * os, ub = (long long)xl * os + (os - 1);
+    const long long va = (long long)y0 * os, vb = (long long)yl * os + (os - 1);
+    const long long cu[4] = {ua, ub, ua, ub}, cv[4] = {va, va, vb, vb};
+    double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double xi = fma(a0, (double)cu[k], fma(a1, (double)cv[k], a2));
+        const double yi = fma(a3, (double)cu[k], fma(a4, (double)cv[k], a5));
+        mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
+        mny = fmin(mny, yi); mxy = fmax(mxy, yi);
+    }
+    // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
+    // fixed-point evaluation is then exact: the true sums fit 64 bits); false for NaN coefficients
+    const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
+    const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
+                      (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
+    TileRec rec;
+#pragma unroll
+    for (int k = 0; k < 6; k++) rec.F[k] = sane ? __double2ll_rn(A[k] * 4294967296.0) : 0;
+    int bx0 = 0, by0 = 0, w = 0, h = 0;
+    unsigned flags = 0;
+    if (sane) {
+        flags |= kSane;
+        // the footprint from the SAME integer coordinates the pixels will use (linear: extremes at the corners)
+        long long jx0 = 0x7fffffffffffffffLL, jx1 = -jx0, jy0 = jx0, jy1 = -jx0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long X = (unsigned long long)rec.F[0] * (unsigned long long)cu[k] + (unsigned long long)rec.F[1] * (unsigned long long)cv[k] + (unsigned long long)rec.F[2];
+            const unsigned long long Y = (unsigned long long)rec.F[3] * (unsigned long long)cu[k] + (unsigned long long)rec.F[4] * (unsigned long long)cv[k] + (unsigned long long)rec.F[5];
+            const long long jx = (long long)X >> 32, jy = (long long)Y >> 32;
+            jx0 = jx < jx0 ? jx : jx0; jx1 = jx > jx1 ? jx : jx1;
+            jy0 = jy < jy0 ? jy : jy0; jy1 = jy > jy1 ? jy : jy1;
+        }
+        bx0 = (int)jx0 - 2;
+        by0 = (int)jy0 - 2;
+        const long long wl = jx1 - jx0 + 6, hl = jy1 - jy0 + 6;
+        const bool staged = wl <= kGenericFloats && hl <= kGenericFloats && wl * hl <= kGenericFloats;
+        if (staged) {
+            w = (int)wl;
+            h = (int)hl;
+            flags |= kStaged;
+            const bool interior = bx0 >= 0 && by0 >= 0 && bx0 + w <= w_in && by0 + h <= h_in && y0 + kTileH <= h_out;
+            if (interior) flags |= kInterior;
+#ifndef APGPU_VARIANT_RESAMPLE_NO_FAST
+            if (interior && fast_ok && w <= kFastPitch && h <= kFastRows) flags |= kFast;
+#endif
+        }
+    }
+    rec.bx0 = bx0;
+    rec.by0 = by0;
+    rec.dims = (unsigned)w | ((unsigned)h << 13) | (flags << 26);
+    rec.fs = fs;
+    recs[idx] = rec;
+}
+
+template <bool HAS_MASK, bool OVERSAMPLED>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
-                                                             const double *__restrict__ affines, int per_tile, int conserve_flux,
-                                                             const float *__restrict__ fscale, const float *__restrict__ lut,
-                                                             int log2_phases, float *__restrict__ out, uint8_t *__restrict__ wout,
+                                                             const TileRec *__restrict__ recs, const float *__restrict__ lut,
+                                                             int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out)
 {
-    __shared__ float tile[kLdsFloats];
-    __shared__ TileInfo ti;
+    __shared__ __attribute__((aligned(16))) float tile[kLdsFloats];
     const int64_t f = blockIdx.z;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     FrameView fv;
@@ -175,52 +451,55 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     fv.mask = HAS_MASK ? mask : nullptr;
     fv.h_in = h_in;
     fv.w_in = w_in;
-    if (threadIdx.x == 0) {
-        // one transform per frame, or one per output tile (= per workgroup)
-        const double *A = affines + 6 * (per_tile ? (f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x : f);
-        const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
-        float fs = fscale ? fscale[f] : 1.0f;
-        if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // output pixel area in input pixels
-        ti.fs = fs;
-        // input footprint of the tile: an affine map takes its extremes at the tile corners
-        const double xa = (double)x0, xb = (double)(x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1);
-        const double ya = (double)y0, yb = (double)(y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1);
-        double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
-        const double cx[4] = {xa, xb, xa, xb}, cy[4] = {ya, ya, yb, yb};
+    const TileRec *rp = recs + ((f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);    // uniform address: scalar loads
+    TileCtx tc;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const double xi = fma(a0, cx[k], fma(a1, cy[k], a2));
-            const double yi = fma(a3, cx[k], fma(a4, cy[k], a5));
-            mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
-            mny = fmin(mny, yi); mxy = fmax(mxy, yi);
-        }
-        // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
-        // fixed-point evaluation is then exact: the true sums fit 64 bits); false for NaN coefficients
-        const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
-        const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
-                          (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
+    for (int k = 0; k < 6; k++) tc.F[k] = rp->F[k];
+    tc.bx0 = rp->bx0;
+    tc.by0 = rp->by0;
+    const unsigned dims = rp->dims;
+    tc.fw = (int)(dims & 0x1fffu);
+    tc.fh = (int)((dims >> 13) & 0x1fffu);
+    const unsigned flags = dims >> 26;
+    tc.staged = (flags & kStaged) != 0;
+    tc.sane = (flags & kSane) != 0;
+    tc.fs = rp->fs;
+    const bool fast = (flags & kFast) != 0, interior = (flags & kInterior) != 0;
+    const int tid = threadIdx.x;
+    if (fast) {
+        // 3 footprint rows of 80 columns per trip (240 of the 256 lanes), every load of the tile in flight before the first
+        // LDS store; columns beyond the footprint's width are read too (inside the frame's buffer, or returned as 0 by the
+        // bounds check) and never used
+        const v4i irsrc = make_rsrc(fv.src, (unsigned)(h_in * w_in) * 4u);
+        const v4i mrsrc = make_rsrc(mask, (unsigned)(h_in * w_in));
+        if (tid < 3 * kFastPitch) {
+            const int r = tid / kFastPitch, c = tid - r * kFastPitch;
+            const int e0 = (tc.by0 + r) * w_in + tc.bx0 + c;
+            const int estep = 3 * w_in;
+            constexpr int TRIPS = (kFastRows + 2) / 3;
+            float val[TRIPS];
+            char mk[TRIPS];
 #pragma unroll
-        for (int k = 0; k < 6; k++) ti.F[k] = sane ? __double2ll_rn(A[k] * 4294967296.0) : 0;
-        int bx0 = 0, by0 = 0, w = 0, h = 0;
-        bool staged = false;
-        if (sane) {
-            // (one pixel of slack on every side: the corners are evaluated in float64, the pixels in fixed point, and the two
-            // can fall on different sides of an integer)
-            bx0 = (int)floor(mnx) - 3;
-            by0 = (int)floor(mny) - 3;
-            w = (int)floor(mxx) + 4 - bx0 + 1;
-            h = (int)floor(mxy) + 4 - by0 + 1;
-            staged = w > 0 && h > 0 && w <= kLdsFloats && h <= kLdsFloats && w * h <= kLdsFloats;
+            for (int k = 0; k < TRIPS; k++) {
+                val[k] = 0.f;
+                mk[k] = 0;
+                if (3 * k < tc.fh) {                            // (scalar test)
+                    val[k] = buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
+                    if constexpr (HAS_MASK) mk[k] = buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < TRIPS; k++) {
+                if (3 * k < tc.fh && r + 3 * k < kFastRows) {
+                    const bool good = (fabsf(val[k]) < __builtin_inff()) && mk[k] == 0;
+                    const float xv = good ? val[k] : __builtin_nanf("");
+                    tile[tid + 3 * kFastPitch * k] = xv;                       // copy A
+                    tile[kFastOffB - 1 + tid + 3 * kFastPitch * k] = xv;       // copy B: element e - 1 (e = 0 lands in the gap)
+                }
+            }
         }
-        ti.bx0 = bx0; ti.by0 = by0; ti.fw = w; ti.fh = h;
-        ti.staged = staged;
-        ti.sane = sane;
-        ti.interior = staged && bx0 >= 0 && by0 >= 0 && bx0 + w <= w_in && by0 + h <= h_in && y0 + kTileH <= h_out;
-    }
-    __syncthreads();
-    const bool staged = ti.staged != 0, interior = ti.interior != 0;
-    if (staged) {
-        const int bx0 = ti.bx0, by0 = ti.by0, fw = ti.fw, h = ti.fh;
+    } else if (tc.staged) {
+        const int bx0 = tc.bx0, by0 = tc.by0, fw = tc.fw, h = tc.fh;
         // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
         // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
         // a trip are in flight together; validity is applied afterwards
@@ -236,13 +515,13 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                 for (int u = 0; u < RU; u++) {
                     const int row = by0 + r0 + 4 * u;
                     const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
-                    const float *rp = fv.src + (int64_t)rc * w_in;
+                    const float *rp2 = fv.src + (int64_t)rc * w_in;
                     const uint8_t *mp = HAS_MASK ? mask + (int64_t)rc * w_in : nullptr;
 #pragma unroll
                     for (int q = 0; q < 2; q++) {
                         const int col = bx0 + c0 + q * kWave + lane;
                         const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
-                        val[u][q] = rp[cc];
+                        val[u][q] = rp2[cc];
                         if constexpr (HAS_MASK) mk[u][q] = mp[cc];
                         else mk[u][q] = 0;
                     }
@@ -266,17 +545,80 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     __syncthreads();
 
     // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12
-    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int lx = tid % kTileW, ly = tid / kTileW;
     const int x = x0 + lx;
     if (x >= w_out) return;
     const int yb0 = y0 + ly;
     const int sh = 32 - log2_phases;
+    if (fast) {
+        // stores through a buffer resource based at the tile's first pixel: 32-bit offsets (w_out < 2^26, checked by the launcher)
+        const int64_t t0 = (f * h_out + y0) * (int64_t)w_out + x0;
+        const v4i orsrc = make_rsrc(out + t0, 0xffffffffu);
+        const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
+        const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
+        const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
+        pixels_fast<OVERSAMPLED>(tc, tile, lrsrc, sh, os, x, yb0, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        return;
+    }
     const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;
     float *op = out + o0;
     uint8_t *wp = wout ? wout + o0 : nullptr;
     const int64_t row_stride = 4 * (int64_t)w_out;
-    if (interior) resample_pixels<true>(ti, fv, tile, lut, sh, x, yb0, h_out, row_stride, op, wp);
-    else resample_pixels<false>(ti, fv, tile, lut, sh, x, yb0, h_out, row_stride, op, wp);
+    if (interior) pixels_general<true, OVERSAMPLED>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
+    else pixels_general<false, OVERSAMPLED>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
+}
+
+int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask, const double *affines,
+                    int32_t affines_per_tile, int32_t conserve_flux, const float *fscale, const float *lut, int32_t n_phases,
+                    int32_t os, float *out, uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream, const char *who)
+{
+    if (!frames || !affines || !lut || !out) return fail(APGPU_EINVAL, "%s: NULL pointer argument", who);
+    if (n_frames <= 0 || n_frames > 65535) return fail(APGPU_EINVAL, "%s: n_frames = %d (1..65535)", who, n_frames);
+    if (h_in < 6 || w_in < 6 || h_out <= 0 || w_out <= 0) return fail(APGPU_EINVAL, "%s: bad shape", who);
+    if (os < 1 || os > 16) return fail(APGPU_EINVAL, "%s: oversampling %d (1..16)", who, os);
+    // (the fine grid's coordinates stay below 2^30 as well)
+    if (h_in > 0x3fffffff || w_in > 0x3fffffff || h_out * os > 0x3fffffff || w_out * os > 0x3fffffff)
+        return fail(APGPU_EUNSUPPORTED, "%s: image sides are limited to 2^30 (fine) pixels", who);
+    if (n_phases < 2 || n_phases > (1 << 20) || (n_phases & (n_phases - 1)))
+        return fail(APGPU_EINVAL, "%s: n_phases = %d (a power of two, 2 .. 2^20: the phase is the top bits of a 32-bit fraction)", who, n_phases);
+    int log2_phases = 0;
+    while ((1 << log2_phases) < n_phases) log2_phases++;
+    if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "%s: lut must be 8-byte aligned", who);
+    const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
+    if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "%s: output too large", who);
+    hipStream_t st = as_stream(stream);
+    // the per-tile records: 64 bytes per 1024 output pixels, stream-ordered scratch
+    const int64_t ntiles = (int64_t)n_frames * gx * gy;
+    TileRec *recs = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&recs), (size_t)ntiles * sizeof(TileRec), st);
+    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "%s: cannot allocate %lld tile records: %s", who, (long long)ntiles, hipGetErrorString(e));
+    // the fast path addresses a frame and a tile's output rows with 32-bit byte offsets
+    const int fast_ok = (h_in * w_in < (1LL << 30)) && (w_out < (1LL << 26));
+    const int64_t tb = (ntiles + 255) / 256;
+    if (tb > 0x7fffffffLL) {
+        (void)hipFreeAsync(recs, st);
+        return fail(APGPU_EUNSUPPORTED, "%s: too many tiles", who);
+    }
+    hipLaunchKernelGGL(resample_tiles_kernel, dim3((unsigned)tb), dim3(256), 0, st, affines, affines_per_tile, conserve_flux, fscale, (int)os,
+                       (int)gx, (int)gy, ntiles, (int)h_in, (int)w_in, (int)h_out, (int)w_out, fast_ok, recs);
+    int rc = check_launch(who);
+    if (rc == APGPU_OK) {
+        const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
+#define APGPU_RESAMPLE_LAUNCH(M, O)                                                                                                  \
+    hipLaunchKernelGGL((resample_affine_kernel<M, O>), grid, dim3(256), 0, st, frames, mask, recs, lut, log2_phases, (int)os, out, \
+                       weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out)
+        if (mask) {
+            if (os > 1) APGPU_RESAMPLE_LAUNCH(true, true);
+            else APGPU_RESAMPLE_LAUNCH(true, false);
+        } else {
+            if (os > 1) APGPU_RESAMPLE_LAUNCH(false, true);
+            else APGPU_RESAMPLE_LAUNCH(false, false);
+        }
+#undef APGPU_RESAMPLE_LAUNCH
+        rc = check_launch(who);
+    }
+    (void)hipFreeAsync(recs, st);
+    return rc;
 }
 
 }  // namespace
@@ -286,27 +628,17 @@ extern "C" int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, 
                                          const float *fscale, const float *lut, int32_t n_phases, float *out,
                                          uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream)
 {
-    if (!frames || !affines || !lut || !out) return fail(APGPU_EINVAL, "resample_affine: NULL pointer argument");
-    if (n_frames <= 0 || n_frames > 65535) return fail(APGPU_EINVAL, "resample_affine: n_frames = %d (1..65535)", n_frames);
-    if (h_in < 6 || w_in < 6 || h_out <= 0 || w_out <= 0) return fail(APGPU_EINVAL, "resample_affine: bad shape");
-    if (h_in > 0x3fffffff || w_in > 0x3fffffff || h_out > 0x3fffffff || w_out > 0x3fffffff)
-        return fail(APGPU_EUNSUPPORTED, "resample_affine: image sides are limited to 2^30 pixels");
-    if (n_phases < 2 || n_phases > (1 << 20) || (n_phases & (n_phases - 1)))
-        return fail(APGPU_EINVAL, "resample_affine: n_phases = %d (a power of two, 2 .. 2^20: the phase is the top bits of a 32-bit fraction)", n_phases);
-    int log2_phases = 0;
-    while ((1 << log2_phases) < n_phases) log2_phases++;
-    if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "resample_affine: lut must be 8-byte aligned");
-    const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
-    if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "resample_affine: output too large");
-    hipStream_t st = as_stream(stream);
-    const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
-    if (mask)
-        hipLaunchKernelGGL(resample_affine_kernel<true>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, log2_phases, out,
-                           weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
-    else
-        hipLaunchKernelGGL(resample_affine_kernel<false>, grid, dim3(256), 0, st, frames, mask, affines, affines_per_tile, conserve_flux, fscale, lut, log2_phases, out,
-                           weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);
-    return check_launch("resample_affine");
+    return launch_resample(frames, n_frames, h_in, w_in, mask, affines, affines_per_tile, conserve_flux, fscale, lut, n_phases, 1, out,
+                           weight_out, h_out, w_out, stream, "resample_affine");
+}
+
+extern "C" int apgpu_resample_oversampled_f32(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask,
+                                              const double *fine_affines, int32_t affines_per_tile, int32_t conserve_flux,
+                                              const float *fscale, const float *lut, int32_t n_phases, int32_t oversampling, float *out,
+                                              uint8_t *weight_out, int64_t h_out, int64_t w_out, void *stream)
+{
+    return launch_resample(frames, n_frames, h_in, w_in, mask, fine_affines, affines_per_tile, conserve_flux, fscale, lut, n_phases,
+                           oversampling, out, weight_out, h_out, w_out, stream, "resample_oversampled");
 }
 
 // ---- OVERSAMPLING n and COMBINE_TYPE WEIGHTED (include/apgpu.h, F3 continued) --------------------------------------

@@ -736,12 +736,7 @@ def block_mean(fine, oversampling):
     return out
 
 
-def resample_oversampled(frames, affines, oversampling, fscale=None, mask=None, out_shape=None, n_phases=1024, conserve_flux=False,
-                         fine_affines=None):
-    """SWarp's OVERSAMPLING n (resample_all.sh:112, 339): every output pixel is the mean of n x n Lanczos-3 interpolations at
-    the centres of its sub-pixels.  One frame at a time through an n-times finer grid (n^2 x the output size in HBM), then
-    apgpu_block_mean_f32.  `fine_affines`: per-tile transforms of the FINE grid ([N, ty, tx, 6], e.g. wcs.tile_affines of the
-    n-times finer output WCS) instead of one transform per frame.  Returns [N, h, w] float32, NaN where undefined."""
+def _oversampling_args(frames, affines, oversampling, fscale, out_shape, conserve_flux, fine_affines, tile_scale):
     frames = _f32c(frames, 'frames')
     if frames.dim() == 2:
         frames = frames[None]
@@ -751,22 +746,65 @@ def resample_oversampled(frames, affines, oversampling, fscale=None, mask=None, 
         raise ValueError('oversampling must be 1..16')
     h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
     if fine_affines is None:
-        fine_aff, fshape = oversampled_affines(affines, n, (h, w))
+        fine_aff, _ = oversampled_affines(affines, n, (h, w))
         if fine_aff.shape[0] == 1 and N > 1:
             fine_aff = fine_aff.expand(N, 6)
+        if fine_aff.shape[0] != N:
+            raise ValueError('affines must hold one 2x3 transform per frame')
     else:
-        fine_aff, fshape = torch.as_tensor(fine_affines, dtype=torch.float64), (h * n, w * n)
-    fs = None if fscale is None else torch.as_tensor(fscale, dtype=torch.float32).reshape(-1)
-    if fs is not None and fs.numel() == 1 and N > 1:
+        fine_aff = torch.as_tensor(fine_affines, dtype=torch.float64)
+        ty, tx = -(-h * n // (16 * tile_scale)), -(-w * n // (64 * tile_scale))
+        if tuple(fine_aff.shape) != (N, ty, tx, 6):
+            raise ValueError('per-tile fine affines must be [N, %d, %d, 6] for a %d x %d output at oversampling %d' % (ty, tx, h, w, n))
+    fs = torch.ones(N, dtype=torch.float32) if fscale is None else torch.as_tensor(fscale, dtype=torch.float32).reshape(-1).cpu()
+    if fs.numel() == 1 and N > 1:
         fs = fs.expand(N)
-    out = torch.empty((N, h, w), dtype=torch.float32, device=frames.device)
+    if fs.numel() != N:
+        raise ValueError('fscale must hold one value per frame')
     # |det| of the fine transform is 1 / n^2 of the output pixel's: the block MEAN of flux-conserving fine values times n^2
     # is the output pixel's value, so the scale goes into the per-frame flux factor
     area = float(n * n) if conserve_flux else 1.0
+    return frames, N, H, W, n, h, w, fine_aff, (fs.to(torch.float64) * area).to(torch.float32)
+
+
+def resample_oversampled(frames, affines, oversampling, fscale=None, mask=None, out_shape=None, n_phases=1024, conserve_flux=False,
+                         fine_affines=None):
+    """SWarp's OVERSAMPLING n (resample_all.sh:112, 339): every output pixel is the mean of n x n Lanczos-3 interpolations at
+    the centres of its sub-pixels, in ONE kernel (apgpu_resample_oversampled_f32: the sub-samples of a pixel are evaluated and
+    averaged in registers; the n-times finer image never exists).  `fine_affines`: transforms of the FINE grid per OUTPUT
+    tile ([N, ceil(h/16), ceil(w/64), 6], e.g. wcs.tile_affines(fine_wcs, in_wcs, fine_shape, tile_scale=n)) instead of one
+    transform per frame.  Returns [N, h, w] float32, NaN where undefined."""
+    _need_cuda(frames)
+    frames, N, H, W, n, h, w, fine_aff, fs = _oversampling_args(frames, affines, oversampling, fscale, out_shape, conserve_flux,
+                                                                 fine_affines, int(oversampling))
+    dev = frames.device
+    mk = None
+    if mask is not None:
+        _need_cuda(mask)
+        if tuple(mask.shape) != (H, W):
+            raise ValueError('mask must be [H,W]')
+        mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
+    fine_aff = fine_aff.contiguous().to(dev)
+    fs = fs.contiguous().to(dev)
+    lut = lanczos3_table(n_phases, dev)
+    out = torch.empty((N, h, w), dtype=torch.float32, device=dev)
+    check(_lib.load().apgpu_resample_oversampled_f32(_ptr(frames), N, H, W, _ptr(mk) if mk is not None else None, _ptr(fine_aff),
+                                                     int(fine_aff.dim() == 4), int(bool(conserve_flux)), _ptr(fs), _ptr(lut), int(n_phases), n,
+                                                     _ptr(out), None, h, w, _stream()))
+    return out
+
+
+def resample_oversampled_two_step(frames, affines, oversampling, fscale=None, mask=None, out_shape=None, n_phases=1024,
+                                  conserve_flux=False, fine_affines=None):
+    """The two-step form of resample_oversampled (rounds 2-3a): one frame at a time through the n-times finer grid (n^2 x the
+    output size in HBM: apgpu_resample_affine_f32), then apgpu_block_mean_f32.  Bit-identical to the fused kernel for one
+    transform per frame; kept as its cross-check and for the benchmark.  `fine_affines` here is per tile of the FINE grid."""
+    frames, N, H, W, n, h, w, fine_aff, fs = _oversampling_args(frames, affines, oversampling, fscale, out_shape, conserve_flux,
+                                                                 fine_affines, 1)
+    out = torch.empty((N, h, w), dtype=torch.float32, device=frames.device)
     for i in range(N):
-        f_i = area * (1.0 if fs is None else float(fs[i]))
-        fine, _ = resample_affine(frames[i:i + 1], fine_aff[i:i + 1], fscale=[f_i], mask=mask, out_shape=fshape, n_phases=n_phases,
-                                  weight=False, conserve_flux=conserve_flux)
+        fine, _ = resample_affine(frames[i:i + 1], fine_aff[i:i + 1], fscale=fs[i:i + 1], mask=mask, out_shape=(h * n, w * n),
+                                  n_phases=n_phases, weight=False, conserve_flux=conserve_flux)
         check(_lib.load().apgpu_block_mean_f32(_ptr(fine), h, w, n, _ptr(out[i]), _stream()))
     return out
 

@@ -89,13 +89,15 @@ class TanWcs:
 TILE_H, TILE_W = 16, 64          # the resample kernel's output tile (csrc/resample.hip)
 
 
-def tile_affines(out_wcs, in_wcs, out_shape):
+def tile_affines(out_wcs, in_wcs, out_shape, tile_scale=1):
     """Per-tile affine approximation of the map output pixel -> input pixel (through the sky): the exact map at
     the tile centre plus its central-difference Jacobian over the tile.  Over a 64 x 16 pixel tile of an
     arcsecond-scale image the second-order terms of TAN -> TAN are < 1e-3 pixel (the kernel's phase table
     resolves 1/1024 pixel).  Returns float64 [tiles_y, tiles_x, 6]: xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5
-    with ABSOLUTE output pixel coordinates x, y."""
+    with ABSOLUTE output pixel coordinates x, y.  tile_scale = n: `out_wcs` / `out_shape` describe the n-times finer grid of
+    an OVERSAMPLING n resample and a tile is the 64 n x 16 n fine pixels of one output tile (apgpu_resample_oversampled_f32)."""
     ny, nx = out_shape
+    TILE_H, TILE_W = 16 * int(tile_scale), 64 * int(tile_scale)
     ty, tx = (ny + TILE_H - 1) // TILE_H, (nx + TILE_W - 1) // TILE_W
     yc = np.arange(ty, dtype=np.float64)[:, None] * TILE_H + (TILE_H - 1) / 2.0 + np.zeros((1, tx))
     xc = np.arange(tx, dtype=np.float64)[None, :] * TILE_W + (TILE_W - 1) / 2.0 + np.zeros((ty, 1))

@@ -323,7 +323,21 @@ int apgpu_resample_affine_f32(const float *frames, int32_t n_frames, int64_t h_i
                               const float *lut, int32_t n_phases, float *out, uint8_t *weight_out, int64_t h_out,
                               int64_t w_out, void *stream);
 
-/* F3 (continued)  The two SWarp settings of resample_all.sh that go beyond one interpolation per output pixel.
+/* F3 (continued)  SWarp's OVERSAMPLING n (resample_all.sh:112, 339: 4) in one pass: every output pixel is the mean of n x n
+ *     interpolations at the centres of its sub-pixels.  fine_affines maps pixel (u, v) of the n-times FINER grid - output
+ *     pixel (x, y) owns u = n x .. n x + n - 1, v = n y .. n y + n - 1 - to input coordinates (ops.oversampled_affines, or
+ *     wcs.tile_affines of the n-times finer WCS); with affines_per_tile != 0 there is one transform per TILE_H x TILE_W tile
+ *     of the OUTPUT grid, [n_frames][tiles_y][tiles_x][6].  Each sub-sample is apgpu_resample_affine_f32's value at (u, v)
+ *     (flux scale, conserve_flux = |det| of the fine transform, NaN rules included); out = (float)(sum * (1.0 / n^2)) with the
+ *     sum accumulated in float64 in row-major order (v outer, u inner) - bit-identical to apgpu_block_mean_f32 of the fine
+ *     resample, without the n^2-times larger image ever existing.  oversampling 1..16 (1 = apgpu_resample_affine_f32).
+ *     Exact definition: oracle/apref.c apref_resample_oversampled_f32. */
+int apgpu_resample_oversampled_f32(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask,
+                                   const double *fine_affines, int32_t affines_per_tile, int32_t conserve_flux, const float *fscale,
+                                   const float *lut, int32_t n_phases, int32_t oversampling, float *out, uint8_t *weight_out,
+                                   int64_t h_out, int64_t w_out, void *stream);
+
+/* F3 (continued)  The two-step form of OVERSAMPLING, and COMBINE_TYPE WEIGHTED.
  *     apgpu_block_mean_f32: OVERSAMPLING n (resample_all.sh:112, 339: 4) - the frame is resampled onto a grid n times finer
  *     (apgpu_resample_affine_f32 with the transform of the sub-pixel centres) and every output pixel is the mean of its
  *     n x n sub-samples: fine [n*h_out, n*w_out] float32 -> out [h_out, w_out] float32, float64 accumulation in row-major
