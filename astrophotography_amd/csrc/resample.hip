@@ -17,8 +17,8 @@
 // path the tile takes - 64 bytes per tile that the main kernel reads with ONE scalar load (rounds 1-2 did the float64 corner
 // arithmetic in every lane, round 3 first in thread 0 behind an LDS broadcast and a barrier).
 // The main kernel stages the footprint in LDS and evaluates the taps from there:
-//   FAST tiles (the window of every pixel inside the frame, footprint at most 80 x 32: registration-sized rotations up to
-//   ~8 degrees, frames below 2^30 pixels): fixed LDS pitch of 80 floats and TWO copies of the footprint, the second shifted
+//   FAST tiles (the window of every pixel inside the frame, footprint at most 80 x 26: registration-sized rotations up to
+//   ~2.5 degrees, frames below 2^30 pixels): fixed LDS pitch of 80 floats and TWO copies of the footprint, the second shifted
 //   by one float, so that every lane reads its six taps of a row as three ALIGNED ds_read_b64 from the copy that matches the
 //   parity of its first column - 256 B/clk where ds_read2_b32 gets 128 (MI355X guide, LDS table) - with all 18 reads of a
 //   window off one address register (row j at the immediate offset 320 j).  The second copy starts 32 banks after the first
@@ -30,29 +30,35 @@
 // HBM traffic is one read of the input (+ halo, mostly L2 hits) and one write of the output: 8 B per pixel.
 #include "common.h"
 
+typedef float apgpu_v2f __attribute__((ext_vector_type(2)));
+typedef float apgpu_v4f __attribute__((ext_vector_type(4)));
+typedef int apgpu_v4i __attribute__((ext_vector_type(4)));
+// Raw buffer instructions by their LLVM names (this clang's __builtin_amdgcn_raw_buffer_load_b128 / _b64 emit a ONE-dword
+// load): resource in four SGPRs, 32-bit byte offset per lane, bounds-checked against the resource's size.
+__device__ float apgpu_buffer_load_f32(apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ apgpu_v2f apgpu_buffer_load_v2f32(apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ apgpu_v4f apgpu_buffer_load_v4f32(apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ char apgpu_buffer_load_i8(apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i8");
+__device__ void apgpu_buffer_store_f32(float v, apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void apgpu_buffer_store_i8(char v, apgpu_v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
+
 namespace {
 using namespace apgpu;
 
 constexpr int kTileW = APGPU_RESAMPLE_TILE_W, kTileH = APGPU_RESAMPLE_TILE_H;
 constexpr int kGenericFloats = 4096;                 // general path: footprint up to 16 KB at its own pitch
-constexpr int kFastPitch = 80, kFastRows = 32;       // fast path: fixed pitch (320 B: row j of a window = immediate offset)
-constexpr int kFastCopy = kFastPitch * kFastRows;    // 2560 floats per copy
-constexpr int kFastOffB = kFastCopy + 32;            // copy B (shifted by one float) starts 32 banks after copy A
-constexpr int kLdsFloats = kFastOffB + kFastCopy;    // 20.1 KB: seven workgroups per CU
-static_assert(kFastOffB % 64 == 32 && kFastPitch % 2 == 0 && kLdsFloats >= kGenericFloats, "LDS layout");
+#ifndef APGPU_RESAMPLE_FAST_ROWS
+#define APGPU_RESAMPLE_FAST_ROWS 26
+#endif
+constexpr int kFastPitch = 80, kFastRows = APGPU_RESAMPLE_FAST_ROWS;   // fast path: fixed pitch (320 B: row j of a window = immediate offset)
+constexpr int kFastCopy = kFastPitch * kFastRows;    // 2080 floats per copy
+constexpr int kFastOffB = ((kFastCopy + 1 + 31) / 64) * 64 + 32;   // copy B (shifted by one float) starts 32 banks after copy A, behind a gap
+constexpr int kLdsFloats = kFastOffB + kFastCopy > kGenericFloats ? kFastOffB + kFastCopy : kGenericFloats;   // 16.5 KB: nine workgroups per CU
+static_assert(kFastOffB % 64 == 32 && kFastOffB > kFastCopy && kFastPitch % 2 == 0, "LDS layout");
 constexpr unsigned kRsrcFlags = 0x00020000;          // raw buffer, 32-bit elements (gfx9 family word 3)
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// Raw buffer instructions by their LLVM names (this clang's __builtin_amdgcn_raw_buffer_load_b128 / _b64 emit a ONE-dword
-// load): resource in four SGPRs, 32-bit byte offset per lane, bounds-checked against the resource's size.
-__device__ float buffer_load_f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-__device__ v2f buffer_load_v2f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
-__device__ v4f buffer_load_v4f32(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ char buffer_load_i8(v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i8");
-__device__ void buffer_store_f32(float v, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
-__device__ void buffer_store_i8(char v, v4i rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.i8");
+typedef apgpu_v2f v2f;
+typedef apgpu_v4f v4f;
+typedef apgpu_v4i v4i;
 
 // p and bytes are wave-uniform
 __device__ __forceinline__ v4i make_rsrc(const void *p, unsigned bytes)
@@ -70,8 +76,8 @@ typedef __attribute__((address_space(3))) const v2f *lds_pair_p;            // t
 #else
 typedef __attribute__((address_space(3))) const volatile v2f *lds_pair_p;   // volatile: one ds_read_b64 each (256 B/clk)
 #endif
-#ifndef APGPU_RESAMPLE_UNROLL
-#define APGPU_RESAMPLE_UNROLL 1
+#ifndef APGPU_RESAMPLE_ROWS_PER_BATCH
+#define APGPU_RESAMPLE_ROWS_PER_BATCH 3
 #endif
 
 enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8 };
@@ -123,10 +129,10 @@ __device__ __forceinline__ Weights load_weights(const float *__restrict__ lut, i
 __device__ __forceinline__ Weights load_weights(v4i lut, int px, int py)
 {
     const int ox = (int)__umul24((unsigned)px, 24u), oy = (int)__umul24((unsigned)py, 24u);
-    const v4f a = buffer_load_v4f32(lut, ox, 0, 0);
-    const v2f b = buffer_load_v2f32(lut, ox + 16, 0, 0);
-    const v4f c = buffer_load_v4f32(lut, oy, 0, 0);
-    const v2f d = buffer_load_v2f32(lut, oy + 16, 0, 0);
+    const v4f a = apgpu_buffer_load_v4f32(lut, ox, 0, 0);
+    const v2f b = apgpu_buffer_load_v2f32(lut, ox + 16, 0, 0);
+    const v4f c = apgpu_buffer_load_v4f32(lut, oy, 0, 0);
+    const v2f d = apgpu_buffer_load_v2f32(lut, oy + 16, 0, 0);
     Weights w;
     w.wx01 = v2f{a.x, a.y};
     w.wx23 = v2f{a.z, a.w};
@@ -193,22 +199,34 @@ __device__ __forceinline__ FastPrep prep_fast(unsigned long long X, unsigned lon
     return p;
 }
 
-// the value before the flux scale
+// the value before the flux scale.  The window is read and reduced in two halves of three rows (9 reads each) with a
+// scheduling fence between them: 18 instead of 36 sample registers alive, which is what lets 8+ waves share a SIMD.
 __device__ __forceinline__ float eval_fast(const FastPrep &p, const float *tile)
 {
     lds_pair_p t = (lds_pair_p)(tile + p.idx);
-    v2f smp[6][3];
+    const Weights &w = p.w;
+    const float wy[6] = {w.wy01.x, w.wy01.y, w.wy23.x, w.wy23.y, w.wy45.x, w.wy45.y};
+    v2f V = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        smp[j][0] = t[j * (kFastPitch / 2) + 0];
-        smp[j][1] = t[j * (kFastPitch / 2) + 1];
-        smp[j][2] = t[j * (kFastPitch / 2) + 2];
+    for (int h = 0; h < 6; h += APGPU_RESAMPLE_ROWS_PER_BATCH) {
+        v2f smp[APGPU_RESAMPLE_ROWS_PER_BATCH][3];
+#pragma unroll
+        for (int j = 0; j < APGPU_RESAMPLE_ROWS_PER_BATCH; j++) {
+            smp[j][0] = t[(h + j) * (kFastPitch / 2) + 0];
+            smp[j][1] = t[(h + j) * (kFastPitch / 2) + 1];
+            smp[j][2] = t[(h + j) * (kFastPitch / 2) + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < APGPU_RESAMPLE_ROWS_PER_BATCH; j++) {
+            v2f acc = w.wx01 * smp[j][0];
+            acc = __builtin_elementwise_fma(w.wx23, smp[j][1], acc);
+            acc = __builtin_elementwise_fma(w.wx45, smp[j][2], acc);
+            const v2f wyj = {wy[h + j], wy[h + j]};
+            V = (h + j == 0) ? wyj * acc : __builtin_elementwise_fma(wyj, acc, V);
+        }
+        if (h + APGPU_RESAMPLE_ROWS_PER_BATCH < 6) __builtin_amdgcn_sched_barrier(0);
     }
-    return window_sum(p.w, [&](int j, v2f &s01, v2f &s23, v2f &s45) {
-        s01 = smp[j][0];
-        s23 = smp[j][1];
-        s45 = smp[j][2];
-    });
+    return V.x + V.y;
 }
 
 template <bool OVERSAMPLED>
@@ -225,19 +243,17 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
     unsigned long long Y = F3 * u0 + F4 * v0 + F5;
     const unsigned long long dX = F1 * (4ull * n), dY = F4 * (4ull * n);
     if constexpr (!OVERSAMPLED) {
-        FastPrep nxt = prep_fast(X, Y, sh, cxo, cyo, lut);
-#pragma unroll
+        // one pixel per trip, table rows loaded in the trip that uses them: a variant that fetched the next pixel's rows
+        // one trip ahead (12 more registers) measured 3 % slower, two pixels per trip no faster
+#pragma unroll 1
         for (int k = 0; k < kTileH / 4; k++) {
-            const FastPrep cur = nxt;
-            if (k + 1 < kTileH / 4) {
-                X += dX;
-                Y += dY;
-                nxt = prep_fast(X, Y, sh, cxo, cyo, lut);
-            }
+            const FastPrep cur = prep_fast(X, Y, sh, cxo, cyo, lut);
+            X += dX;
+            Y += dY;
             const float v = eval_fast(cur, tile);
             const float res = (v == v) ? v * fs : __builtin_nanf("");
-            buffer_store_f32(res, orsrc, ooff, 0, 0);
-            if (want_w) buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
+            apgpu_buffer_store_f32(res, orsrc, ooff, 0, 0);
+            if (want_w) apgpu_buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
             ooff += ostep;
         }
     } else {
@@ -263,8 +279,8 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
             const float res = (float)(acc * inv);
             X += dX;
             Y += dY;
-            buffer_store_f32(res, orsrc, ooff, 0, 0);
-            if (want_w) buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
+            apgpu_buffer_store_f32(res, orsrc, ooff, 0, 0);
+            if (want_w) apgpu_buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
             ooff += ostep;
         }
     }
@@ -439,19 +455,35 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
 
 template <bool HAS_MASK, bool OVERSAMPLED>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
-                                                             const TileRec *__restrict__ recs, const float *__restrict__ lut,
+                                                             const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
+                                                             const float *__restrict__ lut,
                                                              int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out)
 {
     __shared__ __attribute__((aligned(16))) float tile[kLdsFloats];
-    const int64_t f = blockIdx.z;
-    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    // Tile order: grid = (tiles per frame rounded up to 8, frames).  Workgroups are dispatched round-robin over the 8 XCDs
+    // (x fastest, and gridDim.x is a multiple of 8: workgroup x runs on XCD x % 8); a frame's tiles are cut into 8 contiguous
+    // ranges, one per XCD, and consecutive workgroups of an XCD take consecutive tiles of its range, so that the halo a tile
+    // shares with its neighbours is a hit in that XCD's L2 rather than a second fetch (one workgroup per tile in launch order
+    // left 39 % hits and cost 7 %; with this order FETCH_SIZE is 1.03 x the input).
+    const int per_frame = gx * gy;
+#ifdef APGPU_VARIANT_RESAMPLE_LINEAR
+    const int rem = blockIdx.x;
+#else
+    const int chunk = (per_frame + 7) >> 3;
+    const int rem = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+#endif
+    if (rem >= per_frame) return;
+    const int64_t f = blockIdx.y;
+    const int t = (int)f * per_frame + rem;
+    const int tyi = rem / gx, txi = rem - tyi * gx;
+    const int x0 = txi * kTileW, y0 = tyi * kTileH;
     FrameView fv;
     fv.src = frames + f * (int64_t)h_in * w_in;
     fv.mask = HAS_MASK ? mask : nullptr;
     fv.h_in = h_in;
     fv.w_in = w_in;
-    const TileRec *rp = recs + ((f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);    // uniform address: scalar loads
+    const TileRec *rp = recs + t;                                 // uniform address: scalar loads
     TileCtx tc;
 #pragma unroll
     for (int k = 0; k < 6; k++) tc.F[k] = rp->F[k];
@@ -466,6 +498,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     tc.fs = rp->fs;
     const bool fast = (flags & kFast) != 0, interior = (flags & kInterior) != 0;
     const int tid = threadIdx.x;
+
     if (fast) {
         // 3 footprint rows of 80 columns per trip (240 of the 256 lanes), every load of the tile in flight before the first
         // LDS store; columns beyond the footprint's width are read too (inside the frame's buffer, or returned as 0 by the
@@ -484,8 +517,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                 val[k] = 0.f;
                 mk[k] = 0;
                 if (3 * k < tc.fh) {                            // (scalar test)
-                    val[k] = buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
-                    if constexpr (HAS_MASK) mk[k] = buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
+                    val[k] = apgpu_buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
+                    if constexpr (HAS_MASK) mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
                 }
             }
 #pragma unroll
@@ -585,28 +618,24 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
     while ((1 << log2_phases) < n_phases) log2_phases++;
     if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "%s: lut must be 8-byte aligned", who);
     const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
-    if (gx > 0x7fffffffLL || gy > 65535) return fail(APGPU_EUNSUPPORTED, "%s: output too large", who);
     hipStream_t st = as_stream(stream);
     // the per-tile records: 64 bytes per 1024 output pixels, stream-ordered scratch
     const int64_t ntiles = (int64_t)n_frames * gx * gy;
+    if (ntiles > 0x7ffffff0LL) return fail(APGPU_EUNSUPPORTED, "%s: too many tiles (%lld)", who, (long long)ntiles);
     TileRec *recs = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&recs), (size_t)ntiles * sizeof(TileRec), st);
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "%s: cannot allocate %lld tile records: %s", who, (long long)ntiles, hipGetErrorString(e));
     // the fast path addresses a frame and a tile's output rows with 32-bit byte offsets
     const int fast_ok = (h_in * w_in < (1LL << 30)) && (w_out < (1LL << 26));
     const int64_t tb = (ntiles + 255) / 256;
-    if (tb > 0x7fffffffLL) {
-        (void)hipFreeAsync(recs, st);
-        return fail(APGPU_EUNSUPPORTED, "%s: too many tiles", who);
-    }
     hipLaunchKernelGGL(resample_tiles_kernel, dim3((unsigned)tb), dim3(256), 0, st, affines, affines_per_tile, conserve_flux, fscale, (int)os,
                        (int)gx, (int)gy, ntiles, (int)h_in, (int)w_in, (int)h_out, (int)w_out, fast_ok, recs);
     int rc = check_launch(who);
     if (rc == APGPU_OK) {
-        const dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)n_frames);
-#define APGPU_RESAMPLE_LAUNCH(M, O)                                                                                                  \
-    hipLaunchKernelGGL((resample_affine_kernel<M, O>), grid, dim3(256), 0, st, frames, mask, recs, lut, log2_phases, (int)os, out, \
-                       weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out)
+        const dim3 grid((unsigned)(((gx * gy + 7) / 8) * 8), (unsigned)n_frames);
+#define APGPU_RESAMPLE_LAUNCH(M, O)                                                                                                      \
+    hipLaunchKernelGGL((resample_affine_kernel<M, O>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx, (int)gy, lut, \
+                       log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out)
         if (mask) {
             if (os > 1) APGPU_RESAMPLE_LAUNCH(true, true);
             else APGPU_RESAMPLE_LAUNCH(true, false);

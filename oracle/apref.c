@@ -907,10 +907,13 @@ void apref_set_num_threads(int n)
  * 4 integer instructions where the float64 evaluation needed ~25); floor = xin >> 32, sub-pixel phase = the top log2(n_phases)
  * bits of the fraction, rounded to nearest.  A 64 x 16 output tile whose corner coordinates (float64, fma order below) leave
  * +-1e9 pixels, or whose coefficients are not below 2^30 in magnitude, is undefined (NaN) as a whole. */
-static int resample_tile_fx(const double *A, long x0, long y0, long w_out, long h_out, int64_t *F)
+/* os = 1, or the oversampling factor: A then maps the pixels of the os-times finer grid, and the tile's corners are the
+ * first / last fine pixels of its output pixels. */
+static int resample_tile_fx(const double *A, long x0, long y0, long w_out, long h_out, long os, int64_t *F)
 {
-    const double xa = (double)x0, xb = (double)(x0 + 63 < w_out - 1 ? x0 + 63 : w_out - 1);
-    const double ya = (double)y0, yb = (double)(y0 + 15 < h_out - 1 ? y0 + 15 : h_out - 1);
+    const long xl = x0 + 63 < w_out - 1 ? x0 + 63 : w_out - 1, yl = y0 + 15 < h_out - 1 ? y0 + 15 : h_out - 1;
+    const double xa = (double)(x0 * os), xb = (double)(xl * os + (os - 1));
+    const double ya = (double)(y0 * os), yb = (double)(yl * os + (os - 1));
     const double cx[4] = {xa, xb, xa, xb}, cy[4] = {ya, ya, yb, yb};
     for (int k = 0; k < 4; k++) {
         const double xi = fma(A[0], cx[k], fma(A[1], cy[k], A[2]));
@@ -924,15 +927,48 @@ static int resample_tile_fx(const double *A, long x0, long y0, long w_out, long 
     return 1;
 }
 
-int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
-                              const double *affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
-                              int n_phases,
-                              float *out, uint8_t *weight_out, long h_out, long w_out)
+/* The interpolated value at (fine) output pixel (u, v) under the fixed-point transform F, times fs; NaN if undefined. */
+static float resample_sample_fx(const float *src, const uint8_t *mask, long h_in, long w_in, const int64_t *F, int64_t u, int64_t v,
+                                const float *lut, int sh, float fs)
 {
-    if (!frames || !affines || !lut || !out || n_phases < 2 || (n_phases & (n_phases - 1))) return -1;
+    const int64_t xin = (int64_t)((uint64_t)F[0] * (uint64_t)u + (uint64_t)F[1] * (uint64_t)v + (uint64_t)F[2]);
+    const int64_t yin = (int64_t)((uint64_t)F[3] * (uint64_t)u + (uint64_t)F[4] * (uint64_t)v + (uint64_t)F[5]);
+    const int64_t ix = xin >> 32, iy = yin >> 32;
+    /* the 6x6 window must lie inside the frame */
+    if (!(ix >= 2 && iy >= 2 && ix <= w_in - 4 && iy <= h_in - 4)) return NAN;
+    const uint32_t frx = (uint32_t)xin, fry = (uint32_t)yin;
+    const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
+    const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
+    const float *wx = lut + 6 * px, *wy = lut + 6 * py;
+    int ok = 1;
+    float ve = 0.f, vo = 0.f;
+    for (int j = 0; j < 6; j++) {
+        const long row = iy - 2 + j;
+        const float *s = src + row * w_in + (ix - 2);
+        for (int i = 0; i < 6; i++)
+            if (!isfinite(s[i]) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
+        const float e = fmaf(wx[4], s[4], fmaf(wx[2], s[2], wx[0] * s[0]));   /* even taps */
+        const float o = fmaf(wx[5], s[5], fmaf(wx[3], s[3], wx[1] * s[1]));   /* odd taps  */
+        ve = (j == 0) ? wy[0] * e : fmaf(wy[j], e, ve);
+        vo = (j == 0) ? wy[0] * o : fmaf(wy[j], o, vo);
+    }
+    const float val = ve + vo;
+    return (ok && val == val) ? val * fs : NAN;
+}
+
+/* os = 1: apref_resample_affine_f32.  os > 1: SWarp's OVERSAMPLING (resample_all.sh:112, 339) - `affines` belongs to the
+ * os-times finer grid (one per frame, or one per 16 x 64 tile of the OUTPUT grid), every output pixel is
+ * (float)(sum * (1.0 / os^2)) of its os x os samples accumulated in float64 in row-major order: the same numbers as
+ * apref_block_mean_f32 of the fine resample (the GPU's one-pass apgpu_resample_oversampled_f32 restated). */
+static int resample_any(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
+                        const double *affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
+                        int n_phases, long os, float *out, uint8_t *weight_out, long h_out, long w_out)
+{
+    if (!frames || !affines || !lut || !out || n_phases < 2 || (n_phases & (n_phases - 1)) || os < 1 || os > 16) return -1;
     int log2p = 0;
     while ((1 << log2p) < n_phases) log2p++;
     const int sh = 32 - log2p;
+    const double inv = 1.0 / (double)(os * os);
 #pragma omp parallel for collapse(2) schedule(static)
     for (long f = 0; f < n_frames; f++)
         for (long y = 0; y < h_out; y++) {
@@ -942,41 +978,41 @@ int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, lon
             for (long x = 0; x < w_out; x++) {
                 /* one transform per frame, or one per 16 x 64 output tile (piecewise-affine registration) */
                 const double *A = affines + 6 * (per_tile ? (f * tiles_y + y / 16) * tiles_x + x / 64 : f);
-                /* FSCALASTRO_TYPE VARIABLE: output pixel area in input pixels */
+                /* FSCALASTRO_TYPE VARIABLE: (fine) output pixel area in input pixels */
                 const float fs = conserve_flux ? (float)((double)fs0 * fabs(fma(A[0], A[4], -(A[1] * A[3])))) : fs0;
                 int64_t F[6];
                 float res = NAN;
-                uint8_t wt = 0;
-                if (resample_tile_fx(A, (x / 64) * 64, (y / 16) * 16, w_out, h_out, F)) {
-                    const int64_t xin = (int64_t)((uint64_t)F[0] * (uint64_t)x + (uint64_t)F[1] * (uint64_t)y + (uint64_t)F[2]);
-                    const int64_t yin = (int64_t)((uint64_t)F[3] * (uint64_t)x + (uint64_t)F[4] * (uint64_t)y + (uint64_t)F[5]);
-                    const int64_t ix = xin >> 32, iy = yin >> 32;
-                    /* the 6x6 window must lie inside the frame */
-                    if (ix >= 2 && iy >= 2 && ix <= w_in - 4 && iy <= h_in - 4) {
-                        const uint32_t frx = (uint32_t)xin, fry = (uint32_t)yin;
-                        const int px = (int)((frx >> sh) + ((frx >> (sh - 1)) & 1u));
-                        const int py = (int)((fry >> sh) + ((fry >> (sh - 1)) & 1u));
-                        const float *wx = lut + 6 * px, *wy = lut + 6 * py;
-                        int ok = 1;
-                        float ve = 0.f, vo = 0.f;
-                        for (int j = 0; j < 6; j++) {
-                            const long row = iy - 2 + j;
-                            const float *s = src + row * w_in + (ix - 2);
-                            for (int i = 0; i < 6; i++)
-                                if (!isfinite(s[i]) || (mask && mask[row * w_in + ix - 2 + i])) ok = 0;
-                            const float e = fmaf(wx[4], s[4], fmaf(wx[2], s[2], wx[0] * s[0]));   /* even taps */
-                            const float o = fmaf(wx[5], s[5], fmaf(wx[3], s[3], wx[1] * s[1]));   /* odd taps  */
-                            ve = (j == 0) ? wy[0] * e : fmaf(wy[j], e, ve);
-                            vo = (j == 0) ? wy[0] * o : fmaf(wy[j], o, vo);
-                        }
-                        const float v = ve + vo;
-                        if (ok && v == v) res = v * fs;
-                        wt = (res == res) ? 1 : 0;       /* weight plane: out is defined */
+                if (resample_tile_fx(A, (x / 64) * 64, (y / 16) * 16, w_out, h_out, os, F)) {
+                    if (os == 1) {
+                        res = resample_sample_fx(src, mask, h_in, w_in, F, x, y, lut, sh, fs);
+                    } else {
+                        double acc = 0.0;            /* a NaN sample makes the sum, and the pixel, NaN */
+                        for (long a = 0; a < os; a++)
+                            for (long b = 0; b < os; b++)
+                                acc += (double)resample_sample_fx(src, mask, h_in, w_in, F, x * os + b, y * os + a, lut, sh, fs);
+                        res = (float)(acc * inv);
                     }
                 }
                 out[(f * h_out + y) * w_out + x] = res;
-                if (weight_out) weight_out[(f * h_out + y) * w_out + x] = wt;
+                if (weight_out) weight_out[(f * h_out + y) * w_out + x] = (res == res) ? 1 : 0;   /* weight plane: out is defined */
             }
         }
     return 0;
+}
+
+int apref_resample_affine_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
+                              const double *affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
+                              int n_phases,
+                              float *out, uint8_t *weight_out, long h_out, long w_out)
+{
+    return resample_any(frames, n_frames, h_in, w_in, mask, affines, per_tile, conserve_flux, fscale, lut, n_phases, 1, out, weight_out,
+                        h_out, w_out);
+}
+
+int apref_resample_oversampled_f32(const float *frames, long n_frames, long h_in, long w_in, const uint8_t *mask,
+                                   const double *fine_affines, int per_tile, int conserve_flux, const float *fscale, const float *lut,
+                                   int n_phases, int oversampling, float *out, uint8_t *weight_out, long h_out, long w_out)
+{
+    return resample_any(frames, n_frames, h_in, w_in, mask, fine_affines, per_tile, conserve_flux, fscale, lut, n_phases, oversampling, out,
+                        weight_out, h_out, w_out);
 }

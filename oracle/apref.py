@@ -366,6 +366,34 @@ def lanczos3_table(n_phases=1024):
     return np.ascontiguousarray(w.astype(np.float32))
 
 
+def resample_oversampled(frames, fine_affines, oversampling, fscale=None, mask=None, out_shape=None, n_phases=1024, lut=None,
+                         conserve_flux=False):
+    """F3 with SWarp's OVERSAMPLING n in one pass (apref_resample_oversampled_f32): fine_affines [N,6] or one per 16 x 64 OUTPUT
+    tile map pixels of the n-times finer grid to the input; fscale is applied as given (ops.resample_oversampled folds n^2 in
+    for conserve_flux).  Returns (out [N,h,w] float32, weight u8)."""
+    frames = _c(np.asarray(frames), np.float32)
+    if frames.ndim == 2:
+        frames = frames[None]
+    N, H, W = frames.shape
+    h, w = (H, W) if out_shape is None else out_shape
+    aff = np.asarray(fine_affines, dtype=np.float64)
+    per_tile = aff.ndim == 4
+    aff = _c(aff if per_tile else aff.reshape(N, 6), np.float64)
+    if per_tile:
+        assert aff.shape == (N, (h + 15) // 16, (w + 63) // 64, 6)
+    lut = lanczos3_table(n_phases) if lut is None else _c(lut, np.float32)
+    fs = None if fscale is None else _c(np.asarray(fscale, dtype=np.float32).reshape(N), np.float32)
+    mk = None if mask is None else _c(np.asarray(mask), np.uint8)
+    out = np.empty((N, h, w), np.float32)
+    wt = np.empty((N, h, w), np.uint8)
+    rc = lib().apref_resample_oversampled_f32(_p(frames), C.c_long(N), C.c_long(H), C.c_long(W), _p(mk) if mk is not None else None,
+                                              _p(aff), C.c_int(int(per_tile)), C.c_int(int(bool(conserve_flux))),
+                                              _p(fs) if fs is not None else None, _p(lut), C.c_int(n_phases), C.c_int(int(oversampling)),
+                                              _p(out), _p(wt), C.c_long(h), C.c_long(w))
+    assert rc == 0
+    return out, wt
+
+
 def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, lut=None, conserve_flux=False):
     """F3: affine Lanczos-3 resample of [N,H,W] float32 frames (definition in apref.c).  affines [N,6] float64
     map output (x, y) to input (xin, yin).  Returns (out [N,h,w] float32 with NaN where undefined, weight u8)."""

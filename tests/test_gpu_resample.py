@@ -278,6 +278,47 @@ def test_oversampling_vs_oracle_composition(ops, apref):
     assert np.array_equal(bm, want, equal_nan=True) and np.isnan(bm[1, 1]) and np.isfinite(bm).sum() == 14
 
 
+def test_oversampling_one_pass_bitexact_vs_oracle(ops, apref):
+    """apgpu_resample_oversampled_f32 (the n x n sub-samples of a pixel evaluated and averaged in registers) against the
+    oracle's one-pass statement, bit for bit: per-frame and per-OUTPUT-tile fine transforms, a bad-pixel mask, rotations from
+    registration-sized (the aligned two-copy LDS path) to 25 degrees with a scale change (general / gather path), and the
+    two-step form (fine resample + block mean) as a cross-check."""
+    import torch
+    rng = np.random.default_rng(4242)
+    N, H, W = 4, 150, 210
+    out_shape = (97, 139)                                                  # ragged last tiles in both directions
+    frames = rng.normal(500, 60, (N, H, W)).astype(np.float32)
+    frames[2, 70, 100] = np.inf
+    mask = (rng.random((H, W)) < 0.002).astype(np.uint8)
+    fs = rng.uniform(0.5, 2.0, N).astype(np.float32)
+    A = _affines(rng, N, max_rot_deg=0.5, scale_jitter=0.02)
+    th = np.deg2rad(25.0)
+    A[3] = [1.3 * np.cos(th), -1.3 * np.sin(th), 40.0, 1.3 * np.sin(th), 1.3 * np.cos(th), -20.0]
+    t = torch.from_numpy(frames).cuda()
+    for n in (2, 3, 4):
+        fine_aff, _ = ops.oversampled_affines(A, n, out_shape)
+        for conserve in (False, True):
+            scale = (fs.astype(np.float64) * (n * n if conserve else 1)).astype(np.float32)
+            ref, _ = apref.resample_oversampled(frames, fine_aff.numpy(), n, fscale=scale, mask=mask, out_shape=out_shape, conserve_flux=conserve)
+            got = ops.resample_oversampled(t, A, n, fscale=fs, mask=torch.from_numpy(mask).cuda(), out_shape=out_shape, conserve_flux=conserve)
+            assert_biteq(got.cpu().numpy(), ref, 'one-pass oversampling %d conserve=%s' % (n, conserve))
+            two = ops.resample_oversampled_two_step(t, A, n, fscale=fs, mask=torch.from_numpy(mask).cuda(), out_shape=out_shape, conserve_flux=conserve)
+            assert_biteq(two.cpu().numpy(), ref, 'two-step oversampling %d conserve=%s' % (n, conserve))
+    assert np.isfinite(ref[:3]).mean() > 0.5 and np.isfinite(ref[3]).any()
+    # one transform per OUTPUT tile (wcs.tile_affines(..., tile_scale=n) in ApResample): perturbed copies of the frame's own
+    n = 4
+    fine_aff, _ = ops.oversampled_affines(A, n, out_shape)
+    ty, tx = (out_shape[0] + 15) // 16, (out_shape[1] + 63) // 64
+    tiles = np.repeat(np.repeat(fine_aff.numpy()[:, None, None, :], ty, 1), tx, 2)
+    tiles[..., 2] += rng.uniform(-0.3, 0.3, tiles.shape[:-1])
+    tiles[..., 5] += rng.uniform(-0.3, 0.3, tiles.shape[:-1])
+    ref, _ = apref.resample_oversampled(frames, tiles, n, fscale=fs, out_shape=out_shape)
+    got = ops.resample_oversampled(t, None, n, fscale=fs, out_shape=out_shape, fine_affines=tiles)
+    assert_biteq(got.cpu().numpy(), ref, 'one-pass oversampling, per-tile transforms')
+    with pytest.raises(ValueError):
+        ops.resample_oversampled(t, None, n, out_shape=out_shape, fine_affines=tiles[:, :-1])
+
+
 def test_oversampling_conserves_flux_on_a_coarser_grid(ops):
     """The case oversampling exists for: output pixels 2.5 input pixels wide.  One Lanczos sample per output pixel aliases (the
     flux of a star depends on where it falls); 4 x 4 sub-samples recover the total to a few 1e-3."""

@@ -385,3 +385,39 @@ def test_coadd_output_gain_bookkeeping():
     assert abs(ApResample('CRITICAL', combine='WEIGHTED')._output_gain(g, f, [2, 2, 2, 2]) - 4 * 45.0) < 1e-9
     assert abs(ApResample('CRITICAL', combine='WEIGHTED')._output_gain(g, f, [1, 1e-9, 1e-9, 1e-9]) - 45.0) < 1e-6
     assert ApResample('CRITICAL', combine='MEDIAN')._output_gain([1.5, None], [1, 1], None) is None
+
+
+def test_oracle_one_pass_oversampling_equals_fine_resample_plus_block_mean():
+    """Pins apref_resample_oversampled_f32 (the restatement the GPU's one-pass OVERSAMPLING kernel is checked against) to the
+    oracle pieces it replaces: apref_resample_affine_f32 on the n-times finer grid, then a float64 row-major block mean."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from oracle import apref
+    rng = np.random.default_rng(9)
+    N, H, W = 2, 80, 100
+    out_shape = (50, 70)
+    frames = rng.normal(200, 20, (N, H, W)).astype(np.float32)
+    frames[0, 40, 50] = np.nan
+    mask = (rng.random((H, W)) < 0.003).astype(np.uint8)
+    th = np.deg2rad([0.7, -2.0])
+    A = np.stack([1.1 * np.cos(th), -1.1 * np.sin(th), [5.0, 9.0], 1.1 * np.sin(th), 1.1 * np.cos(th), [7.0, 3.0]], 1)
+    for n in (2, 3):
+        off = 0.5 / n - 0.5
+        fine_aff = np.stack([A[:, 0] / n, A[:, 1] / n, A[:, 2] + (A[:, 0] + A[:, 1]) * off,
+                             A[:, 3] / n, A[:, 4] / n, A[:, 5] + (A[:, 3] + A[:, 4]) * off], 1)
+        fs = np.array([0.5, 1.75], np.float32)
+        got, wt = apref.resample_oversampled(frames, fine_aff, n, fscale=fs, mask=mask, out_shape=out_shape, conserve_flux=True)
+        fine, _ = apref.resample_affine(frames, fine_aff, fscale=fs, mask=mask, out_shape=(out_shape[0] * n, out_shape[1] * n),
+                                        conserve_flux=True)
+        want = np.empty_like(got)
+        for f in range(N):
+            for y in range(out_shape[0]):
+                for x in range(out_shape[1]):
+                    acc = 0.0
+                    for a in range(n):
+                        for b in range(n):
+                            acc += float(fine[f, y * n + a, x * n + b])
+                    want[f, y, x] = np.float32(acc * (1.0 / (n * n)))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or np.array_equal(got, want, equal_nan=True)
+        assert np.array_equal(wt, np.isfinite(got).astype(np.uint8))
+        assert np.isfinite(got).mean() > 0.5

@@ -13,7 +13,7 @@ SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAV
 i=0
 for S in "${SETS[@]}"; do
   i=$((i+1))
-  rocprofv3 --pmc $S --output-format csv -d $OUT/p$i -- python3 $REPO/"$@" > $OUT/b$i.txt 2> $OUT/p$i.log
+  timeout 180 rocprofv3 --pmc $S --output-format csv -d $OUT/p$i -- python3 $REPO/"$@" > $OUT/b$i.txt 2> $OUT/p$i.log
 done
 python3 - <<PY
 import csv,glob,collections
