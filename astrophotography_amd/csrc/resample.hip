@@ -51,7 +51,7 @@ constexpr int kGenericFloats = 4096;                 // general path: footprint 
 #define APGPU_RESAMPLE_FAST_ROWS 26
 #endif
 constexpr int kFastPitch = 80, kFastRows = APGPU_RESAMPLE_FAST_ROWS;   // fast path: fixed pitch (320 B: row j of a window = immediate offset)
-constexpr int kFastCopy = kFastPitch * kFastRows;    // 2080 floats per copy
+constexpr int kFastCopy = kFastPitch * (kFastRows + 2);   // floats per copy: the fill writes whole trips of 3 rows (27 for 26)
 constexpr int kFastOffB = ((kFastCopy + 1 + 31) / 64) * 64 + 32;   // copy B (shifted by one float) starts 32 banks after copy A, behind a gap
 constexpr int kLdsFloats = kFastOffB + kFastCopy > kGenericFloats ? kFastOffB + kFastCopy : kGenericFloats;   // 16.5 KB: nine workgroups per CU
 static_assert(kFastOffB % 64 == 32 && kFastOffB > kFastCopy && kFastPitch % 2 == 0, "LDS layout");
@@ -187,15 +187,25 @@ struct FastPrep {
     int idx;                    // float index of the window's first pair (even)
 };
 
-__device__ __forceinline__ FastPrep prep_fast(unsigned long long X, unsigned long long Y, int sh, int cxo, int cyo, v4i lut)
+// a * b + c with a, b < 2^24: one instruction (the compiler's own choice for `(s & 1) * constant` was compare + select)
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c)
 {
-    int jx, jy, px, py;
-    phases(X, Y, sh, jx, jy, px, py);
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
+// Xr, Yr: the fixed-point input coordinates minus the footprint origin + 2 (the window starts two taps before floor()), so
+// that their high dwords ARE the window's first column / row inside the footprint; the fractions are those of X, Y.
+__device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned long long Yr, int sh, v4i lut)
+{
+    int js, jr, px, py;
+    phases(Xr, Yr, sh, js, jr, px, py);
     FastPrep p;
     p.w = load_weights(lut, px, py);
-    const unsigned s = (unsigned)(jx - cxo), r = (unsigned)(jy - cyo);   // first column / row of the window inside the footprint
+    const unsigned s = (unsigned)js, r = (unsigned)jr;
     // an odd first column reads copy B, where element k holds the footprint's k + 1: the same six taps from the even k = s - 1
-    p.idx = (int)(__umul24(r, (unsigned)kFastPitch) + s + __umul24(s & 1u, (unsigned)(kFastOffB - 1)));
+    p.idx = (int)mad_u24(s & 1u, (unsigned)(kFastOffB - 1), mad_u24(r, (unsigned)kFastPitch, s));
     return p;
 }
 
@@ -230,24 +240,28 @@ __device__ __forceinline__ float eval_fast(const FastPrep &p, const float *tile)
 }
 
 template <bool OVERSAMPLED>
-__device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, v4i lut, int sh, int os, int x, int yb0,
+__device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, v4i lut, int sh, int os, int x0, int y0, int lx, int ly,
                                             v4i orsrc, v4i wrsrc, bool want_w, int ooff, int ostep)
 {
     const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
-    const int cxo = tc.bx0 + 2, cyo = tc.by0 + 2;
     const float fs = tc.fs;
     const unsigned long long n = OVERSAMPLED ? (unsigned long long)os : 1ull;
-    const unsigned long long u0 = (unsigned long long)(long long)x * n, v0 = (unsigned long long)(long long)yb0 * n;
-    // 64-bit two's-complement sums: exact, because the true coordinates fit (sane), whatever the partial products do
-    unsigned long long X = F0 * u0 + F1 * v0 + F2;
-    unsigned long long Y = F3 * u0 + F4 * v0 + F5;
+    // 64-bit two's-complement sums: exact, because the true coordinates fit (sane), whatever the partial products do.
+    // Tile-uniform part on the scalar unit (the tile's first pixel, minus the footprint origin), the lane's offset inside
+    // the tile - at most 63 columns and 3 rows - as two small products.
+    const unsigned long long us = (unsigned long long)(long long)x0 * n, vs = (unsigned long long)(long long)y0 * n;
+    const unsigned long long Xs = F0 * us + F1 * vs + F2 - ((unsigned long long)(unsigned)(tc.bx0 + 2) << 32);
+    const unsigned long long Ys = F3 * us + F4 * vs + F5 - ((unsigned long long)(unsigned)(tc.by0 + 2) << 32);
+    const unsigned long long ul = (unsigned long long)(unsigned)lx * n, vl = (unsigned long long)(unsigned)ly * n;
+    unsigned long long X = Xs + F0 * ul + F1 * vl;
+    unsigned long long Y = Ys + F3 * ul + F4 * vl;
     const unsigned long long dX = F1 * (4ull * n), dY = F4 * (4ull * n);
     if constexpr (!OVERSAMPLED) {
         // one pixel per trip, table rows loaded in the trip that uses them: a variant that fetched the next pixel's rows
         // one trip ahead (12 more registers) measured 3 % slower, two pixels per trip no faster
 #pragma unroll 1
         for (int k = 0; k < kTileH / 4; k++) {
-            const FastPrep cur = prep_fast(X, Y, sh, cxo, cyo, lut);
+            const FastPrep cur = prep_fast(X, Y, sh, lut);
             X += dX;
             Y += dY;
             const float v = eval_fast(cur, tile);
@@ -267,7 +281,7 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
                 unsigned long long Xb = Xa, Yb = Ya;
 #pragma unroll 1
                 for (int b = 0; b < os; b++) {
-                    const FastPrep cur = prep_fast(Xb, Yb, sh, cxo, cyo, lut);
+                    const FastPrep cur = prep_fast(Xb, Yb, sh, lut);
                     const float v = eval_fast(cur, tile);
                     acc += (double)((v == v) ? v * fs : __builtin_nanf(""));
                     Xb += F0;
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             }
 #pragma unroll
             for (int k = 0; k < TRIPS; k++) {
-                if (3 * k < tc.fh && r + 3 * k < kFastRows) {
+                if (3 * k < tc.fh) {                            // (scalar test; a trip's rows beyond fh land in the spare rows)
                     const bool good = (fabsf(val[k]) < __builtin_inff()) && mk[k] == 0;
                     const float xv = good ? val[k] : __builtin_nanf("");
                     tile[tid + 3 * kFastPitch * k] = xv;                       // copy A
@@ -590,7 +604,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
         const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
-        pixels_fast<OVERSAMPLED>(tc, tile, lrsrc, sh, os, x, yb0, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        pixels_fast<OVERSAMPLED>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
         return;
     }
     const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;
