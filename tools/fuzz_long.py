@@ -157,7 +157,8 @@ def resample_case(seed):
     """apgpu_resample_affine_f32 against the oracle: any rotation / scale / shift (LDS-staged and direct-gather tiles), masks,
     flux scales, output shapes, table resolutions."""
     rng = np.random.default_rng(seed)
-    N, H, W = int(rng.integers(1, 4)), int(rng.integers(6, 150)), int(rng.integers(6, 200))
+    big = rng.integers(0, 3) == 0                            # room for interior tiles: the aligned two-copy LDS path
+    N, H, W = int(rng.integers(1, 4)), int(rng.integers(6, 400 if big else 150)), int(rng.integers(6, 600 if big else 200))
     frames = rng.normal(300, 30, (N, H, W)).astype(np.float32)
     if rng.integers(0, 2):
         frames[rng.integers(0, N), rng.integers(0, H), rng.integers(0, W)] = np.nan
@@ -179,6 +180,27 @@ def resample_case(seed):
                                     out_shape=out_shape, n_phases=nph, conserve_flux=cf)
     assert np.array_equal(got.cpu().numpy(), ref, equal_nan=True), what
     assert np.array_equal(wgot.cpu().numpy(), wref), 'weights ' + what
+    # OVERSAMPLING in one pass against the oracle's one-pass statement (per-frame or per-output-tile fine transforms)
+    n = int(rng.integers(2, 6))
+    h, w = (H, W) if out_shape is None else out_shape
+    if h * w * n * n * N < 3_000_000:
+        fine_aff, _ = ops.oversampled_affines(A, n, (h, w))
+        fine_aff = fine_aff.numpy()
+        fs_n = np.ones(N, np.float32) if fs is None else fs
+        scale = (fs_n.astype(np.float64) * (n * n if cf else 1)).astype(np.float32)
+        mk = None if mask is None else torch.from_numpy(mask).cuda()
+        if rng.integers(0, 2):
+            ref2, _ = apref.resample_oversampled(frames, fine_aff, n, fscale=scale, mask=mask, out_shape=(h, w), n_phases=nph, conserve_flux=cf)
+            got2 = ops.resample_oversampled(torch.from_numpy(frames).cuda(), A, n, fscale=fs_n, mask=mk, out_shape=(h, w), n_phases=nph, conserve_flux=cf)
+        else:
+            ty, tx = (h + 15) // 16, (w + 63) // 64
+            tiles = np.repeat(np.repeat(fine_aff[:, None, None, :], ty, 1), tx, 2)
+            tiles[..., 2] += rng.uniform(-0.4, 0.4, tiles.shape[:-1])
+            tiles[..., 5] += rng.uniform(-0.4, 0.4, tiles.shape[:-1])
+            ref2, _ = apref.resample_oversampled(frames, tiles, n, fscale=scale, mask=mask, out_shape=(h, w), n_phases=nph, conserve_flux=cf)
+            got2 = ops.resample_oversampled(torch.from_numpy(frames).cuda(), None, n, fscale=fs_n, mask=mk, out_shape=(h, w), n_phases=nph,
+                                            conserve_flux=cf, fine_affines=tiles)
+        assert np.array_equal(got2.cpu().numpy(), ref2, equal_nan=True), f'oversampling {n} ' + what
 
 
 def arith_case(seed):
