@@ -47,14 +47,19 @@ using namespace apgpu;
 
 constexpr int kTileW = APGPU_RESAMPLE_TILE_W, kTileH = APGPU_RESAMPLE_TILE_H;
 constexpr int kGenericFloats = 4096;                 // general path: footprint up to 16 KB at its own pitch
-#ifndef APGPU_RESAMPLE_FAST_ROWS
-#define APGPU_RESAMPLE_FAST_ROWS 26
-#endif
-constexpr int kFastPitch = 80, kFastRows = APGPU_RESAMPLE_FAST_ROWS;   // fast path: fixed pitch (320 B: row j of a window = immediate offset)
-constexpr int kFastCopy = kFastPitch * (kFastRows + 2);   // floats per copy: the fill writes whole trips of 3 rows (27 for 26)
-constexpr int kFastOffB = ((kFastCopy + 1 + 31) / 64) * 64 + 32;   // copy B (shifted by one float) starts 32 banks after copy A, behind a gap
-constexpr int kLdsFloats = kFastOffB + kFastCopy > kGenericFloats ? kFastOffB + kFastCopy : kGenericFloats;   // 16.5 KB: nine workgroups per CU
-static_assert(kFastOffB % 64 == 32 && kFastOffB > kFastCopy && kFastPitch % 2 == 0, "LDS layout");
+constexpr int kFastPitch = 80;                       // fast path: fixed pitch (320 B: row j of a window = immediate offset)
+// TH = output rows per workgroup: 16 (one API tile: the only choice with one transform per tile) or 32 (two vertically
+// adjacent tiles of a frame that has ONE transform: half the workgroup launches and tile set-up, 42 instead of 2 x 26
+// footprint rows).  The fast path takes footprints of up to TH + 10 rows (rotations up to ~2.5 degrees).
+template <int TH>
+struct FastGeom {
+    static constexpr int kRows = TH + 10;
+    static constexpr int kTrips = (kRows + 2) / 3;                       // 3 footprint rows per fill trip
+    static constexpr int kCopy = kFastPitch * 3 * kTrips;                // floats per copy: the fill writes whole trips
+    static constexpr int kOffB = ((kCopy + 1 + 31) / 64) * 64 + 32;      // copy B (shifted by one float) starts 32 banks after copy A, behind a gap
+    static constexpr int kLdsFloats = kOffB + kCopy > kGenericFloats ? kOffB + kCopy : kGenericFloats;   // 17.6 KB (TH 16) / 29.1 KB (TH 32)
+    static_assert(kOffB % 64 == 32 && kOffB > kCopy && kFastPitch % 2 == 0, "LDS layout");
+};
 constexpr unsigned kRsrcFlags = 0x00020000;          // raw buffer, 32-bit elements (gfx9 family word 3)
 typedef apgpu_v2f v2f;
 typedef apgpu_v4f v4f;
@@ -80,7 +85,7 @@ typedef __attribute__((address_space(3))) const volatile v2f *lds_pair_p;   // v
 #define APGPU_RESAMPLE_ROWS_PER_BATCH 3
 #endif
 
-enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8 };
+enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8, kSaneTop = 16, kSaneBot = 32 };   // kSane: every 16-row half of the workgroup's tile is defined
 
 // What the tile pass works out per output tile (everything tile-uniform), 64 bytes.
 struct alignas(64) TileRec {
@@ -174,7 +179,7 @@ __device__ __forceinline__ void phases(unsigned long long X, unsigned long long 
 struct TileCtx {
     long long F[6];
     int bx0, by0, fw, fh;
-    bool staged, sane;
+    bool staged, sane_top, sane_bot;                     // sane_*: the 16-row API tile holding the workgroup's upper / lower rows is defined
     float fs;
 };
 
@@ -197,6 +202,7 @@ __device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c)
 
 // Xr, Yr: the fixed-point input coordinates minus the footprint origin + 2 (the window starts two taps before floor()), so
 // that their high dwords ARE the window's first column / row inside the footprint; the fractions are those of X, Y.
+template <int OFFB>
 __device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned long long Yr, int sh, v4i lut)
 {
     int js, jr, px, py;
@@ -205,7 +211,7 @@ __device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned lo
     p.w = load_weights(lut, px, py);
     const unsigned s = (unsigned)js, r = (unsigned)jr;
     // an odd first column reads copy B, where element k holds the footprint's k + 1: the same six taps from the even k = s - 1
-    p.idx = (int)mad_u24(s & 1u, (unsigned)(kFastOffB - 1), mad_u24(r, (unsigned)kFastPitch, s));
+    p.idx = (int)mad_u24(s & 1u, (unsigned)(OFFB - 1), mad_u24(r, (unsigned)kFastPitch, s));
     return p;
 }
 
@@ -239,7 +245,7 @@ __device__ __forceinline__ float eval_fast(const FastPrep &p, const float *tile)
     return V.x + V.y;
 }
 
-template <bool OVERSAMPLED>
+template <bool OVERSAMPLED, int TH>
 __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, v4i lut, int sh, int os, int x0, int y0, int lx, int ly,
                                             v4i orsrc, v4i wrsrc, bool want_w, int ooff, int ostep)
 {
@@ -260,8 +266,8 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
         // one pixel per trip, table rows loaded in the trip that uses them: a variant that fetched the next pixel's rows
         // one trip ahead (12 more registers) measured 3 % slower, two pixels per trip no faster
 #pragma unroll 1
-        for (int k = 0; k < kTileH / 4; k++) {
-            const FastPrep cur = prep_fast(X, Y, sh, lut);
+        for (int k = 0; k < TH / 4; k++) {
+            const FastPrep cur = prep_fast<FastGeom<TH>::kOffB>(X, Y, sh, lut);
             X += dX;
             Y += dY;
             const float v = eval_fast(cur, tile);
@@ -273,7 +279,7 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
     } else {
         const double inv = 1.0 / (double)(os * os);
 #pragma unroll 1
-        for (int k = 0; k < kTileH / 4; k++) {
+        for (int k = 0; k < TH / 4; k++) {
             double acc = 0.0;                                     // a NaN sub-sample makes the sum, and the pixel, NaN
             unsigned long long Xa = X, Ya = Y;
 #pragma unroll 1
@@ -281,7 +287,7 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
                 unsigned long long Xb = Xa, Yb = Ya;
 #pragma unroll 1
                 for (int b = 0; b < os; b++) {
-                    const FastPrep cur = prep_fast(Xb, Yb, sh, lut);
+                    const FastPrep cur = prep_fast<FastGeom<TH>::kOffB>(Xb, Yb, sh, lut);
                     const float v = eval_fast(cur, tile);
                     acc += (double)((v == v) ? v * fs : __builtin_nanf(""));
                     Xb += F0;
@@ -305,12 +311,12 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 // selects they feed disappear.  y_ok: the pixel's row is inside the output.
 template <bool INTERIOR>
 __device__ __forceinline__ float sample_general(const TileCtx &tc, const FrameView &fv, const float *tile, const float *__restrict__ lut,
-                                                unsigned long long X, unsigned long long Y, int sh)
+                                                unsigned long long X, unsigned long long Y, int sh, bool sane)
 {
     int jx, jy, px, py;
     phases(X, Y, sh, jx, jy, px, py);
     // 2 <= ix <= w_in - 4 (the 6 x 6 window inside the frame)
-    const bool inside = INTERIOR || (tc.sane && (unsigned)(jx - 2) < (unsigned)(fv.w_in - 5) && (unsigned)(jy - 2) < (unsigned)(fv.h_in - 5));
+    const bool inside = INTERIOR || (sane && (unsigned)(jx - 2) < (unsigned)(fv.w_in - 5) && (unsigned)(jy - 2) < (unsigned)(fv.h_in - 5));
     const int ix = inside ? jx : 0, iy = inside ? jy : 0;
     const Weights wts = load_weights(lut, inside ? px : 0, inside ? py : 0);
     float v;
@@ -345,7 +351,7 @@ __device__ __forceinline__ float sample_general(const TileCtx &tc, const FrameVi
 }
 
 // The pixels of one lane: column x, rows yb0, yb0 + 4, ...
-template <bool INTERIOR, bool OVERSAMPLED>
+template <bool INTERIOR, bool OVERSAMPLED, int TH>
 __device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameView &fv, const float *tile, const float *__restrict__ lut,
                                                int sh, int os, int x, int yb0, int h_out, int64_t row_stride, float *op, uint8_t *wp)
 {
@@ -358,12 +364,13 @@ __device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameVie
     const double inv = 1.0 / (double)(os * os);
     // One pixel per trip (not unrolled): residency hides latency better than batching (round 1 measurement).
 #pragma unroll 1
-    for (int k = 0; k < kTileH / 4; k++) {
+    for (int k = 0; k < TH / 4; k++) {
         const int y = yb0 + 4 * k;
+        const bool sane = (TH == 16 || k < 4) ? tc.sane_top : tc.sane_bot;   // rows ly + 4k: k < 4 is the upper API tile
         if (!INTERIOR && y >= h_out) break;
         float res;
         if constexpr (!OVERSAMPLED) {
-            res = sample_general<INTERIOR>(tc, fv, tile, lut, X, Y, sh);
+            res = sample_general<INTERIOR>(tc, fv, tile, lut, X, Y, sh, sane);
         } else {
             double acc = 0.0;
             unsigned long long Xa = X, Ya = Y;
@@ -372,7 +379,7 @@ __device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameVie
                 unsigned long long Xb = Xa, Yb = Ya;
 #pragma unroll 1
                 for (int b = 0; b < os; b++) {
-                    acc += (double)sample_general<INTERIOR>(tc, fv, tile, lut, Xb, Yb, sh);
+                    acc += (double)sample_general<INTERIOR>(tc, fv, tile, lut, Xb, Yb, sh, sane);
                     Xb += F0;
                     Yb += F3;
                 }
@@ -393,49 +400,60 @@ __device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameVie
 }
 
 // ---- the tile pass ---------------------------------------------------------------------------------------------------
-// One thread per (frame, tile).  os = 1, or the oversampling factor: the transform then belongs to the os-times finer grid
-// and the tile covers the fine pixels of its 64 x 16 output pixels.
+// One thread per (frame, workgroup tile).  th = 16 or 32 output rows per workgroup tile (gy counts those).  os = 1, or the
+// oversampling factor: the transform then belongs to the os-times finer grid and a tile covers the fine pixels of its output
+// pixels.  Whether a pixel is DEFINED is decided per 64 x 16 API tile (the oracle's rule: corner coordinates within +-1e9,
+// coefficients below 2^30); a 32-row workgroup tile carries that flag for its upper and its lower half.
+__device__ __forceinline__ bool tile_corners_ok(const double *a, long long ua, long long ub, long long va, long long vb)
+{
+    const long long cu[4] = {ua, ub, ua, ub}, cv[4] = {va, va, vb, vb};
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double xi = fma(a[0], (double)cu[k], fma(a[1], (double)cv[k], a[2]));
+        const double yi = fma(a[3], (double)cu[k], fma(a[4], (double)cv[k], a[5]));
+        ok = ok && (xi > -1e9) && (xi < 1e9) && (yi > -1e9) && (yi < 1e9);      // false for NaN
+    }
+    return ok;
+}
+
 __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__restrict__ affines, int per_tile, int conserve_flux,
-                                                            const float *__restrict__ fscale, int os, int gx, int gy, int64_t ntiles,
+                                                            const float *__restrict__ fscale, int os, int th, int gx, int gy, int64_t ntiles,
                                                             int h_in, int w_in, int h_out, int w_out, int fast_ok, TileRec *__restrict__ recs)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ntiles) return;
     const int tx = (int)(idx % gx), ty = (int)((idx / gx) % gy);
     const int64_t f = idx / ((int64_t)gx * gy);
-    const int x0 = tx * kTileW, y0 = ty * kTileH;
-    // one transform per frame, or one per output tile
+    const int x0 = tx * kTileW, y0 = ty * th;
+    // one transform per frame, or one per output tile (th = 16 then)
     const double *A = affines + 6 * (per_tile ? idx : f);
-    const double a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5];
+    const double a[6] = {A[0], A[1], A[2], A[3], A[4], A[5]};
     float fs = fscale ? fscale[f] : 1.0f;
-    if (conserve_flux) fs = (float)((double)fs * fabs(fma(a0, a4, -(a1 * a3))));   // (fine) output pixel area in input pixels
-    // corner pixels of the tile on the (fine) output grid: an affine map takes its extremes there
+    if (conserve_flux) fs = (float)((double)fs * fabs(fma(a[0], a[4], -(a[1] * a[3]))));   // (fine) output pixel area in input pixels
+    // the coefficients below 2^30 (the fixed-point evaluation is then exact while the true sums fit 64 bits); false for NaN
+    const double amax = fmax(fmax(fmax(fabs(a[0]), fabs(a[1])), fmax(fabs(a[2]), fabs(a[3]))), fmax(fabs(a[4]), fabs(a[5])));
+    const bool coef_ok = (amax < 1073741824.0) && (a[0] == a[0]) && (a[1] == a[1]) && (a[2] == a[2]) && (a[3] == a[3]) && (a[4] == a[4]) && (a[5] == a[5]);
+    // corner pixels on the (fine) output grid, per API tile: an affine map takes its extremes there
     const int xl = x0 + kTileW - 1 < w_out - 1 ? x0 + kTileW - 1 : w_out - 1;
-    const int yl = y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1;
     const long long ua = (long long)x0 * os, ub = (long long)xl * os + (os - 1);
-    const long long va = (long long)y0 * os, vb = (long long)yl * os + (os - 1);
-    const long long cu[4] = {ua, ub, ua, ub}, cv[4] = {va, va, vb, vb};
-    double mnx = __builtin_inf(), mxx = -__builtin_inf(), mny = __builtin_inf(), mxy = -__builtin_inf();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const double xi = fma(a0, (double)cu[k], fma(a1, (double)cv[k], a2));
-        const double yi = fma(a3, (double)cu[k], fma(a4, (double)cv[k], a5));
-        mnx = fmin(mnx, xi); mxx = fmax(mxx, xi);
-        mny = fmin(mny, yi); mxy = fmax(mxy, yi);
-    }
-    // the tile is defined if its corner coordinates stay within +-1e9 pixels and the coefficients below 2^30 (the
-    // fixed-point evaluation is then exact: the true sums fit 64 bits); false for NaN coefficients
-    const double amax = fmax(fmax(fmax(fabs(a0), fabs(a1)), fmax(fabs(a2), fabs(a3))), fmax(fabs(a4), fabs(a5)));
-    const bool sane = (mnx > -1e9) && (mxx < 1e9) && (mny > -1e9) && (mxy < 1e9) && (amax < 1073741824.0) &&
-                      (a0 == a0) && (a1 == a1) && (a2 == a2) && (a3 == a3) && (a4 == a4) && (a5 == a5);
+    const int yl_top = y0 + kTileH - 1 < h_out - 1 ? y0 + kTileH - 1 : h_out - 1;
+    const bool has_bot = th > kTileH && y0 + kTileH < h_out;
+    const int yl_bot = y0 + th - 1 < h_out - 1 ? y0 + th - 1 : h_out - 1;
+    const bool sane_top = coef_ok && tile_corners_ok(a, ua, ub, (long long)y0 * os, (long long)yl_top * os + (os - 1));
+    const bool sane_bot = has_bot ? coef_ok && tile_corners_ok(a, ua, ub, (long long)(y0 + kTileH) * os, (long long)yl_bot * os + (os - 1)) : sane_top;
+    const bool sane = sane_top && sane_bot;
     TileRec rec;
 #pragma unroll
-    for (int k = 0; k < 6; k++) rec.F[k] = sane ? __double2ll_rn(A[k] * 4294967296.0) : 0;
+    for (int k = 0; k < 6; k++) rec.F[k] = coef_ok ? __double2ll_rn(a[k] * 4294967296.0) : 0;
     int bx0 = 0, by0 = 0, w = 0, h = 0;
-    unsigned flags = 0;
+    unsigned flags = (sane_top ? kSaneTop : 0u) | (sane_bot ? kSaneBot : 0u);
     if (sane) {
         flags |= kSane;
         // the footprint from the SAME integer coordinates the pixels will use (linear: extremes at the corners)
+        const int yl = has_bot ? yl_bot : yl_top;
+        const long long va = (long long)y0 * os, vb = (long long)yl * os + (os - 1);
+        const long long cu[4] = {ua, ub, ua, ub}, cv[4] = {va, va, vb, vb};
         long long jx0 = 0x7fffffffffffffffLL, jx1 = -jx0, jy0 = jx0, jy1 = -jx0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -453,10 +471,10 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
             w = (int)wl;
             h = (int)hl;
             flags |= kStaged;
-            const bool interior = bx0 >= 0 && by0 >= 0 && bx0 + w <= w_in && by0 + h <= h_in && y0 + kTileH <= h_out;
+            const bool interior = bx0 >= 0 && by0 >= 0 && bx0 + w <= w_in && by0 + h <= h_in && y0 + th <= h_out;
             if (interior) flags |= kInterior;
 #ifndef APGPU_VARIANT_RESAMPLE_NO_FAST
-            if (interior && fast_ok && w <= kFastPitch && h <= kFastRows) flags |= kFast;
+            if (interior && fast_ok && w <= kFastPitch && h <= th + 10) flags |= kFast;
 #endif
         }
     }
@@ -467,14 +485,15 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
     recs[idx] = rec;
 }
 
-template <bool HAS_MASK, bool OVERSAMPLED>
+template <bool HAS_MASK, bool OVERSAMPLED, int TH>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
                                                              const float *__restrict__ lut,
                                                              int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out)
 {
-    __shared__ __attribute__((aligned(16))) float tile[kLdsFloats];
+    using G = FastGeom<TH>;
+    __shared__ __attribute__((aligned(16))) float tile[G::kLdsFloats];
     // Tile order: grid = (tiles per frame rounded up to 8, frames).  Workgroups are dispatched round-robin over the 8 XCDs
     // (x fastest, and gridDim.x is a multiple of 8: workgroup x runs on XCD x % 8); a frame's tiles are cut into 8 contiguous
     // ranges, one per XCD, and consecutive workgroups of an XCD take consecutive tiles of its range, so that the halo a tile
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const int64_t f = blockIdx.y;
     const int t = (int)f * per_frame + rem;
     const int tyi = rem / gx, txi = rem - tyi * gx;
-    const int x0 = txi * kTileW, y0 = tyi * kTileH;
+    const int x0 = txi * kTileW, y0 = tyi * TH;
     FrameView fv;
     fv.src = frames + f * (int64_t)h_in * w_in;
     fv.mask = HAS_MASK ? mask : nullptr;
@@ -508,7 +527,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     tc.fh = (int)((dims >> 13) & 0x1fffu);
     const unsigned flags = dims >> 26;
     tc.staged = (flags & kStaged) != 0;
-    tc.sane = (flags & kSane) != 0;
+    tc.sane_top = (flags & kSaneTop) != 0;
+    tc.sane_bot = (flags & kSaneBot) != 0;
     tc.fs = rp->fs;
     const bool fast = (flags & kFast) != 0, interior = (flags & kInterior) != 0;
     const int tid = threadIdx.x;
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
             const int r = tid / kFastPitch, c = tid - r * kFastPitch;
             const int e0 = (tc.by0 + r) * w_in + tc.bx0 + c;
             const int estep = 3 * w_in;
-            constexpr int TRIPS = (kFastRows + 2) / 3;
+            constexpr int TRIPS = G::kTrips;
             float val[TRIPS];
             char mk[TRIPS];
 #pragma unroll
@@ -541,7 +561,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                     const bool good = (fabsf(val[k]) < __builtin_inff()) && mk[k] == 0;
                     const float xv = good ? val[k] : __builtin_nanf("");
                     tile[tid + 3 * kFastPitch * k] = xv;                       // copy A
-                    tile[kFastOffB - 1 + tid + 3 * kFastPitch * k] = xv;       // copy B: element e - 1 (e = 0 lands in the gap)
+                    tile[G::kOffB - 1 + tid + 3 * kFastPitch * k] = xv;       // copy B: element e - 1 (e = 0 lands in the gap)
                 }
             }
         }
@@ -604,15 +624,15 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
         const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
-        pixels_fast<OVERSAMPLED>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        pixels_fast<OVERSAMPLED, TH>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
         return;
     }
     const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;
     float *op = out + o0;
     uint8_t *wp = wout ? wout + o0 : nullptr;
     const int64_t row_stride = 4 * (int64_t)w_out;
-    if (interior) pixels_general<true, OVERSAMPLED>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
-    else pixels_general<false, OVERSAMPLED>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
+    if (interior) pixels_general<true, OVERSAMPLED, TH>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
+    else pixels_general<false, OVERSAMPLED, TH>(tc, fv, tile, lut, sh, os, x, yb0, h_out, row_stride, op, wp);
 }
 
 int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t w_in, const uint8_t *mask, const double *affines,
@@ -631,25 +651,37 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
     int log2_phases = 0;
     while ((1 << log2_phases) < n_phases) log2_phases++;
     if (reinterpret_cast<uintptr_t>(lut) & 7) return fail(APGPU_EINVAL, "%s: lut must be 8-byte aligned", who);
-    const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + kTileH - 1) / kTileH;
+    // 32 output rows per workgroup where a frame has one transform, else the 16 of the API tile
+#ifdef APGPU_VARIANT_RESAMPLE_TH16
+    const int th = kTileH;
+#else
+    const int th = (!affines_per_tile && h_out > kTileH) ? 2 * kTileH : kTileH;
+#endif
+    const int64_t gx = (w_out + kTileW - 1) / kTileW, gy = (h_out + th - 1) / th;
     hipStream_t st = as_stream(stream);
-    // the per-tile records: 64 bytes per 1024 output pixels, stream-ordered scratch
+    // the per-tile records: 64 bytes per workgroup tile, stream-ordered scratch
     const int64_t ntiles = (int64_t)n_frames * gx * gy;
     if (ntiles > 0x7ffffff0LL) return fail(APGPU_EUNSUPPORTED, "%s: too many tiles (%lld)", who, (long long)ntiles);
     TileRec *recs = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&recs), (size_t)ntiles * sizeof(TileRec), st);
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "%s: cannot allocate %lld tile records: %s", who, (long long)ntiles, hipGetErrorString(e));
     // the fast path addresses a frame and a tile's output rows with 32-bit byte offsets
-    const int fast_ok = (h_in * w_in < (1LL << 30)) && (w_out < (1LL << 26));
+    const int fast_ok = (h_in * w_in < (1LL << 30)) && (w_out < (1LL << 25));
     const int64_t tb = (ntiles + 255) / 256;
-    hipLaunchKernelGGL(resample_tiles_kernel, dim3((unsigned)tb), dim3(256), 0, st, affines, affines_per_tile, conserve_flux, fscale, (int)os,
+    hipLaunchKernelGGL(resample_tiles_kernel, dim3((unsigned)tb), dim3(256), 0, st, affines, affines_per_tile, conserve_flux, fscale, (int)os, th,
                        (int)gx, (int)gy, ntiles, (int)h_in, (int)w_in, (int)h_out, (int)w_out, fast_ok, recs);
     int rc = check_launch(who);
     if (rc == APGPU_OK) {
         const dim3 grid((unsigned)(((gx * gy + 7) / 8) * 8), (unsigned)n_frames);
-#define APGPU_RESAMPLE_LAUNCH(M, O)                                                                                                      \
-    hipLaunchKernelGGL((resample_affine_kernel<M, O>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx, (int)gy, lut, \
-                       log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out)
+#define APGPU_RESAMPLE_LAUNCH(M, O)                                                                                                            \
+    do {                                                                                                                                       \
+        if (th == kTileH)                                                                                                                      \
+            hipLaunchKernelGGL((resample_affine_kernel<M, O, kTileH>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx, (int)gy, \
+                               lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);                       \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((resample_affine_kernel<M, O, 2 * kTileH>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx,    \
+                               (int)gy, lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);              \
+    } while (0)
         if (mask) {
             if (os > 1) APGPU_RESAMPLE_LAUNCH(true, true);
             else APGPU_RESAMPLE_LAUNCH(true, false);
