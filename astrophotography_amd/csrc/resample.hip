@@ -202,8 +202,8 @@ __device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c)
 
 // Xr, Yr: the fixed-point input coordinates minus the footprint origin + 2 (the window starts two taps before floor()), so
 // that their high dwords ARE the window's first column / row inside the footprint; the fractions are those of X, Y.
-template <int OFFB>
-__device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned long long Yr, int sh, v4i lut)
+template <int OFFB, typename LutT>
+__device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned long long Yr, int sh, LutT lut)
 {
     int js, jr, px, py;
     phases(Xr, Yr, sh, js, jr, px, py);
@@ -245,8 +245,8 @@ __device__ __forceinline__ float eval_fast(const FastPrep &p, const float *tile)
     return V.x + V.y;
 }
 
-template <bool OVERSAMPLED, int TH>
-__device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, v4i lut, int sh, int os, int x0, int y0, int lx, int ly,
+template <bool OVERSAMPLED, int TH, int UNR, typename LutT>
+__device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile, LutT lut, int sh, int os, int x0, int y0, int lx, int ly,
                                             v4i orsrc, v4i wrsrc, bool want_w, int ooff, int ostep)
 {
     const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
@@ -265,7 +265,7 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
     if constexpr (!OVERSAMPLED) {
         // one pixel per trip, table rows loaded in the trip that uses them: a variant that fetched the next pixel's rows
         // one trip ahead (12 more registers) measured 3 % slower, two pixels per trip no faster
-#pragma unroll 1
+#pragma unroll UNR
         for (int k = 0; k < TH / 4; k++) {
             const FastPrep cur = prep_fast<FastGeom<TH>::kOffB>(X, Y, sh, lut);
             X += dX;
@@ -485,6 +485,96 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
     recs[idx] = rec;
 }
 
+// The footprint of a FAST tile on its way from global memory to LDS: 3 rows of 80 columns per trip (240 of the 256 lanes),
+// every load of the tile in flight before the first LDS store.  Columns beyond the footprint's width are read too (inside
+// the frame's buffer, or returned as 0 by the bounds check) and never used.
+template <bool HAS_MASK, int TRIPS>
+struct FastFill {
+    float val[TRIPS];
+    char mk[TRIPS];
+};
+
+template <bool HAS_MASK, int TRIPS>
+__device__ __forceinline__ void fast_fill_issue(FastFill<HAS_MASK, TRIPS> &ff, const float *src, const uint8_t *mask, int bx0, int by0, int fh,
+                                                int h_in, int w_in, int tid)
+{
+    const v4i irsrc = make_rsrc(src, (unsigned)(h_in * w_in) * 4u);
+    const v4i mrsrc = make_rsrc(mask, (unsigned)(h_in * w_in));
+    const int r = tid / kFastPitch, c = tid - r * kFastPitch;
+    const int e0 = (by0 + r) * w_in + bx0 + c;
+    const int estep = 3 * w_in;
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        ff.val[k] = 0.f;
+        ff.mk[k] = 0;
+        if (3 * k < fh && tid < 3 * kFastPitch) {               // (the first test is scalar)
+            ff.val[k] = apgpu_buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
+            if constexpr (HAS_MASK) ff.mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
+        }
+    }
+}
+
+template <bool HAS_MASK, int TRIPS, int OFFB>
+__device__ __forceinline__ void fast_fill_store(const FastFill<HAS_MASK, TRIPS> &ff, int fh, float *tile, int tid)
+{
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        if (3 * k < fh && tid < 3 * kFastPitch) {               // (a trip's rows beyond fh land in the spare rows)
+            const bool good = (fabsf(ff.val[k]) < __builtin_inff()) && ff.mk[k] == 0;
+            const float xv = good ? ff.val[k] : __builtin_nanf("");
+            tile[tid + 3 * kFastPitch * k] = xv;                       // copy A
+            tile[OFFB - 1 + tid + 3 * kFastPitch * k] = xv;            // copy B: element e - 1 (e = 0 lands in the gap)
+        }
+    }
+}
+
+// General staged fill (validity by position applied here): a wave takes every 4th footprint row (row address math is
+// scalar), 3 rows and up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of a trip
+// are in flight together.  HAS_MASK is a template flag: as a run-time test every mask load became a branch followed by a
+// full wait, which serialised the whole batch of loads.
+template <bool HAS_MASK>
+__device__ __forceinline__ void general_fill(const TileCtx &tc, const FrameView &fv, float *tile, int tid)
+{
+    const int bx0 = tc.bx0, by0 = tc.by0, fw = tc.fw, h = tc.fh;
+    const int h_in = fv.h_in, w_in = fv.w_in;
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave), lane = tid % kWave;
+    constexpr int RU = 3;
+    for (int r0 = wave; r0 < h; r0 += 4 * RU) {
+        for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
+            float val[RU][2];
+            uint8_t mk[RU][2];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int row = by0 + r0 + 4 * u;
+                const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
+                const float *rp2 = fv.src + (int64_t)rc * w_in;
+                const uint8_t *mp = HAS_MASK ? fv.mask + (int64_t)rc * w_in : nullptr;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int col = bx0 + c0 + q * kWave + lane;
+                    const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
+                    val[u][q] = rp2[cc];
+                    if constexpr (HAS_MASK) mk[u][q] = mp[cc];
+                    else mk[u][q] = 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int r = r0 + 4 * u;
+                const int row = by0 + r;
+                const bool row_ok = row >= 0 && row < h_in;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int c = c0 + q * kWave + lane;
+                    const int col = bx0 + c;
+                    const bool good = row_ok && col >= 0 && col < w_in && (fabsf(val[u][q]) < __builtin_inff()) && mk[u][q] == 0;
+                    if (r < h && c < fw) tile[r * fw + c] = good ? val[u][q] : __builtin_nanf("");
+                }
+            }
+        }
+    }
+}
+
 template <bool HAS_MASK, bool OVERSAMPLED, int TH>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
@@ -534,80 +624,11 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const int tid = threadIdx.x;
 
     if (fast) {
-        // 3 footprint rows of 80 columns per trip (240 of the 256 lanes), every load of the tile in flight before the first
-        // LDS store; columns beyond the footprint's width are read too (inside the frame's buffer, or returned as 0 by the
-        // bounds check) and never used
-        const v4i irsrc = make_rsrc(fv.src, (unsigned)(h_in * w_in) * 4u);
-        const v4i mrsrc = make_rsrc(mask, (unsigned)(h_in * w_in));
-        if (tid < 3 * kFastPitch) {
-            const int r = tid / kFastPitch, c = tid - r * kFastPitch;
-            const int e0 = (tc.by0 + r) * w_in + tc.bx0 + c;
-            const int estep = 3 * w_in;
-            constexpr int TRIPS = G::kTrips;
-            float val[TRIPS];
-            char mk[TRIPS];
-#pragma unroll
-            for (int k = 0; k < TRIPS; k++) {
-                val[k] = 0.f;
-                mk[k] = 0;
-                if (3 * k < tc.fh) {                            // (scalar test)
-                    val[k] = apgpu_buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
-                    if constexpr (HAS_MASK) mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < TRIPS; k++) {
-                if (3 * k < tc.fh) {                            // (scalar test; a trip's rows beyond fh land in the spare rows)
-                    const bool good = (fabsf(val[k]) < __builtin_inff()) && mk[k] == 0;
-                    const float xv = good ? val[k] : __builtin_nanf("");
-                    tile[tid + 3 * kFastPitch * k] = xv;                       // copy A
-                    tile[G::kOffB - 1 + tid + 3 * kFastPitch * k] = xv;       // copy B: element e - 1 (e = 0 lands in the gap)
-                }
-            }
-        }
+        FastFill<HAS_MASK, G::kTrips> ff;
+        fast_fill_issue<HAS_MASK, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+        fast_fill_store<HAS_MASK, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
     } else if (tc.staged) {
-        const int bx0 = tc.bx0, by0 = tc.by0, fw = tc.fw, h = tc.fh;
-        // branch-free fill: a wave takes every 4th footprint row (row address math is scalar), 3 rows and
-        // up to 2 x 64 columns per trip with clamped - always valid - addresses, so that all the loads of
-        // a trip are in flight together; validity is applied afterwards
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), lane = threadIdx.x % kWave;
-        // HAS_MASK is a template flag: as a run-time test every mask load became a branch followed by a
-        // full wait, which serialised the whole batch of loads
-        constexpr int RU = 3;
-        for (int r0 = wave; r0 < h; r0 += 4 * RU) {
-            for (int c0 = 0; c0 < fw; c0 += 2 * kWave) {
-                float val[RU][2];
-                uint8_t mk[RU][2];
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int row = by0 + r0 + 4 * u;
-                    const int rc = row < 0 ? 0 : (row >= h_in ? h_in - 1 : row);
-                    const float *rp2 = fv.src + (int64_t)rc * w_in;
-                    const uint8_t *mp = HAS_MASK ? mask + (int64_t)rc * w_in : nullptr;
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int col = bx0 + c0 + q * kWave + lane;
-                        const int cc = col < 0 ? 0 : (col >= w_in ? w_in - 1 : col);
-                        val[u][q] = rp2[cc];
-                        if constexpr (HAS_MASK) mk[u][q] = mp[cc];
-                        else mk[u][q] = 0;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int r = r0 + 4 * u;
-                    const int row = by0 + r;
-                    const bool row_ok = row >= 0 && row < h_in;
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const int c = c0 + q * kWave + lane;
-                        const int col = bx0 + c;
-                        const bool good = row_ok && col >= 0 && col < w_in && (fabsf(val[u][q]) < __builtin_inff()) && mk[u][q] == 0;
-                        if (r < h && c < fw) tile[r * fw + c] = good ? val[u][q] : __builtin_nanf("");
-                    }
-                }
-            }
-        }
+        general_fill<HAS_MASK>(tc, fv, tile, tid);
     }
     __syncthreads();
 
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
         const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
-        pixels_fast<OVERSAMPLED, TH>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        pixels_fast<OVERSAMPLED, TH, 1>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
         return;
     }
     const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;
