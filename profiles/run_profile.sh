@@ -18,10 +18,10 @@ rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py --steps 20 --warmup 3 "$@" > $OUT/bench_line.json 2> $OUT/bench_line.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2> $OUT/trace.log
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2> $OUT/trace.log
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.log
+  timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.log
 done
 python3 $REPO/profiles/summarize.py $OUT $TAG
