@@ -122,7 +122,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // every padding slot ends as the +inf sentinel.  FULL stacks pass nframes = NP, MINN = NP: nothing of this remains.
 template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
-                                               bool dodiv, float (&v)[NP], int nframes = NP)
+                                               bool dodiv, float (&v)[NP], int nframes = NP, int plo = 0)
 {
     // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
     // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
@@ -163,7 +163,8 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
         if constexpr (MINN < NP) {
 #pragma unroll
             for (int g = 0; g < CNT; g++)
-                if (F0 + g >= MINN && F0 + g >= nframes) v[F0 + g] = __builtin_inff();   // scalar test per slot, one v_mov per pad
+                if (F0 + g >= MINN && F0 + g >= nframes)                                   // scalar tests per slot, one v_mov per pad;
+                    v[F0 + g] = (F0 + g < nframes + plo) ? -__builtin_inff() : __builtin_inff();   // the first plo pads sort to the bottom (split pads)
         }
         const bool range_ok = !RANGE_GUARD || !dodiv || (mx < 0x1p50f && mn > 0x1p-50f);
         return nf_ok && range_ok && (acc.x == 0.f) && (acc.y == 0.f);
@@ -196,13 +197,17 @@ __device__ __forceinline__ float uniform_pick(const float (&v)[NP], int idx)
 }
 
 // nvalid (wave-uniform): the column's finite values occupy v[0 .. nvalid), +inf sentinels follow; MINN <= nvalid.
+// plo (wave-uniform, split pads): the column starts with plo -inf sentinels; the finite values occupy v[plo .. plo + nvalid).
 template <int NP, int MINN = NP>
-__device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv, int nvalid = NP)
+__device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv, int nvalid = NP, int plo = 0)
 {
-    const float lo = v[0];
+    float lo = v[0];
     float hi;
     if constexpr (MINN >= NP) hi = v[NP - 1];
-    else hi = uniform_pick<(MINN > 0 ? MINN - 1 : 0), NP>(v, __builtin_amdgcn_readfirstlane(nvalid) - 1);
+    else {
+        if (plo > 0) lo = uniform_pick<0, NP>(v, plo);
+        hi = uniform_pick<(MINN > 0 ? MINN - 1 : 0), NP>(v, plo + __builtin_amdgcn_readfirstlane(nvalid) - 1);
+    }
     const bool big_ok = fmaxf(fabsf(lo), fabsf(hi)) < 0x1p50f;
     const bool one_sign = lo > 0x1p-50f || hi < -0x1p-50f;    // then min |q| = |lo| or |hi| and it is above 2^-50
     bool small_ok = one_sign;
@@ -231,7 +236,7 @@ struct ColumnCtx {
 // valid values.  RAWREG: take the raw values from `raw` (already in registers, !CALIB) instead of re-reading them.
 template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int NRAW>
 __device__ __forceinline__ int load_column_exact(const StackParams &prm, const FrameScalars<NP> &fs, int64_t p, const ColumnCtx &cx,
-                                                 const RawT (&raw)[NRAW], float (&v)[NP])
+                                                 const RawT (&raw)[NRAW], float (&v)[NP], int plo = 0)
 {
     const int N = prm.N;
     int n = 0;
@@ -262,6 +267,7 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
         ok = ok && (FULL || f < N) && !cx.skip;
         n += ok ? 1 : 0;
         v[f] = ok ? x : __builtin_inff();
+        if (!FULL && f >= N && f < N + plo) v[f] = -__builtin_inff();      // split pads (wave-uniform test)
     }
     return n;
 }
@@ -273,7 +279,7 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
 // reciprocal division are deferred to the sorted column (cx.range_pending, see load_sorted_column).
 template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), bool FORCE_HALVES = false>
 __device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
-                                           float (&v)[NP], ColumnCtx &cx)
+                                           float (&v)[NP], ColumnCtx &cx, int plo = 0)
 {
     const int N = prm.N;
     const int64_t p = base + lane;
@@ -307,15 +313,15 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             constexpr int HN = NP / 2;
             RawT half[HN];
             load_raw<NP, RawT, FULL, 0, HN, MINN>(prm, base, lane, half);
-            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N)
-                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N);
+            good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
+                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo);
             load_raw<NP, RawT, FULL, HN, HN, MINN>(prm, base, lane, half);
-            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N)
-                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N);
+            const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
+                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo);
             good = good && good2;
         } else {
-            if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N);
-            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N);
+            if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
+            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
         }
         if (wave_all(good && !cx.skip)) {
             cx.range_pending = !GUARD;
@@ -330,7 +336,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
         // rare: a non-finite value, a masked pixel or an out-of-range operand somewhere in the wave:
         // redo the column exactly
     }
-    return load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, p, cx, raw, v);
+    return load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, p, cx, raw, v, plo);
 }
 
 // Slot counts / padding schemes for which the float32 fast path exists: full columns with a core between two tails.
@@ -338,6 +344,12 @@ constexpr int kFastTail = 4;
 // (up to 96 slots: with the fast path next to the exact one the 104 .. 128-slot kernels need more than 256 VGPRs, i.e. one
 // wavefront per SIMD - 128 frames 2.7 -> 3.9 ms; such stacks take the chunked kernel, stack_chunks.hip, when they qualify)
 constexpr bool fast32_possible(int np, int minn) { return np >= 16 && np <= 96 && np % 4 == 0 && minn >= np; }
+// Padded stacks (N between two slot counts, at most 7 padding slots): the same fast path with tails of 8 and SPLIT PADS - the
+// first (NP - N) / 2 padding slots are -inf, the others +inf, so that after the sort the real values sit in the middle of the
+// column: the median keeps its static position, the mirror pairs of the core stay mirror pairs, and the pads are simply the
+// first values "already trimmed" from either tail (clip_fast32 starts with a = pads below, b = NP - pads above).
+constexpr int kFastTailPadded = 8;
+constexpr bool fast32_possible_padded(int np, int minn) { return np >= 24 && np <= 96 && np % 4 == 0 && minn < np && np - minn <= 8; }
 
 // Whether the lean reduction will try its float32 fast path (stack_reduce.h, clip_fast32) - wave-uniform, from the arguments.
 __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)
@@ -348,20 +360,31 @@ __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)
     return prm.fast32 != 0 && prm.center == APGPU_CENTER_MEDIAN && (prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2);
 }
 
+// Padding slots of a padded stack that go to the BOTTOM of the column (wave-uniform, from the arguments alone).
+template <int NP>
+__device__ __forceinline__ int pad_low(const StackParams &prm)
+{
+    return fast32_wanted(prm) ? (NP - prm.N) >> 1 : 0;
+}
+
 // Column loaded AND sorted ascending (sentinels last).  When the fast calibration deferred its range guards, they are
 // evaluated on the sorted column; a failing lane sends the wave through the exact path and a second sort (rare).
 // PRUNE_T > 0 and *pruned on entry (wave-uniform: the caller wants the fast path): a column without sentinels in the whole
 // wave is sorted with the pruned network (its ends and middle window only, make_pruned_net) and *pruned stays true;
 // otherwise the sort is complete and *pruned is cleared.
 template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0,
-          bool FORCE_HALVES = false>
+          bool FORCE_HALVES = false, bool SPLIT_PADS = false>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
                                                   int lane, float (&v)[NP], bool *pruned = nullptr)
 {
     ColumnCtx cx;
-    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES>(prm, fs, base, lane, v, cx);
+    // SPLIT_PADS (padded stacks headed for the float32 fast path, fast32_possible_padded): the first plo padding slots become
+    // -inf, the rest +inf; the caller (reduce_and_store) knows - from the same arguments - and undoes it for the exact path
+    int plo = 0;
+    if constexpr (SPLIT_PADS) plo = pad_low<NP>(prm);
+    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES>(prm, fs, base, lane, v, cx, plo);
     bool prune = false;
-    if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == NP);
+    if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == (FULL ? NP : prm.N));
     if constexpr (PRUNE_T > 0) {
         if (prune) sort_column<NP, PRUNE_T>(v);
         else sort_column<NP>(v);
@@ -371,9 +394,9 @@ __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const 
     if constexpr (CALIB) {
         // (the range test reads the two ends of the column - sorted by the pruned network too - and, for columns of mixed
         // sign, scans all magnitudes, in any order)
-        if (cx.range_pending && !wave_all(range_ok_sorted<NP, MINN>(v, cx.dodiv, n))) {
+        if (cx.range_pending && !wave_all(range_ok_sorted<NP, MINN>(v, cx.dodiv, n, plo))) {
             RawT none[1] = {};
-            n = load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base + lane, cx, none, v);
+            n = load_column_exact<NP, RawT, CALIB, FINITE_ONLY, FULL>(prm, fs, base + lane, cx, none, v, plo);
             sort_column<NP>(v);
             prune = false;
         }

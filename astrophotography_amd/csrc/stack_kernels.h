@@ -59,6 +59,11 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA |
         bool pruned = fast32_wanted(prm);
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, padded_minn(NP, FULL), kFastTail>(prm, fs, base, lane, v, &pruned);
         reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p, pruned);
+    } else if constexpr (fast32_possible_padded(NP, padded_minn(NP, FULL))) {
+        // padded stacks: split pads (-inf below, +inf above the real values) and tails of 8 - see fast32_possible_padded
+        bool pruned = fast32_wanted(prm);
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, padded_minn(NP, FULL), kFastTailPadded, false, true>(prm, fs, base, lane, v, &pruned);
+        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p, pruned);
     } else {
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
         reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p);

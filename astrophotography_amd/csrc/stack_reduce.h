@@ -284,12 +284,12 @@ __device__ __forceinline__ float fast32_t(const Fast32 &f, float x)
     return w * w;
 }
 
-template <int I, int NP>
-__device__ __forceinline__ void trim_low_fast(const float (&v)[NP], Fast32 &f, const float (&SL)[kFastTail + 1], const float (&QL)[kFastTail + 1])
+template <int I, int NP, int T = kFastTail>
+__device__ __forceinline__ void trim_low_fast(const float (&v)[NP], Fast32 &f, const float (&SL)[T + 1], const float (&QL)[T + 1])
 {
     const float t = fast32_t(f, v[I]);
     const bool at = f.a == I;
-    if constexpr (I < kFastTail) {
+    if constexpr (I < T) {
         const bool rej = at && (t > f.tl_hi);
         const bool maybe = at && (t > f.tl_lo);
         f.unsure = f.unsure || (maybe != rej);
@@ -298,16 +298,16 @@ __device__ __forceinline__ void trim_low_fast(const float (&v)[NP], Fast32 &f, c
             f.Slo = SL[I + 1];
             f.Qlo = QL[I + 1];
         }
-        if (wave_any(f.a > I)) trim_low_fast<I + 1, NP>(v, f, SL, QL);   // some lane's cursor is (now or from an earlier pass) past I
+        if (wave_any(f.a > I)) trim_low_fast<I + 1, NP, T>(v, f, SL, QL);   // some lane's cursor is (now or from an earlier pass, or by padding) past I
     } else {
         f.unsure = f.unsure || (at && (t > f.tl_lo));       // would trim into the core
     }
 }
 
-template <int K, int NP>                                     // K = number of upper-tail elements still in the range
-__device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, const float (&SH)[kFastTail + 1], const float (&QH)[kFastTail + 1])
+template <int K, int NP, int T = kFastTail>                  // K = number of upper-tail elements still in the range
+__device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, const float (&SH)[T + 1], const float (&QH)[T + 1])
 {
-    constexpr int I = NP - kFastTail + K - 1;               // the element under test: the highest one in the range
+    constexpr int I = NP - T + K - 1;                       // the element under test: the highest one in the range
     const float t = fast32_t(f, v[I]);
     const bool at = f.b == I + 1;
     if constexpr (K > 0) {
@@ -319,19 +319,32 @@ __device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, 
             f.Shi = SH[K - 1];
             f.Qhi = QH[K - 1];
         }
-        if (wave_any(f.b <= I)) trim_high_fast<K - 1, NP>(v, f, SH, QH);
+        if (wave_any(f.b <= I)) trim_high_fast<K - 1, NP, T>(v, f, SH, QH);
     } else {
         f.unsure = f.unsure || (at && (t > f.th_lo));
     }
 }
 
-// Returns true (wave-uniform) when every lane of the wave completed on the fast path; a, b, cf, S, Q are then final.
-template <int NP>
-__device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, float su2f, int maxiters, int &a_out, int &b_out,
-                                            float &cf_out, float &S_out, float &Q_out)
+// arr[idx] for a WAVE-UNIFORM idx in [0, N): scalar compare-and-branch chain
+template <int LO, int N>
+__device__ __forceinline__ float uniform_elem(const float (&arr)[N], int idx)
 {
-    constexpr int T = kFastTail;
-    static_assert(NP >= 16 && NP % 4 == 0, "fast path needs a core");
+    if constexpr (LO >= N - 1) return arr[N - 1];
+    else {
+        if (idx <= LO) return arr[LO];
+        return uniform_elem<LO + 1, N>(arr, idx);
+    }
+}
+
+// Returns true (wave-uniform) when every lane of the wave completed on the fast path; a, b, cf, S, Q are then final.
+// T: tail length.  plo / phi (wave-uniform; padded stacks with split pads, stack_calibrate.h): v[0 .. plo) are -inf and
+// v[NP - phi .. NP) +inf sentinels, phi - plo in {0, 1}, both at most T - 4: the clip simply starts with them trimmed.
+template <int NP, int T = kFastTail>
+__device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, float su2f, int maxiters, int &a_out, int &b_out,
+                                            float &cf_out, float &S_out, float &Q_out, int plo = 0, int phi = 0)
+{
+    static_assert(NP >= 2 * T + 8 && NP % 4 == 0, "fast path needs a core");
+    const bool padded = T > kFastTail;                      // (compile time: full stacks keep every index static)
     const float cf = v[(NP - 1) >> 1];
     // core sums: four chains, fixed association.  S adds the deviations in mirror pairs (i, NP-1-i) of the sorted column:
     // a pair nearly cancels, so the partial sums - and with them the float32 rounding errors, which scale with the
@@ -362,13 +375,26 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
         QH[k] = __builtin_fmaf(d, d, QH[k - 1]);
     }
     Fast32 f;
-    f.a = 0;
-    f.b = NP;
-    f.Slo = SL[0]; f.Qlo = QL[0]; f.Shi = SH[T]; f.Qhi = QH[T];
+    float vlo = v[0], vhi = v[NP - 1];
+    if (!padded) {
+        f.a = 0;
+        f.b = NP;
+        f.Slo = SL[0]; f.Qlo = QL[0]; f.Shi = SH[T]; f.Qhi = QH[T];
+        f.m2 = v[NP >> 1];
+    } else {
+        f.a = plo;
+        f.b = NP - phi;
+        f.Slo = uniform_elem<0, T + 1>(SL, plo);
+        f.Qlo = uniform_elem<0, T + 1>(QL, plo);
+        f.Shi = uniform_elem<0, T + 1>(SH, T - phi);
+        f.Qhi = uniform_elem<0, T + 1>(QH, T - phi);
+        f.m2 = (phi > plo) ? cf : v[NP >> 1];               // an odd number of values: the middle one twice
+        vlo = uniform_pick<0, NP>(v, plo);                  // (scalar compare chains: a few steps from the given start)
+        vhi = uniform_pick<NP - T, NP>(v, NP - 1 - phi);
+    }
     f.m1 = cf;
-    f.m2 = v[NP >> 1];
     // range guard on the extreme deviations (sorted column: they sit at the ends)
-    const float dmax = fmaxf(cf - v[0], v[NP - 1] - cf);
+    const float dmax = fmaxf(cf - vlo, vhi - cf);
     f.unsure = !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
     const float rho = APGPU_FAST32_RHO;
     const float sl4 = 4.f * sl2f, su4 = 4.f * su2f;
@@ -387,8 +413,8 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
         f.tl_lo = __builtin_fmaf(tl, -rho, tl);
         f.th_hi = __builtin_fmaf(th, rho, th);
         f.th_lo = __builtin_fmaf(th, -rho, th);
-        trim_low_fast<0, NP>(v, f, SL, QL);
-        trim_high_fast<T, NP>(v, f, SH, QH);
+        trim_low_fast<0, NP, T>(v, f, SL, QL);
+        trim_high_fast<T, NP, T>(v, f, SH, QH);
         it++;
         const bool changed = (f.a != a0) || (f.b != b0);
         if (!(wave_any(changed) && (maxiters < 0 || it < maxiters))) break;
@@ -399,13 +425,13 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     }
     // astropy applies the FINAL bounds to every value: a value trimmed by an earlier pass comes back if it lies inside them.
     // Here: the innermost trimmed value of either side must be surely outside, otherwise the exact path decides.
-    if (wave_any(f.a > 0)) {
+    if (wave_any(f.a > plo)) {
         const float t = fast32_t(f, pick_rel<0, T, NP>(v, (f.a - 1) & (T - 1)));
-        f.unsure = f.unsure || (f.a > 0 && !(t > f.tl_hi));
+        f.unsure = f.unsure || (f.a > plo && !(t > f.tl_hi));
     }
-    if (wave_any(f.b < NP)) {
-        const float t = fast32_t(f, pick_rel<NP - T, T, NP>(v, f.b & (T - 1)));        // NP % 4 == 0: (b - (NP - T)) & 3
-        f.unsure = f.unsure || (f.b < NP && !(t > f.th_hi));
+    if (wave_any(f.b < NP - phi)) {
+        const float t = fast32_t(f, pick_rel<NP - T, T, NP>(v, (f.b - (NP - T)) & (T - 1)));
+        f.unsure = f.unsure || (f.b < NP - phi && !(t > f.th_hi));
     }
     // the final sums (the last pass may have trimmed) and the mean-accuracy guard rms(d) <= |c| / 2
     S = (Sc + f.Slo) + f.Shi;
@@ -574,6 +600,19 @@ __device__ __forceinline__ void clip_exact(const float (&v)[NP], const int n, co
     Q_out = st.Q;
 }
 
+// v[i] = v[i + P] for a wave-uniform P in [0, 3], +inf sentinels moved in at the top: undoes split pads (rare path).
+template <int NP>
+__device__ __forceinline__ void shift_down(float (&v)[NP], int P)
+{
+#pragma unroll
+    for (int bit = 1; bit <= 2; bit *= 2) {
+        if (P & bit) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) v[i] = (i + bit < NP) ? v[i + bit] : __builtin_inff();
+        }
+    }
+}
+
 // Lean reduction (mean / count / moments outputs, std deviation): the benchmarked path.  Everything after
 // the column load is in registers: sort, moments, clipping iterations, outputs.
 // pruned (wave-uniform): the column came out of the pruned network (load_sorted_column) - the caller has established
@@ -599,7 +638,24 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     float cf, Sf = 0.f;
     double S, Q;
     bool done = false;
+    int ns_eff = ns;                                        // slots the output planes' loops visit
 #ifndef APGPU_VARIANT_NO_FAST32
+    if constexpr (fast32_possible_padded(NP, MINN)) {
+        // padded stack with split pads (the kernel loaded the column with SPLIT_PADS, same decision from the same arguments):
+        // the fast path starts with the pads trimmed; for the exact path the column is moved down onto the -inf pads first
+        const int plo = pad_low<NP>(prm);
+        if (fast32_wanted(prm)) {
+            if (pruned) {                                    // (load_sorted_column: every lane of the wave holds all N values)
+                float Qf;
+                done = clip_fast32<NP, kFastTailPadded>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf, plo, NP - ns - plo);
+                S = (double)Sf;
+                Q = (double)Qf;
+                if (!done) sort_column<NP>(v);
+            }
+            if (!done) shift_down<NP>(v, plo);
+            else ns_eff = NP;                                // the survivors v[a .. b) sit between the pads: scan every slot
+        }
+    }
     if constexpr (fast32_possible(NP, MINN)) {
         // float32 fast path (see clip_fast32): full columns, median centre; float64-layout moments carry a sum of squares
         // that callers turn into a std, so they stay on the exact path (the float32 layout is refused a std anyway)
@@ -646,7 +702,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         if (prm.std) {
             // one wave-uniform test per slot even for full stacks: the scalar branches keep the two passes as 64 short blocks
             // (as one straight-line block the register allocator keeps every converted value alive: 256 VGPRs + scratch)
-            int nslots = ns;
+            int nslots = ns_eff;
             asm volatile("" : "+s"(nslots));
             double s1 = 0.0;
 #pragma unroll

@@ -729,14 +729,14 @@ def test_sigclip_global_median_neighbours(ops, apref):
 
 
 def test_fast32_path_guards_on_adversarial_columns(ops, apref):
-    """The float32 fast path of the lean stack kernels (clip_fast32 / stack_chunks_kernel) against the float64 path
-    (exact=True) and the oracle on columns built to hit its guards: means near zero against the spread (the mean-accuracy
+    """The float32 fast path of the lean stack kernels (clip_fast32 - full and padded slot counts - / stack_chunks_kernel)
+    against the float64 path (exact=True) and the oracle on columns built to hit its guards: means near zero against the spread (the mean-accuracy
     guard), outliers of 1e4..1e30 times the spread, constant and two-level columns, spreads of a few ulp, negative and
     mixed-sign values, values needing more than four trims per side, columns sitting next to a clip bound.  Survivor
     counts must be identical everywhere, means within 1 ulp."""
     rng = np.random.default_rng(2025)
     H, W = 16, 256
-    for N in (16, 32, 64, 96, 160, 256):
+    for N in (16, 30, 32, 37, 52, 58, 64, 75, 96, 160, 256):                          # 30, 37, 52, 58, 75: padded stacks (split pads, tails of 8)
         cols = []
         base = rng.normal(0.0, 1.0, (N, H, W))
         level = np.array([0.0, 1e-3, 1.0, 50.0, 500.0, 5e4, -300.0, 1e-20])[rng.integers(0, 8, (H, W))]

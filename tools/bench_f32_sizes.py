@@ -14,7 +14,7 @@ masters = synth.make_masters(H, W, config_id=2, device='cuda')
 nflat, _ = ops.flat_normalize(masters['flat'])
 frames = synth.make_frames(128, masters, nflat, config_id=2)
 calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=synth.EXP_RATIO)
-for n in (128, 112, 100, 96, 80, 72, 64, 56, 52, 48, 40, 36, 32, 24, 16, 8):
+for n in (128, 112, 100, 96, 80, 75, 72, 64, 61, 58, 56, 52, 48, 45, 40, 37, 36, 32, 30, 24, 20, 16, 8):
     med, _ = timeit(lambda: ops.stack_sigclip(frames[:n], calib=calib, outputs=('mean',)), reps=5)
     gbs = (4 * n + 16) * H * W / med / 1e6
     med2, _ = timeit(lambda: ops.stack_median(frames[:n], calib=calib), reps=5)
