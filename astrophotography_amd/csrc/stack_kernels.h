@@ -277,7 +277,10 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
 // the survivors are summed in sorted order in both.
 // -------------------------------------------------------------------------------------------------
 template <int NP, bool CALIB, bool FULL>
-__global__ __launch_bounds__(256, NP <= 64 ? 3 : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
+#ifndef APGPU_U16PAIRS_MIN_BLOCKS
+#define APGPU_U16PAIRS_MIN_BLOCKS 3
+#endif
+__global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
 {
     __shared__ FrameScalars<NP> fs;
     const int lane = threadIdx.x;
