@@ -366,6 +366,19 @@ def test_oversampling_geometry_host_logic():
             ra, dec = w.pix2sky(x, y)
             raf, decf = wf.pix2sky(n * x + (n - 1) / 2.0, n * y + (n - 1) / 2.0)
             assert abs(ra - raf) < 1e-10 and abs(dec - decf) < 1e-10
+        # one-pass OVERSAMPLING takes one fine-grid transform per OUTPUT tile (16 x 64 output = 16 n x 64 n fine pixels)
+        win = wcs.TanWcs.from_center(83.81, -5.41, 2.1, (60, 70))
+        out_shape = (40, 150)
+        tiles = wcs.tile_affines(wf := wcs.TanWcs.from_center(83.8, -5.4, 2.0, out_shape).oversampled(n), win,
+                                 (out_shape[0] * n, out_shape[1] * n), tile_scale=n)
+        assert tiles.shape == ((out_shape[0] + 15) // 16, (out_shape[1] + 63) // 64, 6)
+        for (ty, tx) in ((0, 0), (2, 2), (1, 1)):
+            for (du, dv) in ((0, 0), (64 * n - 1, 16 * n - 1), (10, 3)):
+                u, v = tx * 64 * n + du, ty * 16 * n + dv
+                ra, dec = wf.pix2sky(float(u), float(v))
+                xe, ye = win.sky2pix(ra, dec)
+                a = tiles[ty, tx]
+                assert abs(a[0] * u + a[1] * v + a[2] - xe) < 2e-3 and abs(a[3] * u + a[4] * v + a[5] - ye) < 2e-3
     from astrophotography_amd.core.ApMeasureBackground import _fill_excluded
     from oracle import background_ref as br
     rng = np.random.default_rng(5)
