@@ -85,13 +85,13 @@ typedef __attribute__((address_space(3))) const volatile v2f *lds_pair_p;   // v
 #define APGPU_RESAMPLE_ROWS_PER_BATCH 3
 #endif
 
-enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8, kSaneTop = 16, kSaneBot = 32 };   // kSane: every 16-row half of the workgroup's tile is defined
+enum : unsigned { kStaged = 1, kSane = 2, kInterior = 4, kFast = 8, kSaneTop = 16, kSaneBot = 32, kInlineMask = 64 };   // kSane: every 16-row half of the workgroup's tile is defined
 
 // What the tile pass works out per output tile (everything tile-uniform), 64 bytes.
 struct alignas(64) TileRec {
     long long F[6];             // the transform in 32.32 fixed point (of the fine grid when oversampling)
     int bx0, by0;               // first input column / row of the footprint
-    unsigned dims;              // footprint width | height << 13 | flags << 26
+    unsigned dims;              // footprint width | height << 12 | flags << 24 (a staged footprint is at most 682 wide / tall)
     float fs;                   // flux scale
 };
 
@@ -404,6 +404,85 @@ __device__ __forceinline__ void pixels_general(const TileCtx &tc, const FrameVie
 // oversampling factor: the transform then belongs to the os-times finer grid and a tile covers the fine pixels of its output
 // pixels.  Whether a pixel is DEFINED is decided per 64 x 16 API tile (the oracle's rule: corner coordinates within +-1e9,
 // coefficients below 2^30); a 32-row workgroup tile carries that flag for its upper and its lower half.
+// ---- bad-pixel mask by scatter ---------------------------------------------------------------------------------------
+// A masked input pixel makes NaN every output pixel whose 6 x 6 window holds it.  With the usual handful of bad pixels per
+// ten thousand it is cheaper to resample WITHOUT the mask (the mask bytes double the footprint loads of every tile: 5.8
+// against 4.2 ms for C5's 16 x 8192^2 share) and to poison those output pixels afterwards: mask_list_kernel compacts the bad
+// pixels into a list (capacity: 1 / 64 of the pixels, at most 2^20; more than that, or per-tile transforms, or a strongly magnifying transform whose
+// preimage of a 6 x 6 input square is large: the mask is applied in the resample kernel as before - decided on the device,
+// tile by tile, nothing synchronises with the host), mask_scatter_kernel walks list x frames, inverts the frame's transform
+// in float64 to bound the candidate output pixels and tests each candidate with the kernel's own fixed-point coordinates.
+constexpr int kMaskListCapMax = 1 << 20;                 // the list holds up to 1 / 64 of the frame's pixels, at most this many
+
+// the frame's transform can be handled by the scatter: coefficients usable, invertible, preimage of a 6 x 6 input square at
+// most ~50 (fine) output pixels wide and tall
+__device__ __forceinline__ bool mask_scatter_ok(const double *a)
+{
+    const double amax = fmax(fmax(fmax(fabs(a[0]), fabs(a[1])), fmax(fabs(a[2]), fabs(a[3]))), fmax(fabs(a[4]), fabs(a[5])));
+    const double det = fma(a[0], a[4], -(a[1] * a[3]));
+    const bool coef_ok = (amax < 1073741824.0) && (a[0] == a[0]) && (a[1] == a[1]) && (a[2] == a[2]) && (a[3] == a[3]) && (a[4] == a[4]) && (a[5] == a[5]);
+    const double hw = 3.0 * (fabs(a[4]) + fabs(a[1])), hh = 3.0 * (fabs(a[3]) + fabs(a[0]));     // half extents * |det|
+    return coef_ok && fabs(det) > 1e-300 && hw <= 24.0 * fabs(det) && hh <= 24.0 * fabs(det);
+}
+
+__global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restrict__ mask, int64_t n, int cap, int *__restrict__ ctl,
+                                                       int *__restrict__ list)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        if (mask[p]) {
+            const int i = atomicAdd(&ctl[0], 1);
+            if (i < cap) list[i] = (int)p;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_scatter_kernel(const int *__restrict__ ctl, const int *__restrict__ list, int cap,
+                                                          const double *__restrict__ affines, int os, int w_in, float *__restrict__ out,
+                                                          uint8_t *__restrict__ wout, int h_out, int w_out)
+{
+    const int count = ctl[0];
+    if (count > cap) return;                                   // the resample kernel applied the mask itself
+    const int64_t f = blockIdx.y;
+    const double *A = affines + 6 * f;
+    const double a[6] = {A[0], A[1], A[2], A[3], A[4], A[5]};
+    if (!mask_scatter_ok(a)) return;                           // (ditto, for this frame)
+    long long F[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) F[k] = __double2ll_rn(a[k] * 4294967296.0);
+    const double idet = 1.0 / fma(a[0], a[4], -(a[1] * a[3]));
+    const long long wf = (long long)w_out * os, hf = (long long)h_out * os;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+        const int p = list[e];
+        const int by = p / w_in, bx = p - by * w_in;
+        // preimage of the input square [bx - 3, bx + 4) x [by - 3, by + 4) on the (fine) output grid: a parallelogram; its box
+        double u0 = __builtin_inf(), u1 = -__builtin_inf(), v0 = __builtin_inf(), v1 = -__builtin_inf();
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double xi = (double)(bx + ((c & 1) ? 4 : -3)) - a[2], yi = (double)(by + ((c & 2) ? 4 : -3)) - a[5];
+            const double u = (a[4] * xi - a[1] * yi) * idet, v = (a[0] * yi - a[3] * xi) * idet;
+            u0 = fmin(u0, u); u1 = fmax(u1, u);
+            v0 = fmin(v0, v); v1 = fmax(v1, v);
+        }
+        long long ua = (long long)floor(u0) - 2, ub = (long long)ceil(u1) + 2, va = (long long)floor(v0) - 2, vb = (long long)ceil(v1) + 2;
+        ua = ua < 0 ? 0 : ua; va = va < 0 ? 0 : va;
+        ub = ub > wf - 1 ? wf - 1 : ub; vb = vb > hf - 1 ? hf - 1 : vb;
+        for (long long v = va; v <= vb; v++) {
+            for (long long u = ua; u <= ub; u++) {
+                // the kernel's own coordinates: the window of (u, v) covers columns jx - 2 .. jx + 3, rows jy - 2 .. jy + 3
+                const unsigned long long X = (unsigned long long)F[0] * (unsigned long long)u + (unsigned long long)F[1] * (unsigned long long)v + (unsigned long long)F[2];
+                const unsigned long long Y = (unsigned long long)F[3] * (unsigned long long)u + (unsigned long long)F[4] * (unsigned long long)v + (unsigned long long)F[5];
+                const long long jx = (long long)X >> 32, jy = (long long)Y >> 32;
+                if (jx >= bx - 3 && jx <= bx + 2 && jy >= by - 3 && jy <= by + 2) {
+                    const int64_t o = (f * h_out + v / os) * (int64_t)w_out + u / os;
+                    out[o] = __builtin_nanf("");
+                    if (wout) wout[o] = 0;
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ bool tile_corners_ok(const double *a, long long ua, long long ub, long long va, long long vb)
 {
     const long long cu[4] = {ua, ub, ua, ub}, cv[4] = {va, va, vb, vb};
@@ -419,7 +498,7 @@ __device__ __forceinline__ bool tile_corners_ok(const double *a, long long ua, l
 
 __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__restrict__ affines, int per_tile, int conserve_flux,
                                                             const float *__restrict__ fscale, int os, int th, int gx, int gy, int64_t ntiles,
-                                                            int h_in, int w_in, int h_out, int w_out, int fast_ok, TileRec *__restrict__ recs)
+                                                            int h_in, int w_in, int h_out, int w_out, int fast_ok, int mask_scatter, TileRec *__restrict__ recs)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= ntiles) return;
@@ -448,6 +527,7 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
     for (int k = 0; k < 6; k++) rec.F[k] = coef_ok ? __double2ll_rn(a[k] * 4294967296.0) : 0;
     int bx0 = 0, by0 = 0, w = 0, h = 0;
     unsigned flags = (sane_top ? kSaneTop : 0u) | (sane_bot ? kSaneBot : 0u);
+    if (!(mask_scatter && !per_tile && mask_scatter_ok(a))) flags |= kInlineMask;     // a mask, if any, is applied in the resample kernel
     if (sane) {
         flags |= kSane;
         // the footprint from the SAME integer coordinates the pixels will use (linear: extremes at the corners)
@@ -480,7 +560,7 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
     }
     rec.bx0 = bx0;
     rec.by0 = by0;
-    rec.dims = (unsigned)w | ((unsigned)h << 13) | (flags << 26);
+    rec.dims = (unsigned)w | ((unsigned)h << 12) | (flags << 24);
     rec.fs = fs;
     recs[idx] = rec;
 }
@@ -580,7 +660,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
                                                              const float *__restrict__ lut,
                                                              int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
-                                                             int h_in, int w_in, int h_out, int w_out)
+                                                             int h_in, int w_in, int h_out, int w_out, const int *__restrict__ mask_ctl, int mask_cap)
 {
     using G = FastGeom<TH>;
     __shared__ __attribute__((aligned(16))) float tile[G::kLdsFloats];
@@ -603,7 +683,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const int x0 = txi * kTileW, y0 = tyi * TH;
     FrameView fv;
     fv.src = frames + f * (int64_t)h_in * w_in;
-    fv.mask = HAS_MASK ? mask : nullptr;
+    fv.mask = nullptr;
     fv.h_in = h_in;
     fv.w_in = w_in;
     const TileRec *rp = recs + t;                                 // uniform address: scalar loads
@@ -613,9 +693,9 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     tc.bx0 = rp->bx0;
     tc.by0 = rp->by0;
     const unsigned dims = rp->dims;
-    tc.fw = (int)(dims & 0x1fffu);
-    tc.fh = (int)((dims >> 13) & 0x1fffu);
-    const unsigned flags = dims >> 26;
+    tc.fw = (int)(dims & 0xfffu);
+    tc.fh = (int)((dims >> 12) & 0xfffu);
+    const unsigned flags = dims >> 24;
     tc.staged = (flags & kStaged) != 0;
     tc.sane_top = (flags & kSaneTop) != 0;
     tc.sane_bot = (flags & kSaneBot) != 0;
@@ -623,12 +703,25 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     const bool fast = (flags & kFast) != 0, interior = (flags & kInterior) != 0;
     const int tid = threadIdx.x;
 
+    // the mask is applied here (footprint fill / gather) when the tile says so or the bad-pixel list overflowed; otherwise
+    // mask_scatter_kernel poisons the affected output pixels afterwards (wave-uniform choice between whole code paths: as a
+    // test around each mask load it serialised the loads)
+    bool inline_mask = false;
+    if constexpr (HAS_MASK) inline_mask = (flags & kInlineMask) != 0 || mask_ctl[0] > mask_cap;
+    if (inline_mask) fv.mask = mask;
     if (fast) {
-        FastFill<HAS_MASK, G::kTrips> ff;
-        fast_fill_issue<HAS_MASK, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
-        fast_fill_store<HAS_MASK, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
+        if (inline_mask) {
+            FastFill<true, G::kTrips> ff;
+            fast_fill_issue<true, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+            fast_fill_store<true, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
+        } else {
+            FastFill<false, G::kTrips> ff;
+            fast_fill_issue<false, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+            fast_fill_store<false, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
+        }
     } else if (tc.staged) {
-        general_fill<HAS_MASK>(tc, fv, tile, tid);
+        if (inline_mask) general_fill<true>(tc, fv, tile, tid);
+        else general_fill<false>(tc, fv, tile, tid);
     }
     __syncthreads();
 
@@ -688,9 +781,32 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "%s: cannot allocate %lld tile records: %s", who, (long long)ntiles, hipGetErrorString(e));
     // the fast path addresses a frame and a tile's output rows with 32-bit byte offsets
     const int fast_ok = (h_in * w_in < (1LL << 30)) && (w_out < (1LL << 25));
+    // bad-pixel mask: list + counter for the scatter form (see mask_list_kernel); pixel indices fit an int then
+#ifdef APGPU_VARIANT_RESAMPLE_MASK_INLINE
+    const int mask_scatter = 0;
+#else
+    const int mask_scatter = mask && !affines_per_tile && h_in * w_in < (1LL << 31);
+#endif
+    int *mctl = nullptr;
+    int64_t mcap64 = h_in * w_in / 64;
+    if (mcap64 < 256) mcap64 = 256;
+    const int kMaskListCap = (int)(mcap64 > kMaskListCapMax ? kMaskListCapMax : mcap64);
+    if (mask) {
+        e = hipMallocAsync(reinterpret_cast<void **>(&mctl), (size_t)(2 + (mask_scatter ? kMaskListCap : 0)) * sizeof(int), st);
+        if (e == hipSuccess) e = hipMemsetAsync(mctl, 0, 2 * sizeof(int), st);
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(recs, st);
+            return fail(APGPU_ELAUNCH, "%s: cannot allocate the mask list: %s", who, hipGetErrorString(e));
+        }
+        if (mask_scatter) {
+            int64_t g = (h_in * w_in + 255) / 256;
+            if (g > kNumCU * 32) g = kNumCU * 32;
+            hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)g), dim3(256), 0, st, mask, h_in * w_in, kMaskListCap, mctl, mctl + 2);
+        }
+    }
     const int64_t tb = (ntiles + 255) / 256;
     hipLaunchKernelGGL(resample_tiles_kernel, dim3((unsigned)tb), dim3(256), 0, st, affines, affines_per_tile, conserve_flux, fscale, (int)os, th,
-                       (int)gx, (int)gy, ntiles, (int)h_in, (int)w_in, (int)h_out, (int)w_out, fast_ok, recs);
+                       (int)gx, (int)gy, ntiles, (int)h_in, (int)w_in, (int)h_out, (int)w_out, fast_ok, mask_scatter, recs);
     int rc = check_launch(who);
     if (rc == APGPU_OK) {
         const dim3 grid((unsigned)(((gx * gy + 7) / 8) * 8), (unsigned)n_frames);
@@ -698,10 +814,10 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
     do {                                                                                                                                       \
         if (th == kTileH)                                                                                                                      \
             hipLaunchKernelGGL((resample_affine_kernel<M, O, kTileH>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx, (int)gy, \
-                               lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);                       \
+                               lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out, mctl, kMaskListCap);         \
         else                                                                                                                                   \
             hipLaunchKernelGGL((resample_affine_kernel<M, O, 2 * kTileH>), grid, dim3(256), 0, st, frames, mask, recs, (int)ntiles, (int)gx,    \
-                               (int)gy, lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out);              \
+                               (int)gy, lut, log2_phases, (int)os, out, weight_out, (int)h_in, (int)w_in, (int)h_out, (int)w_out, mctl, kMaskListCap); \
     } while (0)
         if (mask) {
             if (os > 1) APGPU_RESAMPLE_LAUNCH(true, true);
@@ -712,8 +828,14 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
         }
 #undef APGPU_RESAMPLE_LAUNCH
         rc = check_launch(who);
+        if (rc == APGPU_OK && mask_scatter) {
+            hipLaunchKernelGGL(mask_scatter_kernel, dim3(64, (unsigned)n_frames), dim3(256), 0, st, mctl, mctl + 2, kMaskListCap, affines, (int)os,
+                               (int)w_in, out, weight_out, (int)h_out, (int)w_out);
+            rc = check_launch(who);
+        }
     }
     (void)hipFreeAsync(recs, st);
+    if (mctl) (void)hipFreeAsync(mctl, st);
     return rc;
 }
 

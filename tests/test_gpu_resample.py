@@ -319,6 +319,34 @@ def test_oversampling_one_pass_bitexact_vs_oracle(ops, apref):
         ops.resample_oversampled(t, None, n, out_shape=out_shape, fine_affines=tiles[:, :-1])
 
 
+def test_mask_by_scatter_and_inline_agree_with_the_oracle(ops, apref):
+    """A bad-pixel mask reaches the output two ways (csrc/resample.hip): few bad pixels are compacted into a list and the
+    output pixels whose windows hold them are poisoned after an unmasked resample (mask_scatter_kernel); a list that overflows
+    (more than 1/64 of the pixels), per-tile transforms or a strongly magnifying transform apply the mask inside the resample
+    kernel.  Every route must give the oracle's NaN pattern and values bit for bit, weight plane included."""
+    import torch
+    rng = np.random.default_rng(31337)
+    N, H, W = 3, 200, 260
+    frames = rng.normal(400, 40, (N, H, W)).astype(np.float32)
+    A = _affines(rng, N, max_rot_deg=2.0, scale_jitter=0.05)
+    A[2] = [0.02, 0.0, 50.0, 0.0, 0.02, 60.0]                               # 50x magnification: the scatter declines this frame
+    t = torch.from_numpy(frames).cuda()
+    for frac in (0.0005, 0.004, 0.05):                                       # list, list, overflow (> 1/64 of the pixels)
+        mask = (rng.random((H, W)) < frac).astype(np.uint8)
+        mask[0, 0] = mask[H - 1, W - 1] = mask[100, 130] = 1
+        for out_shape in ((H, W), (150, 333)):
+            ref, wref = apref.resample_affine(frames, A, mask=mask, out_shape=out_shape)
+            got, wgot = ops.resample_affine(t, A, mask=torch.from_numpy(mask).cuda(), out_shape=out_shape)
+            assert_biteq(got.cpu().numpy(), ref, 'masked resample, bad fraction %g' % frac)
+            assert np.array_equal(wgot.cpu().numpy(), wref)
+        n = 3
+        fine_aff, _ = ops.oversampled_affines(A, n, (H, W))
+        ref, _ = apref.resample_oversampled(frames, fine_aff.numpy(), n, mask=mask, out_shape=(H, W))
+        got = ops.resample_oversampled(t, A, n, mask=torch.from_numpy(mask).cuda(), out_shape=(H, W))
+        assert_biteq(got.cpu().numpy(), ref, 'masked one-pass oversampling, bad fraction %g' % frac)
+    assert np.isnan(ref).mean() > 0.3 and np.isfinite(ref).mean() > 0.05
+
+
 def test_oversampling_conserves_flux_on_a_coarser_grid(ops):
     """The case oversampling exists for: output pixels 2.5 input pixels wide.  One Lanczos sample per output pixel aliases (the
     flux of a star depends on where it falls); 4 x 4 sub-samples recover the total to a few 1e-3."""
