@@ -428,8 +428,24 @@ __device__ __forceinline__ bool mask_scatter_ok(const double *a)
 __global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restrict__ mask, int64_t n, int cap, int *__restrict__ ctl,
                                                        int *__restrict__ list)
 {
+    // 16 mask bytes per lane and load (the frames' masks are 16-byte aligned like every plane here; a misaligned one takes the
+    // byte loop); a zero quad - almost all of them - costs one compare
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const bool vec = (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+    const int64_t n16 = vec ? n / 16 : 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += stride) {
+        const uint4 w = reinterpret_cast<const uint4 *>(mask)[q];
+        if ((w.x | w.y | w.z | w.w) == 0) continue;
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) {
+                const int i = atomicAdd(&ctl[0], 1);
+                if (i < cap) list[i] = (int)(q * 16 + k);
+            }
+        }
+    }
+    for (int64_t p = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         if (mask[p]) {
             const int i = atomicAdd(&ctl[0], 1);
             if (i < cap) list[i] = (int)p;
@@ -799,7 +815,8 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
             return fail(APGPU_ELAUNCH, "%s: cannot allocate the mask list: %s", who, hipGetErrorString(e));
         }
         if (mask_scatter) {
-            int64_t g = (h_in * w_in + 255) / 256;
+            int64_t g = (h_in * w_in / 16 + 255) / 256;
+            if (g < 1) g = 1;
             if (g > kNumCU * 32) g = kNumCU * 32;
             hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)g), dim3(256), 0, st, mask, h_in * w_in, kMaskListCap, mctl, mctl + 2);
         }
