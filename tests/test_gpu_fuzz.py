@@ -69,8 +69,20 @@ def test_random_stack_configs(ops, apref, seed):
     outs = ('mean', 'count') if dv == 'std' and rng.integers(0, 2) else ('mean', 'count', 'median', 'std')
     r = ops.stack_sigclip(_dev(cube, ops), sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv, calib=calib, pixmask=pm,
                           outputs=outs)
-    assert np.array_equal(r['count'].cpu().numpy(), nref), what
-    assert_ulp(r['mean'].cpu().numpy(), mref, 1, what)
+    # Exact ties: integer-valued frames whose calibration only shifts a column (no flat, one exposure ratio)
+    # can put a value exactly ON a clip bound, where astropy's own answer hangs on the last bit of its frame-order sums.  A
+    # pixel is on a tie when the oracle itself changes its count under a 1e-9 relative change of sigma; such pixels (found by
+    # the 20-minute run of round 3: 1 pixel in 6000 cases) are left out.
+    got_cnt, got_mean = r['count'].cpu().numpy(), r['mean'].cpu().numpy()
+    tie = np.zeros((H, W), bool)
+    for (y, x) in np.argwhere(got_cnt != nref)[:8]:
+        with np.errstate(all='ignore'):
+            c_lo = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 - 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)['count'][0, 0]
+            c_hi = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 + 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)['count'][0, 0]
+        tie[y, x] = c_lo != c_hi
+    assert tie.sum() <= 2, 'too many tie pixels ' + what
+    assert np.array_equal(got_cnt[~tie], nref[~tie]), what
+    assert_ulp(got_mean[~tie], mref[~tie], 1, what)
     med, cnt = ops.stack_median(_dev(cube, ops), calib=calib, pixmask=pm, want_count=True)
     mm = apref.stack_median(cal).astype(np.float32)
     nn = (~np.isnan(cal)).sum(0).astype(np.int32)
@@ -91,8 +103,8 @@ def test_random_stack_configs(ops, apref, seed):
                     c2[k] = c2[k][r0:r1]
         rs = ops.stack_sigclip(sub, sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv, calib=c2,
                                pixmask=None if pm is None else pm[r0:r1], outputs=('mean', 'count'))
-        assert np.array_equal(rs['count'].cpu().numpy(), nref[r0:r1]), 'stripe ' + what
-        assert_ulp(rs['mean'].cpu().numpy(), mref[r0:r1], 1, 'stripe ' + what)
+        assert np.array_equal(rs['count'].cpu().numpy()[~tie[r0:r1]], nref[r0:r1][~tie[r0:r1]]), 'stripe ' + what
+        assert_ulp(rs['mean'].cpu().numpy()[~tie[r0:r1]], mref[r0:r1][~tie[r0:r1]], 1, 'stripe ' + what)
 
 
 def test_too_many_frames_is_refused(ops):
