@@ -12,13 +12,14 @@
 //   OVERSAMPLING n: the transform is that of the n-times finer grid, every output pixel the float64 mean of its n x n
 //   sub-samples in row-major order (= apgpu_block_mean_f32 of the fine resample, without the fine image ever existing).
 //
-// Two launches.  resample_tiles_kernel works out, once per 64 x 16 output tile, what every lane of that tile's workgroup
+// Two launches (four with a bad-pixel mask, see "mask by scatter" below).  resample_tiles_kernel works out, once per
+// workgroup tile - 64 x 16 output pixels, or 64 x 32 where a frame has ONE transform -, what every lane of that tile's workgroup
 // needs: the fixed-point coefficients, the flux scale, the input footprint (exact: the integer corner coordinates) and which
 // path the tile takes - 64 bytes per tile that the main kernel reads with ONE scalar load (rounds 1-2 did the float64 corner
 // arithmetic in every lane, round 3 first in thread 0 behind an LDS broadcast and a barrier).
 // The main kernel stages the footprint in LDS and evaluates the taps from there:
-//   FAST tiles (the window of every pixel inside the frame, footprint at most 80 x 26: registration-sized rotations up to
-//   ~2.5 degrees, frames below 2^30 pixels): fixed LDS pitch of 80 floats and TWO copies of the footprint, the second shifted
+//   FAST tiles (the window of every pixel inside the frame, footprint at most 80 x (tile rows + 10): registration-sized
+//   rotations up to ~2.5 degrees, frames below 2^30 pixels): fixed LDS pitch of 80 floats and TWO copies of the footprint, the second shifted
 //   by one float, so that every lane reads its six taps of a row as three ALIGNED ds_read_b64 from the copy that matches the
 //   parity of its first column - 256 B/clk where ds_read2_b32 gets 128 (MI355X guide, LDS table) - with all 18 reads of a
 //   window off one address register (row j at the immediate offset 320 j).  The second copy starts 32 banks after the first
