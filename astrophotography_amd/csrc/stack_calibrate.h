@@ -116,11 +116,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // RANGE_GUARD = false: the quotient-range test is left to the caller, who reads it off the ends of the SORTED column
 // (range_ok_sorted) instead of tracking max |q| and min |q| through the loop (one v_max3 + one v_min3 per frame pair).
-// (Hoisting e * D for a stack with one exposure ratio was built and measured: no fewer VALU instructions after the
-// compiler's own scheduling and 2 % slower with the extra workgroup vote - not kept.)
+// UNI_E (round 4): every frame has the exposure ratio fs.e[0] (the caller's wave vote over the staged scalars,
+// exposures_uniform) - the dark term e * D is formed once per pixel instead of once per frame pair (one v_pk_mul_f32 less
+// per pair; round 2 tried it with a workgroup vote and a run-time select and found nothing - as a template parameter
+// behind one ballot per wave it removes 31 of the 281 calibration instructions of the 64-frame kernel).
 // nframes / MINN (padded stacks): groups of 8 slots that are entirely padding (>= nframes, wave-uniform) are skipped;
 // every padding slot ends as the +inf sentinel.  FULL stacks pass nframes = NP, MINN = NP: nothing of this remains.
-template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP>
+template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP, bool UNI_E = false>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
                                                bool dodiv, float (&v)[NP], int nframes = NP, int plo = 0)
 {
@@ -134,6 +136,8 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
     if constexpr (NP >= 2) {
         v2f acc = {0.f, 0.f};
         const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
+        const float ds0 = fs.e[0] * D;                       // :450 for every frame when UNI_E
+        const v2f ds_uni = {ds0, ds0};
 #pragma unroll
         for (int g = 0; g < CNT; g += 2) {
             const int f = F0 + g;
@@ -144,8 +148,11 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 x = x + ped;                                 // ApCalibrate.py:318-326; a zero pedestal adds +0.0,
             }                                                // which changes nothing but the sign of a -0.0 input
             x = x - b2;                                      // :439
-            const v2f e2 = {fs.e[f], fs.e[f + 1]};
-            const v2f ds = e2 * D2;                          // :450
+            v2f ds = ds_uni;
+            if constexpr (!UNI_E) {
+                const v2f e2 = {fs.e[f], fs.e[f + 1]};
+                ds = e2 * D2;                                // :450
+            }
             x = x - ds;                                      // :451
             const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
             const v2f r0 = __builtin_elementwise_fma(nf2, q0, x);
@@ -224,6 +231,16 @@ __device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv
     return !dodiv || (big_ok && small_ok);
 }
 
+// Wave vote over the staged per-frame scalars: every frame has the exposure ratio of frame 0 (a NaN ratio fails the test and
+// takes the per-frame path).  One or two LDS reads, one compare and one ballot per wave.
+template <int NP>
+__device__ __forceinline__ bool exposures_uniform(const FrameScalars<NP> &fs)
+{
+    bool same = true;
+    for (int t = threadIdx.x & 63; t < NP; t += 64) same = same && (fs.e[t] == fs.e[0]);
+    return wave_all(same);
+}
+
 // Per-lane context of a column load: what the exact fallback and the deferred range check need.
 struct ColumnCtx {
     float b, D, nf;
@@ -286,6 +303,9 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
 #ifndef APGPU_HALVES_MIN
 #define APGPU_HALVES_MIN 104
 #endif
+#ifndef APGPU_HOIST_DARK
+#define APGPU_HOIST_DARK 1
+#endif
     constexpr bool HALVES = CALIB && (NP >= APGPU_HALVES_MIN || FORCE_HALVES);  // 104 .. 128 slots: two half columns (register budget: 2 waves/SIMD)
     // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
     // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
@@ -321,6 +341,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             good = good && good2;
         } else {
             if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
+            else if (APGPU_HOIST_DARK && exposures_uniform<NP>(fs)) good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, true>(fs, raw, b, D, nf, dodiv, v, N, plo);
             else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
         }
         if (wave_all(good && !cx.skip)) {

@@ -34,8 +34,10 @@ using namespace apgpu;
 
 // EXTRA: the rich kernels (sorted column parked in LDS: mad_std, float64 planes).  PLUS (lean only): median and std planes
 // straight from the register-resident column - the same kernel as the benchmarked one with a longer epilogue.
+// (round 4: 3 - with the hoisted dark term's second calibration body the 64-slot kernel would take 177 VGPRs, two wavefronts
+// per SIMD; capped at 168 the spills land in the exact-fallback blocks only, tools/isa_blocks.py)
 #ifndef APGPU_LEAN_MIN_BLOCKS
-#define APGPU_LEAN_MIN_BLOCKS 2
+#define APGPU_LEAN_MIN_BLOCKS 3
 #endif
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
 __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA || PLUS ? 2 : APGPU_LEAN_MIN_BLOCKS) : 1) void stack_sigclip_kernel(const StackParams prm)
@@ -231,7 +233,7 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
         // non-decreasing map: finite masters and a positive (or unused) flat
         const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
         // FULL columns come out sorted (non-decreasing map of a sorted raw column), so their range guards are read off the ends
-        bool good = calibrate_fast<NP, float, false, 0, NP, !FULL>(fs, rawf, b, D, nf, dv, v);
+        bool good = calibrate_fast<NP, float, false, 0, NP, !FULL, NP, true>(fs, rawf, b, D, nf, dv, v);   // (one exposure ratio: the workgroup's precondition)
         if constexpr (FULL) good = good && (!increasing || range_ok_sorted<NP>(v, dv));
         fast = fast && good && increasing;
     } else {

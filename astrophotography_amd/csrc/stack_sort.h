@@ -189,10 +189,162 @@ __device__ __forceinline__ void window_net_from(float (&v)[NP])
     }
 }
 
-// PRUNE_T > 0: only the outputs clip_fast32 reads come out sorted (make_pruned_net).
+// -------------------------------------------------------------------------------------------------
+// Round 4: networks of 2-, 3- and 4-sorters for the float32 columns.  A compare-exchange costs two instructions for two
+// outputs; v_min3 / v_med3 / v_max3 sort THREE values in three instructions, and a layer of 3-sorters moves every value past
+// two others where a layer of compare-exchanges moves it past one.  tools/netsearch/netsearch.cpp (beam search, cost =
+// instructions, verified on every 0-1 input the pre-sorted structure allows) found:
+//   16 values: sort4 on the rows and on the columns of the 4 x 4 matrix (8 x 7) + ten 3-sorters = 86 instructions
+//              (four sort4 + Batcher's 4+4 and 8+8 merges: 114);
+//   8 values: eight 3-sorters = 24 (two sort4 + merge: 32);
+//   merge of two sorted 16-blocks: 118 (Batcher: 65 compare-exchanges = 130).
+// Above that the merge levels p = 32, 64 stay Batcher's.  A network for NP wires is the network for the next multiple of 16
+// RESTRICTED to the wires below NP: the missing inputs are +inf, an inf never leaves the highest wire of a sorter, so a
+// sorter simply loses those wires (a 3-sorter becomes a compare-exchange, a one-wire sorter disappears).
+// -------------------------------------------------------------------------------------------------
+struct NetOp {
+    unsigned char w[4];     // wires in rank order (ascending); the lowest gets the minimum
+    unsigned char k;        // 2: compare-exchange, 3: min3 / med3 / max3, 4: sort4
+    unsigned char stage;    // 0: sorts a 16-block, 1: merges two 16-blocks, 2: Batcher merge levels p >= 32 (tools/netsearch/verify_opnet.cpp)
+};
+
+template <int NP>
+struct OpNet {
+    NetOp op[NP * 9 + 24];  // NP = 128: 8 x 18 + 4 x 46 + 2 x 161 + 321 = 971 < 1176
+    int n;
+};
+
+constexpr NetOp kSort16Ops[18] = {
+    {{0, 1, 2, 3}, 4},    {{4, 5, 6, 7}, 4},    {{8, 9, 10, 11}, 4},  {{12, 13, 14, 15}, 4},       // rows
+    {{0, 4, 8, 12}, 4},   {{1, 5, 9, 13}, 4},   {{2, 6, 10, 14}, 4},  {{3, 7, 11, 15}, 4},         // columns
+    {{3, 5, 12, 0}, 3},   {{7, 10, 13, 0}, 3},  {{5, 6, 9, 0}, 3},    {{2, 5, 8, 0}, 3},   {{1, 2, 4, 0}, 3},
+    {{7, 9, 12, 0}, 3},   {{11, 13, 14, 0}, 3}, {{6, 7, 8, 0}, 3},    {{10, 11, 12, 0}, 3}, {{3, 4, 5, 0}, 3}};
+constexpr NetOp kSort8Ops[8] = {{{0, 1, 2, 0}, 3}, {{3, 4, 5, 0}, 3}, {{0, 6, 7, 0}, 3}, {{1, 4, 6, 0}, 3},
+                                {{2, 5, 7, 0}, 3}, {{0, 1, 3, 0}, 3}, {{2, 3, 4, 0}, 3}, {{4, 5, 6, 0}, 3}};
+// two sorted 16-blocks (wires 0..15, 16..31) -> 32 sorted
+constexpr NetOp kMerge16Ops[] = {
+    {{8, 22, 0, 0}, 2},   {{9, 23, 0, 0}, 2},   {{7, 21, 0, 0}, 2},   {{10, 24, 0, 0}, 2},  {{11, 25, 0, 0}, 2},  {{6, 20, 0, 0}, 2},
+    {{12, 26, 0, 0}, 2},  {{5, 19, 0, 0}, 2},   {{4, 18, 0, 0}, 2},   {{3, 17, 0, 0}, 2},   {{13, 19, 27, 0}, 3}, {{14, 20, 28, 0}, 3},
+    {{15, 21, 29, 0}, 3}, {{2, 10, 16, 0}, 3},  {{12, 18, 0, 0}, 2},  {{7, 11, 17, 0}, 3},  {{1, 9, 13, 0}, 3},   {{0, 8, 12, 0}, 3},
+    {{18, 22, 30, 0}, 3}, {{19, 23, 31, 0}, 3}, {{20, 24, 0, 0}, 2},  {{14, 16, 18, 0}, 3}, {{13, 15, 17, 0}, 3}, {{21, 25, 0, 0}, 2},
+    {{6, 8, 10, 0}, 3},   {{1, 5, 7, 0}, 3},    {{26, 28, 30, 0}, 3}, {{25, 27, 31, 0}, 3}, {{0, 4, 6, 0}, 3},    {{20, 22, 0, 0}, 2},
+    {{15, 17, 19, 0}, 3}, {{12, 14, 16, 0}, 3}, {{9, 11, 12, 0}, 3},  {{1, 3, 4, 0}, 3},    {{21, 22, 23, 0}, 3}, {{23, 24, 26, 0}, 3},
+    {{0, 1, 2, 0}, 3},    {{25, 26, 0, 0}, 2},  {{29, 30, 31, 0}, 3}, {{7, 8, 0, 0}, 2},    {{17, 18, 0, 0}, 2},  {{9, 10, 0, 0}, 2},
+    {{5, 6, 0, 0}, 2},    {{19, 20, 0, 0}, 2},  {{15, 16, 0, 0}, 2},  {{27, 28, 0, 0}, 2},  {{13, 14, 0, 0}, 2}};
+
+// appends `o` shifted by `off`, restricted to the wires below NP
+template <int NP>
+constexpr void add_op(OpNet<NP> &net, const NetOp &o, int off, int stage)
+{
+    NetOp r{};
+    r.stage = (unsigned char)stage;
+    int k = 0;
+    for (int i = 0; i < o.k; i++)
+        if (o.w[i] + off < NP) r.w[k++] = (unsigned char)(o.w[i] + off);
+    if (k >= 2) {
+        r.k = (unsigned char)k;
+        net.op[net.n++] = r;
+    }
+}
+
+// T > 0: pruned to what clip_fast32 reads (see make_pruned_net): backward liveness over the sorters.
+template <int NP, int T>
+constexpr OpNet<NP> make_opnet()
+{
+    OpNet<NP> net{};
+    net.n = 0;
+    for (int base = 0; base < NP; base += 16) {
+        if (NP - base <= 8) {
+            for (const NetOp &o : kSort8Ops) add_op<NP>(net, o, base, 0);
+        } else {
+            for (const NetOp &o : kSort16Ops) add_op<NP>(net, o, base, 0);
+        }
+    }
+    for (int base = 0; base + 16 < NP; base += 32)
+        for (const NetOp &o : kMerge16Ops) add_op<NP>(net, o, base, 1);
+    constexpr int P2 = next_pow2(NP);
+    for (int p = 32; p < P2; p *= 2)
+        for (int k = p; k >= 1; k /= 2)
+            for (int j = k % p; j <= P2 - 1 - k; j += 2 * k) {
+                const int lim = (k - 1 < P2 - j - k - 1) ? k - 1 : P2 - j - k - 1;
+                for (int i = 0; i <= lim; i++)
+                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2)) {
+                        const NetOp ce = {{(unsigned char)(i + j), (unsigned char)(i + j + k), 0, 0}, 2, 2};
+                        add_op<NP>(net, ce, 0, 2);
+                    }
+            }
+    if (T > 0) {
+        bool live[NP] = {};
+        for (int i = 0; i < T; i++) live[i] = live[NP - 1 - i] = true;
+        for (int i = (NP - T - 1) / 2; i <= (NP + T) / 2; i++) live[i] = true;
+        bool keep[NP * 9 + 24] = {};
+        for (int c = net.n - 1; c >= 0; c--) {
+            bool any = false;
+            for (int i = 0; i < net.op[c].k; i++) any = any || live[net.op[c].w[i]];
+            if (any) {
+                keep[c] = true;
+                for (int i = 0; i < net.op[c].k; i++) live[net.op[c].w[i]] = true;
+            }
+        }
+        int n = 0;
+        for (int c = 0; c < net.n; c++)
+            if (keep[c]) net.op[n++] = net.op[c];
+        net.n = n;
+    }
+    return net;
+}
+
+// (evaluated once per (NP, T), not once per sorter: the build would take three times as long)
+template <int NP, int T>
+inline constexpr OpNet<NP> kOpNet = make_opnet<NP, T>();
+
+__device__ __forceinline__ void sort3(float &a, float &b, float &c)
+{
+    float x0, x1, x2;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(x0) : "v"(a), "v"(b), "v"(c));
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(x1) : "v"(a), "v"(b), "v"(c));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(x2) : "v"(a), "v"(b), "v"(c));
+    a = x0;
+    b = x1;
+    c = x2;
+}
+
+template <int NP, int T, int I>
+__device__ __forceinline__ void opnet_apply(float (&v)[NP])
+{
+    constexpr NetOp o = kOpNet<NP, T>.op[I];
+    if constexpr (o.k == 2) cmpx(v[o.w[0]], v[o.w[1]]);
+    else if constexpr (o.k == 3) sort3(v[o.w[0]], v[o.w[1]], v[o.w[2]]);
+    else sort4(v[o.w[0]], v[o.w[1]], v[o.w[2]], v[o.w[3]]);
+}
+
+template <int NP, int T, int BASE, int... I>
+__device__ __forceinline__ void opnet_chunk(float (&v)[NP], std::integer_sequence<int, I...>)
+{
+    (opnet_apply<NP, T, BASE + I>(v), ...);
+}
+
+template <int NP, int T, int BASE = 0>
+__device__ __forceinline__ void opnet_from(float (&v)[NP])
+{
+    constexpr int total = kOpNet<NP, T>.n;
+    constexpr int CH = 64;
+    if constexpr (BASE < total) {
+        constexpr int len = (total - BASE < CH) ? total - BASE : CH;
+        opnet_chunk<NP, T, BASE>(v, std::make_integer_sequence<int, len>{});
+        opnet_from<NP, T, BASE + len>(v);
+    }
+}
+
+// PRUNE_T > 0: only the outputs clip_fast32 reads come out sorted (make_pruned_net / make_opnet).
 template <int NP, int PRUNE_T = 0>
 __device__ __forceinline__ void sort_column(float (&v)[NP])
 {
+#ifndef APGPU_VARIANT_BATCHER_ONLY
+    if constexpr (NP >= 8 && NP % 4 == 0) {
+        opnet_from<NP, PRUNE_T>(v);
+    } else
+#endif
     if constexpr (NP >= 4 && NP % 4 == 0) {
 #pragma unroll
         for (int g = 0; g < NP; g += 4) sort4(v[g], v[g + 1], v[g + 2], v[g + 3]);
