@@ -61,6 +61,21 @@ __device__ __forceinline__ float div_by_recip(float x, float nf, float y)
     return __builtin_fmaf(r1, y, q1);
 }
 
+// Full stacks without pedestals read the exposure ratios with scalar loads (calibrate_fast, E_DIRECT) and stage nothing.
+#ifndef APGPU_DIRECT_RATIOS
+#define APGPU_DIRECT_RATIOS 1
+#endif
+constexpr bool direct_ratios(bool full) { return full && APGPU_DIRECT_RATIOS; }
+
+// Whether a kernel of the given kind has to stage the per-frame scalars in LDS (wave-uniform, from the arguments).
+template <bool CALIB, bool FULL>
+__device__ __forceinline__ bool needs_staging(const StackParams &prm)
+{
+    if constexpr (!FULL) return true;                       // padding slots: clamped frame index, pad vector
+    else if constexpr (!CALIB) return false;
+    else return !direct_ratios(FULL) || prm.pedestal != nullptr;
+}
+
 // Per-frame scalars (exposure ratio, pedestal) staged in LDS once per workgroup: as SGPR values the
 // 2*NP scalars exceed the 102-SGPR budget and get spilled to VGPR lanes; from LDS they arrive as
 // broadcast ds_read_b128 (4 frames per instruction) just before use.
@@ -70,6 +85,34 @@ struct FrameScalars {
     float ped[NP];
     float pad[NP];          // -inf for a real frame, +inf for a padding slot (f >= N): v = max(v, pad) pads a column
 };
+
+// The same in two steps (round 4): stage_fetch issues the global loads of this thread's slot, stage_commit writes LDS and
+// synchronises - so that a kernel can put its column loads in between and does not pay two memory round trips in a row
+// (the first wavefront's loads of the ratios, the barrier, and only then every wavefront's frame loads).  NP <= blockDim.x.
+template <int NP>
+__device__ __forceinline__ void stage_fetch(const StackParams &prm, float &e, float &ped)
+{
+    const int t = threadIdx.x;
+    e = 0.f;
+    ped = 0.f;
+    if (t < NP) {
+        const int ff = t < prm.N ? t : prm.N - 1;
+        if (prm.exp_ratio) e = prm.exp_ratio[ff];
+        if (prm.pedestal) ped = prm.pedestal[ff];
+    }
+}
+
+template <int NP>
+__device__ __forceinline__ void stage_commit(const StackParams &prm, FrameScalars<NP> &fs, float e, float ped)
+{
+    const int t = threadIdx.x;
+    if (t < NP) {
+        fs.e[t] = e;
+        fs.ped[t] = ped;
+        fs.pad[t] = t < prm.N ? -__builtin_inff() : __builtin_inff();
+    }
+    __syncthreads();
+}
 
 template <int NP>
 __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, FrameScalars<NP> &fs)
@@ -122,9 +165,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // behind one ballot per wave it removes 31 of the 281 calibration instructions of the 64-frame kernel).
 // nframes / MINN (padded stacks): groups of 8 slots that are entirely padding (>= nframes, wave-uniform) are skipped;
 // every padding slot ends as the +inf sentinel.  FULL stacks pass nframes = NP, MINN = NP: nothing of this remains.
-template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP, bool UNI_E = false>
+// E_DIRECT (round 4; full stacks without pedestals): the exposure ratios are read straight from the caller's array `eg` - a
+// wave-uniform address with a constant offset, i.e. scalar loads into SGPR pairs that v_pk_mul_f32 takes as they are - instead
+// of from the LDS copy: no staging pass, no barrier before the first frame load, no ds_read in the calibration.
+template <int NP, typename RawT, bool HAS_PED, int F0 = 0, int CNT = NP, bool RANGE_GUARD = true, int MINN = NP, bool UNI_E = false,
+          bool E_DIRECT = false>
 __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const RawT (&raw)[CNT], float b, float D, float nf,
-                                               bool dodiv, float (&v)[NP], int nframes = NP, int plo = 0)
+                                               bool dodiv, float (&v)[NP], int nframes = NP, int plo = 0, const float *eg = nullptr)
 {
     // lanes that do not divide (no flat / nflat == 0) run the same code with a divisor of exactly 1:
     // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
@@ -136,7 +183,7 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
     if constexpr (NP >= 2) {
         v2f acc = {0.f, 0.f};
         const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
-        const float ds0 = fs.e[0] * D;                       // :450 for every frame when UNI_E
+        const float ds0 = UNI_E ? fs.e[0] * D : 0.f;         // :450 for every frame when UNI_E
         const v2f ds_uni = {ds0, ds0};
 #pragma unroll
         for (int g = 0; g < CNT; g += 2) {
@@ -149,7 +196,14 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
             }                                                // which changes nothing but the sign of a -0.0 input
             x = x - b2;                                      // :439
             v2f ds = ds_uni;
-            if constexpr (!UNI_E) {
+            if constexpr (E_DIRECT) {
+                // constant address space: the array is not written while the kernel runs, and only such (or provably
+                // unclobbered) uniform loads are selected as scalar loads - behind the staging branch's barrier these are not
+                typedef const float __attribute__((address_space(4))) cfloat;
+                const cfloat *ec = (const cfloat *)(uintptr_t)eg;
+                const v2f e2 = {ec[f], ec[f + 1]};
+                ds = e2 * D2;                                // :450
+            } else if constexpr (!UNI_E) {
                 const v2f e2 = {fs.e[f], fs.e[f + 1]};
                 ds = e2 * D2;                                // :450
             }
@@ -179,7 +233,7 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
         float x = to_f32(raw[0]);
         if constexpr (HAS_PED) x = x + fs.ped[0];
         x = x - b;
-        const float ds = fs.e[0] * D;
+        const float ds = (E_DIRECT ? eg[0] : fs.e[0]) * D;
         x = x - ds;
         const float q = div_by_recip(x, nfe, y);
         v[0] = q;
@@ -231,6 +285,31 @@ __device__ __forceinline__ bool range_ok_sorted(const float (&v)[NP], bool dodiv
     return !dodiv || (big_ok && small_ok);
 }
 
+// A column's loads issued EARLY (round 4): the per-pixel masters first - the calibration's first instruction needs them, and
+// the memory counter retires in order: issued after the 64 frame loads (rounds 1-3) they held the whole calibration back until
+// the last frame had arrived - then the frames.  Issued before the frame-scalar barrier (stage_commit) by the kernels that can.
+template <int NP, typename RawT>
+struct EarlyLoads {
+    RawT raw[NP];
+    float b, d, nf;
+    bool skip;
+};
+
+template <int NP, typename RawT, bool CALIB, bool FULL, int MINN>
+__device__ __forceinline__ void issue_early_loads(const StackParams &prm, int64_t base, int lane, EarlyLoads<NP, RawT> &L)
+{
+    const int64_t p = base + lane;
+    L.b = 0.f; L.d = 0.f; L.nf = 1.f;
+    if constexpr (CALIB) {
+        L.b = prm.bias[p];
+        L.d = prm.dark[p];
+        if (prm.nflat) L.nf = prm.nflat[p];
+    }
+    L.skip = prm.pixmask && prm.pixmask[p];
+    __builtin_amdgcn_sched_barrier(0);
+    load_raw<NP, RawT, FULL, 0, NP, MINN>(prm, base, lane, L.raw);
+}
+
 // Wave vote over the staged per-frame scalars: every frame has the exposure ratio of frame 0 (a NaN ratio fails the test and
 // takes the per-frame path).  One or two LDS reads, one compare and one ballot per wave.
 template <int NP>
@@ -270,8 +349,11 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
             x = to_f32(raw[f < NRAW ? f : 0]);
         }
         if constexpr (CALIB) {
-            const float e = fs.e[f];
-            const float ped = fs.ped[f];
+            // (from the caller's arrays, not the LDS copy: kernels that read the ratios directly never stage it; rare path)
+            typedef const float __attribute__((address_space(4))) cfloat;       // (scalar loads: see calibrate_fast)
+            const int ff = (FULL || f < N) ? f : N - 1;
+            const float e = prm.exp_ratio ? ((const cfloat *)(uintptr_t)prm.exp_ratio)[ff] : 0.f;
+            const float ped = prm.pedestal ? ((const cfloat *)(uintptr_t)prm.pedestal)[ff] : 0.f;
             if (ped != 0.f) x = x + ped;                     // ApCalibrate.py:318-326
             x = x - cx.b;                                    // :439
             const float ds = e * cx.D;                       // :450
@@ -294,37 +376,55 @@ __device__ __forceinline__ int load_column_exact(const StackParams &prm, const F
 // FULL = the stack has exactly NP frames: no padding logic at all (no clamped frame indices, no
 // wave-wide (f < N) masks - NP of those cost 2 SGPRs each and end up spilled to VGPR lanes), and the range guards of the
 // reciprocal division are deferred to the sorted column (cx.range_pending, see load_sorted_column).
-template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), bool FORCE_HALVES = false>
+template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), bool FORCE_HALVES = false, bool PRE = false>
 __device__ __forceinline__ int load_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base, int lane,
-                                           float (&v)[NP], ColumnCtx &cx, int plo = 0)
+                                           float (&v)[NP], ColumnCtx &cx, int plo = 0, const EarlyLoads<NP, RawT> &pre = EarlyLoads<NP, RawT>())
 {
     const int N = prm.N;
     const int64_t p = base + lane;
 #ifndef APGPU_HALVES_MIN
 #define APGPU_HALVES_MIN 104
 #endif
+// (measured, round 4: with the hoisted-dark body next to the per-frame one the 64-slot kernel needs 177 VGPRs - two
+// wavefronts per SIMD, 1.11 ms - or, capped at 168 by its launch bounds, 4 spilled VGPRs = a scratch allocation per wave:
+// 1.635 instead of 1.662 instructions per wave but 1.5-4.7 % SLOWER on two boxes.  Off for the one-pixel-per-lane kernels;
+// the uint16 pair kernels, whose precondition is one exposure ratio, use UNI_E unconditionally.)
 #ifndef APGPU_HOIST_DARK
-#define APGPU_HOIST_DARK 1
+#define APGPU_HOIST_DARK 0
 #endif
     constexpr bool HALVES = CALIB && (NP >= APGPU_HALVES_MIN || FORCE_HALVES);  // 104 .. 128 slots: two half columns (register budget: 2 waves/SIMD)
     // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
     // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
     constexpr bool GUARD = NP >= 104;
-    RawT raw[HALVES ? 1 : NP];
-    if constexpr (!HALVES) load_raw<NP, RawT, FULL, 0, NP, MINN>(prm, base, lane, raw);
+    // PRE: the loads were issued by the caller (`pre`); otherwise here
+    static_assert(!(PRE && HALVES), "half-column kernels load their own halves");
+    EarlyLoads<NP, RawT> here;
+    if constexpr (PRE) {
+    } else if constexpr (!HALVES) {
+        issue_early_loads<NP, RawT, CALIB, FULL, MINN>(prm, base, lane, here);
+    } else {
+        here.b = 0.f; here.d = 0.f; here.nf = 1.f;
+        if constexpr (CALIB) {
+            here.b = prm.bias[p];
+            here.d = prm.dark[p];
+            if (prm.nflat) here.nf = prm.nflat[p];
+        }
+        here.skip = prm.pixmask && prm.pixmask[p];
+    }
+    const EarlyLoads<NP, RawT> &L = PRE ? pre : here;
+    const RawT (&raw)[NP] = L.raw;
     cx.b = 0.f; cx.D = 0.f; cx.nf = 1.f;
     cx.dodiv = false;
     cx.range_pending = false;
     if constexpr (CALIB) {
-        cx.b = prm.bias[p];
-        const float d = prm.dark[p];
-        cx.D = prm.still_biased ? d - cx.b : d;              // ApCalibrate.py:440-445
+        cx.b = L.b;
+        cx.D = prm.still_biased ? L.d - cx.b : L.d;          // ApCalibrate.py:440-445
         if (prm.nflat) {
-            cx.nf = prm.nflat[p];
+            cx.nf = L.nf;
             cx.dodiv = (cx.nf != 0.f);                       // ApCalibrate.py:462 (NaN != 0 is True)
         }
     }
-    cx.skip = prm.pixmask && prm.pixmask[p];
+    cx.skip = L.skip;
     if constexpr (CALIB) {
         const float b = cx.b, D = cx.D, nf = cx.nf;
         const bool dodiv = cx.dodiv;
@@ -334,15 +434,15 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             RawT half[HN];
             load_raw<NP, RawT, FULL, 0, HN, MINN>(prm, base, lane, half);
             good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
-                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo);
+                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN, false, direct_ratios(FULL)>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
             load_raw<NP, RawT, FULL, HN, HN, MINN>(prm, base, lane, half);
             const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
-                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo);
+                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN, false, direct_ratios(FULL)>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
             good = good && good2;
         } else {
             if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
             else if (APGPU_HOIST_DARK && exposures_uniform<NP>(fs)) good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, true>(fs, raw, b, D, nf, dodiv, v, N, plo);
-            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
+            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, false, direct_ratios(FULL)>(fs, raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
         }
         if (wave_all(good && !cx.skip)) {
             cx.range_pending = !GUARD;
@@ -394,16 +494,16 @@ __device__ __forceinline__ int pad_low(const StackParams &prm)
 // wave is sorted with the pruned network (its ends and middle window only, make_pruned_net) and *pruned stays true;
 // otherwise the sort is complete and *pruned is cleared.
 template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0,
-          bool FORCE_HALVES = false, bool SPLIT_PADS = false>
+          bool FORCE_HALVES = false, bool SPLIT_PADS = false, bool PRE = false>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
-                                                  int lane, float (&v)[NP], bool *pruned = nullptr)
+                                                  int lane, float (&v)[NP], bool *pruned = nullptr, const EarlyLoads<NP, RawT> &pre = EarlyLoads<NP, RawT>())
 {
     ColumnCtx cx;
     // SPLIT_PADS (padded stacks headed for the float32 fast path, fast32_possible_padded): the first plo padding slots become
     // -inf, the rest +inf; the caller (reduce_and_store) knows - from the same arguments - and undoes it for the exact path
     int plo = 0;
     if constexpr (SPLIT_PADS) plo = pad_low<NP>(prm);
-    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES>(prm, fs, base, lane, v, cx, plo);
+    int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES, PRE>(prm, fs, base, lane, v, cx, plo, pre);
     bool prune = false;
     if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == (FULL ? NP : prm.N));
     if constexpr (PRUNE_T > 0) {

@@ -34,20 +34,29 @@ using namespace apgpu;
 
 // EXTRA: the rich kernels (sorted column parked in LDS: mad_std, float64 planes).  PLUS (lean only): median and std planes
 // straight from the register-resident column - the same kernel as the benchmarked one with a longer epilogue.
-// (round 4: 3 - with the hoisted dark term's second calibration body the 64-slot kernel would take 177 VGPRs, two wavefronts
-// per SIMD; capped at 168 the spills land in the exact-fallback blocks only, tools/isa_blocks.py)
+// (Round 4, measured and dropped: workgroups of 64 lanes, and persistent workgroups walking the tiles with stride gridDim.x
+// so that a finished wavefront's slot is refilled by its own next tile - either pushes the 64-slot kernel over 168 VGPRs,
+// i.e. to two wavefronts per SIMD: 1.09 / 1.24 ms against 1.02 on the same box.)
 #ifndef APGPU_LEAN_MIN_BLOCKS
-#define APGPU_LEAN_MIN_BLOCKS 3
+#define APGPU_LEAN_MIN_BLOCKS 2
 #endif
+#ifndef APGPU_LEAN_BLOCK
+#define APGPU_LEAN_BLOCK 256
+#endif
+
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
-__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA || PLUS ? 2 : APGPU_LEAN_MIN_BLOCKS) : 1) void stack_sigclip_kernel(const StackParams prm)
+__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN_BLOCK), NP <= 64 ? (EXTRA || PLUS ? 2 : APGPU_LEAN_MIN_BLOCKS) : 1) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
     __shared__ ColumnLds<NP, EXTRA> cols;        // lane-private columns: no barrier around their use
-    if constexpr (CALIB || !FULL) stage_frame_scalars<NP>(prm, fs);
+    // Full calibrated stacks without pedestals read the exposure ratios with scalar loads and stage nothing: no barrier before
+    // the first frame load.  (Round 4 also tried issuing the loads BEFORE the barrier of the staged kernels: the first
+    // wavefront's wait for its ratios is an in-order vmcnt(0) that then covers its 67 column loads as well - worse.)
+    constexpr int MINN = padded_minn(NP, FULL);
+    if (needs_staging<CALIB, FULL>(prm)) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
 
     float v[NP];
@@ -55,20 +64,20 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA |
     if constexpr (EXTRA) {
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
         reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
-    } else if constexpr (fast32_possible(NP, padded_minn(NP, FULL))) {
+    } else if constexpr (fast32_possible(NP, MINN)) {
         // full stacks headed for the float32 fast path only sort what it reads (pruned network); `pruned` tells the reduction
         // to complete the sort should it have to fall back to the exact path
         bool pruned = fast32_wanted(prm);
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, padded_minn(NP, FULL), kFastTail>(prm, fs, base, lane, v, &pruned);
-        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p, pruned);
-    } else if constexpr (fast32_possible_padded(NP, padded_minn(NP, FULL))) {
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTail>(prm, fs, base, lane, v, &pruned);
+        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p, pruned);
+    } else if constexpr (fast32_possible_padded(NP, MINN)) {
         // padded stacks: split pads (-inf below, +inf above the real values) and tails of 8 - see fast32_possible_padded
         bool pruned = fast32_wanted(prm);
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, padded_minn(NP, FULL), kFastTailPadded, false, true>(prm, fs, base, lane, v, &pruned);
-        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p, pruned);
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTailPadded, false, true>(prm, fs, base, lane, v, &pruned);
+        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p, pruned);
     } else {
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
-        reduce_and_store<NP, padded_minn(NP, FULL), PLUS>(prm, v, n, p);
+        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p);
     }
 }
 
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
-    if constexpr (CALIB || !FULL) stage_frame_scalars<NP>(prm, fs);
+    if (needs_staging<CALIB, FULL>(prm)) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
     const int n = load_sorted_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);
@@ -445,7 +454,7 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const bool rich = needs_lds || (wants_planes && !plus);
 #endif
     const bool full = prm.N == NP;
-    const int block = rich ? rich_block<NP>() : 256;
+    const int block = rich ? rich_block<NP>() : ((plus || median_only) ? 256 : APGPU_LEAN_BLOCK);
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (describe) {
