@@ -47,18 +47,20 @@ constexpr int prev_slots(int np)
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(uint16_t x) { return (float)x; }
 
-// x / nf for a per-pixel divisor with y = RN(1 / nf) precomputed: two Newton steps on the quotient with
-// exact FMA residuals (Markstein): q0 = RN(x*y) is within 1.5 ulp, q1 is faithful, q2 = RN(x / nf)
-// provided nothing over/underflows - the caller guards the ranges and falls back to IEEE division.
-// 5 instructions instead of the 12 of the IEEE sequence (v_div_scale x2, v_rcp, 6 FMA, v_div_fmas,
-// v_div_fixup), 64 times per pixel.
-__device__ __forceinline__ float div_by_recip(float x, float nf, float y)
+// x / nf for a per-pixel divisor with y = RN(1 / nf) and yl = fma(-nf, y, 1) * y (the reciprocal's rounding error: 1 / nf =
+// y + yl to 2^-48) precomputed.  q0 = RN(x y + RN(x yl)) is a FAITHFUL quotient (the true one to 2^-47 before its rounding);
+// r = x - nf q0 is exact in an FMA; q = RN(q0 + r y) is then the correctly rounded x / nf (Markstein's theorem: correctly
+// rounded reciprocal + faithful quotient + exact residual), provided nothing over/underflows - the caller guards the ranges
+// and falls back to IEEE division.  4 instructions (rounds 1-3: RN(x y) - only within 1.5 ulp - and TWO residual steps, 5)
+// instead of the 12 of the IEEE sequence (v_div_scale x2, v_rcp, 6 FMA, v_div_fmas, v_div_fixup), 64 times per pixel;
+// tools/div_check.hip: 1.3e11 random, special-divisor and next-to-a-rounding-boundary operand pairs, no mismatch with __fdiv_rn.
+__device__ __forceinline__ float recip_low(float nf, float y) { return __builtin_fmaf(-nf, y, 1.0f) * y; }
+
+__device__ __forceinline__ float div_by_recip(float x, float nf, float y, float yl)
 {
-    const float q0 = x * y;
+    const float q0 = __builtin_fmaf(x, y, x * yl);
     const float r0 = __builtin_fmaf(-nf, q0, x);
-    const float q1 = __builtin_fmaf(r0, y, q0);
-    const float r1 = __builtin_fmaf(-nf, q1, x);
-    return __builtin_fmaf(r1, y, q1);
+    return __builtin_fmaf(r0, y, q0);
 }
 
 // Full stacks without pedestals read the exposure ratios with scalar loads (calibrate_fast, E_DIRECT) and stage nothing.
@@ -177,12 +179,13 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
     // q0 = x, r0 = 0, ... -> x, bit for bit; no per-value select
     const float nfe = dodiv ? nf : 1.0f;
     const float y = __fdiv_rn(1.0f, nfe);
+    const float yl = recip_low(nfe, y);
     const float anf = fabsf(nfe);
     const bool nf_ok = (anf >= 0x1p-40f && anf <= 0x1p40f);
     float mx = 0.f, mn = __builtin_inff();
     if constexpr (NP >= 2) {
         v2f acc = {0.f, 0.f};
-        const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, zero2 = {0.f, 0.f};
+        const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, yl2 = {yl, yl}, zero2 = {0.f, 0.f};
         const float ds0 = UNI_E ? fs.e[0] * D : 0.f;         // :450 for every frame when UNI_E
         const v2f ds_uni = {ds0, ds0};
 #pragma unroll
@@ -208,11 +211,9 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 ds = e2 * D2;                                // :450
             }
             x = x - ds;                                      // :451
-            const v2f q0 = x * y2;                           // :462-464 via reciprocal + 2 FMA corrections
+            const v2f q0 = __builtin_elementwise_fma(x, y2, x * yl2);    // :462-464: faithful quotient (div_by_recip)
             const v2f r0 = __builtin_elementwise_fma(nf2, q0, x);
-            const v2f q1 = __builtin_elementwise_fma(r0, y2, q0);
-            const v2f r1 = __builtin_elementwise_fma(nf2, q1, x);
-            const v2f q = __builtin_elementwise_fma(r1, y2, q1);
+            const v2f q = __builtin_elementwise_fma(r0, y2, q0);
             v[f] = q.x;
             v[f + 1] = q.y;
             acc = __builtin_elementwise_fma(q, zero2, acc);  // NaN iff some value is not finite
@@ -235,7 +236,7 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
         x = x - b;
         const float ds = (E_DIRECT ? eg[0] : fs.e[0]) * D;
         x = x - ds;
-        const float q = div_by_recip(x, nfe, y);
+        const float q = div_by_recip(x, nfe, y, yl);
         v[0] = q;
         const float acc = __builtin_fmaf(q, 0.0f, 0.0f);
         const bool range_ok = !dodiv || (fabsf(q) < 0x1p50f && fabsf(q) > 0x1p-50f);

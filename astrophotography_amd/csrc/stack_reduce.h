@@ -304,24 +304,26 @@ __device__ __forceinline__ void trim_low_fast(const float (&v)[NP], Fast32 &f, c
     }
 }
 
+// th_hi / th_lo: the upper thresholds (the lower ones again when sigma_lower == sigma_upper - clip_fast32)
 template <int K, int NP, int T = kFastTail>                  // K = number of upper-tail elements still in the range
-__device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, const float (&SH)[T + 1], const float (&QH)[T + 1])
+__device__ __forceinline__ void trim_high_fast(const float (&v)[NP], Fast32 &f, const float (&SH)[T + 1], const float (&QH)[T + 1],
+                                               const float th_hi, const float th_lo)
 {
     constexpr int I = NP - T + K - 1;                       // the element under test: the highest one in the range
     const float t = fast32_t(f, v[I]);
     const bool at = f.b == I + 1;
     if constexpr (K > 0) {
-        const bool rej = at && (t > f.th_hi);
-        const bool maybe = at && (t > f.th_lo);
+        const bool rej = at && (t > th_hi);
+        const bool maybe = at && (t > th_lo);
         f.unsure = f.unsure || (maybe != rej);
         if (rej) {
             f.b = I;
             f.Shi = SH[K - 1];
             f.Qhi = QH[K - 1];
         }
-        if (wave_any(f.b <= I)) trim_high_fast<K - 1, NP, T>(v, f, SH, QH);
+        if (wave_any(f.b <= I)) trim_high_fast<K - 1, NP, T>(v, f, SH, QH, th_hi, th_lo);
     } else {
-        f.unsure = f.unsure || (at && (t > f.th_lo));
+        f.unsure = f.unsure || (at && (t > th_lo));
     }
 }
 
@@ -418,6 +420,7 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     f.unsure = !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
     const float rho = APGPU_FAST32_RHO;
     const float sl4 = 4.f * sl2f, su4 = 4.f * su2f;
+    const int max_passes = __builtin_amdgcn_readfirstlane(maxiters);
     float S, Q;
     int it = 0;
     for (;;) {
@@ -428,16 +431,19 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
         const float nQ = f.nf * Q;
         const float V = __builtin_fmaf(-S, S, nQ);
         f.unsure = f.unsure || !(V >= 0.25f * nQ);
-        const float tl = sl4 * V, th = su4 * V;
+        const float tl = sl4 * V;
         f.tl_hi = __builtin_fmaf(tl, rho, tl);
         f.tl_lo = __builtin_fmaf(tl, -rho, tl);
+        trim_low_fast<0, NP, T>(v, f, SL, QL);
+        // (one sigma for both sides would make these the lower thresholds again - 3 instructions per pass less behind a
+        // wave-uniform branch, but the second copy of the chain costs 3 VGPRs: 170, over the three-wavefront budget)
+        const float th = su4 * V;
         f.th_hi = __builtin_fmaf(th, rho, th);
         f.th_lo = __builtin_fmaf(th, -rho, th);
-        trim_low_fast<0, NP, T>(v, f, SL, QL);
-        trim_high_fast<T, NP, T>(v, f, SH, QH);
+        trim_high_fast<T, NP, T>(v, f, SH, QH, f.th_hi, f.th_lo);
         it++;
         const bool changed = (f.a != a0) || (f.b != b0);
-        if (!(wave_any(changed) && (maxiters < 0 || it < maxiters))) break;
+        if (!(wave_any(changed) && (max_passes < 0 || it < max_passes))) break;
         // the middle pair of the new range: a <= T, b >= NP - T keep it inside a 5-slot window around NP / 2
         constexpr int LO1 = (NP - T - 1) >> 1, LO2 = (NP - T) >> 1;
         f.m1 = pick_rel<LO1, T + 1, NP>(v, ((f.a + f.b - 1) >> 1) - LO1);

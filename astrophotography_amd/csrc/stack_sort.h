@@ -197,7 +197,7 @@ __device__ __forceinline__ void window_net_from(float (&v)[NP])
 //   16 values: sort4 on the rows and on the columns of the 4 x 4 matrix (8 x 7) + ten 3-sorters = 86 instructions
 //              (four sort4 + Batcher's 4+4 and 8+8 merges: 114);
 //   8 values: eight 3-sorters = 24 (two sort4 + merge: 32);
-//   merge of two sorted 16-blocks: 118 (Batcher: 65 compare-exchanges = 130).
+//   merge of two sorted 16-blocks: 116 (Batcher: 65 compare-exchanges = 130).
 // Above that the merge levels p = 32, 64 stay Batcher's.  A network for NP wires is the network for the next multiple of 16
 // RESTRICTED to the wires below NP: the missing inputs are +inf, an inf never leaves the highest wire of a sorter, so a
 // sorter simply loses those wires (a 3-sorter becomes a compare-exchange, a one-wire sorter disappears).
@@ -223,14 +223,14 @@ constexpr NetOp kSort8Ops[8] = {{{0, 1, 2, 0}, 3}, {{3, 4, 5, 0}, 3}, {{0, 6, 7,
                                 {{2, 5, 7, 0}, 3}, {{0, 1, 3, 0}, 3}, {{2, 3, 4, 0}, 3}, {{4, 5, 6, 0}, 3}};
 // two sorted 16-blocks (wires 0..15, 16..31) -> 32 sorted
 constexpr NetOp kMerge16Ops[] = {
-    {{8, 22, 0, 0}, 2},   {{9, 23, 0, 0}, 2},   {{7, 21, 0, 0}, 2},   {{10, 24, 0, 0}, 2},  {{11, 25, 0, 0}, 2},  {{6, 20, 0, 0}, 2},
-    {{12, 26, 0, 0}, 2},  {{5, 19, 0, 0}, 2},   {{4, 18, 0, 0}, 2},   {{3, 17, 0, 0}, 2},   {{13, 19, 27, 0}, 3}, {{14, 20, 28, 0}, 3},
-    {{15, 21, 29, 0}, 3}, {{2, 10, 16, 0}, 3},  {{12, 18, 0, 0}, 2},  {{7, 11, 17, 0}, 3},  {{1, 9, 13, 0}, 3},   {{0, 8, 12, 0}, 3},
-    {{18, 22, 30, 0}, 3}, {{19, 23, 31, 0}, 3}, {{20, 24, 0, 0}, 2},  {{14, 16, 18, 0}, 3}, {{13, 15, 17, 0}, 3}, {{21, 25, 0, 0}, 2},
-    {{6, 8, 10, 0}, 3},   {{1, 5, 7, 0}, 3},    {{26, 28, 30, 0}, 3}, {{25, 27, 31, 0}, 3}, {{0, 4, 6, 0}, 3},    {{20, 22, 0, 0}, 2},
-    {{15, 17, 19, 0}, 3}, {{12, 14, 16, 0}, 3}, {{9, 11, 12, 0}, 3},  {{1, 3, 4, 0}, 3},    {{21, 22, 23, 0}, 3}, {{23, 24, 26, 0}, 3},
-    {{0, 1, 2, 0}, 3},    {{25, 26, 0, 0}, 2},  {{29, 30, 31, 0}, 3}, {{7, 8, 0, 0}, 2},    {{17, 18, 0, 0}, 2},  {{9, 10, 0, 0}, 2},
-    {{5, 6, 0, 0}, 2},    {{19, 20, 0, 0}, 2},  {{15, 16, 0, 0}, 2},  {{27, 28, 0, 0}, 2},  {{13, 14, 0, 0}, 2}};
+    {{9, 23, 0, 0}, 2}, {{8, 22, 0, 0}, 2}, {{7, 21, 0, 0}, 2}, {{10, 24, 0, 0}, 2}, {{6, 20, 0, 0}, 2}, {{11, 25, 0, 0}, 2},
+    {{5, 19, 0, 0}, 2}, {{12, 26, 0, 0}, 2}, {{4, 12, 18, 0}, 3}, {{13, 19, 27, 0}, 3}, {{3, 17, 0, 0}, 2}, {{14, 20, 28, 0}, 3},
+    {{15, 21, 29, 0}, 3}, {{2, 10, 16, 0}, 3}, {{7, 11, 17, 0}, 3}, {{1, 9, 13, 0}, 3}, {{0, 8, 12, 0}, 3}, {{18, 22, 30, 0}, 3},
+    {{19, 23, 31, 0}, 3}, {{20, 24, 0, 0}, 2}, {{14, 16, 18, 0}, 3}, {{13, 15, 17, 0}, 3}, {{21, 23, 25, 0}, 3}, {{24, 26, 30, 0}, 3},
+    {{6, 8, 10, 0}, 3}, {{1, 3, 5, 0}, 3}, {{0, 4, 6, 0}, 3}, {{25, 27, 31, 0}, 3}, {{5, 6, 7, 0}, 3}, {{15, 17, 19, 0}, 3},
+    {{19, 20, 22, 0}, 3}, {{12, 14, 16, 0}, 3}, {{9, 11, 12, 0}, 3}, {{27, 28, 30, 0}, 3}, {{0, 1, 2, 0}, 3}, {{29, 30, 31, 0}, 3},
+    {{13, 14, 0, 0}, 2}, {{7, 8, 0, 0}, 2}, {{21, 22, 0, 0}, 2}, {{23, 24, 0, 0}, 2}, {{25, 26, 0, 0}, 2}, {{17, 18, 0, 0}, 2},
+    {{9, 10, 0, 0}, 2}, {{15, 16, 0, 0}, 2}, {{3, 4, 0, 0}, 2}};
 
 // appends `o` shifted by `off`, restricted to the wires below NP
 template <int NP>

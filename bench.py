@@ -47,19 +47,22 @@ def parse(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--frames', type=int, default=64, help='frames per GPU (weak scaling; C2: 64)')
+    ap.add_argument('--frames', type=int, default=None, help='frames per GPU (weak scaling); default: the BASELINE configuration of '
+                                                            'the workload (C2: 64, C4: 64, C5: 16 = the per-GPU share of 128)')
     ap.add_argument('--total-frames', type=int, default=256, help='frames of the whole job with --scaling strong (C3: 256)')
-    ap.add_argument('--height', type=int, default=4096)
-    ap.add_argument('--width', type=int, default=4096)
+    ap.add_argument('--height', type=int, default=None, help='default: BASELINE (C2: 4096, C4: 6248, C5: 8192)')
+    ap.add_argument('--width', type=int, default=None, help='default: BASELINE (C2: 4096, C4: 4176, C5: 8192)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'u16'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--parallelism', default='nshard', choices=['nshard', 'rowshard'])
     ap.add_argument('--exchange', default='f64', choices=['f64', 'f32'],
-                    help='N-shard all-reduce payload: f64 sum + i32 count (12 B/pixel, float64 combine) or f32 sum + count (8 B/pixel)')
+                    help='N-shard exchange payload: packed float64 sum + count planes (16 B/pixel, float64 combine) or float32 sum + '
+                         'count (8 B/pixel)')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
-                    help='c2 (default, the BASELINE metric): fused calibrate + clipped mean; c4: uint16 Bayer frames, per-channel '
-                         'flat + fused calibrate + median stack (use --height 6248 --width 4176); c5: bad-pixel mask + per-frame '
-                         'affine Lanczos-3 resample + 5-iteration clipped mean (use --frames 16 --height 8192 --width 8192)')
+                    help='c2 (default, the BASELINE metric): fused calibrate + clipped mean, 64 x 4096 x 4096 f32; c4: uint16 Bayer '
+                         'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
+                         'affine Lanczos-3 resample + 5-iteration clipped mean, the per-GPU share 16 x 8192 x 8192 of 128 frames '
+                         '(a bare --workload runs BASELINE\'s dimensions; --frames / --height / --width override them)')
     ap.add_argument('--stripes', type=int, default=0, help='row stripes for collective/compute overlap (N > 1); 0 = by payload '
                                                             '(parallel.default_stripes: 4 for 4096 x 4096)')
     ap.add_argument('--hier-shards', type=int, default=8, help='--scaling strong: the job is this many shards of '
@@ -72,7 +75,16 @@ def parse(argv=None):
     ap.add_argument('--selftest-cpu', action='store_true',
                     help='launcher/rendezvous/reporting self-test on CPU: gloo backend, a trivial stand-in step, no kernels '
                          '(tests/test_bench_launcher.py); the JSON line is marked "selftest": true and carries no roofline')
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    base = {'c2': (64, 4096, 4096), 'c4': (64, 6248, 4176), 'c5': (16, 8192, 8192)}[args.workload]
+    args.baseline_dims = args.frames is None and args.height is None and args.width is None
+    if args.frames is None:
+        args.frames = base[0]
+    if args.height is None:
+        args.height = base[1]
+    if args.width is None:
+        args.width = base[2]
+    return args
 
 
 # -------------------------------------------------------------------------------------------------------------
@@ -453,6 +465,8 @@ def main(argv=None):
                                         outputs=('mean',) if single_launch else (('moments_f64p',) if args.exchange == 'f64' else ('moments',)))
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
     cfg_name = 'C3' if strong else 'C2'
+    if not strong and not (N == 64 and H_glob == 4096 and W == 4096 and args.dtype == 'f32'):
+        cfg_name = 'C2-like (not BASELINE\'s 64x4096x4096 f32)'
     workload = '%s: %dx%dx%d %s per GPU, fused bias/dark/flat + 3-sigma maxiters-5 median-centred clipped mean' % (
         cfg_name, N, H, W, args.dtype)
     if wl == 'c4':
@@ -460,17 +474,21 @@ def main(argv=None):
         args.dtype = 'u16'
         kernel_name = ops.stack_kernel_name(N, 'u16', calibrated=True, median_only=True)
         metric = 'Mpixels/sec calibrate+median-stack (uint16 Bayer)'
-        workload = 'C4: %dx%dx%d u16 RGGB mosaic, per-channel flat normalisation, fused bias/dark/flat + median stack' % (N, H, W)
+        workload = '%s: %dx%dx%d u16 RGGB mosaic, per-channel flat normalisation, fused bias/dark/flat + median stack' % (
+            'C4' if (N, H, W) == (64, 6248, 4176) else 'C4-like (not BASELINE\'s 64x6248x4176)', N, H, W)
     if wl == 'c5':
         algo_bytes = (8 * N * P + P) + (4 * N * P + out_bytes * P)     # resample read+write (+mask), stack read + outputs
         kernel_name = 'resample_affine_kernel + ' + ops.stack_kernel_name(N, 'f32', calibrated=False) + ' (step = both launches)'
         metric = 'Mpixels/sec mask+affine-resample+sigma-clip-stack'
-        workload = 'C5 (per-GPU share): %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (N, H, W)
+        workload = '%s: %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (
+            'C5 (per-GPU share of 128x8192x8192 on 8 GPUs)' if (N, H, W) == (16, 8192, 8192) else 'C5-like (not BASELINE\'s 16x8192x8192 share)', N, H, W)
     achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
     # HBM traffic per launch from the PMC counters: collected by profiles/run_profile.sh (separate --pmc passes of THIS
     # command under rocprofv3; counters cannot be read from inside the process) and looked up by workload key.
     traffic = None
+    traffic_source = None
+    valu = None                                              # the second bound: VALU issue (SQ counters of the same command)
     tkey = '%s:%dx%dx%d:%s:%s' % (wl, N, H, W, args.dtype, 'single' if single_launch else args.exchange)
     tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tfile) and world == 1:
@@ -479,6 +497,10 @@ def main(argv=None):
             ent = td.get('workloads', {}).get(tkey)
             if ent and ent.get('kernel') == kernel_name:        # counters of ANOTHER kernel build are not this kernel's traffic
                 traffic = ent.get('hbm_bytes_per_launch')
+                traffic_source = 'profiles/pmc_traffic.json (%s)' % ent.get('tag')
+                if ent.get('valu'):
+                    valu = dict(ent['valu'], source='profiles/pmc_traffic.json (%s): SQ_INSTS_VALU / SQ_WAVES, SQ_ACTIVE_INST_VALU x 4 / '
+                                                   '(SIMDs x GRBM_GUI_ACTIVE / XCDs), GRBM_GUI_ACTIVE / XCDs / duration' % ent.get('tag'))
         except Exception:
             traffic = None
 
@@ -520,9 +542,14 @@ def main(argv=None):
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload, 'frames_per_gpu': N, 'frames_total': n_total if not rowshard else N,
                        'height': H, 'width': W, 'parallelism': par},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_key': tkey,
-                         'kernel': kernel_name,
+            # `bound`: the roofline the kernel is PRICED against (bytes / HBM peak, the contract's fields); `limiter`: what the
+            # counters say holds it back today - the fused float32 clip kernels issue VALU instructions ~90 % of the time
+            # (roofline.valu, measured), the uint16 median kernel streams.
+            'roofline': {'bound': 'hbm', 'limiter': ('valu_issue' if (valu and valu.get('busy_frac', 0) > 0.8) else
+                                                     ('hbm' if wl == 'c4' else 'valu_issue (not re-measured for this key)')),
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source, 'traffic_key': tkey,
+                         'valu': valu, 'kernel': kernel_name,
                          'avg_launch_ms': avg_kernel_ms, 'min_launch_ms': kern_ms[0], 'algorithmic_bytes': algo_bytes,
                          'measured_copy_GBps': copy_gbs, 'frac_of_measured_copy': achieved / copy_gbs if copy_gbs else None},
         }

@@ -9,7 +9,7 @@
 #  4. --pmc SQ_INSTS_VALU SQ_WAVES  -> VALU instructions per wave (the VALU-issue-bound claim of DESIGN 4.1)
 #  5. --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS
 #  6. --pmc GRBM_GUI_ACTIVE         -> busy cycles of the dispatch -> the clock the chip actually held
-#  7. --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES -> average resident waves
+#  7. --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU -> average resident waves, VALU busy fraction
 TAG=${1:-r02}
 shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,7 +20,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $REPO/bench.py --steps 20 --warmup 3 "$@" > $OUT/bench_line.json 2> $OUT/bench_line.log
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_trace.json 2> $OUT/trace.log
 i=0
-for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"; do
+for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.log
 done

@@ -93,6 +93,10 @@ if 'SQ_INSTS_VALU' in avg and avg.get('SQ_WAVES'):
 if 'GRBM_GUI_ACTIVE' in avg and durs:
     # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs of the chip
     res["gpu_clock_ghz_during_kernel"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / (sum(durs) / len(durs))
+if 'SQ_ACTIVE_INST_VALU' in avg and 'GRBM_GUI_ACTIVE' in avg:
+    # SQ_ACTIVE_INST_VALU counts in units of 4 cycles (one wave64 issue slot of a SIMD), summed over the chip's 1024 SIMDs;
+    # GRBM_GUI_ACTIVE / 8 = the kernel's busy cycles per XCD
+    res['valu_busy_frac'] = avg['SQ_ACTIVE_INST_VALU'] * 4.0 / (1024.0 * avg['GRBM_GUI_ACTIVE'] / 8.0)
 if 'SQ_WAVE_CYCLES' in avg and avg.get('SQ_BUSY_CYCLES'):
     res['sq_wave_cycles_over_busy_cycles'] = avg['SQ_WAVE_CYCLES'] / avg['SQ_BUSY_CYCLES']
 json.dump(res, open(os.path.join(out, 'summary_%s.json' % tag), 'w'), indent=1)
