@@ -19,6 +19,10 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_h.hip',
     'stack_inst_u16_calib_h.hip',
     'stack_inst_u16_plain_h.hip',
+    'stack_inst_f32_calib_o.hip',
+    'stack_inst_f32_plain_o.hip',
+    'stack_inst_u16_calib_o.hip',
+    'stack_inst_u16_plain_o.hip',
     'stack_inst_f32_calib_g.hip',
     'stack_inst_f32_plain_g.hip',
     'stack_inst_u16_calib_g.hip',
@@ -31,6 +35,10 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_f.hip',
     'stack_inst_u16_calib_f.hip',
     'stack_inst_u16_plain_f.hip',
+    'stack_inst_f32_calib_n.hip',
+    'stack_inst_f32_plain_n.hip',
+    'stack_inst_u16_calib_n.hip',
+    'stack_inst_u16_plain_n.hip',
     'stack_inst_f32_calib_e.hip',
     'stack_inst_f32_plain_e.hip',
     'stack_inst_u16_calib_e.hip',
@@ -43,14 +51,26 @@ SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip
     'stack_inst_f32_plain_d.hip',
     'stack_inst_u16_calib_d.hip',
     'stack_inst_u16_plain_d.hip',
+    'stack_inst_f32_calib_m.hip',
+    'stack_inst_f32_plain_m.hip',
+    'stack_inst_u16_calib_m.hip',
+    'stack_inst_u16_plain_m.hip',
     'stack_inst_f32_calib_c.hip',
     'stack_inst_f32_plain_c.hip',
     'stack_inst_u16_calib_c.hip',
     'stack_inst_u16_plain_c.hip',
+    'stack_inst_f32_calib_l.hip',
+    'stack_inst_f32_plain_l.hip',
+    'stack_inst_u16_calib_l.hip',
+    'stack_inst_u16_plain_l.hip',
     'stack_inst_f32_calib_b.hip',
     'stack_inst_f32_plain_b.hip',
     'stack_inst_u16_calib_b.hip',
     'stack_inst_u16_plain_b.hip',
+    'stack_inst_f32_calib_k.hip',
+    'stack_inst_f32_plain_k.hip',
+    'stack_inst_u16_calib_k.hip',
+    'stack_inst_u16_plain_k.hip',
     'stack_inst_f32_calib_a.hip',
     'stack_inst_f32_plain_a.hip',
     'stack_inst_u16_calib_a.hip',

@@ -35,7 +35,7 @@ constexpr int padded_minn(int np, bool full) { return (full || np >= 128) ? np :
 
 constexpr int prev_slots(int np)
 {
-    constexpr int counts[] = {1, 4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 80, 96, 104, 112, 128};
+    constexpr int counts[] = {1, 4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 72, 80, 88, 96, 104, 112, 120, 128};
     int prev = 0;
     for (int c : counts) {
         if (c >= np) break;

@@ -13,7 +13,7 @@
 //   * its 8 lowest / 8 highest values, merged into the running global tails GL / GH (bitonic 8 + 8 -> 8; the values
 //     pushed out of a tail are ADDED to the running sums - sums only ever grow by what belongs to them, clip_fast32's
 //     rule against subtracting an outlier from a total it dominates);
-//   * a window of 32 values around ITS middle.  A chunk is a random subset of the column, so the column's middle order
+//   * a window of 32 values around ITS middle.  A chunk is a stride-K sample of the column (interleaved chunks, round 4: robust to drift in acquisition order), so the column's middle order
 //     statistics have local rank c_k / 2 +- 4 (one sigma) in it: the 4-sigma window holds them.  After the last chunk the
 //     K windows are merged (two levels of Batcher's odd-even merge, pruned to the 16 middle outputs) and the element of
 //     global rank r is merged element r - (number of values below the windows) - PROVIDED it lies in the zone
@@ -161,18 +161,21 @@ __device__ __forceinline__ bool load_chunk(const StackParams &q, const FrameScal
 
 // One chunk: frames [f0, f0 + c) of the stack -> tails merged, window kept, sums accumulated.  Returns false for a lane
 // whose chunk holds a non-finite value (or whose pixel is masked): its wave goes to the exact kernel.
-template <typename RawT, bool CALIB, bool FULLCH, int KIDX>
-__device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameScalars<kChunkSlots> &fs, int f0, int c, int64_t base,
+// Round 4 (advisor): the chunks are INTERLEAVED - chunk k holds frames k, k + NCH, k + 2 NCH, .. - so that every chunk is a
+// stride-NCH sample of the whole sequence: a stack that drifts in acquisition order (sky background over a night, dark
+// current with temperature) no longer separates the chunk medians, which would empty the zone the windows vouch for and
+// send every wavefront to the redo list (correct, but the chunk pass AND the exact pass were paid).
+template <typename RawT, bool CALIB, bool FULLCH, int KIDX, int NCH>
+__device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameScalars<kChunkSlots> &fs, int kchunk, int c, int64_t base,
                                            int lane, float (&GL)[kChunkTail], float (&GH)[kChunkTail], float (&win)[kChunkWin],
                                            float &c0, float &Stot, float &Qtot, float &Lmax, float &Umin)
 {
     constexpr int NP = kChunkSlots, T = kChunkTail;
     __builtin_amdgcn_sched_barrier(0);                      // chunks do not overlap: the scheduler otherwise stretches live ranges across them
     StackParams q = prm;                                    // the chunk as a stack of its own
-    q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)f0 * prm.stride;
-    q.N = c;
-    if (prm.exp_ratio) q.exp_ratio = prm.exp_ratio + f0;
-    if (prm.pedestal) q.pedestal = prm.pedestal + f0;
+    q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)kchunk * prm.stride;
+    q.stride = prm.stride * NCH;
+    q.N = c;                                                // (the per-frame scalars come from the staged copy fs, gathered with the same stride)
     float v[NP];
     const bool ok = load_chunk<RawT, CALIB, FULLCH>(q, fs, base, lane, v);     // v[0 .. c) are the chunk, sorted; false: redo
     float lo[T], hi[T];
@@ -314,9 +317,8 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     const int cbase = N / K, cextra = N % K;
     for (int k = 0; k < K; k++) {
         const int c = cbase + (k < cextra ? 1 : 0);
-        const int f0 = k * cbase + (k < cextra ? k : cextra);
         for (int t = threadIdx.x; t < kChunkSlots; t += blockDim.x) {
-            const int ff = f0 + (t < c ? t : c - 1);
+            const int ff = k + (t < c ? t : c - 1) * K;     // interleaved chunks: frames k, k + K, ..
             fs[k].e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
             fs[k].ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
             fs[k].pad[t] = t < c ? -__builtin_inff() : __builtin_inff();
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     if constexpr (K >= 3) {
         float win[W];
         const int c = cbase + (0 < cextra ? 1 : 0);
-        ok = chunk_step<RawT, CALIB, FULLCH, 0>(prm, fs[0], 0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
+        ok = chunk_step<RawT, CALIB, FULLCH, 0, K>(prm, fs[0], 0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
@@ -345,8 +347,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     if constexpr (K == 4) {
         float win[W];
         const int c = cbase + (1 < cextra ? 1 : 0);
-        const int f0 = cbase + (1 < cextra ? 1 : cextra);
-        ok = chunk_step<RawT, CALIB, FULLCH, 1>(prm, fs[1], f0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
+        ok = chunk_step<RawT, CALIB, FULLCH, 1, K>(prm, fs[1], 1, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
@@ -354,15 +355,13 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     {
         constexpr int k = K - 2;                            // (K = 2: this is the first chunk)
         const int c = cbase + (k < cextra ? 1 : 0);
-        const int f0 = k * cbase + (k < cextra ? k : cextra);
-        ok = chunk_step<RawT, CALIB, FULLCH, (k == 0 ? 0 : 2)>(prm, fs[k], f0, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
+        ok = chunk_step<RawT, CALIB, FULLCH, (k == 0 ? 0 : 2), K>(prm, fs[k], k, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
     }
     {
         constexpr int k = K - 1;
         const int c = cbase;                                // the last chunk never gets an extra frame
-        const int f0 = k * cbase + cextra;
-        ok = chunk_step<RawT, CALIB, FULLCH, 3>(prm, fs[k], f0, c, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin) && ok;
+        ok = chunk_step<RawT, CALIB, FULLCH, 3, K>(prm, fs[k], k, c, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin) && ok;
         below += c / 2 - W / 2;
     }
     float X[4 * W];                                         // the K windows side by side, +inf beyond them
@@ -511,13 +510,20 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), (size_t)(nwaves + 1) * sizeof(int32_t), st);
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot allocate the redo list: %s", hipGetErrorString(e));
     e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): memset: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(redo, st);
+        return fail(APGPU_ELAUNCH, "stack (chunks): memset: %s", hipGetErrorString(e));
+    }
     const size_t lds = (size_t)(K - 2) * kChunkWin * 256 * sizeof(float);
     if (lds > 48 * 1024) {
         const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, true>)
                                   : reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, false>);
         e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        if (e != hipSuccess) {                              // no room for the parked windows: the exact kernel does the whole stack
+            (void)hipGetLastError();
+            (void)hipFreeAsync(redo, st);
+            return launch_big_exact(prm, u16, CALIB, false, st, nullptr, nullptr);
+        }
     }
     if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);
     else hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);

@@ -61,6 +61,26 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
 
     float v[NP];
     APGPU_MARK("load_calibrate_sort");
+#ifdef APGPU_VARIANT_STRIP
+    // measurement only (tools/variant_lib.sh): the kernel WITHOUT its clip (1: load + calibrate + pruned sort, the sorted
+    // column's needed outputs summed; 2: load + calibrate, the column summed) - the instruction floor of DESIGN 4.1
+    if constexpr (!EXTRA && !PLUS && fast32_possible(NP, MINN)) {
+        float acc = 0.f;
+        if (APGPU_VARIANT_STRIP == 1) {
+            bool pruned = true;
+            load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTail>(prm, fs, base, lane, v, &pruned);
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc += v[i];
+        } else {
+            ColumnCtx cx;
+            load_column<NP, RawT, CALIB, true, FULL, MINN>(prm, fs, base, lane, v, cx);
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc += v[i];
+        }
+        if (prm.mean) prm.mean[p] = acc;
+        return;
+    }
+#endif
     if constexpr (EXTRA) {
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
         reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
@@ -492,9 +512,10 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     extern template int launch_one<NP, uint16_t, true>(const StackParams &, bool, hipStream_t, char *);   \
     extern template int launch_one<NP, uint16_t, false>(const StackParams &, bool, hipStream_t, char *);
 APGPU_DECLARE_LAUNCH(1) APGPU_DECLARE_LAUNCH(4) APGPU_DECLARE_LAUNCH(8) APGPU_DECLARE_LAUNCH(12) APGPU_DECLARE_LAUNCH(16)
-APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(40) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(56)
-APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(72) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(104)
-APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(128)
+APGPU_DECLARE_LAUNCH(20) APGPU_DECLARE_LAUNCH(24) APGPU_DECLARE_LAUNCH(28) APGPU_DECLARE_LAUNCH(32) APGPU_DECLARE_LAUNCH(36)
+APGPU_DECLARE_LAUNCH(40) APGPU_DECLARE_LAUNCH(44) APGPU_DECLARE_LAUNCH(48) APGPU_DECLARE_LAUNCH(52) APGPU_DECLARE_LAUNCH(56)
+APGPU_DECLARE_LAUNCH(60) APGPU_DECLARE_LAUNCH(64) APGPU_DECLARE_LAUNCH(72) APGPU_DECLARE_LAUNCH(80) APGPU_DECLARE_LAUNCH(88)
+APGPU_DECLARE_LAUNCH(96) APGPU_DECLARE_LAUNCH(104) APGPU_DECLARE_LAUNCH(112) APGPU_DECLARE_LAUNCH(120) APGPU_DECLARE_LAUNCH(128)
 #undef APGPU_DECLARE_LAUNCH
 #endif
 
@@ -502,24 +523,32 @@ template <typename RawT, bool CALIB>
 int launch_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe = nullptr)
 {
     const int N = prm.N;
-    // slot counts: powers of two, their 3/4 points and, from 32 up, the 5/8 and 7/8 points (pruned networks); 72 and 104 fill
-    // the two widest gaps (65..80, 97..112)
+    // slot counts: every multiple of 4 up to 64, every multiple of 8 from there to 128 (round 4: a stack between two slot
+    // counts runs the padded kernel, which costs more than the next full one - so the gaps are at most 3 / 7 frames wide)
     if (N <= 1) return launch_one<1, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 4) return launch_one<4, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 8) return launch_one<8, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 12) return launch_one<12, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 16) return launch_one<16, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 20) return launch_one<20, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 24) return launch_one<24, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 28) return launch_one<28, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 32) return launch_one<32, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 36) return launch_one<36, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 40) return launch_one<40, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 44) return launch_one<44, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 48) return launch_one<48, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 52) return launch_one<52, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 56) return launch_one<56, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 60) return launch_one<60, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 64) return launch_one<64, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 72) return launch_one<72, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 80) return launch_one<80, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 88) return launch_one<88, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 96) return launch_one<96, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 104) return launch_one<104, RawT, CALIB>(prm, median_only, st, describe);
     if (N <= 112) return launch_one<112, RawT, CALIB>(prm, median_only, st, describe);
+    if (N <= 120) return launch_one<120, RawT, CALIB>(prm, median_only, st, describe);
     return launch_one<128, RawT, CALIB>(prm, median_only, st, describe);
 }
 

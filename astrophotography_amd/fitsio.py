@@ -573,8 +573,10 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
     if dtype == 'auto':
         if all(lay is not None and lay[2] for lay in lays):
             sdt = torch.uint16
-        elif any((lay is not None and lay[1] == -64) or (lay is None and int(h['BITPIX']) in (-64, 64, 32))
+        elif any((lay is not None and lay[1] == -64) or (lay is None and int(h['BITPIX']) == -64)
                  for lay, h in zip(lays, hdrs)):
+            # float64 only for BITPIX -64: the reference converts every NON-float raw frame to float32 whatever its
+            # integer width (core/ApCalibrate.py:301-305), so BITPIX 8 / 16 / 32 / 64 integers go to float32 like there
             sdt = torch.float64
         else:
             sdt = torch.float32
@@ -601,6 +603,8 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
                     if lay is None:
                         continue
                     free[b].wait()
+                    if stop.is_set():
+                        return
                     free[b].clear()
                     if uploaded[b] is not None:
                         uploaded[b].synchronize()
@@ -621,11 +625,13 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
                 ready.put((None, None, exc))
             ready.put((None, None, None))
 
+        stop = threading.Event()
         th = threading.Thread(target=reader, daemon=True)
         th.start()
         cs = torch.cuda.Stream(device=dev)
         cs.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(cs):
+        try:
+          with torch.cuda.stream(cs):
             while True:
                 k, b, exc = ready.get()
                 if exc is not None:
@@ -650,7 +656,19 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
                         slab[k].view(torch.int16).copy_(dst.view(torch.int16))
                     else:
                         slab[k].copy_(dst.to(sdt))
-        th.join()
+        finally:
+            # whatever happened above (a failed device call, an exception forwarded from the reader): release the reader -
+            # it may be waiting for a staging buffer or for room in the queue - and wait for it, so that no thread and no
+            # pinned buffer outlives the call
+            stop.set()
+            for ev in free:
+                ev.set()
+            while th.is_alive():
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
         torch.cuda.current_stream(dev).wait_stream(cs)
         for t in staged:
             t.record_stream(torch.cuda.current_stream(dev))

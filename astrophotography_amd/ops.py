@@ -261,7 +261,7 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
     return res
 
 
-def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, finalize=True, **clip):
+def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, finalize=True, exact=False, **clip):
     """A stack of MORE than APGPU_MAX_STACK (512) frames on one GPU: the frames are reduced in chunks of at most `chunk`
     (default: the largest equal split not above 512), every chunk clipped against its own statistics, and the float64
     moments of the chunks accumulate in one buffer (apgpu_stack_args.moments_f64 = 2) - the single-GPU form of the
@@ -302,7 +302,7 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, fina
         a.sigma_upper = float(sg if su is None else su)
         a.moments = mom['buffer'].data_ptr()
         a.moments_f64 = (3 if k == 0 else 4) if packed else (1 if k == 0 else 2)
-        a.flags = 0 if want_std else _lib.STACK_MOMENTS_MEAN
+        a.flags = (0 if want_std else _lib.STACK_MOMENTS_MEAN) | (_lib.STACK_EXACT_MOMENTS if exact else 0)   # exact: float64 clip only
         check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
     if not finalize:
         return mom

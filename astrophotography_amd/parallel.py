@@ -12,11 +12,21 @@ Two partitionings of a stack job:
   communication stream while stripe k+1 is being reduced, so the collective hides behind the kernel
   instead of following it.
 
-  Two exchange payloads (``exchange=``), each ONE all-reduce per stripe:
-    'f64' (default)  the packed float64 moment planes (sum, count[, sumsq]) of include/apgpu.h's layout 3 - 16 bytes per
+  Exchange forms (``exchange=``):
+    'rs'  (default for world > 1 when a stripe's rows divide by the world size; round 4)  the same packed float64 planes,
+                     but REDUCE-SCATTERED by rows - every rank receives the combined (sum, count[, sumsq]) of its own
+                     1/world of the stripe's rows, finalises those rows, and the float32 mean (and std) rows are
+                     ALL-GATHERED: per pixel (world-1)/world x (16 + 4) bytes leave a rank instead of the all-reduce's
+                     2 (world-1)/world x 16 (17.5 against 28 bytes at 8 ranks), and a rank finalises 1/world of the
+                     pixels.  Same float64 combine rounded once (the ranks' sums are added in float64 either way; the
+                     order of the additions is the collective's).  Stripes whose rows do not divide fall back to 'f64'.
+    'f64'            ONE all-reduce per stripe (the north star's literal form) of the packed float64 moment planes (sum, count[, sumsq]) of include/apgpu.h's layout 3 - 16 bytes per
                      pixel, 24 with a std: the count rides along as a float64 (exact to 2^53), so a single call carries
-                     everything; the ranks' float64 partial sums are added in float64 and the combined mean is the
-                     float64 combine of SURVEY 8(e) rounded ONCE to float32;
+                     everything; the ranks' float64 partial sums are added in float64 and the combined mean is rounded
+                     once to float32.  (A mean-only exchange lets the moment kernel take its float32 fast path - a rank's
+                     sum is then n c + the float32 sum of the deviations, within ~1e-8 of the float64 sum of its
+                     survivors; exact=True forces the float64 clip, and then the result IS the float64 combine of
+                     SURVEY 8(e) rounded once);
     'f32'            float32 sum + float32 count (8 bytes): every rank rounds its sum to float32 and
                      RCCL adds in float32 - about 1e-7 relative per rank, mean only (no std: float32
                      sums of squares about zero cancel catastrophically for CCD-range data).
@@ -75,8 +85,10 @@ def _slice_calib(calib, r0, r1):
     return c
 
 
-def _default_local_moments(frames, calib, r0, r1, clip, exchange, want_std=False, hier_chunk=None):
-    """Partial moments of rows [r0, r1): dict(sum, count[, sumsq], prefix[, buffer]) of [r1 - r0, W] planes."""
+def _default_local_moments(frames, calib, r0, r1, clip, exchange, want_std=False, hier_chunk=None, exact=False):
+    """Partial moments of rows [r0, r1): dict(sum, count[, sumsq], prefix[, buffer]) of [r1 - r0, W] planes.
+    exact: APGPU_STACK_EXACT_MOMENTS - the float64 clip only, so that the float64 sums ARE the float64 sums of the survivors
+    (by default a mean-only exchange lets the kernel take its float32 fast path: sum = n c + float32 S)."""
     from . import ops
     sub = frames[:, r0:r1]
     c = _slice_calib(calib, r0, r1)
@@ -84,11 +96,11 @@ def _default_local_moments(frames, calib, r0, r1, clip, exchange, want_std=False
     if exchange == 'f32':
         if chunked:
             raise ValueError("hierarchical chunks accumulate float64 moments: use exchange='f64'")
-        m = ops.stack_sigclip(sub, calib=c, outputs=('moments',), **clip)['moments']
+        m = ops.stack_sigclip(sub, calib=c, outputs=('moments',), exact=exact, **clip)['moments']
         return dict(sum=m[0], count=m[1], prefix=m[:2])         # (sum, count) is one contiguous float32 block
     if chunked:
-        return ops.stack_sigclip_chunked(sub, chunk=hier_chunk, want_std=want_std, packed=True, finalize=False, calib=c, **clip)
-    return ops.stack_sigclip(sub, calib=c, outputs=('moments_f64p',), moments_mean_only=not want_std, **clip)['moments_f64p']
+        return ops.stack_sigclip_chunked(sub, chunk=hier_chunk, want_std=want_std, packed=True, finalize=False, calib=c, exact=exact, **clip)
+    return ops.stack_sigclip(sub, calib=c, outputs=('moments_f64p',), moments_mean_only=not want_std, exact=exact, **clip)['moments_f64p']
 
 
 def _default_finalize(m, out_mean, out_std, exchange):
@@ -109,11 +121,47 @@ def _exchange(m, exchange, want_std, group):
     dist.all_reduce(m['buffer'] if (want_std and exchange == 'f64') else m['prefix'], op=dist.ReduceOp.SUM, group=group)
 
 
+def _exchange_rs(m, want_std, group, finalize, out_mean, out_std):
+    """The reduce-scatter form of one stripe (rows divisible by the world size): every packed float64 plane [h, W] is
+    reduce-scattered by rows, the rank finalises ITS rows, the float32 result rows are all-gathered into out_mean
+    (out_std).  Returns the rank's combined moment rows (dict(sum, count[, sumsq], rows=(a, b)))."""
+    world, rank = _world(group)
+    names = ('sum', 'count', 'sumsq') if want_std else ('sum', 'count')
+    h, W = m['sum'].shape
+    hb = h // world
+    own = {}
+    for k in names:
+        plane = m[k]
+        own[k] = torch.empty((hb, W), dtype=plane.dtype, device=plane.device)
+        dist.reduce_scatter_tensor(own[k], plane, op=dist.ReduceOp.SUM, group=group)
+    my_mean = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device)
+    my_std = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device) if want_std else None
+    finalize(own, my_mean, my_std, 'f64')
+    dist.all_gather_into_tensor(out_mean, my_mean, group=group)
+    if want_std:
+        dist.all_gather_into_tensor(out_std, my_std, group=group)
+    own['rows'] = (rank * hb, (rank + 1) * hb)
+    own['_keep'] = (my_mean, my_std)
+    return own
+
+
 def exchange_bytes_per_pixel(exchange='f64', want_std=False):
-    """Bytes per output pixel each rank contributes to the all-reduce."""
+    """Bytes per output pixel of the moment planes each rank contributes to the exchange."""
     if exchange == 'f32':
         return 8
     return 24 if want_std else 16
+
+
+def exchange_bytes_on_wire(exchange, world, n_pixels, want_std=False):
+    """Bytes one rank SENDS per step for n_pixels output pixels (ring collectives): all-reduce = 2 (w-1)/w x payload;
+    'rs' = (w-1)/w x (payload + the float32 result planes that are all-gathered)."""
+    if world <= 1:
+        return 0
+    f = (world - 1) / world
+    payload = exchange_bytes_per_pixel('f64' if exchange == 'rs' else exchange, want_std)
+    if exchange == 'rs':
+        return int(f * (payload + (8 if want_std else 4)) * n_pixels)
+    return int(2 * f * payload * n_pixels)
 
 
 def default_stripes(H, W, exchange='f64', want_std=False):
@@ -142,7 +190,7 @@ def _record(m, stream):
 
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
                  n_stripes=None, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
-                 exchange='f64', want_std=False, hier_chunk=None, timings=None):
+                 exchange=None, want_std=False, hier_chunk=None, timings=None, exact=False):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank
     (want_std: (mean, std)).
 
@@ -152,18 +200,21 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     docstring.  timings: a list that receives one (start, end) pair of CUDA events per stripe around its all-reduce on the
     communication stream (bench.py's exchange_ms).
     """
-    if exchange not in ('f64', 'f32'):
-        raise ValueError("exchange must be 'f64' or 'f32'")
-    if want_std and exchange != 'f64':
-        raise ValueError("a standard deviation needs exchange='f64' (float32 sums of squares cancel)")
+    if exchange is None:
+        exchange = 'rs'
+    if exchange not in ('rs', 'f64', 'f32'):
+        raise ValueError("exchange must be 'rs', 'f64' or 'f32'")
+    if want_std and exchange == 'f32':
+        raise ValueError("a standard deviation needs exchange='rs' or 'f64' (float32 sums of squares cancel)")
     if local_moments is None:
         import functools
-        local_moments = functools.partial(_default_local_moments, want_std=want_std, hier_chunk=hier_chunk)
+        local_moments = functools.partial(_default_local_moments, want_std=want_std, hier_chunk=hier_chunk, exact=exact)
     finalize = finalize or _default_finalize
     world, _ = _world(group)
     n_local, H, W = frames_local.shape
+    payload = 'f64' if exchange == 'rs' else exchange        # the moment layout the kernels write
     if n_stripes is None:
-        n_stripes = default_stripes(H, W, exchange, want_std)
+        n_stripes = default_stripes(H, W, payload, want_std)
     clip = dict(sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc)
     on_gpu = frames_local.is_cuda
     collective = (world > 1) or (force_collective and dist.is_available() and dist.is_initialized())
@@ -183,7 +234,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
         for k, (r0, r1) in enumerate(stripes):
             cs = lanes[k % 2]
             with torch.cuda.stream(cs):
-                m = local_moments(frames_local, calib, r0, r1, clip, exchange)
+                m = local_moments(frames_local, calib, r0, r1, clip, payload)
                 ev = torch.cuda.Event()
                 ev.record(cs)
                 _record(m, cs)
@@ -193,21 +244,33 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
                 if timings is not None:
                     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     t0.record(comm)
-                _exchange(m, exchange, want_std, group)
-                if timings is not None:
-                    t1.record(comm)
-                    timings.append((t0, t1))
-                finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, exchange)
-                _record(m, comm)
+                if exchange == 'rs' and (r1 - r0) % world == 0:
+                    own = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None)
+                    _record(own, comm)
+                    if timings is not None:
+                        t1.record(comm)
+                        timings.append((t0, t1))
+                    _record(m, comm)
+                    m = own
+                else:
+                    _exchange(m, payload, want_std, group)
+                    if timings is not None:
+                        t1.record(comm)
+                        timings.append((t0, t1))
+                    finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, payload)
+                    _record(m, comm)
             parts.append(m)
         for st in lanes + [comm]:
             main.wait_stream(st)
     else:
         for (r0, r1) in stripes:
-            m = local_moments(frames_local, calib, r0, r1, clip, exchange)
-            if collective:
-                _exchange(m, exchange, want_std, group)
-            finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, exchange)
+            m = local_moments(frames_local, calib, r0, r1, clip, payload)
+            if collective and exchange == 'rs' and (r1 - r0) % world == 0:
+                m = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None)
+            else:
+                if collective:
+                    _exchange(m, payload, want_std, group)
+                finalize(m, mean[r0:r1], std[r0:r1] if want_std else None, payload)
             parts.append(m)
     out = (mean, std) if want_std else mean
     if return_moments:

@@ -55,9 +55,11 @@ def parse(argv=None):
     ap.add_argument('--dtype', default='f32', choices=['f32', 'u16'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--parallelism', default='nshard', choices=['nshard', 'rowshard'])
-    ap.add_argument('--exchange', default='f64', choices=['f64', 'f32'],
-                    help='N-shard exchange payload: packed float64 sum + count planes (16 B/pixel, float64 combine) or float32 sum + '
-                         'count (8 B/pixel)')
+    ap.add_argument('--exchange', default='rs', choices=['rs', 'f64', 'f32'],
+                    help='N-shard exchange: rs (default) = packed float64 sum + count planes reduce-scattered by rows, every rank '
+                         'finalises its rows, float32 mean rows all-gathered (17.5 B/pixel on the wire at 8 ranks); f64 = ONE '
+                         'all-reduce per stripe of the same planes (16 B/pixel payload, 28 on the wire; the north star\'s literal '
+                         'form); f32 = one all-reduce of float32 sum + count (8 B/pixel payload)')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
                     help='c2 (default, the BASELINE metric): fused calibrate + clipped mean, 64 x 4096 x 4096 f32; c4: uint16 Bayer '
                          'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
@@ -341,7 +343,8 @@ def main(argv=None):
             return 2
         hier_chunk = args.total_frames // args.hier_shards
     single_launch = (world == 1 and not args.force_collective and hier_chunk is None) or rowshard
-    n_stripes = args.stripes or parallel.default_stripes(H, W, args.exchange)
+    payload = 'f64' if args.exchange == 'rs' else args.exchange      # the moment layout the kernels write
+    n_stripes = args.stripes or parallel.default_stripes(H, W, payload)
     timings = []                                             # (start, end) events around every stripe's all-reduce
 
     def step():
@@ -459,10 +462,10 @@ def main(argv=None):
     avg_kernel_ms = sum(kern_ms) / len(kern_ms)
     esize = 4 if args.dtype == 'f32' else 2
     nshard_multi = not single_launch
-    out_bytes = 4 if single_launch else (24 if args.exchange == 'f64' else 12)     # mean plane | moment planes written
+    out_bytes = 4 if single_launch else (24 if payload == 'f64' else 12)           # mean plane | moment planes written
     algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
     kernel_name = ops.stack_kernel_name(min(N, hier_chunk) if hier_chunk else N, args.dtype, calibrated=True,
-                                        outputs=('mean',) if single_launch else (('moments_f64p',) if args.exchange == 'f64' else ('moments',)))
+                                        outputs=('mean',) if single_launch else (('moments_f64p',) if payload == 'f64' else ('moments',)))
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
     cfg_name = 'C3' if strong else 'C2'
     if not strong and not (N == 64 and H_glob == 4096 and W == 4096 and args.dtype == 'f32'):
@@ -532,6 +535,9 @@ def main(argv=None):
             par = 'N-shard x%d (%d of %d frames per rank%s), %d stripes, ONE all-reduce per stripe of %s' % (
                 world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes,
                 'float64 sum + count (16 B/pixel)' if args.exchange == 'f64' else 'float32 sum + count (8 B/pixel)')
+            if args.exchange == 'rs':
+                par = 'N-shard x%d (%d of %d frames per rank%s), %d stripes, per stripe: reduce-scatter of the float64 sum + count planes by rows, every rank finalises its rows, all-gather of the float32 mean rows' % (
+                    world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes)
         if world == 1 and hier_chunk:
             par = 'single GPU, hierarchical: %d shards of %d frames clipped per shard, float64 moments added' % (N // hier_chunk, hier_chunk)
         line = {
@@ -558,7 +564,9 @@ def main(argv=None):
                                         'bytes / step time on the launch stream' % (
                                             n_stripes if world > 1 or args.force_collective else 1,
                                             ' x %d shards' % (N // hier_chunk) if hier_chunk and N > hier_chunk else ''))
-            line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(args.exchange)
+            line['exchange'] = args.exchange
+            line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(payload)
+            line['exchange_bytes_on_wire'] = parallel.exchange_bytes_on_wire(args.exchange, world, P)
             line['exchange_ms'] = exchange_ms
             line['stripes'] = n_stripes
             if hier_chunk:

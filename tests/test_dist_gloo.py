@@ -152,3 +152,85 @@ def test_nshard_and_rowshard_gloo(tmp_path, world, n_total):
     full_ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean',))['mean'].astype(np.float32)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f'rows{r}.npy'), full_ref)
+
+
+def _rs_worker(rank, world, port, n_total, shape, out_dir):
+    """exchange='rs' against the all-reduce form on the same data: collective kinds, shapes, dtypes and bytes."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from astrophotography_amd import parallel
+    cube, bias, dark = _data(n_total, shape)
+    lo, hi = parallel.shard_frames(n_total, world, rank)
+    calib = dict(bias=torch.from_numpy(bias), dark=torch.from_numpy(dark), nflat=None, exp_ratio=0.4)
+    mine = torch.from_numpy(cube[lo:hi])
+    kw = dict(sigma=3.0, maxiters=5, local_moments=_oracle_local_moments, finalize=_cpu_finalize)
+    calls = []
+    real = dict(ar=dist.all_reduce, rs=dist.reduce_scatter_tensor, ag=dist.all_gather_into_tensor)
+
+    def ar(t, *a, **k):
+        calls.append(('all_reduce', tuple(t.shape), t.dtype, t.numel() * t.element_size()))
+        return real['ar'](t, *a, **k)
+
+    def rs(out, inp, *a, **k):
+        calls.append(('reduce_scatter', tuple(inp.shape), inp.dtype, inp.numel() * inp.element_size()))
+        return real['rs'](out, inp, *a, **k)
+
+    def ag(out, inp, *a, **k):
+        calls.append(('all_gather', tuple(out.shape), out.dtype, out.numel() * out.element_size()))
+        return real['ag'](out, inp, *a, **k)
+    parallel.dist.all_reduce, parallel.dist.reduce_scatter_tensor, parallel.dist.all_gather_into_tensor = ar, rs, ag
+    H, W = shape
+    n_stripes = 2
+    h = H // n_stripes
+    # the default exchange IS 'rs'
+    mean_rs, parts = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, return_moments=True, **kw)
+    # per stripe: one reduce-scatter per float64 plane (sum, count) of [h, W], one all-gather of the float32 mean rows
+    exp = []
+    for _ in range(n_stripes):
+        exp += [('reduce_scatter', (h, W), torch.float64, 8 * h * W)] * 2 + [('all_gather', (h, W), torch.float32, 4 * h * W)]
+    assert calls == exp, calls
+    assert all(p['sum'].shape == (h // world, W) and p['rows'] == (rank * (h // world), (rank + 1) * (h // world)) for p in parts)
+    del calls[:]
+    (mean_s, std_s), _ = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, exchange='rs', want_std=True, return_moments=True, **kw)
+    assert [c[0] for c in calls] == (['reduce_scatter'] * 3 + ['all_gather'] * 2) * n_stripes, calls
+    del calls[:]
+    (mean_ar, std_ar) = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, exchange='f64', want_std=True, **kw)
+    assert [c[0] for c in calls] == ['all_reduce'] * n_stripes and all(c[1][0] == 3 for c in calls), calls
+    del calls[:]
+    # a stripe whose rows do not divide by the world size takes the all-reduce form (here: 3 stripes of 16 rows -> 6, 5, 5)
+    mean_rag = parallel.stack_nshard(mine, calib, n_stripes=3, exchange='rs', **kw)
+    kinds = [c[0] for c in calls]
+    assert 'all_reduce' in kinds or world in (1,), kinds
+    parallel.dist.all_reduce, parallel.dist.reduce_scatter_tensor, parallel.dist.all_gather_into_tensor = real['ar'], real['rs'], real['ag']
+    # bytes a rank sends per step (ring collectives)
+    f = (world - 1) / world
+    assert parallel.exchange_bytes_on_wire('rs', world, H * W) == int(f * 20 * H * W)
+    assert parallel.exchange_bytes_on_wire('f64', world, H * W) == int(2 * f * 16 * H * W)
+    assert parallel.exchange_bytes_on_wire('f32', world, H * W) == int(2 * f * 8 * H * W)
+    np.savez(os.path.join(out_dir, f'rs{rank}.npz'), mean_rs=mean_rs.numpy(), mean_s=mean_s.numpy(), std_s=std_s.numpy(),
+             mean_ar=mean_ar.numpy(), std_ar=std_ar.numpy(), mean_rag=mean_rag.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,n_total', [(2, 24), (4, 50), (8, 96)])
+def test_nshard_reduce_scatter_exchange_gloo(tmp_path, world, n_total):
+    """exchange='rs' (reduce-scatter of the float64 planes by rows + all-gather of the float32 result rows): collective
+    count / shapes / bytes for world 2, 4 and 8, every rank holds the whole image, and the result EQUALS the all-reduce
+    form's (the same float64 sums, added by a different collective; on these data bit for bit)."""
+    shape = (16, 16)                                                  # 2 stripes of 8 rows: divisible by 2, 4 and 8
+    port = _free_port()
+    mp.spawn(_rs_worker, args=(world, port, n_total, shape, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f'rs{r}.npz') for r in range(world)]
+    for k in res[0].files:
+        for r in range(1, world):
+            assert np.array_equal(res[0][k], res[r][k]), k
+    a = res[0]
+    # float64 sums of at most 8 addends per pixel: the order of the additions can move the float64 sum by an ulp, the
+    # float32 mean by at most one ulp and almost never
+    for x, y in ((a['mean_rs'], a['mean_ar']), (a['mean_s'], a['mean_ar']), (a['mean_rag'], a['mean_ar'])):
+        ulp = np.abs(x.view(np.int32).astype(np.int64) - y.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1 and (ulp == 0).mean() > 0.99
+    np.testing.assert_allclose(a['std_s'], a['std_ar'], rtol=1e-6)

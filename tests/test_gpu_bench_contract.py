@@ -66,7 +66,7 @@ def test_multi_rank_paths_on_one_gpu():
     env['APGPU_BENCH_ONE_GPU_TEST'] = '1'
     base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--height', '128',
             '--width', '512', '--frames', '16', '--no-cpu-baseline']
-    for extra in ([], ['--exchange', 'f32'], ['--scaling', 'strong', '--total-frames', '64', '--hier-shards', '4'],
+    for extra in ([], ['--exchange', 'f32'], ['--exchange', 'f64'], ['--scaling', 'strong', '--total-frames', '64', '--hier-shards', '4'],
                   ['--parallelism', 'rowshard'], ['--scaling', 'strong', '--total-frames', '64', '--parallelism', 'rowshard']):
         r = subprocess.run(base + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         assert r.returncode == 0, (extra, r.stderr[-3000:])
@@ -78,6 +78,9 @@ def test_multi_rank_paths_on_one_gpu():
             assert d['exchange_ms'] is not None and d['exchange_ms'] >= 0 and d['stripes'] >= 1
             assert d['rowshard']['value'] > 0 and d['rowshard']['ms_per_step'] > 0
             assert d['exchange_bytes_per_pixel'] == (8 if 'f32' in extra else 16)
+            assert d['exchange'] == (extra[1] if '--exchange' in extra else 'rs')
+            px = 128 * 512
+            assert d['exchange_bytes_on_wire'] == {'rs': int(0.5 * 20 * px), 'f64': int(2 * 0.5 * 16 * px), 'f32': int(2 * 0.5 * 8 * px)}[d['exchange']]
         if '--scaling' in extra and '--parallelism' not in extra:
             assert d['hier_shards'] == 4 and d['config']['frames_per_gpu'] == 32 and d['config']['frames_total'] == 64
             assert d['roofline']['kernel'].startswith('stack_sigclip_kernel<16,')        # shards of 16 frames

@@ -277,7 +277,9 @@ def test_nshard_collective_path_on_one_gpu():
         legacy = ops.stack_sigclip(frames, calib=calib, outputs=('moments_f64',))['moments_f64']     # float64 path (no flag)
         assert torch.equal(legacy['count'], direct['count']) and torch.equal(direct64['count'].to(torch.int32), direct['count'])
         assert float(((legacy['sum'] - direct64['sum']).abs() / legacy['sum'].abs()).max()) < 1e-7   # float32 vs float64 sums
-        for exchange in ('f64', 'f32'):
+        for exchange in ('f64', 'f32', 'rs'):
+            # ('rs' with 5 stripes of 96 rows: ragged stripes exist, and with ONE rank every stripe divides - the
+            #  reduce-scatter / finalise-own-rows / all-gather form runs with real kernels and an RCCL group)
             mean, parts = parallel.stack_nshard(frames, calib, n_stripes=5, force_collective=True, return_moments=True,
                                                 exchange=exchange)
             torch.cuda.synchronize()
@@ -289,10 +291,15 @@ def test_nshard_collective_path_on_one_gpu():
                 assert torch.equal(torch.cat([p['count'] for p in parts], 0).to(torch.int32), direct['count'])
             # mean from the moments (sum / count) vs the kernel's float64 mean c + S/n: within 1 ulp
             assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'moments-finalised mean ' + exchange)
-        mean, std = parallel.stack_nshard(frames, calib, n_stripes=3, force_collective=True, want_std=True)
+        for exchange in ('rs', 'f64'):
+            mean, std = parallel.stack_nshard(frames, calib, n_stripes=3, force_collective=True, want_std=True, exchange=exchange)
+            torch.cuda.synchronize()
+            assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'mean with std ' + exchange)
+            assert float(((std - direct['std']).abs() / direct['std']).max()) < 1e-5
+        # exact=True: the float64 clip only - the moments are the float64 sums of the survivors (legacy layout's values)
+        mean_x, parts_x = parallel.stack_nshard(frames, calib, n_stripes=2, force_collective=True, return_moments=True, exchange='f64', exact=True)
         torch.cuda.synchronize()
-        assert_ulp(mean.cpu().numpy(), direct['mean'].cpu().numpy(), 1, 'mean with std')
-        assert float(((std - direct['std']).abs() / direct['std']).max()) < 1e-5
+        assert torch.equal(torch.cat([p['sum'] for p in parts_x], 0), legacy['sum'])
         # row-sharded exact path: two half images reduce to the same pixels
         top = parallel.stack_rowshard(frames[:, :48], dict(calib, bias=calib['bias'][:48], dark=calib['dark'][:48], nflat=nflat[:48]))
         assert torch.equal(top['mean'], direct['mean'][:48])

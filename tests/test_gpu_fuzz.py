@@ -77,10 +77,22 @@ def test_random_stack_configs(ops, apref, seed):
     tie = np.zeros((H, W), bool)
     for (y, x) in np.argwhere(got_cnt != nref)[:8]:
         with np.errstate(all='ignore'):
-            c_lo = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 - 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)['count'][0, 0]
-            c_hi = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 + 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)['count'][0, 0]
+            r_lo = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 - 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)
+            r_hi = apref.stack_sigclip(cal[:, y:y + 1, x:x + 1], sigma=sigma * (1 + 1e-9), maxiters=maxiters, cenfunc=cen, stdfunc=dv)
+        c_lo, c_hi = r_lo['count'][0, 0], r_hi['count'][0, 0]
         tie[y, x] = c_lo != c_hi
+        if tie[y, x]:
+            # a tie pixel is not a free pass: the kernel's answer must be the oracle's on ONE side of the tie
+            side = r_lo if got_cnt[y, x] == c_lo else r_hi
+            assert got_cnt[y, x] == side['count'][0, 0], 'tie pixel count matches neither side ' + what
+            assert_ulp(got_mean[y:y + 1, x:x + 1], side['mean'].astype(np.float32), 1, 'tie pixel mean ' + what)
     assert tie.sum() <= 2, 'too many tie pixels ' + what
+    if dv == 'std' and cen == 'median' and outs == ('mean', 'count'):
+        # the float32 fast path claims the survivor sets of the float64 path by construction: fast == exact, every pixel
+        rx = ops.stack_sigclip(_dev(cube, ops), sigma=sigma, maxiters=maxiters, cenfunc=cen, stdfunc=dv, calib=calib, pixmask=pm,
+                               outputs=outs, exact=True)
+        assert np.array_equal(rx['count'].cpu().numpy(), got_cnt), 'fast32 vs exact counts ' + what
+        assert_ulp(rx['mean'].cpu().numpy(), got_mean, 1, 'fast32 vs exact mean ' + what)
     assert np.array_equal(got_cnt[~tie], nref[~tie]), what
     assert_ulp(got_mean[~tie], mref[~tie], 1, what)
     med, cnt = ops.stack_median(_dev(cube, ops), calib=calib, pixmask=pm, want_count=True)

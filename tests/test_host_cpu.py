@@ -434,3 +434,22 @@ def test_oracle_one_pass_oversampling_equals_fine_resample_plus_block_mean():
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or np.array_equal(got, want, equal_nan=True)
         assert np.array_equal(wt, np.isfinite(got).astype(np.uint8))
         assert np.isfinite(got).mean() > 0.5
+
+
+def test_sort_networks_pass_the_zero_one_principle(tmp_path):
+    """The float32 columns are sorted by networks of 2-, 3- and 4-sorters found by search (csrc/stack_sort.h, make_opnet):
+    tools/netsearch/verify_opnet.cpp checks every slot count's network - complete and pruned to what the float32 clip
+    reads - on the 0-1 inputs its pre-sorted structure allows (each 16-block exhaustively)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    exe = str(tmp_path / 'verify_opnet')
+    r = subprocess.run([hipcc, '-O2', '-std=c++17', '-fconstexpr-steps=100000000', '-I', os.path.join(ROOT, 'include'), '-I',
+                        os.path.join(ROOT, 'astrophotography_amd', 'csrc'), os.path.join(ROOT, 'tools', 'netsearch', 'verify_opnet.cpp'),
+                        '-o', exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-3000:]
+    assert 'NP  64 T 4:  750 instructions' in r.stdout          # the headline kernel's network (890 with sort4 + Batcher)

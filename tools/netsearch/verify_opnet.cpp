@@ -116,7 +116,15 @@ int main()
     ok &= verify<8, 0>();
     ok &= verify<12, 0>();
     ok &= verify<16, 0>();
+    ok &= verify<20, 0>();
     ok &= verify<24, 0>();
+    ok &= verify<28, 0>();
+    ok &= verify<36, 0>();
+    ok &= verify<44, 0>();
+    ok &= verify<52, 0>();
+    ok &= verify<60, 0>();
+    ok &= verify<88, 0>();
+    ok &= verify<120, 0>();
     ok &= verify<32, 0>();
     ok &= verify<40, 0>();
     ok &= verify<48, 0>();
@@ -129,7 +137,14 @@ int main()
     ok &= verify<112, 0>();
     ok &= verify<128, 0>();
     ok &= verify<16, 4>();
+    ok &= verify<20, 4>();
     ok &= verify<24, 4>();
+    ok &= verify<28, 4>();
+    ok &= verify<36, 4>();
+    ok &= verify<44, 4>();
+    ok &= verify<52, 4>();
+    ok &= verify<60, 4>();
+    ok &= verify<88, 4>();
     ok &= verify<32, 4>();
     ok &= verify<40, 4>();
     ok &= verify<48, 4>();
@@ -139,6 +154,12 @@ int main()
     ok &= verify<80, 4>();
     ok &= verify<96, 4>();
     ok &= verify<24, 8>();
+    ok &= verify<28, 8>();
+    ok &= verify<36, 8>();
+    ok &= verify<44, 8>();
+    ok &= verify<52, 8>();
+    ok &= verify<60, 8>();
+    ok &= verify<88, 8>();
     ok &= verify<32, 8>();
     ok &= verify<40, 8>();
     ok &= verify<48, 8>();
