@@ -28,10 +28,11 @@ struct StackParams {
 
 // The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a
 // stack that runs with NP slots has more than prev_slots(NP) frames, so only the slots from there on can be padding.
-// Padded stacks of 112 / 128 slots keep the older scheme (every slot loaded and calibrated, padding lifted to +inf with
+// Padded stacks of 112 / 120 / 128 slots (round 4: 112 and 120 too - with the skipping scheme they take 258 VGPRs, one wavefront
+// per SIMD) keep the older scheme (every slot loaded and calibrated, padding lifted to +inf with
 // one v_max per slot): the per-slot scalar tests cost them ~50 VGPRs, i.e. the second wavefront per SIMD.
 constexpr int prev_slots(int np);
-constexpr int padded_minn(int np, bool full) { return (full || np >= 128) ? np : prev_slots(np); }
+constexpr int padded_minn(int np, bool full) { return (full || np >= 112) ? np : prev_slots(np); }
 
 constexpr int prev_slots(int np)
 {
@@ -63,18 +64,23 @@ __device__ __forceinline__ float div_by_recip(float x, float nf, float y, float 
     return __builtin_fmaf(r0, y, q0);
 }
 
-// Full stacks without pedestals read the exposure ratios with scalar loads (calibrate_fast, E_DIRECT) and stage nothing.
+// Stacks without pedestals read the exposure ratios with scalar loads (calibrate_fast, E_DIRECT; padding slots through a
+// clamped index) and stage nothing in LDS.
 #ifndef APGPU_DIRECT_RATIOS
 #define APGPU_DIRECT_RATIOS 1
 #endif
-constexpr bool direct_ratios(bool full) { return full && APGPU_DIRECT_RATIOS; }
+#ifndef APGPU_DIRECT_RATIOS_PADDED
+#define APGPU_DIRECT_RATIOS_PADDED 1
+#endif
+constexpr bool direct_ratios(bool) { return APGPU_DIRECT_RATIOS != 0; }
 
-// Whether a kernel of the given kind has to stage the per-frame scalars in LDS (wave-uniform, from the arguments).
-template <bool CALIB, bool FULL>
+// Whether a kernel of the given kind has to stage the per-frame scalars in LDS (wave-uniform, from the arguments):
+// pedestals, and the padded 128-slot kernels' pad vector (the lift scheme of load_column, MINN >= NP).
+template <bool CALIB, bool FULL, int NP = 0>
 __device__ __forceinline__ bool needs_staging(const StackParams &prm)
 {
-    if constexpr (!FULL) return true;                       // padding slots: clamped frame index, pad vector
-    else if constexpr (!CALIB) return false;
+    if constexpr (!CALIB) return false;
+    else if constexpr (!FULL && (NP >= 112 || !APGPU_DIRECT_RATIOS_PADDED)) return true;
     else return !direct_ratios(FULL) || prm.pedestal != nullptr;
 }
 
@@ -204,7 +210,10 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 // unclobbered) uniform loads are selected as scalar loads - behind the staging branch's barrier these are not
                 typedef const float __attribute__((address_space(4))) cfloat;
                 const cfloat *ec = (const cfloat *)(uintptr_t)eg;
-                const v2f e2 = {ec[f], ec[f + 1]};
+                // (padding slots - f >= MINN can be one - read the last frame's ratio: the array has nframes entries)
+                const int f0 = (f < MINN || f < nframes) ? f : nframes - 1;
+                const int f1 = (f + 1 < MINN || f + 1 < nframes) ? f + 1 : nframes - 1;
+                const v2f e2 = {ec[f0], ec[f1]};
                 ds = e2 * D2;                                // :450
             } else if constexpr (!UNI_E) {
                 const v2f e2 = {fs.e[f], fs.e[f + 1]};
@@ -397,6 +406,9 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
     // the range guards are read off the sorted column (load_sorted_column) - except for the largest slot counts, where
     // keeping the lane's masters alive across the sort would push the kernel over 256 VGPRs (one wavefront per SIMD)
     constexpr bool GUARD = NP >= 104;
+    // exposure ratios by scalar loads - except in the padded kernels of the lift scheme (MINN >= NP), whose padding slots are
+    // calibrated like frames: they keep the staged copy with its clamped frame index
+    constexpr bool EDIR = direct_ratios(FULL) && (FULL || (APGPU_DIRECT_RATIOS_PADDED && MINN < NP));
     // PRE: the loads were issued by the caller (`pre`); otherwise here
     static_assert(!(PRE && HALVES), "half-column kernels load their own halves");
     EarlyLoads<NP, RawT> here;
@@ -435,15 +447,15 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             RawT half[HN];
             load_raw<NP, RawT, FULL, 0, HN, MINN>(prm, base, lane, half);
             good = prm.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
-                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN, false, direct_ratios(FULL)>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
+                                : calibrate_fast<NP, RawT, false, 0, HN, GUARD, MINN, false, EDIR>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
             load_raw<NP, RawT, FULL, HN, HN, MINN>(prm, base, lane, half);
             const bool good2 = prm.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, GUARD, MINN>(fs, half, b, D, nf, dodiv, v, N, plo)
-                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN, false, direct_ratios(FULL)>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
+                                            : calibrate_fast<NP, RawT, false, HN, HN, GUARD, MINN, false, EDIR>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
             good = good && good2;
         } else {
             if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
             else if (APGPU_HOIST_DARK && exposures_uniform<NP>(fs)) good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, true>(fs, raw, b, D, nf, dodiv, v, N, plo);
-            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, false, direct_ratios(FULL)>(fs, raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
+            else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, false, EDIR>(fs, raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
         }
         if (wave_all(good && !cx.skip)) {
             cx.range_pending = !GUARD;
@@ -471,7 +483,10 @@ constexpr bool fast32_possible(int np, int minn) { return np >= 16 && np <= 96 &
 // column: the median keeps its static position, the mirror pairs of the core stay mirror pairs, and the pads are simply the
 // first values "already trimmed" from either tail (clip_fast32 starts with a = pads below, b = NP - pads above).
 constexpr int kFastTailPadded = 8;
-constexpr bool fast32_possible_padded(int np, int minn) { return np >= 24 && np <= 96 && np % 4 == 0 && minn < np && np - minn <= 8; }
+// (round 4: with slot counts at every multiple of 4 up to 64 a padded stack there has at most 3 pads - one below, two above
+// the real values - so tails of 6 leave four trimmable values per side: a smaller pruned network and 8 table registers less)
+constexpr int fast_tail_padded(int np) { return np <= 64 ? 6 : kFastTailPadded; }
+constexpr bool fast32_possible_padded(int np, int minn) { return np >= 20 && np <= 96 && np % 4 == 0 && minn < np && np - minn <= 8; }
 
 // Whether the lean reduction will try its float32 fast path (stack_reduce.h, clip_fast32) - wave-uniform, from the arguments.
 __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)

@@ -43,9 +43,19 @@ using namespace apgpu;
 #ifndef APGPU_LEAN_BLOCK
 #define APGPU_LEAN_BLOCK 256
 #endif
+// (lean kernels of 72 .. 128 slots: two wavefronts per SIMD = at most 256 VGPRs; left alone the padded 112- and 120-slot
+// kernels take 258 - ONE wavefront per SIMD, 4.0 ms where the full 112-slot kernel takes 2.2)
+#ifndef APGPU_WIDE_MIN_BLOCKS
+#define APGPU_WIDE_MIN_BLOCKS 2
+#endif
+#ifndef APGPU_PADDED_MIN_BLOCKS
+#define APGPU_PADDED_MIN_BLOCKS 2
+#endif
 
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
-__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN_BLOCK), NP <= 64 ? (EXTRA || PLUS ? 2 : APGPU_LEAN_MIN_BLOCKS) : 1) void stack_sigclip_kernel(const StackParams prm)
+// (padded lean kernels: capped at the three-wavefront register budget - 172 VGPRs uncapped -, the spills land in the
+// exact-fallback blocks; full ones need 166 by themselves)
+__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN_BLOCK), NP <= 64 ? (EXTRA || PLUS ? 2 : (FULL ? APGPU_LEAN_MIN_BLOCKS : APGPU_PADDED_MIN_BLOCKS)) : ((EXTRA || PLUS) ? 1 : APGPU_WIDE_MIN_BLOCKS)) void stack_sigclip_kernel(const StackParams prm)
 {
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
     // the first frame load.  (Round 4 also tried issuing the loads BEFORE the barrier of the staged kernels: the first
     // wavefront's wait for its ratios is an in-order vmcnt(0) that then covers its 67 column loads as well - worse.)
     constexpr int MINN = padded_minn(NP, FULL);
-    if (needs_staging<CALIB, FULL>(prm)) stage_frame_scalars<NP>(prm, fs);
+    if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
 
     float v[NP];
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
     } else if constexpr (fast32_possible_padded(NP, MINN)) {
         // padded stacks: split pads (-inf below, +inf above the real values) and tails of 8 - see fast32_possible_padded
         bool pruned = fast32_wanted(prm);
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTailPadded, false, true>(prm, fs, base, lane, v, &pruned);
+        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, fast_tail_padded(NP), false, true>(prm, fs, base, lane, v, &pruned);
         reduce_and_store<NP, MINN, PLUS>(prm, v, n, p, pruned);
     } else {
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
-    if (needs_staging<CALIB, FULL>(prm)) stage_frame_scalars<NP>(prm, fs);
+    if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
     if (p >= prm.P) return;
     float v[NP];
     const int n = load_sorted_column<NP, RawT, CALIB, false, FULL>(prm, fs, base, lane, v);

@@ -33,6 +33,18 @@ __device__ __forceinline__ bool above(const ClipState &st, double xd)
     return (w > 0.0) && (w * w > st.Thi);
 }
 
+// The kernel's argument block read LATE (round 4): the kernarg pointer, made opaque where it is used, so that the scalar loads
+// happen THERE - the output pointers and clip parameters used to be read at kernel entry and then either sat in SGPRs across
+// the calibration and the sort (spilled to VGPR lanes) or were parked in 15 VGPRs; read after the sort they cost a handful
+// of s_load and no register that lives through the column phase.  Valid in kernels whose first argument is the StackParams.
+typedef const StackParams __attribute__((address_space(4))) LateParams;
+__device__ __forceinline__ LateParams *late_params()
+{
+    LateParams *kp = (LateParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
 // Moves a wave-uniform value into VGPRs.  The kernel arguments arrive in 40 SGPRs; whatever stays live
 // across the clipping loop is spilled to VGPR lanes and re-read (v_readlane) on every iteration, so the
 // handful of values needed inside / after the loop are parked in VGPRs once instead.
@@ -265,6 +277,9 @@ __device__ __forceinline__ void store_moments(void *out, int f64_layout, int64_t
 // guard rms(d) <= |c| / 2 keeps columns whose mean is small against their spread (sky-subtracted data) on the exact path.
 // Requirements: full stack (n = NP for the whole wave, no sentinel), median centre, std deviation, NP >= 16.
 // -------------------------------------------------------------------------------------------------
+#ifndef APGPU_LATE_PARAMS
+#define APGPU_LATE_PARAMS 1
+#endif
 #ifndef APGPU_FAST32_RHO
 #define APGPU_FAST32_RHO 0x1p-15f
 #endif
@@ -452,11 +467,11 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     // astropy applies the FINAL bounds to every value: a value trimmed by an earlier pass comes back if it lies inside them.
     // Here: the innermost trimmed value of either side must be surely outside, otherwise the exact path decides.
     if (wave_any(f.a > plo)) {
-        const float t = fast32_t(f, pick_rel<0, T, NP>(v, (f.a - 1) & (T - 1)));
+        const float t = fast32_t(f, pick_rel<0, T, NP>(v, f.a > 0 ? f.a - 1 : 0));       // (T need not be a power of two)
         f.unsure = f.unsure || (f.a > plo && !(t > f.tl_hi));
     }
     if (wave_any(f.b < NP - phi)) {
-        const float t = fast32_t(f, pick_rel<NP - T, T, NP>(v, (f.b - (NP - T)) & (T - 1)));
+        const float t = fast32_t(f, pick_rel<NP - T, T, NP>(v, f.b < NP ? f.b - (NP - T) : 0));
         f.unsure = f.unsure || (f.b < NP - phi && !(t > f.th_hi));
     }
     // the final sums (the last pass may have trimmed) and the mean-accuracy guard rms(d) <= |c| / 2
@@ -648,7 +663,16 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
                                                  const bool pruned = false)
 {
     const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
-    // everything the loop and the epilogue need from the kernel arguments, parked before the sort
+    // everything the loop and the epilogue need from the kernel arguments: read from the argument block HERE, after the sort
+#if APGPU_LATE_PARAMS
+    LateParams *const kp = late_params();
+    void *const out_moments = kp->moments;
+    const int mom64 = kp->moments64;
+    const double sl2 = kp->sl2, su2 = kp->su2;
+    const int maxiters = kp->maxiters;
+    const bool use_median = kp->center == APGPU_CENTER_MEDIAN;
+    const int fast32 = kp->fast32;
+#else
     float *const out_mean = park_in_vgpr(prm.mean);
     int32_t *const out_count = park_in_vgpr(prm.count);
     void *const out_moments = park_in_vgpr(prm.moments);
@@ -658,6 +682,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     const int maxiters = park_in_vgpr(prm.maxiters);
     const bool use_median = park_in_vgpr((int)prm.center) == APGPU_CENTER_MEDIAN;
     const int fast32 = park_in_vgpr(prm.fast32);
+#endif
     APGPU_MARK("fast32");                                    // v: sorted ascending, sentinels last (load_sorted_column)
 
     int a, b;
@@ -673,7 +698,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
         if (fast32_wanted(prm)) {
             if (pruned) {                                    // (load_sorted_column: every lane of the wave holds all N values)
                 float Qf;
-                done = clip_fast32<NP, kFastTailPadded>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf, plo, NP - ns - plo);
+                done = clip_fast32<NP, fast_tail_padded(NP)>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf, plo, NP - ns - plo);
                 S = (double)Sf;
                 Q = (double)Qf;
                 if (!done) sort_column<NP>(v);
@@ -696,6 +721,12 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
 #endif
     if (!done) clip_exact<NP, MINN>(v, n, ns, sl2, su2, maxiters, use_median, a, b, cf, S, Q);
     APGPU_MARK("output");
+#if APGPU_LATE_PARAMS
+    LateParams *const ko = late_params();                    // (a second read: nothing of the first one stays live across the clip)
+    float *const out_mean = ko->mean;
+    int32_t *const out_count = ko->count;
+    const int64_t Pn = ko->P;
+#endif
     const double c = (double)cf;
 
     const int cnt = b - a;

@@ -498,7 +498,8 @@ def main(argv=None):
         try:
             td = json.load(open(tfile))
             ent = td.get('workloads', {}).get(tkey)
-            if ent and ent.get('kernel') == kernel_name:        # counters of ANOTHER kernel build are not this kernel's traffic
+            # (per LAUNCH like `achieved`: only a step that IS one launch of that kernel reports it)
+            if ent and ent.get('kernel') == kernel_name and single_launch:   # counters of ANOTHER kernel build are not this kernel's traffic
                 traffic = ent.get('hbm_bytes_per_launch')
                 traffic_source = 'profiles/pmc_traffic.json (%s)' % ent.get('tag')
                 if ent.get('valu'):

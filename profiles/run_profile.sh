@@ -25,3 +25,5 @@ for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVES" "SQ_INSTS_SALU SQ_
   timeout 300 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$i -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_pmc_$i.json 2> $OUT/pmc_$i.log
 done
 python3 $REPO/profiles/summarize.py $OUT $TAG
+# the raw rocprofv3 output is large (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf $OUT/trace $OUT/pmc_[0-9]*

@@ -50,6 +50,8 @@ def _rank_main(rank, world, port, out_dir):
                  exp_ratio=0.4)
     mine = torch.from_numpy(cube[lo:hi]).to(dev)
     mean64, std64 = parallel.stack_nshard(mine, calib, n_stripes=3, exchange='f64', want_std=True)
+    # the reduce-scatter form (the default): 37 rows in 1 stripe do not divide by 2 -> all-reduce fallback; a 36-row cut does
+    mean_rs, std_rs = parallel.stack_nshard(mine[:, :36], parallel._slice_calib(calib, 0, 36), n_stripes=2, want_std=True)
     mean32 = parallel.stack_nshard(mine, calib, n_stripes=4, exchange='f32')
     r0, r1 = parallel.row_block(H, world, rank)
     rows = torch.from_numpy(cube[:, r0:r1]).to(dev)
@@ -57,7 +59,7 @@ def _rank_main(rank, world, port, out_dir):
     full = parallel.gather_rows(blk, H)
     torch.cuda.synchronize()
     np.savez(os.path.join(out_dir, f'r{rank}.npz'), mean64=mean64.cpu().numpy(), std64=std64.cpu().numpy(),
-             mean32=mean32.cpu().numpy(), rows=full.cpu().numpy())
+             mean32=mean32.cpu().numpy(), rows=full.cpu().numpy(), mean_rs=mean_rs.cpu().numpy(), std_rs=std_rs.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,6 +100,8 @@ def test_nshard_and_rowshard_two_gpus_rccl(tmp_path):
     assert_ulp(res[0]['mean64'], mean_ref.astype(np.float32), 1, 'float64 exchange vs the float64 combine')
     np.testing.assert_allclose(res[0]['mean32'], mean_ref, rtol=3e-7)
     np.testing.assert_allclose(res[0]['std64'], np.sqrt(np.maximum(tot2 / cnt - mean_ref ** 2, 0)), rtol=1e-5)
+    assert_ulp(res[0]['mean_rs'], mean_ref[:36].astype(np.float32), 1, 'reduce-scatter exchange vs the float64 combine')
+    np.testing.assert_allclose(res[0]['std_rs'], np.sqrt(np.maximum(tot2 / cnt - mean_ref ** 2, 0))[:36], rtol=1e-5)
     full_ref = apref.stack_sigclip(cal, sigma=3.0, maxiters=5, want=('mean',))['mean'].astype(np.float32)
     assert_ulp(res[0]['rows'], full_ref, 1, 'row-shard + gather vs the full-stack oracle')
 
@@ -108,7 +112,7 @@ def test_bench_launcher_two_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
     base = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--height', '256',
             '--width', '512', '--frames', '16']
-    for extra in ([], ['--exchange', 'f32'], ['--scaling', 'strong', '--total-frames', '32'], ['--parallelism', 'rowshard']):
+    for extra in ([], ['--exchange', 'f32'], ['--exchange', 'f64'], ['--scaling', 'strong', '--total-frames', '32'], ['--parallelism', 'rowshard']):
         r = subprocess.run(base + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
