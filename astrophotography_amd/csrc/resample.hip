@@ -426,6 +426,24 @@ __device__ __forceinline__ bool mask_scatter_ok(const double *a)
     return coef_ok && fabs(det) > 1e-300 && hw <= 24.0 * fabs(det) && hh <= 24.0 * fabs(det);
 }
 
+// Wave-aggregated append (round 4): one atomicAdd per wavefront that holds bad pixels instead of one per bad pixel - every
+// atomic of the per-pixel form hit the same counter and serialised (0.24 ms for an 8192 x 8192 mask with ~0.1 % bad pixels,
+// against the 13 us it takes to read the mask).  `c` bad pixels of this lane -> the lane's first slot in the list.
+__device__ __forceinline__ int mask_list_reserve(int c, int *ctl)
+{
+    int incl = c;                                           // inclusive scan over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63) >= d) incl += up;
+    }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if ((threadIdx.x & 63) == 63) base = atomicAdd(&ctl[0], total);
+    base = __shfl(base, 63, 64);
+    return base + incl - c;
+}
+
 __global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restrict__ mask, int64_t n, int cap, int *__restrict__ ctl,
                                                        int *__restrict__ list)
 {
@@ -434,15 +452,24 @@ __global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restric
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool vec = (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
     const int64_t n16 = vec ? n / 16 : 0;
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += stride) {
-        const uint4 w = reinterpret_cast<const uint4 *>(mask)[q];
-        if ((w.x | w.y | w.z | w.w) == 0) continue;
+    const int64_t n16r = (n16 + 63) / 64 * 64;              // whole wavefronts walk the loop together (the scan needs all lanes)
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16r; q += stride) {
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        if (q < n16) w = reinterpret_cast<const uint4 *>(mask)[q];
+        const bool any = (w.x | w.y | w.z | w.w) != 0;
+        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
         const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+        int c = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) {
-                const int i = atomicAdd(&ctl[0], 1);
-                if (i < cap) list[i] = (int)(q * 16 + k);
+        for (int k = 0; k < 16; k++) c += ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1 : 0;
+        int i = mask_list_reserve(c, ctl);
+        if (c) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) {
+                    if (i < cap) list[i] = (int)(q * 16 + k);
+                    i++;
+                }
             }
         }
     }

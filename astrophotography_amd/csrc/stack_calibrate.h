@@ -24,6 +24,7 @@ struct StackParams {
     int moments64;          // layout of `moments` (see above)
     double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
     int fast32;             // 0: float64 clip only; 1: float32 fast path for mean / count / float32 moments; 2: also float64-layout moments
+    int32_t *redo;          // stack_fast_kernel: [0] = number of entries, [1 ..] = 64-pixel block indices it could not finish
 };
 
 // The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a
@@ -192,7 +193,12 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
     if constexpr (NP >= 2) {
         v2f acc = {0.f, 0.f};
         const v2f b2 = {b, b}, D2 = {D, D}, nf2 = {-nfe, -nfe}, y2 = {y, y}, yl2 = {yl, yl}, zero2 = {0.f, 0.f};
-        const float ds0 = UNI_E ? fs.e[0] * D : 0.f;         // :450 for every frame when UNI_E
+        float e0 = 0.f;
+        if constexpr (UNI_E) {
+            if constexpr (E_DIRECT) e0 = ((const float __attribute__((address_space(4))) *)(uintptr_t)eg)[0];
+            else e0 = fs.e[0];
+        }
+        const float ds0 = e0 * D;                            // :450 for every frame when UNI_E
         const v2f ds_uni = {ds0, ds0};
 #pragma unroll
         for (int g = 0; g < CNT; g += 2) {
@@ -205,7 +211,8 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
             }                                                // which changes nothing but the sign of a -0.0 input
             x = x - b2;                                      // :439
             v2f ds = ds_uni;
-            if constexpr (E_DIRECT) {
+            if constexpr (UNI_E) {
+            } else if constexpr (E_DIRECT) {
                 // constant address space: the array is not written while the kernel runs, and only such (or provably
                 // unclobbered) uniform loads are selected as scalar loads - behind the staging branch's barrier these are not
                 typedef const float __attribute__((address_space(4))) cfloat;
@@ -215,7 +222,7 @@ __device__ __forceinline__ bool calibrate_fast(const FrameScalars<NP> &fs, const
                 const int f1 = (f + 1 < MINN || f + 1 < nframes) ? f + 1 : nframes - 1;
                 const v2f e2 = {ec[f0], ec[f1]};
                 ds = e2 * D2;                                // :450
-            } else if constexpr (!UNI_E) {
+            } else {
                 const v2f e2 = {fs.e[f], fs.e[f + 1]};
                 ds = e2 * D2;                                // :450
             }
@@ -328,6 +335,20 @@ __device__ __forceinline__ bool exposures_uniform(const FrameScalars<NP> &fs)
     bool same = true;
     for (int t = threadIdx.x & 63; t < NP; t += 64) same = same && (fs.e[t] == fs.e[0]);
     return wave_all(same);
+}
+
+// The same vote on the caller's array itself (kernels that read the ratios with scalar loads and stage nothing): scalar loads
+// and scalar compares only - no VALU instruction.
+template <int NP>
+__device__ __forceinline__ bool ratios_uniform(const float *eg, int nframes)
+{
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat *ec = (const cfloat *)(uintptr_t)eg;
+    const int e0 = __builtin_amdgcn_readfirstlane(__float_as_int(ec[0]));
+    bool same = true;
+#pragma unroll
+    for (int f = 1; f < NP; f++) same = same && (f >= nframes || __builtin_amdgcn_readfirstlane(__float_as_int(ec[f < nframes ? f : 0])) == e0);
+    return same;
 }
 
 // Per-lane context of a column load: what the exact fallback and the deferred range check need.
@@ -454,7 +475,7 @@ __device__ __forceinline__ int load_column(const StackParams &prm, const FrameSc
             good = good && good2;
         } else {
             if (prm.pedestal) good = calibrate_fast<NP, RawT, true, 0, NP, GUARD, MINN>(fs, raw, b, D, nf, dodiv, v, N, plo);
-            else if (APGPU_HOIST_DARK && exposures_uniform<NP>(fs)) good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, true>(fs, raw, b, D, nf, dodiv, v, N, plo);
+            else if (APGPU_HOIST_DARK && FULL && EDIR && ratios_uniform<NP>(prm.exp_ratio, NP)) good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, true, true>(fs, raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
             else good = calibrate_fast<NP, RawT, false, 0, NP, GUARD, MINN, false, EDIR>(fs, raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio);
         }
         if (wave_all(good && !cx.skip)) {

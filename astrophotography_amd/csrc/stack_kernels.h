@@ -111,6 +111,120 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Round 4: the FAST kernel and its redo list.  stack_sigclip_kernel carries, next to the float32 fast path, everything that
+// path may have to fall back to - the exact calibration with its reload, the complete sorting network, the float64 clip,
+// the pedestal body - and the register allocation of the whole function (166 VGPRs: three wavefronts per SIMD) is set by
+// code the benchmark data runs in 0.6 % of its wavefronts.  This kernel holds ONLY the fast path (full stacks, float32
+// frames, median centre / std deviation, lean outputs, no pedestals): masters + frame loads, packed calibration with
+// scalar-load ratios, pruned network, clip_fast32, outputs - 104 VGPRs, FOUR wavefronts per SIMD, no LDS, no barrier.  A
+// wavefront that cannot finish (a lane outside the calibration's guards, a non-finite value, a masked pixel, a comparison
+// inside the float32 margins, a fifth value to trim, the image's last partial tile) stores nothing and appends its 64-pixel
+// block to prm.redo; stack_redo_kernel - the complete path of stack_sigclip_kernel, exact clip only - walks that list.
+// Results are those of stack_sigclip_kernel bit for bit: the same functions run, only in two kernels.  Same-box A/B on the
+// 64-frame benchmark: 0.944 -> 0.872 ms (profiles/r04/ab_fast_kernel.txt).
+// -------------------------------------------------------------------------------------------------
+#ifndef APGPU_FAST_MIN_BLOCKS
+#define APGPU_FAST_MIN_BLOCKS 4
+#endif
+constexpr int kRedoSegs = 256;
+// entries a segment can receive: its workgroups (every kRedoSegs-th of the P / 256 tiles) x 4 wavefronts
+__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs) * 4; }
+template <int NP, typename RawT, bool CALIB>
+__global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void stack_fast_kernel(const StackParams prm)
+{
+    static_assert(fast32_possible(NP, NP), "the fast kernel is the float32 fast path");
+    const int64_t base = (int64_t)blockIdx.x * 256;
+    const int lane = threadIdx.x;
+    const int64_t p = base + lane;
+    __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
+    bool ok = base + 256 <= prm.P;                          // the last, partial tile goes to the redo list whole
+    if (ok) {
+        float v[NP];
+        EarlyLoads<NP, RawT> L;
+        issue_early_loads<NP, RawT, CALIB, true, NP>(prm, base, lane, L);
+        bool good = !L.skip;
+        bool dodiv = false;
+        if constexpr (CALIB) {
+            const float b = L.b;
+            const float D = prm.still_biased ? L.d - b : L.d;             // ApCalibrate.py:440-445
+            float nf = 1.f;
+            if (prm.nflat) {
+                nf = L.nf;
+                dodiv = (nf != 0.f);                        // ApCalibrate.py:462 (NaN != 0 is True)
+            }
+            good = calibrate_fast<NP, RawT, false, 0, NP, false, NP, false, true>(fs, L.raw, b, D, nf, dodiv, v, NP, 0, prm.exp_ratio) && good;
+        } else {
+            v2f acc = {0.f, 0.f};                            // NaN iff some value is not finite
+            const v2f zero2 = {0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NP; f += 2) {
+                const v2f x = {to_f32(L.raw[f]), to_f32(L.raw[f + 1])};
+                v[f] = x.x;
+                v[f + 1] = x.y;
+                acc = __builtin_elementwise_fma(x, zero2, acc);
+            }
+            good = good && (acc.x == 0.f) && (acc.y == 0.f);
+        }
+        ok = wave_all(good);
+        if (ok) {
+            sort_column<NP, kFastTail>(v);
+            if constexpr (CALIB) ok = wave_all(range_ok_sorted<NP>(v, dodiv));
+        }
+        if (ok) {
+            LateParams *const kp = late_params();
+            int a, b;
+            float cf, Sf, Qf;
+            ok = clip_fast32<NP>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf);
+            if (ok) {
+                // the outputs of reduce_and_store's fast branch
+                LateParams *const ko = late_params();
+                const int cnt = b - a;
+                const float nf32 = (float)cnt;
+                const float y = __builtin_amdgcn_rcpf(nf32);
+                const float q0 = Sf * y;
+                const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, Sf), y, q0);
+                if (ko->mean) ko->mean[p] = cf + ms32;       // cnt >= NP - 2 * kFastTail > 0 here
+                if (ko->count) ko->count[p] = cnt;
+                if (ko->moments) store_moments(ko->moments, ko->moments64, ko->P, p, cnt, (double)cf, (double)Sf, (double)Qf);
+                return;
+            }
+        }
+    }
+    if ((lane & 63) == 0) {
+        // kRedoSegs counters, one cache line apart, each with its own stretch of the list (segment = workgroup % kRedoSegs, so
+        // a segment can never overflow its share): a stack whose every wavefront fails would otherwise serialise on one address
+        int32_t *const redo = late_params()->redo;
+        const int seg = blockIdx.x % kRedoSegs;
+        const int slot = atomicAdd(&redo[seg * 16], 1);
+        redo[kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(late_params()->P) + slot] = (int32_t)(p >> 6);
+    }
+}
+
+// The wavefronts stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, true> does for a
+// tile), one list entry per wavefront, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
+template <int NP, typename RawT, bool CALIB>
+__global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
+{
+    __shared__ FrameScalars<NP> fs;
+    if (needs_staging<CALIB, true, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // workgroup b walks segment b % kRedoSegs together with the other workgroups of that segment (gridDim.x / kRedoSegs of them)
+    const int seg = blockIdx.x % kRedoSegs, per_seg = gridDim.x / kRedoSegs;
+    const int nitems = prm.redo[seg * 16];
+    const int32_t *const list = prm.redo + kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(prm.P);
+#pragma unroll 1
+    for (int item = (blockIdx.x / kRedoSegs) * 4 + w; item < nitems; item += per_seg * 4) {
+        const int64_t base = (int64_t)__builtin_amdgcn_readfirstlane(list[item]) * 64;
+        const int64_t p = base + l;
+        if (p < prm.P) {
+            float v[NP];
+            const int n = load_sorted_column<NP, RawT, CALIB, true, true>(prm, fs, base, l, v);
+            reduce_and_store<NP, NP, false>(prm, v, n, p);
+        }
+    }
+}
+
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
 template <int NP, typename RawT, bool CALIB, bool FULL>
 __global__ __launch_bounds__(256) void stack_median_kernel(const StackParams prm)
@@ -268,22 +382,42 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
     } else {
         rawf[0] = (float)cur[0];
     }
+    // Padded stacks on the float32 fast path (round 4; the one-pixel-per-lane kernels have it since round 3): SPLIT PADS - the
+    // kernel wrote the first plo padding slots as raw 0 and the others as raw 65535, so that after the packed sort they sit at
+    // the two ends of the column; here they become -inf / +inf and clip_fast32's padded form starts with them trimmed.
+    constexpr int MINNP = padded_minn(NP, false);
+    constexpr bool SPLIT = !FULL && fast32_possible_padded(NP, MINNP);
+    const int plo = SPLIT ? pad_low<NP>(prm) : 0;
+    const int phi = FULL ? 0 : NP - N - plo;
     if constexpr (CALIB) {
         // non-decreasing map: finite masters and a positive (or unused) flat
         const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
-        // FULL columns come out sorted (non-decreasing map of a sorted raw column), so their range guards are read off the ends
-        bool good = calibrate_fast<NP, float, false, 0, NP, !FULL, NP, true>(fs, rawf, b, D, nf, dv, v);   // (one exposure ratio: the workgroup's precondition)
+        // the columns come out sorted (non-decreasing map of a sorted raw column), so their range guards are read off the ends
+        // (of the real values: the pads' own quotients mean nothing)
+        bool good = calibrate_fast<NP, float, false, 0, NP, false, NP, true>(fs, rawf, b, D, nf, dv, v);   // (one exposure ratio: the workgroup's precondition)
+        if constexpr (!FULL) {
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                if (i < NP - MINNP && i < plo) v[i] = -__builtin_inff();                  // (wave-uniform tests, the end slots only)
+                if (i >= MINNP && i >= NP - phi) v[i] = __builtin_inff();
+            }
+        }
         if constexpr (FULL) good = good && (!increasing || range_ok_sorted<NP>(v, dv));
+        else good = good && (!increasing || range_ok_sorted<NP, (MINNP < NP ? MINNP : 0)>(v, dv, N, plo));
         fast = fast && good && increasing;
     } else {
 #pragma unroll
         for (int f = 0; f < NP; f++) v[f] = rawf[f];
-    }
-    if (wave_all(fast)) {
         if constexpr (!FULL) {
 #pragma unroll
-            for (int f = 0; f < NP; f++) asm("v_max_f32 %0, %1, %2" : "=v"(v[f]) : "v"(v[f]), "v"(fs.pad[f]));
+            for (int i = 0; i < NP; i++) {
+                if (i < NP - MINNP && i < plo) v[i] = -__builtin_inff();
+                if (i >= MINNP && i >= NP - phi) v[i] = __builtin_inff();
+            }
         }
+    }
+    if (wave_all(fast)) {
+        if constexpr (!FULL) pruned = SPLIT && fast32_wanted(prm);      // complete, sorted, every lane holds all N values
     } else {
         pruned = false;                                     // (the column below is sorted completely)
         // rare: exact IEEE calibration of every value (frame order is irrelevant: the per-frame scalars are
@@ -299,9 +433,12 @@ __device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm,
             const bool ok = (fabsf(x) < __builtin_inff()) && (FULL || f < N) && !skip;
             n += ok ? 1 : 0;
             v[f] = ok ? x : __builtin_inff();
+            if (SPLIT && f >= N && f < N + plo) v[f] = -__builtin_inff();       // split pads (wave-uniform test), as load_column_exact
         }
         sort_column<NP>(v);
     }
+    if constexpr (SPLIT) reduce_and_store<NP, MINNP>(prm, v, n, p, pruned);
+    else
     reduce_and_store<NP>(prm, v, n, p, pruned);
 }
 
@@ -364,8 +501,15 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void
             if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (!FULL) {
+            // padding slots: all ones (sorts to the top); with split pads (reduce_sorted_raw_column) the first plo of them zero
+            constexpr int MINNP = padded_minn(NP, false);
+            const int plo = fast32_possible_padded(NP, MINNP) ? pad_low<NP>(prm) : 0;
 #pragma unroll
-            for (int f = 0; f < NP; f++) w[f] |= (uint32_t)((N - 1 - f) >> 31);  // f >= N: all ones, sorts to the top
+            for (int f = 0; f < NP; f++) {
+                if (f >= MINNP || MINNP >= NP) {
+                    if (f >= N) w[f] = (f < N + plo) ? 0u : 0xffffffffu;           // (wave-uniform tests)
+                }
+            }
         }
     }
     // full stacks headed for the float32 fast path only sort what it reads (both pixels at once); a wave that falls back to
@@ -421,6 +565,65 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void
 #pragma unroll
     for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
     reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1, pruned);
+}
+
+// Whether a call takes stack_fast_kernel + stack_redo_kernel (host side; the same conditions as fast32_wanted, plus: a full
+// stack, lean outputs, no pedestals, block indices that fit the list's int32 entries).
+// Only for FUSED-CALIBRATION calls without a pixel mask: raw frames are finite, so a wavefront fails rarely; a slab that has been
+// through a calibration or a resample may hold NaNs anywhere (C5: nearly every wavefront has one) and every failing
+// wavefront is read twice - such stacks keep stack_sigclip_kernel, whose fallback is inline.
+inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool rich, bool plus, bool full)
+{
+#ifdef APGPU_VARIANT_NO_FAST_KERNEL
+    return false;
+#endif
+    if (median_only || rich || plus || !full) return false;
+    if (!prm.bias || prm.pixmask) return false;
+    if (prm.fast32 == 0 || prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
+    if (!(prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2)) return false;
+    if (prm.pedestal) return false;
+    return prm.P / 64 < 0x7fffffffLL;
+}
+
+template <int NP, typename RawT, bool CALIB>
+int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
+{
+    // redo list: kRedoSegs counters (64 bytes apart) + kRedoSegs segments of entries, a stream-ordered temporary
+    const int64_t nwaves = (prm0.P + 63) / 64;
+    const size_t words = (size_t)kRedoSegs * 16 + (size_t)kRedoSegs * (size_t)redo_seg_capacity(prm0.P);
+    int32_t *redo = nullptr;
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), words * sizeof(int32_t), st);
+    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): cannot allocate the redo list: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(redo, 0, (size_t)kRedoSegs * 16 * sizeof(int32_t), st);
+    if (e != hipSuccess) {
+        (void)hipFreeAsync(redo, st);
+        return fail(APGPU_ELAUNCH, "stack (fast): memset: %s", hipGetErrorString(e));
+    }
+    StackParams prm = prm0;
+    prm.redo = redo;
+    hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB>), grid, dim3(256), 0, st, prm);
+    int rc = check_launch("stack kernel (fast)");
+    if (rc == APGPU_OK) {
+        prm.fast32 = 0;                                     // the list is redone by the exact clip
+        // kRedoSegs .. 4 kRedoSegs workgroups (a multiple of the segment count), by the size of the image
+        int64_t per_seg = (nwaves / 4 + 4095) / 4096;
+        per_seg = per_seg < 1 ? 1 : (per_seg > 4 ? 4 : per_seg);
+        hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB>), dim3((unsigned)(kRedoSegs * per_seg)), dim3(256), 0, st, prm);
+        rc = check_launch("stack kernel (redo list)");
+    }
+#ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
+    if (getenv("APGPU_DEBUG_REDO")) {
+        int32_t cnts[kRedoSegs * 16];
+        (void)hipMemcpyAsync(cnts, redo, sizeof(cnts), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        long cnt = 0;
+        for (int sg = 0; sg < kRedoSegs; sg++) cnt += cnts[sg * 16];
+        fprintf(stderr, "stack_fast: %ld of %lld wavefronts on the redo list\n", cnt, (long long)nwaves);
+    }
+#endif
+    const hipError_t ef = hipFreeAsync(redo, st);
+    if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): free: %s", hipGetErrorString(ef));
+    return rc;
 }
 
 // `describe` != nullptr: write the name of the kernel variant this call would launch (as rocprofv3 prints it, without
@@ -488,12 +691,28 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (describe) {
+        if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
+            if (fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
+                return APGPU_OK;
+            }
+        }
         if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
         else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
         else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
         return APGPU_OK;
     }
     const dim3 g((unsigned)grid), b(block);
+    if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
+        // the fast kernel + redo list (see stack_fast_kernel): full stacks on the float32 fast path without pedestals
+        if (fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+            if (describe) {
+                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
+                return APGPU_OK;
+            }
+            return launch_fast<NP, RawT, CALIB>(prm, g, st);
+        }
+    }
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);
         else hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, false>), g, b, 0, st, prm);

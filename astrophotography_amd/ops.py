@@ -340,7 +340,8 @@ def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='m
     return res
 
 
-def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std'):
+def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std',
+                      moments_mean_only=False, exact=False):
     """Name of the kernel variant the library dispatches for such a stack call (apgpu_stack_kernel_name): what the
     bench line and the profiles call the dominant kernel.  Needs no device."""
     lib = _lib.load()
@@ -363,6 +364,7 @@ def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',),
             a.moments = 0x1000
         else:
             setattr(a, k, 0x1000)
+    a.flags = (_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0)
     buf = C.create_string_buffer(256)
     check(lib.apgpu_stack_kernel_name(C.byref(a), int(bool(median_only)), buf, 256))
     return buf.value.decode()

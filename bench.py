@@ -465,7 +465,8 @@ def main(argv=None):
     out_bytes = 4 if single_launch else (24 if payload == 'f64' else 12)           # mean plane | moment planes written
     algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
     kernel_name = ops.stack_kernel_name(min(N, hier_chunk) if hier_chunk else N, args.dtype, calibrated=True,
-                                        outputs=('mean',) if single_launch else (('moments_f64p',) if payload == 'f64' else ('moments',)))
+                                        outputs=('mean',) if single_launch else (('moments_f64p',) if payload == 'f64' else ('moments',)),
+                                        moments_mean_only=not single_launch and payload == 'f64', exact=args.exact_moments and single_launch)
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
     cfg_name = 'C3' if strong else 'C2'
     if not strong and not (N == 64 and H_glob == 4096 and W == 4096 and args.dtype == 'f32'):

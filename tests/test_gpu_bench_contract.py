@@ -31,7 +31,7 @@ def test_default_workload_line():
     rf = d['roofline']
     assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert rf['algorithmic_bytes'] == 4 * 16 * 256 * 512 + 16 * 256 * 512 and rf['avg_launch_ms'] > 0
-    assert rf['kernel'] == 'stack_sigclip_kernel<16, float, true, false, true, false>'      # reported by the library's dispatch
+    assert rf['kernel'] == 'stack_fast_kernel<16, float, true>'      # reported by the library's dispatch (the fast kernel + redo list)
     assert d['rccl_world_size'] == 1 and len(d['per_rank_ms']) == 1
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb
@@ -83,4 +83,4 @@ def test_multi_rank_paths_on_one_gpu():
             assert d['exchange_bytes_on_wire'] == {'rs': int(0.5 * 20 * px), 'f64': int(2 * 0.5 * 16 * px), 'f32': int(2 * 0.5 * 8 * px)}[d['exchange']]
         if '--scaling' in extra and '--parallelism' not in extra:
             assert d['hier_shards'] == 4 and d['config']['frames_per_gpu'] == 32 and d['config']['frames_total'] == 64
-            assert d['roofline']['kernel'].startswith('stack_sigclip_kernel<16,')        # shards of 16 frames
+            assert d['roofline']['kernel'].startswith('stack_fast_kernel<16,')        # shards of 16 frames
