@@ -130,22 +130,30 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
 constexpr int kRedoSegs = 256;
 // entries a segment can receive: its workgroups (every kRedoSegs-th of the P / 256 tiles) x 4 wavefronts
 __host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs) * 4; }
-template <int NP, typename RawT, bool CALIB>
+// FULL = false (since the end of round 4): a padded stack (N between two slot counts) on the same kernel - the padding slots
+// are not loaded, the pads are split (-inf below, +inf above the real values, fast32_possible_padded) and clip_fast32's padded
+// form starts with them trimmed.
+template <int NP, typename RawT, bool CALIB, bool FULL = true>
 __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void stack_fast_kernel(const StackParams prm)
 {
-    static_assert(fast32_possible(NP, NP), "the fast kernel is the float32 fast path");
+    constexpr int MINN = padded_minn(NP, FULL);
+    static_assert(FULL ? fast32_possible(NP, NP) : fast32_possible_padded(NP, MINN), "the fast kernel is the float32 fast path");
+    constexpr int T = FULL ? kFastTail : fast_tail_padded(NP);
     const int64_t base = (int64_t)blockIdx.x * 256;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
+    const int N = FULL ? NP : prm.N;
+    const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
     bool ok = base + 256 <= prm.P;                          // the last, partial tile goes to the redo list whole
     if (ok) {
         float v[NP];
         EarlyLoads<NP, RawT> L;
-        issue_early_loads<NP, RawT, CALIB, true, NP>(prm, base, lane, L);
+        issue_early_loads<NP, RawT, CALIB, FULL, MINN>(prm, base, lane, L);
         bool good = !L.skip;
         bool dodiv = false;
-        if constexpr (CALIB) {
+        static_assert(CALIB, "fused-calibration stacks only (fast_kernel_eligible)");
+        {
             const float b = L.b;
             const float D = prm.still_biased ? L.d - b : L.d;             // ApCalibrate.py:440-445
             float nf = 1.f;
@@ -153,29 +161,18 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
                 nf = L.nf;
                 dodiv = (nf != 0.f);                        // ApCalibrate.py:462 (NaN != 0 is True)
             }
-            good = calibrate_fast<NP, RawT, false, 0, NP, false, NP, false, true>(fs, L.raw, b, D, nf, dodiv, v, NP, 0, prm.exp_ratio) && good;
-        } else {
-            v2f acc = {0.f, 0.f};                            // NaN iff some value is not finite
-            const v2f zero2 = {0.f, 0.f};
-#pragma unroll
-            for (int f = 0; f < NP; f += 2) {
-                const v2f x = {to_f32(L.raw[f]), to_f32(L.raw[f + 1])};
-                v[f] = x.x;
-                v[f + 1] = x.y;
-                acc = __builtin_elementwise_fma(x, zero2, acc);
-            }
-            good = good && (acc.x == 0.f) && (acc.y == 0.f);
+            good = calibrate_fast<NP, RawT, false, 0, NP, false, MINN, false, true>(fs, L.raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio) && good;
         }
         ok = wave_all(good);
         if (ok) {
-            sort_column<NP, kFastTail>(v);
-            if constexpr (CALIB) ok = wave_all(range_ok_sorted<NP>(v, dodiv));
+            sort_column<NP, T>(v);
+            ok = wave_all(range_ok_sorted<NP, MINN>(v, dodiv, N, plo));
         }
         if (ok) {
             LateParams *const kp = late_params();
             int a, b;
             float cf, Sf, Qf;
-            ok = clip_fast32<NP>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf);
+            ok = clip_fast32<NP, T>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf, plo, phi);
             if (ok) {
                 // the outputs of reduce_and_store's fast branch
                 LateParams *const ko = late_params();
@@ -184,7 +181,7 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
                 const float y = __builtin_amdgcn_rcpf(nf32);
                 const float q0 = Sf * y;
                 const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, Sf), y, q0);
-                if (ko->mean) ko->mean[p] = cf + ms32;       // cnt >= NP - 2 * kFastTail > 0 here
+                if (ko->mean) ko->mean[p] = cf + ms32;       // cnt >= N - 8 > 0 here
                 if (ko->count) ko->count[p] = cnt;
                 if (ko->moments) store_moments(ko->moments, ko->moments64, ko->P, p, cnt, (double)cf, (double)Sf, (double)Qf);
                 return;
@@ -203,11 +200,12 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
 
 // The wavefronts stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, true> does for a
 // tile), one list entry per wavefront, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
-template <int NP, typename RawT, bool CALIB>
+template <int NP, typename RawT, bool CALIB, bool FULL = true>
 __global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
 {
+    constexpr int MINN = padded_minn(NP, FULL);
     __shared__ FrameScalars<NP> fs;
-    if (needs_staging<CALIB, true, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
+    if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // workgroup b walks segment b % kRedoSegs together with the other workgroups of that segment (gridDim.x / kRedoSegs of them)
     const int seg = blockIdx.x % kRedoSegs, per_seg = gridDim.x / kRedoSegs;
@@ -219,8 +217,9 @@ __global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
         const int64_t p = base + l;
         if (p < prm.P) {
             float v[NP];
-            const int n = load_sorted_column<NP, RawT, CALIB, true, true>(prm, fs, base, l, v);
-            reduce_and_store<NP, NP, false>(prm, v, n, p);
+            // (prm.fast32 is 0: no split pads - pad_low is 0 -, the complete network, the float64 clip)
+            const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, l, v);
+            reduce_and_store<NP, MINN, false>(prm, v, n, p);
         }
     }
 }
@@ -577,7 +576,7 @@ inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool 
 #ifdef APGPU_VARIANT_NO_FAST_KERNEL
     return false;
 #endif
-    if (median_only || rich || plus || !full) return false;
+    if (median_only || rich || plus) return false;
     if (!prm.bias || prm.pixmask) return false;
     if (prm.fast32 == 0 || prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (!(prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2)) return false;
@@ -585,7 +584,7 @@ inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool 
     return prm.P / 64 < 0x7fffffffLL;
 }
 
-template <int NP, typename RawT, bool CALIB>
+template <int NP, typename RawT, bool CALIB, bool FULL>
 int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
 {
     // redo list: kRedoSegs counters (64 bytes apart) + kRedoSegs segments of entries, a stream-ordered temporary
@@ -601,14 +600,14 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
     }
     StackParams prm = prm0;
     prm.redo = redo;
-    hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB>), grid, dim3(256), 0, st, prm);
+    hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL>), grid, dim3(256), 0, st, prm);
     int rc = check_launch("stack kernel (fast)");
     if (rc == APGPU_OK) {
         prm.fast32 = 0;                                     // the list is redone by the exact clip
         // kRedoSegs .. 4 kRedoSegs workgroups (a multiple of the segment count), by the size of the image
         int64_t per_seg = (nwaves / 4 + 4095) / 4096;
         per_seg = per_seg < 1 ? 1 : (per_seg > 4 ? 4 : per_seg);
-        hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB>), dim3((unsigned)(kRedoSegs * per_seg)), dim3(256), 0, st, prm);
+        hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL>), dim3((unsigned)(kRedoSegs * per_seg)), dim3(256), 0, st, prm);
         rc = check_launch("stack kernel (redo list)");
     }
 #ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
@@ -692,8 +691,14 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     if (describe) {
         if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
-            if (fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+            if (full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
                 snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
+                return APGPU_OK;
+            }
+        }
+        if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false))) {
+            if (!full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, false>", NP, rawname, tf[CALIB]);
                 return APGPU_OK;
             }
         }
@@ -705,12 +710,21 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const dim3 g((unsigned)grid), b(block);
     if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
         // the fast kernel + redo list (see stack_fast_kernel): full stacks on the float32 fast path without pedestals
-        if (fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+        if (full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
             if (describe) {
                 snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
                 return APGPU_OK;
             }
-            return launch_fast<NP, RawT, CALIB>(prm, g, st);
+            return launch_fast<NP, RawT, CALIB, true>(prm, g, st);
+        }
+    }
+    if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false))) {
+        if (!full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
+            if (describe) {
+                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, false>", NP, rawname, tf[CALIB]);
+                return APGPU_OK;
+            }
+            return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
         }
     }
     if (median_only) {
