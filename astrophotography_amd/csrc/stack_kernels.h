@@ -115,21 +115,68 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
 // Round 4: the FAST kernel and its redo list.  stack_sigclip_kernel carries, next to the float32 fast path, everything that
 // path may have to fall back to - the exact calibration with its reload, the complete sorting network, the float64 clip,
 // the pedestal body - and the register allocation of the whole function (166 VGPRs: three wavefronts per SIMD) is set by
-// code the benchmark data runs in 0.6 % of its wavefronts.  This kernel holds ONLY the fast path (full stacks, float32
-// frames, median centre / std deviation, lean outputs, no pedestals): masters + frame loads, packed calibration with
-// scalar-load ratios, pruned network, clip_fast32, outputs - 104 VGPRs, FOUR wavefronts per SIMD, no LDS, no barrier.  A
-// wavefront that cannot finish (a lane outside the calibration's guards, a non-finite value, a masked pixel, a comparison
-// inside the float32 margins, a fifth value to trim, the image's last partial tile) stores nothing and appends its 64-pixel
-// block to prm.redo; stack_redo_kernel - the complete path of stack_sigclip_kernel, exact clip only - walks that list.
-// Results are those of stack_sigclip_kernel bit for bit: the same functions run, only in two kernels.  Same-box A/B on the
-// 64-frame benchmark: 0.944 -> 0.872 ms (profiles/r04/ab_fast_kernel.txt).
+// code the benchmark data runs in 0.6 % of its wavefronts.  This kernel holds ONLY the fast path (float32 frames, median
+// centre / std deviation, lean outputs, no pedestals): masters + frame loads, packed calibration with scalar-load ratios,
+// pruned network, clip_fast32, outputs - 104 VGPRs, FOUR wavefronts per SIMD, no LDS, no barrier.  A PIXEL that cannot
+// finish (outside the calibration's guards, too many non-finite values, masked, a comparison inside the float32 margins, a
+// fifth value to trim, the image's last partial tile) stores nothing and is appended to prm.redo; stack_redo_kernel - the
+// complete path of stack_sigclip_kernel, exact clip only, one listed pixel per lane - walks that list.  The list is per
+// pixel, not per wavefront: the exact path costs a wavefront the same whether one lane needs it or all 64, so the failing
+// lanes of many wavefronts are compacted into few.  Results are those of stack_sigclip_kernel bit for bit: the same
+// functions run, only in two kernels.  Same-box A/B on the 64-frame benchmark: profiles/r04/ab_fast_kernel.txt.
+//
+// Stacks WITHOUT the fused calibration (CALIB = false: frames that have been through ApCalibrate or a resample) may hold
+// non-finite values anywhere - a resampled frame has a 6 x 6 block of NaNs around every masked input pixel, so with 16 frames
+// nearly every wavefront of the C5 share holds one.  There every non-finite value becomes the +inf sentinel BEFORE the sort
+// (two instructions per value), sorts to the top like a padding slot, and the lane's clip starts with its own count of them
+// trimmed (clip_fast32, MODE 2; up to T - 1 per column, more go to the list).
 // -------------------------------------------------------------------------------------------------
 #ifndef APGPU_FAST_MIN_BLOCKS
 #define APGPU_FAST_MIN_BLOCKS 4
 #endif
 constexpr int kRedoSegs = 256;
-// entries a segment can receive: its workgroups (every kRedoSegs-th of the P / 256 tiles) x 4 wavefronts
-__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs) * 4; }
+// entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles)
+__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs) * 256; }
+
+// Appends the failing lanes' pixels to the list: one atomic per wavefront that has any.  kRedoSegs counters, one cache line
+// apart, each with its own stretch of the list (segment = workgroup % kRedoSegs, so a segment can never overflow its share):
+// a stack whose every pixel fails would otherwise serialise on one address.
+__device__ __forceinline__ void redo_push(bool fail, int64_t p)
+{
+    const uint64_t m = __builtin_amdgcn_ballot_w64(fail);
+    if (m == 0) return;
+    LateParams *const kp = late_params();
+    int32_t *const redo = kp->redo;
+    const int seg = blockIdx.x % kRedoSegs;
+    int first = 0;
+    if ((threadIdx.x & 63) == 0) first = atomicAdd(&redo[seg * 16], (int)__builtin_popcountll(m));
+    first = __builtin_amdgcn_readfirstlane(first);
+    const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+    if (fail) redo[kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(kp->P) + first + mine] = (int32_t)p;
+}
+
+// clip_fast32 + the outputs of reduce_and_store's fast branch for the lanes that complete; `good` is cleared for the others.
+template <int NP, int T, bool CALIB>
+__device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &good, int64_t p, int plo, int phi)
+{
+    LateParams *const kp = late_params();
+    int a, b;
+    float cf, Sf, Qf;
+    const bool done = clip_fast32<NP, T, CALIB ? 1 : 2>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf, plo, phi);
+    good = good && done;
+    if (good) {
+        LateParams *const ko = late_params();
+        const int cnt = b - a;
+        const float nf32 = (float)cnt;
+        const float y = __builtin_amdgcn_rcpf(nf32);
+        const float q0 = Sf * y;
+        const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, Sf), y, q0);
+        if (ko->mean) ko->mean[p] = cf + ms32;               // cnt >= 8 here (the core survives)
+        if (ko->count) ko->count[p] = cnt;
+        if (ko->moments) store_moments(ko->moments, ko->moments64, ko->P, p, cnt, (double)cf, (double)Sf, (double)Qf);
+    }
+}
+
 // FULL = false (since the end of round 4): a padded stack (N between two slot counts) on the same kernel - the padding slots
 // are not loaded, the pads are split (-inf below, +inf above the real values, fast32_possible_padded) and clip_fast32's padded
 // form starts with them trimmed.
@@ -138,22 +185,25 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
 {
     constexpr int MINN = padded_minn(NP, FULL);
     static_assert(FULL ? fast32_possible(NP, NP) : fast32_possible_padded(NP, MINN), "the fast kernel is the float32 fast path");
-    constexpr int T = FULL ? kFastTail : fast_tail_padded(NP);
+    static_assert(CALIB || sizeof(RawT) == 4, "unfused stacks: float32 frames");
+    // tails: what the clip can trim per side.  Unfused stacks spend tail entries on their non-finite values (up to T - 1 per
+    // column), so theirs are longer (a core of four values is enough for the sums' four chains)
+    constexpr int T = !CALIB ? (NP >= 20 ? 8 : 6) : (FULL ? kFastTail : fast_tail_padded(NP));
     const int64_t base = (int64_t)blockIdx.x * 256;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
     const int N = FULL ? NP : prm.N;
     const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
-    bool ok = base + 256 <= prm.P;                          // the last, partial tile goes to the redo list whole
-    if (ok) {
+    bool good = false;
+    if (base + 256 <= prm.P) {                              // the last, partial tile goes to the redo list whole
         float v[NP];
         EarlyLoads<NP, RawT> L;
         issue_early_loads<NP, RawT, CALIB, FULL, MINN>(prm, base, lane, L);
-        bool good = !L.skip;
+        good = !L.skip;
         bool dodiv = false;
-        static_assert(CALIB, "fused-calibration stacks only (fast_kernel_eligible)");
-        {
+        int nonfin = 0;                                     // (CALIB = false) the lane's non-finite values
+        if constexpr (CALIB) {
             const float b = L.b;
             const float D = prm.still_biased ? L.d - b : L.d;             // ApCalibrate.py:440-445
             float nf = 1.f;
@@ -162,64 +212,55 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
                 dodiv = (nf != 0.f);                        // ApCalibrate.py:462 (NaN != 0 is True)
             }
             good = calibrate_fast<NP, RawT, false, 0, NP, false, MINN, false, true>(fs, L.raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio) && good;
-        }
-        ok = wave_all(good);
-        if (ok) {
-            sort_column<NP, T>(v);
-            ok = wave_all(range_ok_sorted<NP, MINN>(v, dodiv, N, plo));
-        }
-        if (ok) {
-            LateParams *const kp = late_params();
-            int a, b;
-            float cf, Sf, Qf;
-            ok = clip_fast32<NP, T>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf, plo, phi);
-            if (ok) {
-                // the outputs of reduce_and_store's fast branch
-                LateParams *const ko = late_params();
-                const int cnt = b - a;
-                const float nf32 = (float)cnt;
-                const float y = __builtin_amdgcn_rcpf(nf32);
-                const float q0 = Sf * y;
-                const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, Sf), y, q0);
-                if (ko->mean) ko->mean[p] = cf + ms32;       // cnt >= N - 8 > 0 here
-                if (ko->count) ko->count[p] = cnt;
-                if (ko->moments) store_moments(ko->moments, ko->moments64, ko->P, p, cnt, (double)cf, (double)Sf, (double)Qf);
-                return;
+        } else {
+            // non-finite values (astropy masks them) become +inf sentinels; padding slots: the first plo -inf, the others +inf
+#pragma unroll
+            for (int f = 0; f < NP; f++) {
+                if (FULL || f < MINN || f < N) {
+                    const float x = L.raw[f];
+                    v[f] = fabsf(x) < __builtin_inff() ? x : __builtin_inff();
+                } else {
+                    v[f] = (f < N + plo) ? -__builtin_inff() : __builtin_inff();
+                }
             }
         }
+        if (wave_any(good)) {
+            sort_column<NP, T>(v);
+            if constexpr (CALIB) good = good && range_ok_sorted<NP, MINN>(v, dodiv, N, plo);
+            else {
+                // the sentinels sit at the top: count them in the upper tail (pads included); a full tail = too many
+#pragma unroll
+                for (int k = 1; k <= T; k++) nonfin += (v[NP - k] == __builtin_inff()) ? 1 : 0;
+                good = good && nonfin < T;
+            }
+            if (wave_any(good)) finish_fast_column<NP, T, CALIB>(v, good, p, plo, CALIB ? phi : nonfin);
+        }
     }
-    if ((lane & 63) == 0) {
-        // kRedoSegs counters, one cache line apart, each with its own stretch of the list (segment = workgroup % kRedoSegs, so
-        // a segment can never overflow its share): a stack whose every wavefront fails would otherwise serialise on one address
-        int32_t *const redo = late_params()->redo;
-        const int seg = blockIdx.x % kRedoSegs;
-        const int slot = atomicAdd(&redo[seg * 16], 1);
-        redo[kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(late_params()->P) + slot] = (int32_t)(p >> 6);
-    }
+    redo_push(!good && p < late_params()->P, p);
 }
 
-// The wavefronts stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, true> does for a
-// tile), one list entry per wavefront, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
+// The pixels stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, FULL> does for a
+// pixel), one list entry per lane, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
 template <int NP, typename RawT, bool CALIB, bool FULL = true>
 __global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
 {
     constexpr int MINN = padded_minn(NP, FULL);
     __shared__ FrameScalars<NP> fs;
     if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // workgroup b walks segment b % kRedoSegs together with the other workgroups of that segment (gridDim.x / kRedoSegs of them)
     const int seg = blockIdx.x % kRedoSegs, per_seg = gridDim.x / kRedoSegs;
     const int nitems = prm.redo[seg * 16];
     const int32_t *const list = prm.redo + kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(prm.P);
 #pragma unroll 1
-    for (int item = (blockIdx.x / kRedoSegs) * 4 + w; item < nitems; item += per_seg * 4) {
-        const int64_t base = (int64_t)__builtin_amdgcn_readfirstlane(list[item]) * 64;
-        const int64_t p = base + l;
-        if (p < prm.P) {
+    for (int item0 = (blockIdx.x / kRedoSegs) * 256; item0 < nitems; item0 += per_seg * 256) {
+        const int item = item0 + (int)threadIdx.x;
+        if (item < nitems) {
+            const int pix = list[item];
             float v[NP];
-            // (prm.fast32 is 0: no split pads - pad_low is 0 -, the complete network, the float64 clip)
-            const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, l, v);
-            reduce_and_store<NP, MINN, false>(prm, v, n, p);
+            // (prm.fast32 is 0: no split pads - pad_low is 0 -, the complete network, the float64 clip; a gather: base 0, the
+            // lane's own pixel as the offset)
+            const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, 0, pix, v);
+            reduce_and_store<NP, MINN, false>(prm, v, n, (int64_t)pix);
         }
     }
 }
@@ -566,30 +607,42 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void
     reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1, pruned);
 }
 
-// Whether a call takes stack_fast_kernel + stack_redo_kernel (host side; the same conditions as fast32_wanted, plus: a full
-// stack, lean outputs, no pedestals, block indices that fit the list's int32 entries).
-// Only for FUSED-CALIBRATION calls without a pixel mask: raw frames are finite, so a wavefront fails rarely; a slab that has been
-// through a calibration or a resample may hold NaNs anywhere (C5: nearly every wavefront has one) and every failing
-// wavefront is read twice - such stacks keep stack_sigclip_kernel, whose fallback is inline.
-inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool rich, bool plus, bool full)
+// Whether a call takes stack_fast_kernel + stack_redo_kernel (host side; the same conditions as fast32_wanted, plus: lean
+// outputs, no pedestals, pixel indices that fit the list's int32 entries).
+inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool rich, bool plus)
 {
 #ifdef APGPU_VARIANT_NO_FAST_KERNEL
     return false;
 #endif
     if (median_only || rich || plus) return false;
-    if (!prm.bias || prm.pixmask) return false;
     if (prm.fast32 == 0 || prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (!(prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2)) return false;
     if (prm.pedestal) return false;
-    return prm.P / 64 < 0x7fffffffLL;
+    return prm.P < 0x7fffffffLL;
+}
+
+// The redo list is a stream-ordered temporary of P + 4096 words.  The device's default pool returns freed memory to the
+// system at the next synchronisation unless told otherwise - a fresh 64 .. 270 MB allocation per call; keep up to 1 GiB.
+inline void keep_pool_memory()
+{
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) return;
+    uint64_t keep = 1ull << 30, cur = 0;
+    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur >= keep) return;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
 }
 
 template <int NP, typename RawT, bool CALIB, bool FULL>
 int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
 {
     // redo list: kRedoSegs counters (64 bytes apart) + kRedoSegs segments of entries, a stream-ordered temporary
-    const int64_t nwaves = (prm0.P + 63) / 64;
+    const int64_t ntiles = (prm0.P + 255) / 256;
     const size_t words = (size_t)kRedoSegs * 16 + (size_t)kRedoSegs * (size_t)redo_seg_capacity(prm0.P);
+    keep_pool_memory();
     int32_t *redo = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), words * sizeof(int32_t), st);
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): cannot allocate the redo list: %s", hipGetErrorString(e));
@@ -604,9 +657,10 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
     int rc = check_launch("stack kernel (fast)");
     if (rc == APGPU_OK) {
         prm.fast32 = 0;                                     // the list is redone by the exact clip
-        // kRedoSegs .. 4 kRedoSegs workgroups (a multiple of the segment count), by the size of the image
-        int64_t per_seg = (nwaves / 4 + 4095) / 4096;
-        per_seg = per_seg < 1 ? 1 : (per_seg > 4 ? 4 : per_seg);
+        // kRedoSegs .. 16 kRedoSegs workgroups (a multiple of the segment count), by the size of the image; workgroups beyond
+        // their segment's count leave at once
+        int64_t per_seg = ntiles / (kRedoSegs * 8);
+        per_seg = per_seg < 1 ? 1 : (per_seg > 16 ? 16 : per_seg);
         hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL>), dim3((unsigned)(kRedoSegs * per_seg)), dim3(256), 0, st, prm);
         rc = check_launch("stack kernel (redo list)");
     }
@@ -617,7 +671,7 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
         (void)hipStreamSynchronize(st);
         long cnt = 0;
         for (int sg = 0; sg < kRedoSegs; sg++) cnt += cnts[sg * 16];
-        fprintf(stderr, "stack_fast: %ld of %lld wavefronts on the redo list\n", cnt, (long long)nwaves);
+        fprintf(stderr, "stack_fast: %ld of %lld pixels on the redo list\n", cnt, (long long)prm0.P);
     }
 #endif
     const hipError_t ef = hipFreeAsync(redo, st);
@@ -689,43 +743,23 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const int block = rich ? rich_block<NP>() : ((plus || median_only) ? 256 : APGPU_LEAN_BLOCK);
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    // the fast kernel + redo list (see stack_fast_kernel): float32 stacks on the float32 fast path, lean outputs, no pedestals
+    constexpr bool kFastFull = sizeof(RawT) == 4 && fast32_possible(NP, NP);
+    constexpr bool kFastPadded = sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false));
+    const bool fastk = (full ? kFastFull : kFastPadded) && fast_kernel_eligible(prm, median_only, rich, plus);
     if (describe) {
-        if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
-            if (full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
-                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
-                return APGPU_OK;
-            }
-        }
-        if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false))) {
-            if (!full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
-                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, false>", NP, rawname, tf[CALIB]);
-                return APGPU_OK;
-            }
-        }
-        if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
+        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
+        else if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
         else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
         else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
         return APGPU_OK;
     }
     const dim3 g((unsigned)grid), b(block);
-    if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible(NP, NP)) {
-        // the fast kernel + redo list (see stack_fast_kernel): full stacks on the float32 fast path without pedestals
-        if (full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
-            if (describe) {
-                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s>", NP, rawname, tf[CALIB]);
-                return APGPU_OK;
-            }
-            return launch_fast<NP, RawT, CALIB, true>(prm, g, st);
-        }
+    if constexpr (kFastFull) {
+        if (fastk && full) return launch_fast<NP, RawT, CALIB, true>(prm, g, st);
     }
-    if constexpr (CALIB && sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false))) {
-        if (!full && fast_kernel_eligible(prm, median_only, rich, plus, full)) {
-            if (describe) {
-                snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, false>", NP, rawname, tf[CALIB]);
-                return APGPU_OK;
-            }
-            return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
-        }
+    if constexpr (kFastPadded) {
+        if (fastk && !full) return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
     }
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);

@@ -178,40 +178,49 @@ __device__ __forceinline__ float col_read(const float *col, int i)
 // (astropy/stats/funcs.py:844-850, 917-920; the C loop's mad_buffer).  No second sort: the column is
 // sorted, so the j+1 deviations nearest to med belong to a contiguous window [L, L+j], and the j-th order
 // statistic of the deviations is  min over L of max(|x_L - med|, |x_(L+j) - med|)  (|x - med| is convex
-// along the sorted column, so a window's largest deviation sits at one of its ends).  Windows leaving
-// [a, b) get an infinite deviation.  Every value is the exact float64 |x - med| the reference sorts.
+// along the sorted column, so a window's largest deviation sits at one of its ends).  Every value is the
+// exact float64 |x - med| the reference sorts.
+// Round 4: the minimum is FOUND, not scanned for.  With j = k1 = (n - 1) / 2 the windows start at L in [a, b - k1): their
+// left ends lie at or below the median pair, their right ends at or above it, so dl(L) = |x_L - med| never increases and
+// dr(L) = |x_(L+k1) - med| never decreases along L (x is sorted; float64 subtraction and |.| are monotone) and
+// f(L) = max(dl(L), dr(L)) has its minimum where they cross: a binary search for the first L with dr >= dl (it exists: the
+// last window ends on the column's maximum), then f at that L and the one before.  The even-count partner
+// g(L) = max(dl(L - 1), dr(L)) (the window one longer) crosses at the same L or the next.  12 + 6 LDS reads per pass for
+// 64 slots where the scan made 128, and the float64 arithmetic of 64 windows is gone (the ccdproc configuration of
+// ApMasterCal - one pass of median / mad_std - spent more than half of its time here).
 template <int NP, int B = rich_block<NP>()>
 __device__ __forceinline__ double mad_std_window(const float *col, bool active, int a, int b, double med)
 {
     const int n = b - a;
     const int k1 = n > 0 ? (n - 1) >> 1 : 0;
     const bool even = (n & 1) == 0;
-    const int bk = b - k1;                                  // L + k1 < b  <=>  L < bk
-    const float inf = __builtin_inff();
-    double m1 = __builtin_inf(), m2 = __builtin_inf();
-    double dl_prev = __builtin_inf();
-    constexpr int CH = NP >= 4 ? 4 : NP;                    // windows per trip: 2*CH LDS reads in flight
-    for (int L0 = 0; L0 < NP; L0 += CH) {
-        if (!wave_any(active && L0 + CH > a && L0 < bk)) {     // no lane has a window starting in this chunk
-            dl_prev = __builtin_inf();
-            continue;
-        }
-        float xl[CH], xr[CH];
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            xl[j] = col_read<NP, B>(col, L0 + j);
-            xr[j] = col_read<NP, B>(col, L0 + j + k1);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int L = L0 + j;
-            const double dl = fabs((double)((L >= a) ? xl[j] : inf) - med);
-            const double dr = fabs((double)((L < bk) ? xr[j] : inf) - med);
-            m1 = fmin(m1, fmax(dl, dr));                    // window [L, L + k1]
-            m2 = fmin(m2, fmax(dl_prev, dr));               // window [L - 1, L + k1]
-            dl_prev = dl;
+    const int bk = b - k1;                                  // windows start at L in [a, bk)
+    const double inf = __builtin_inf();
+    int lo = a, hi = bk - 1;                                // the crossing lies in [lo, hi]
+    for (;;) {
+        const bool open = active && lo < hi;
+        if (!wave_any(open)) break;
+        const int mid = (lo + hi) >> 1;
+        const double dl = fabs((double)col_read<NP, B>(col, mid) - med);
+        const double dr = fabs((double)col_read<NP, B>(col, mid + k1) - med);
+        if (open) {
+            if (dr >= dl) hi = mid;
+            else lo = mid + 1;
         }
     }
+    // dl at lo - 2 .. lo, dr at lo - 1 .. lo + 1; windows that leave [a, b) get an infinite deviation
+    double dl[3], dr[3];
+    float xl[3], xr[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) xl[j] = col_read<NP, B>(col, lo - 2 + j);
+#pragma unroll
+    for (int j = 0; j < 3; j++) xr[j] = col_read<NP, B>(col, lo - 1 + j + k1);
+#pragma unroll
+    for (int j = 0; j < 3; j++) dl[j] = (lo - 2 + j >= a) ? fabs((double)xl[j] - med) : inf;
+#pragma unroll
+    for (int j = 0; j < 3; j++) dr[j] = (lo - 1 + j < bk) ? fabs((double)xr[j] - med) : inf;
+    const double m1 = fmin(fmax(dl[1], dr[0]), fmax(dl[2], dr[1]));                                  // f(lo - 1), f(lo)
+    const double m2 = fmin(fmin(fmax(dl[0], dr[0]), fmax(dl[1], dr[1])), fmax(dl[2], dr[2]));       // g(lo - 1), g(lo), g(lo + 1)
     const double x1 = m1, x2 = even ? m2 : m1;
     return (0.5 * (x1 + x2)) * 1.482602218505602;
 }
@@ -356,12 +365,18 @@ __device__ __forceinline__ float uniform_elem(const float (&arr)[N], int idx)
 // Returns true (wave-uniform) when every lane of the wave completed on the fast path; a, b, cf, S, Q are then final.
 // T: tail length.  plo / phi (wave-uniform; padded stacks with split pads, stack_calibrate.h): v[0 .. plo) are -inf and
 // v[NP - phi .. NP) +inf sentinels, phi - plo in {0, 1}, both at most T - 4: the clip simply starts with them trimmed.
-template <int NP, int T = kFastTail>
+// MODE 1 (stack_fast_kernel): the result is PER LANE - whether this lane completed; lanes that did not (or whose column is
+// garbage: the kernel's bad lanes ride along) are the caller's to redo.
+// MODE 2: per lane, and phi is a PER-LANE count (<= T - 1) of +inf sentinels at the top of the column - non-finite values of
+// the stack (np.nan from a resample or an earlier calibration), sorted to the top like padding: the lane's clip starts with
+// them trimmed, its middle pair is picked per lane; the pivot of the sums stays the column's static middle (any pivot within
+// the data gives the same S and Q up to the float32 roundings the margins cover).
+template <int NP, int T = kFastTail, int MODE = 0>
 __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, float su2f, int maxiters, int &a_out, int &b_out,
                                             float &cf_out, float &S_out, float &Q_out, int plo = 0, int phi = 0)
 {
-    static_assert(NP >= 2 * T + 8 && NP % 4 == 0, "fast path needs a core");
-    const bool padded = T > kFastTail;                      // (compile time: full stacks keep every index static)
+    static_assert(NP >= 2 * T + 4 && NP % 4 == 0, "fast path needs a core");
+    const bool padded = T > kFastTail || MODE == 2;         // (compile time: full stacks keep every index static)
     const float cf = v[(NP - 1) >> 1];
     // core sums: four chains, fixed association.  S adds the deviations in mirror pairs (i, NP-1-i) of the sorted column:
     // a pair nearly cancels, so the partial sums - and with them the float32 rounding errors, which scale with the
@@ -423,13 +438,24 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
         f.b = NP - phi;
         f.Slo = uniform_elem<0, T + 1>(SL, plo);
         f.Qlo = uniform_elem<0, T + 1>(QL, plo);
-        f.Shi = uniform_elem<0, T + 1>(SH, T - phi);
-        f.Qhi = uniform_elem<0, T + 1>(QH, T - phi);
-        f.m2 = (phi > plo) ? cf : v[NP >> 1];               // an odd number of values: the middle one twice
+        if constexpr (MODE == 2) {
+            f.Shi = pick_rel<0, T + 1, T + 1>(SH, T - phi);
+            f.Qhi = pick_rel<0, T + 1, T + 1>(QH, T - phi);
+            vhi = pick_rel<NP - T, T, NP>(v, T - 1 - phi);
+        } else {
+            f.Shi = uniform_elem<0, T + 1>(SH, T - phi);
+            f.Qhi = uniform_elem<0, T + 1>(QH, T - phi);
+            f.m2 = (phi > plo) ? cf : v[NP >> 1];           // an odd number of values: the middle one twice
+            vhi = uniform_pick<NP - T, NP>(v, NP - 1 - phi);
+        }
         vlo = uniform_pick<0, NP>(v, plo);                  // (scalar compare chains: a few steps from the given start)
-        vhi = uniform_pick<NP - T, NP>(v, NP - 1 - phi);
     }
     f.m1 = cf;
+    if constexpr (MODE == 2) {
+        constexpr int LO1 = (NP - T - 1) >> 1, LO2 = (NP - T) >> 1;
+        f.m1 = pick_rel<LO1, T + 1, NP>(v, ((f.a + f.b - 1) >> 1) - LO1);
+        f.m2 = pick_rel<LO2, T + 1, NP>(v, ((f.a + f.b) >> 1) - LO2);
+    }
     // range guard on the extreme deviations (sorted column: they sit at the ends)
     const float dmax = fmaxf(cf - vlo, vhi - cf);
     f.unsure = !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
@@ -483,6 +509,7 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     cf_out = cf;
     S_out = S;
     Q_out = Q;
+    if constexpr (MODE != 0) return !f.unsure;
     return !wave_any(f.unsure);
 }
 

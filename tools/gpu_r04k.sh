@@ -1,0 +1,17 @@
+#!/bin/bash
+# round-4 measurement campaign on the final library: run through gpurun
+R=$PWD
+mkdir -p gpurun_out/r04k
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|FAILED|assert" | tail -6 > gpurun_out/r04k/pytest_gpu_tail.txt
+cat gpurun_out/r04k/pytest_gpu_tail.txt
+bash profiles/run_profile.sh r04 > /dev/null 2>&1
+bash profiles/run_profile.sh r04_c5 --workload c5 > /dev/null 2>&1
+bash profiles/run_profile.sh r04_c4 --workload c4 > /dev/null 2>&1
+bash profiles/run_profile.sh r04_c3n1 --scaling strong --gpus 1 > /dev/null 2>&1
+cd $R
+python tools/bench_kernels.py > gpurun_out/r04k/bench_kernels.txt 2>&1
+python tools/bench_f32_sizes.py > gpurun_out/r04k/bench_f32_sizes.txt 2>&1
+python tools/bench_f32_sizes.py --u16 > gpurun_out/r04k/bench_u16_sizes.txt 2>&1
+tail -4 gpurun_out/r04k/bench_f32_sizes.txt gpurun_out/r04k/bench_u16_sizes.txt
+for t in r04 r04_c5 r04_c4 r04_c3n1; do echo "== $t"; cat gpurun_out/prof_$t/bench_line.json | cut -c1-400; done
+du -sh gpurun_out
