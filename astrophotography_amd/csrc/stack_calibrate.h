@@ -138,15 +138,16 @@ __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, Fram
 // F0 / CNT: the slots F0 .. F0+CNT-1 of the column (large slot counts are loaded and calibrated in two halves so that
 // only half of the raw values sit in registers next to v[]); F0 > 0 is a real frame for every N that selects this NP.
 // MINN: slots below MINN are real frames for every N this instantiation serves (prev_slots; 0 = no such knowledge).
-template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP, int MINN = 0>
+// NSTATIC > 0: the frame count is this compile-time value (kernels instantiated per pad count): the tests below fold.
+template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP, int MINN = 0, int NSTATIC = 0>
 __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[CNT])
 {
     // Wave-uniform frame pointer (SGPR pair) + per-lane offset: one coalesced row segment per frame.
     const RawT *fb = static_cast<const RawT *>(prm.frames) + base + (int64_t)F0 * prm.stride;
     // opaque per call: the fast path and its (rare) exact fallback each load the column; sharing the NP
     // clamped address steps between the two calls would keep 2*NP SGPRs live across the calibration
-    int nframes = prm.N;
-    if constexpr (!FULL) asm volatile("" : "+s"(nframes));
+    int nframes = NSTATIC > 0 ? NSTATIC : prm.N;
+    if constexpr (!FULL && NSTATIC == 0) asm volatile("" : "+s"(nframes));
 #pragma unroll
     for (int f = 0; f < CNT; f++) {
         constexpr bool SKIP = !FULL && MINN < NP;           // padding slots are not loaded (wave-uniform test); without
@@ -312,7 +313,7 @@ struct EarlyLoads {
     bool skip;
 };
 
-template <int NP, typename RawT, bool CALIB, bool FULL, int MINN>
+template <int NP, typename RawT, bool CALIB, bool FULL, int MINN, int NSTATIC = 0>
 __device__ __forceinline__ void issue_early_loads(const StackParams &prm, int64_t base, int lane, EarlyLoads<NP, RawT> &L)
 {
     const int64_t p = base + lane;
@@ -324,7 +325,7 @@ __device__ __forceinline__ void issue_early_loads(const StackParams &prm, int64_
     }
     L.skip = prm.pixmask && prm.pixmask[p];
     __builtin_amdgcn_sched_barrier(0);
-    load_raw<NP, RawT, FULL, 0, NP, MINN>(prm, base, lane, L.raw);
+    load_raw<NP, RawT, FULL, 0, NP, MINN, NSTATIC>(prm, base, lane, L.raw);
 }
 
 // Wave vote over the staged per-frame scalars: every frame has the exposure ratio of frame 0 (a NaN ratio fails the test and
@@ -507,7 +508,14 @@ constexpr int kFastTailPadded = 8;
 // (round 4: with slot counts at every multiple of 4 up to 64 a padded stack there has at most 3 pads - one below, two above
 // the real values - so tails of 6 leave four trimmable values per side: a smaller pruned network and 8 table registers less)
 constexpr int fast_tail_padded(int np) { return np <= 64 ? 6 : kFastTailPadded; }
-constexpr bool fast32_possible_padded(int np, int minn) { return np >= 20 && np <= 96 && np % 4 == 0 && minn < np && np - minn <= 8; }
+constexpr bool fast32_possible_padded(int np, int minn) { return np >= 16 && np <= 96 && np % 4 == 0 && minn < np && np - minn <= 8; }
+
+// Slot counts of stack_fast_kernel (stack_kernels.h): the fast path ALONE fits the registers up to 128 slots - 104 .. 128 with the
+// raw column loaded in two halves - where stack_sigclip_kernel, which holds the exact path next to it, stops at 96.  Padded
+// stacks always skip their padding slots there (the lift scheme of padded_minn is the complete kernels' register budget).
+constexpr bool fast_kernel_slots(int np) { return np >= 16 && np <= 128 && np % 4 == 0; }
+constexpr int fast_kernel_minn(int np, bool full) { return full ? np : prev_slots(np); }
+constexpr int fast_kernel_tail(int np, bool full) { return full ? kFastTail : fast_tail_padded(np); }
 
 // Whether the lean reduction will try its float32 fast path (stack_reduce.h, clip_fast32) - wave-uniform, from the arguments.
 __device__ __forceinline__ bool fast32_wanted(const StackParams &prm)

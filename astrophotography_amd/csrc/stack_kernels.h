@@ -135,8 +135,9 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
 #define APGPU_FAST_MIN_BLOCKS 4
 #endif
 constexpr int kRedoSegs = 256;
-// entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles)
-__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs) * 256; }
+// entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles; one tile more for
+// the pair kernels, whose workgroups cover 512 pixels)
+__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs + 1) * 256; }
 
 // Appends the failing lanes' pixels to the list: one atomic per wavefront that has any.  kRedoSegs counters, one cache line
 // apart, each with its own stretch of the list (segment = workgroup % kRedoSegs, so a segment can never overflow its share):
@@ -156,13 +157,13 @@ __device__ __forceinline__ void redo_push(bool fail, int64_t p)
 }
 
 // clip_fast32 + the outputs of reduce_and_store's fast branch for the lanes that complete; `good` is cleared for the others.
-template <int NP, int T, bool CALIB>
+template <int NP, int T, bool CALIB, int PLO = -1, int PHI = -1>
 __device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &good, int64_t p, int plo, int phi)
 {
     LateParams *const kp = late_params();
     int a, b;
     float cf, Sf, Qf;
-    const bool done = clip_fast32<NP, T, CALIB ? 1 : 2>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf, plo, phi);
+    const bool done = clip_fast32<NP, T, CALIB ? 1 : 2, PLO, PHI>(v, (float)kp->sl2, (float)kp->su2, kp->maxiters, a, b, cf, Sf, Qf, plo, phi);
     good = good && done;
     if (good) {
         LateParams *const ko = late_params();
@@ -180,30 +181,55 @@ __device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &g
 // FULL = false (since the end of round 4): a padded stack (N between two slot counts) on the same kernel - the padding slots
 // are not loaded, the pads are split (-inf below, +inf above the real values, fast32_possible_padded) and clip_fast32's padded
 // form starts with them trimmed.
-template <int NP, typename RawT, bool CALIB, bool FULL = true>
-__global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void stack_fast_kernel(const StackParams prm)
+// PADS > 0 (slot counts up to 64, where a padded stack has 1 .. 3 pads): the pad count is a compile-time value - the loads, the
+// sentinels and the clip's starting cursors are static, nothing walks over the pads at run time (clip_fast32, PLO / PHI).
+template <int NP, typename RawT, bool CALIB, bool FULL = true, int PADS = 0>
+__global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || PADS > 0 || NP <= 96) ? 3 : 2)) void stack_fast_kernel(const StackParams prm)
 {
-    constexpr int MINN = padded_minn(NP, FULL);
-    static_assert(FULL ? fast32_possible(NP, NP) : fast32_possible_padded(NP, MINN), "the fast kernel is the float32 fast path");
+    static_assert(PADS == 0 || (!FULL && PADS <= NP - prev_slots(NP)), "static pads: a padded stack");
+    constexpr int MINN = fast_kernel_minn(NP, FULL);
+    constexpr int PLO = PADS > 0 ? (PADS >> 1) : -1, PHI = PADS > 0 ? PADS - (PADS >> 1) : -1;
+    static_assert(fast_kernel_slots(NP), "the fast kernel is the float32 fast path");
     static_assert(CALIB || sizeof(RawT) == 4, "unfused stacks: float32 frames");
     // tails: what the clip can trim per side.  Unfused stacks spend tail entries on their non-finite values (up to T - 1 per
     // column), so theirs are longer (a core of four values is enough for the sums' four chains)
-    constexpr int T = !CALIB ? (NP >= 20 ? 8 : 6) : (FULL ? kFastTail : fast_tail_padded(NP));
+    constexpr int T = !CALIB ? (NP >= 20 ? 8 : 6) : fast_kernel_tail(NP, FULL);
+    constexpr bool HALVES = CALIB && NP >= 104;             // the raw column in two halves: v[] + half of raw[] fit two wavefronts per SIMD
     const int64_t base = (int64_t)blockIdx.x * 256;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
-    const int N = FULL ? NP : prm.N;
+    const int N = FULL ? NP : (PADS > 0 ? NP - PADS : prm.N);
     const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
     bool good = false;
     if (base + 256 <= prm.P) {                              // the last, partial tile goes to the redo list whole
         float v[NP];
-        EarlyLoads<NP, RawT> L;
-        issue_early_loads<NP, RawT, CALIB, FULL, MINN>(prm, base, lane, L);
-        good = !L.skip;
         bool dodiv = false;
         int nonfin = 0;                                     // (CALIB = false) the lane's non-finite values
-        if constexpr (CALIB) {
+        if constexpr (HALVES) {
+            constexpr int HN = NP / 2, NS = PADS > 0 ? NP - PADS : 0;
+            const float b = prm.bias[p];
+            const float D = prm.still_biased ? prm.dark[p] - b : prm.dark[p];      // ApCalibrate.py:440-445
+            float nf = 1.f;
+            if (prm.nflat) {
+                nf = prm.nflat[p];
+                dodiv = (nf != 0.f);                        // ApCalibrate.py:462 (NaN != 0 is True)
+            }
+            good = !(prm.pixmask && prm.pixmask[p]);
+            __builtin_amdgcn_sched_barrier(0);
+            RawT half[HN];
+            load_raw<NP, RawT, FULL, 0, HN, MINN, NS>(prm, base, lane, half);
+            good = calibrate_fast<NP, RawT, false, 0, HN, false, MINN, false, true>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio) && good;
+            load_raw<NP, RawT, FULL, HN, HN, MINN, NS>(prm, base, lane, half);
+            good = calibrate_fast<NP, RawT, false, HN, HN, false, MINN, false, true>(fs, half, b, D, nf, dodiv, v, N, plo, prm.exp_ratio) && good;
+        }
+        EarlyLoads<NP, RawT> L;
+        if constexpr (!HALVES) {
+            issue_early_loads<NP, RawT, CALIB, FULL, MINN, (PADS > 0 ? NP - PADS : 0)>(prm, base, lane, L);
+            good = !L.skip;
+        }
+        if constexpr (HALVES) {
+        } else if constexpr (CALIB) {
             const float b = L.b;
             const float D = prm.still_biased ? L.d - b : L.d;             // ApCalibrate.py:440-445
             float nf = 1.f;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
                 for (int k = 1; k <= T; k++) nonfin += (v[NP - k] == __builtin_inff()) ? 1 : 0;
                 good = good && nonfin < T;
             }
-            if (wave_any(good)) finish_fast_column<NP, T, CALIB>(v, good, p, plo, CALIB ? phi : nonfin);
+            if (wave_any(good)) finish_fast_column<NP, T, CALIB, PLO, PHI>(v, good, p, plo, CALIB ? phi : nonfin);
         }
     }
     redo_push(!good && p < late_params()->P, p);
@@ -607,6 +633,124 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void
     reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1, pruned);
 }
 
+// -------------------------------------------------------------------------------------------------
+// The FAST kernel of the uint16 pair scheme (round 4): what stack_fast_kernel is to stack_sigclip_kernel.  Only the common
+// path of stack_sigclip_u16_pairs_kernel - packed sort of two raw columns (pruned to what the clip reads), one column parked in
+// LDS, packed calibration with one scalar-load exposure ratio, range guards off the ends of the sorted column, clip_fast32 per
+// lane, outputs; no staging pass, no barrier, no exact calibration, no second sort, no float64 clip: four wavefronts per SIMD
+// without spills where the complete kernel holds three with 2-8 spilled registers.  A workgroup whose frames do not share one
+// exposure ratio (wave-uniform scalar test), the image's last partial workgroup, and every pixel that cannot finish here
+// (non-finite or non-positive masters, a guard, a masked pixel, an unsure comparison, a fifth value to trim) go to the redo list
+// - stack_redo_kernel<NP, uint16_t, CALIB, FULL>, the one-pixel-per-lane path, redoes them exactly.
+// -------------------------------------------------------------------------------------------------
+template <int NP, bool CALIB, bool FULL, int T, int MINN, int PLO = -1, int PHI = -1>
+__device__ __forceinline__ bool fast_raw_column(const FrameScalars<NP> &fs, const uint32_t (&cur)[NP / 2], float b, float D, float nf,
+                                                bool dv, bool masked, const float *eg, int64_t p, int N, int plo, int phi)
+{
+    float v[NP];
+    bool good = !masked;
+    {
+        float rawf[NP];
+#pragma unroll
+        for (int k = 0; k < NP / 2; k++) {
+            rawf[2 * k] = (float)(cur[k] & 0xffffu);
+            rawf[2 * k + 1] = (float)(cur[k] >> 16);
+        }
+        if constexpr (CALIB) {
+            // non-decreasing map (finite masters, a positive or unused flat): the calibrated column is sorted like the raw one
+            const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
+            good = calibrate_fast<NP, float, false, 0, NP, false, NP, true, true>(fs, rawf, b, D, nf, dv, v, NP, 0, eg) && increasing && good;
+        } else {
+#pragma unroll
+            for (int f = 0; f < NP; f++) v[f] = rawf[f];
+        }
+    }
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            if (i < NP - MINN && i < plo) v[i] = -__builtin_inff();                  // (wave-uniform tests, the end slots only)
+            if (i >= MINN && i >= NP - phi) v[i] = __builtin_inff();
+        }
+    }
+    if constexpr (CALIB) good = good && range_ok_sorted<NP, (MINN < NP ? MINN : 0)>(v, dv, N, plo);
+    if (wave_any(good)) finish_fast_column<NP, T, true, PLO, PHI>(v, good, p, plo, phi);
+    return good;
+}
+
+template <int NP, bool CALIB, bool FULL, int PADS = 0>
+__global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void stack_fast_u16_pairs_kernel(const StackParams prm)
+{
+    static_assert(PADS == 0 || (!FULL && PADS <= NP - padded_minn(NP, false)), "static pads: a padded stack");
+    constexpr int MINN = padded_minn(NP, FULL);
+    constexpr int PLO = PADS > 0 ? (PADS >> 1) : -1, PHI = PADS > 0 ? PADS - (PADS >> 1) : -1;
+    static_assert(FULL ? fast32_possible(NP, NP) : fast32_possible_padded(NP, MINN), "the fast kernel is the float32 fast path");
+    constexpr int T = FULL ? kFastTail : fast_tail_padded(NP);
+    constexpr int HP = NP / 2;
+    __shared__ uint32_t parked[HP][256];
+    __shared__ FrameScalars<NP> fs;                         // (never touched: one exposure ratio, read by a scalar load)
+    const int lane = threadIdx.x;
+    const int N = FULL ? NP : (PADS > 0 ? NP - PADS : prm.N);
+    const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
+    const int64_t p2 = ((int64_t)blockIdx.x * 256 + lane) * 2;         // this lane's pixel pair (P is even here)
+    bool good0 = false, good1 = false;
+    bool tile_ok = ((int64_t)blockIdx.x + 1) * 512 <= prm.P;
+    if constexpr (CALIB) tile_ok = tile_ok && ratios_uniform<NP>(prm.exp_ratio, N);
+    if (tile_ok) {
+        float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
+        bool dodiv[2] = {false, false};
+        bool skip[2] = {false, false};
+        if constexpr (CALIB) {                              // masters first: the calibration's first instruction needs them
+            const float2 b2 = *reinterpret_cast<const float2 *>(prm.bias + p2);
+            const float2 d2 = *reinterpret_cast<const float2 *>(prm.dark + p2);
+            bb[0] = b2.x; bb[1] = b2.y;
+            dd[0] = prm.still_biased ? d2.x - b2.x : d2.x;  // ApCalibrate.py:440-445
+            dd[1] = prm.still_biased ? d2.y - b2.y : d2.y;
+            if (prm.nflat) {
+                const float2 n2 = *reinterpret_cast<const float2 *>(prm.nflat + p2);
+                nn[0] = n2.x; nn[1] = n2.y;
+                dodiv[0] = n2.x != 0.f;                     // ApCalibrate.py:462 (NaN != 0 is True)
+                dodiv[1] = n2.y != 0.f;
+            }
+        }
+        if (prm.pixmask) {
+            skip[0] = prm.pixmask[p2] != 0;
+            skip[1] = prm.pixmask[p2 + 1] != 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t w[NP];
+        {
+            const uint32_t *fp = reinterpret_cast<const uint32_t *>(static_cast<const uint16_t *>(prm.frames) + (int64_t)blockIdx.x * 512);
+            const int64_t step = prm.stride / 2;
+            int nframes = N;
+            if constexpr (!FULL && PADS == 0) asm volatile("" : "+s"(nframes));  // see load_raw
+#pragma unroll
+            for (int f = 0; f < NP; f++) {
+                if (FULL || f < MINN || f < nframes) w[f] = fp[lane];
+                else w[f] = (f < nframes + plo) ? 0u : 0xffffffffu;    // split pads: the first plo below, the others above the data
+                if (FULL || f + 1 < MINN || f + 1 < nframes) fp += step;
+                if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        pruned_net_pk16<NP, T>(w);
+        // re-pack: the first pixel's column stays in registers, the second one's is parked in LDS meanwhile
+        uint32_t cur[HP];
+#pragma unroll
+        for (int k = 0; k < HP; k++) {
+            cur[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16);
+            parked[k][lane] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u);
+        }
+        good0 = fast_raw_column<NP, CALIB, FULL, T, MINN, PLO, PHI>(fs, cur, bb[0], dd[0], nn[0], dodiv[0], skip[0], prm.exp_ratio, p2, N, plo, phi);
+        int slot = lane;
+        asm volatile("" : "+v"(slot) : : "memory");         // opaque index: no store-to-load forwarding in registers
+#pragma unroll
+        for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
+        good1 = fast_raw_column<NP, CALIB, FULL, T, MINN, PLO, PHI>(fs, cur, bb[1], dd[1], nn[1], dodiv[1], skip[1], prm.exp_ratio, p2 + 1, N, plo, phi);
+    }
+    const int64_t P = late_params()->P;
+    redo_push(!good0 && p2 < P, p2);
+    redo_push(!good1 && p2 + 1 < P, p2 + 1);
+}
+
 // Whether a call takes stack_fast_kernel + stack_redo_kernel (host side; the same conditions as fast32_wanted, plus: lean
 // outputs, no pedestals, pixel indices that fit the list's int32 entries).
 inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool rich, bool plus)
@@ -636,8 +780,9 @@ inline void keep_pool_memory()
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
 }
 
-template <int NP, typename RawT, bool CALIB, bool FULL>
-int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
+// fast(prm) launches the fast kernel, redo(prm, workgroups) the kernel that walks the list.
+template <typename FastLaunch, typename RedoLaunch>
+int launch_with_redo(const StackParams &prm0, hipStream_t st, FastLaunch fast, RedoLaunch redo_launch)
 {
     // redo list: kRedoSegs counters (64 bytes apart) + kRedoSegs segments of entries, a stream-ordered temporary
     const int64_t ntiles = (prm0.P + 255) / 256;
@@ -653,7 +798,7 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
     }
     StackParams prm = prm0;
     prm.redo = redo;
-    hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL>), grid, dim3(256), 0, st, prm);
+    fast(prm);
     int rc = check_launch("stack kernel (fast)");
     if (rc == APGPU_OK) {
         prm.fast32 = 0;                                     // the list is redone by the exact clip
@@ -661,7 +806,7 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
         // their segment's count leave at once
         int64_t per_seg = ntiles / (kRedoSegs * 8);
         per_seg = per_seg < 1 ? 1 : (per_seg > 16 ? 16 : per_seg);
-        hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL>), dim3((unsigned)(kRedoSegs * per_seg)), dim3(256), 0, st, prm);
+        redo_launch(prm, (unsigned)(kRedoSegs * per_seg));
         rc = check_launch("stack kernel (redo list)");
     }
 #ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
@@ -677,6 +822,22 @@ int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
     const hipError_t ef = hipFreeAsync(redo, st);
     if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): free: %s", hipGetErrorString(ef));
     return rc;
+}
+
+template <int NP, typename RawT, bool CALIB, bool FULL, int D = 0>
+int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
+{
+    return launch_with_redo(
+        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL, D>), grid, dim3(256), 0, st, q); },
+        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL>), dim3(wgs), dim3(256), 0, st, q); });
+}
+
+template <int NP, bool CALIB, bool FULL, int D = 0>
+int launch_fast_u16_pairs(const StackParams &prm0, dim3 grid, hipStream_t st)
+{
+    return launch_with_redo(
+        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_u16_pairs_kernel<NP, CALIB, FULL, D>), grid, dim3(256), 0, st, q); },
+        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, uint16_t, CALIB, FULL>), dim3(wgs), dim3(256), 0, st, q); });
 }
 
 // `describe` != nullptr: write the name of the kernel variant this call would launch (as rocprofv3 prints it, without
@@ -705,9 +866,22 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         if (kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+            // the fast kernel of the pair scheme + redo list (stack_fast_u16_pairs_kernel)
+            constexpr bool kFastPairsFull = NP <= 64 && fast32_possible(NP, NP);
+            constexpr bool kFastPairsPadded = NP <= 64 && fast32_possible_padded(NP, padded_minn(NP, false));
+            const bool fastp = (prm.N == NP ? kFastPairsFull : kFastPairsPadded) && fast_kernel_eligible(prm, false, false, false);
             if (describe) {
-                snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
+                if (fastp) snprintf(describe, 256, "stack_fast_u16_pairs_kernel<%d, %s, %s, %d>", NP, tf[CALIB], tf[prm.N == NP], NP - prm.N);
+                else snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
                 return APGPU_OK;
+            }
+            if constexpr (kFastPairsFull) {
+                if (fastp && prm.N == NP) return launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
+            }
+            if constexpr (kFastPairsPadded) {                // (slot counts up to 64: 1 .. 3 pads, one instantiation each)
+                if (fastp && prm.N == NP - 1) return launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP - 2) return launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP - 3) return launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
             }
             if constexpr (kPairsFit) {
                 if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
@@ -744,22 +918,32 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     // the fast kernel + redo list (see stack_fast_kernel): float32 stacks on the float32 fast path, lean outputs, no pedestals
-    constexpr bool kFastFull = sizeof(RawT) == 4 && fast32_possible(NP, NP);
-    constexpr bool kFastPadded = sizeof(RawT) == 4 && fast32_possible_padded(NP, padded_minn(NP, false));
-    const bool fastk = (full ? kFastFull : kFastPadded) && fast_kernel_eligible(prm, median_only, rich, plus);
+    constexpr bool kFastSlots = sizeof(RawT) == 4 && fast_kernel_slots(NP);
+    constexpr int kMaxPads = NP - prev_slots(NP) - 1;                // (the next smaller slot count serves fewer frames)
+    constexpr bool kStaticPads = true;                      // one instantiation per pad count (run-time pads: 225 VGPRs at 128 slots)
+    const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus);
     if (describe) {
-        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
+        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d>", NP, rawname, tf[CALIB], tf[full], kStaticPads ? NP - prm.N : 0);
         else if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
         else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
         else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
         return APGPU_OK;
     }
     const dim3 g((unsigned)grid), b(block);
-    if constexpr (kFastFull) {
+    if constexpr (kFastSlots) {
         if (fastk && full) return launch_fast<NP, RawT, CALIB, true>(prm, g, st);
-    }
-    if constexpr (kFastPadded) {
-        if (fastk && !full) return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
+        if constexpr (kStaticPads) {
+            const int pads = NP - prm.N;
+            if constexpr (kMaxPads >= 1) if (fastk && pads == 1) return launch_fast<NP, RawT, CALIB, false, 1>(prm, g, st);
+            if constexpr (kMaxPads >= 2) if (fastk && pads == 2) return launch_fast<NP, RawT, CALIB, false, 2>(prm, g, st);
+            if constexpr (kMaxPads >= 3) if (fastk && pads == 3) return launch_fast<NP, RawT, CALIB, false, 3>(prm, g, st);
+            if constexpr (kMaxPads >= 4) if (fastk && pads == 4) return launch_fast<NP, RawT, CALIB, false, 4>(prm, g, st);
+            if constexpr (kMaxPads >= 5) if (fastk && pads == 5) return launch_fast<NP, RawT, CALIB, false, 5>(prm, g, st);
+            if constexpr (kMaxPads >= 6) if (fastk && pads == 6) return launch_fast<NP, RawT, CALIB, false, 6>(prm, g, st);
+            if constexpr (kMaxPads >= 7) if (fastk && pads == 7) return launch_fast<NP, RawT, CALIB, false, 7>(prm, g, st);
+        } else if constexpr (kMaxPads > 0) {
+            if (fastk && !full) return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
+        }
     }
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);

@@ -371,10 +371,15 @@ __device__ __forceinline__ float uniform_elem(const float (&arr)[N], int idx)
 // the stack (np.nan from a resample or an earlier calibration), sorted to the top like padding: the lane's clip starts with
 // them trimmed, its middle pair is picked per lane; the pivot of the sums stays the column's static middle (any pivot within
 // the data gives the same S and Q up to the float32 roundings the margins cover).
-template <int NP, int T = kFastTail, int MODE = 0>
+// PLO / PHI >= 0 (static pads: the kernels instantiated per pad count, slot counts up to 64): plo / phi (the wave-uniform
+// part of phi in MODE 2) are these compile-time values - the trim chains start BEHIND the pads instead of walking over them
+// in every pass (13 instructions per pad and pass: the "holes" between the slot counts of small stacks).
+template <int NP, int T = kFastTail, int MODE = 0, int PLO = -1, int PHI = -1>
 __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, float su2f, int maxiters, int &a_out, int &b_out,
                                             float &cf_out, float &S_out, float &Q_out, int plo = 0, int phi = 0)
 {
+    if constexpr (PLO >= 0) plo = PLO;
+    if constexpr (PHI >= 0 && MODE != 2) phi = PHI;
     static_assert(NP >= 2 * T + 4 && NP % 4 == 0, "fast path needs a core");
     const bool padded = T > kFastTail || MODE == 2;         // (compile time: full stacks keep every index static)
     const float cf = v[(NP - 1) >> 1];
@@ -475,13 +480,13 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
         const float tl = sl4 * V;
         f.tl_hi = __builtin_fmaf(tl, rho, tl);
         f.tl_lo = __builtin_fmaf(tl, -rho, tl);
-        trim_low_fast<0, NP, T>(v, f, SL, QL);
+        trim_low_fast<(PLO > 0 ? PLO : 0), NP, T>(v, f, SL, QL);
         // (one sigma for both sides would make these the lower thresholds again - 3 instructions per pass less behind a
         // wave-uniform branch, but the second copy of the chain costs 3 VGPRs: 170, over the three-wavefront budget)
         const float th = su4 * V;
         f.th_hi = __builtin_fmaf(th, rho, th);
         f.th_lo = __builtin_fmaf(th, -rho, th);
-        trim_high_fast<T, NP, T>(v, f, SH, QH, f.th_hi, f.th_lo);
+        trim_high_fast<(PHI > 0 ? T - PHI : T), NP, T>(v, f, SH, QH, f.th_hi, f.th_lo);
         it++;
         const bool changed = (f.a != a0) || (f.b != b0);
         if (!(wave_any(changed) && (max_passes < 0 || it < max_passes))) break;

@@ -738,7 +738,7 @@ def test_fast32_path_guards_on_adversarial_columns(ops, apref):
     counts must be identical everywhere, means within 1 ulp."""
     rng = np.random.default_rng(2025)
     H, W = 16, 256
-    for N in (16, 30, 32, 37, 52, 58, 64, 75, 96, 160, 256):                          # 30, 37, 52, 58, 75: padded stacks (split pads, tails of 8)
+    for N in (13, 16, 30, 32, 37, 52, 58, 64, 75, 96, 100, 119, 128, 160, 256):       # 13, 30, 37, 52, 58, 75, 100, 119: padded stacks (split pads)
         cols = []
         base = rng.normal(0.0, 1.0, (N, H, W))
         level = np.array([0.0, 1e-3, 1.0, 50.0, 500.0, 5e4, -300.0, 1e-20])[rng.integers(0, 8, (H, W))]
@@ -781,7 +781,7 @@ def test_unfused_stacks_with_nonfinite_values(ops, apref):
     survivor counts, means within 1 ulp; full and padded slot counts, a pixel mask, a partial last tile, signalling NaNs."""
     rng = np.random.default_rng(4242)
     H, W = 37, 211                                           # 7807 pixels: 30 full tiles + a partial one
-    for N in (16, 18, 22, 32, 47, 61, 64, 96):
+    for N in (14, 16, 18, 22, 32, 47, 61, 64, 77, 96, 109, 128):
         cube = synth_cube(rng, N, (H, W))
         # NaN blocks that drift from frame to frame, like the footprints of bad pixels under per-frame shifts
         ys, xs = rng.integers(0, H - 6, 40), rng.integers(0, W - 6, 40)

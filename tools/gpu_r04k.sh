@@ -12,6 +12,11 @@ cd $R
 python tools/bench_kernels.py > gpurun_out/r04k/bench_kernels.txt 2>&1
 python tools/bench_f32_sizes.py > gpurun_out/r04k/bench_f32_sizes.txt 2>&1
 python tools/bench_f32_sizes.py --u16 > gpurun_out/r04k/bench_u16_sizes.txt 2>&1
-tail -4 gpurun_out/r04k/bench_f32_sizes.txt gpurun_out/r04k/bench_u16_sizes.txt
-for t in r04 r04_c5 r04_c4 r04_c3n1; do echo "== $t"; cat gpurun_out/prof_$t/bench_line.json | cut -c1-400; done
-du -sh gpurun_out
+python tools/bench_u16_64.py 2>&1 | tail -2
+tail -1 gpurun_out/r04k/bench_f32_sizes.txt gpurun_out/r04k/bench_u16_sizes.txt
+grep -- "<--" gpurun_out/r04k/bench_f32_sizes.txt | cut -c1-12,100-140 | tr '\n' ';'
+echo
+grep -- "<--" gpurun_out/r04k/bench_u16_sizes.txt | cut -c1-12,100-140 | tr '\n' ';'
+echo
+for t in r04 r04_c5 r04_c4 r04_c3n1; do echo "== $t"; cat gpurun_out/prof_$t/bench_line.json | cut -c1-300; done
+head -30 gpurun_out/r04k/bench_kernels.txt | cut -c1-120
