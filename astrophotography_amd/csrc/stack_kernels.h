@@ -237,6 +237,8 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
                 nf = L.nf;
                 dodiv = (nf != 0.f);                        // ApCalibrate.py:462 (NaN != 0 is True)
             }
+            // (measured again on this kernel: a second calibration body for "one exposure ratio", e * D formed once per pixel,
+            // -32 instructions - the two bodies' v[] meet in one register set: 128 VGPRs + 36 spilled; not built)
             good = calibrate_fast<NP, RawT, false, 0, NP, false, MINN, false, true>(fs, L.raw, b, D, nf, dodiv, v, N, plo, prm.exp_ratio) && good;
         } else {
             // non-finite values (astropy masks them) become +inf sentinels; padding slots: the first plo -inf, the others +inf
@@ -863,7 +865,11 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         // register budget: two sorted columns + a calibrated one fit two wavefronts per SIMD up to 96 slots (and 112 full
         // slots); beyond that the one-pixel-per-lane kernel with half-column loads is the faster one
         constexpr bool kPairsFit = NP <= 112;
-        if (kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
+        // beyond 64 slots a PADDED uint16 stack - and any of 120 / 128 slots - is fastest one pixel per lane on the fast kernel
+        // (static pads, half-column loads; measured: N = 89 .. 95 as pairs 2.6-2.9 ms against 1.4-1.5 for float32 frames there)
+        const bool wide_fast = CALIB && NP > 64 && fast_kernel_slots(NP) && (prm.N != NP || NP > 112) &&
+                               fast_kernel_eligible(prm, median_only, rich_out, false);
+        if (!wide_fast && kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
             // the fast kernel of the pair scheme + redo list (stack_fast_u16_pairs_kernel)
@@ -918,10 +924,12 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     // the fast kernel + redo list (see stack_fast_kernel): float32 stacks on the float32 fast path, lean outputs, no pedestals
-    constexpr bool kFastSlots = sizeof(RawT) == 4 && fast_kernel_slots(NP);
+    // (uint16 frames: only the cases of `wide_fast` above - everything else went to the pair kernels)
+    constexpr bool kFastSlots = (sizeof(RawT) == 4 || (CALIB && NP > 64)) && fast_kernel_slots(NP);
     constexpr int kMaxPads = NP - prev_slots(NP) - 1;                // (the next smaller slot count serves fewer frames)
     constexpr bool kStaticPads = true;                      // one instantiation per pad count (run-time pads: 225 VGPRs at 128 slots)
-    const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus);
+    const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus) &&
+                       (sizeof(RawT) == 4 || !full || NP > 112);
     if (describe) {
         if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d>", NP, rawname, tf[CALIB], tf[full], kStaticPads ? NP - prm.N : 0);
         else if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 measurement campaign on the final library: run through gpurun
+# measurement campaign of a round on the final library (full GPU suite, the four profiles, kernel table, size sweeps): run through gpurun
 R=$PWD
 mkdir -p gpurun_out/r04k
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|FAILED|assert" | tail -6 > gpurun_out/r04k/pytest_gpu_tail.txt
