@@ -157,7 +157,13 @@ __device__ __forceinline__ void redo_push(bool fail, int64_t p)
 }
 
 // clip_fast32 + the outputs of reduce_and_store's fast branch for the lanes that complete; `good` is cleared for the others.
-template <int NP, int T, bool CALIB, int PLO = -1, int PHI = -1>
+// PLUS: the median and std planes of the final survivors as well (the three planes of sigma_clipped_stats(axis = 0)).  The
+// median: the middle pair of [a, b), inside the window the pruned network delivers.  The std: numpy's two-pass definition,
+// sqrt(sum((x - mean)^2) / n) in float64 - with the mean taken from the fast path's own sum, c + S / n (off the exact mean by
+// at most ~1e-6 of the column's rms: |dS| <= 19u sqrt(n Q), clip_fast32's budget - a relative 1e-12 on the variance), so only
+// ONE float64 pass remains (3 instructions per value where the complete kernel's two passes take 7); identical survivors have
+// S = 0 exactly and give exactly 0.
+template <int NP, int T, bool CALIB, int PLO = -1, int PHI = -1, bool PLUS = false>
 __device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &good, int64_t p, int plo, int phi)
 {
     LateParams *const kp = late_params();
@@ -176,6 +182,37 @@ __device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &g
         if (ko->count) ko->count[p] = cnt;
         if (ko->moments) store_moments(ko->moments, ko->moments64, ko->P, p, cnt, (double)cf, (double)Sf, (double)Qf);
     }
+    if constexpr (PLUS) {
+        if (wave_any(good)) {
+            LateParams *const ko = late_params();
+            if (ko->median) {
+                constexpr int LO1 = (NP - T - 1) >> 1, LO2 = (NP - T) >> 1;
+                const float m1 = pick_rel<LO1, T + 1, NP>(v, ((a + b - 1) >> 1) - LO1);
+                const float m2 = pick_rel<LO2, T + 1, NP>(v, ((a + b) >> 1) - LO2);
+                if (good) ko->median[p] = (float)(((double)m1 + (double)m2) / 2.0);
+            }
+            if (ko->std) {
+                const float nf32 = (float)(b - a);
+                const float y = __builtin_amdgcn_rcpf(nf32);
+                const float q0 = Sf * y;
+                const double mean64 = (double)cf + (double)__builtin_fmaf(__builtin_fmaf(-nf32, q0, Sf), y, q0);
+                // (a wave-uniform test per slot keeps the pass as NP short blocks: as one straight-line block the register
+                // allocator keeps every converted value alive)
+                int nslots = NP;
+                asm volatile("" : "+s"(nslots));
+                double q1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    if (i >= nslots) continue;
+                    const double dd = widen(v[i]) - mean64;
+                    const bool in = (i >= T && i < NP - T) || ((i >= a) && (i < b));     // the core always survives
+                    const double d = in ? dd : 0.0;
+                    q1 = fma(d, d, q1);
+                }
+                if (good) ko->std[p] = (float)sqrt(q1 > 0.0 ? q1 / (double)(b - a) : 0.0);
+            }
+        }
+    }
 }
 
 // FULL = false (since the end of round 4): a padded stack (N between two slot counts) on the same kernel - the padding slots
@@ -183,7 +220,7 @@ __device__ __forceinline__ void finish_fast_column(const float (&v)[NP], bool &g
 // form starts with them trimmed.
 // PADS > 0 (slot counts up to 64, where a padded stack has 1 .. 3 pads): the pad count is a compile-time value - the loads, the
 // sentinels and the clip's starting cursors are static, nothing walks over the pads at run time (clip_fast32, PLO / PHI).
-template <int NP, typename RawT, bool CALIB, bool FULL = true, int PADS = 0>
+template <int NP, typename RawT, bool CALIB, bool FULL = true, int PADS = 0, bool PLUS = false>
 __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || PADS > 0 || NP <= 96) ? 3 : 2)) void stack_fast_kernel(const StackParams prm)
 {
     static_assert(PADS == 0 || (!FULL && PADS <= NP - prev_slots(NP)), "static pads: a padded stack");
@@ -261,7 +298,7 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
                 for (int k = 1; k <= T; k++) nonfin += (v[NP - k] == __builtin_inff()) ? 1 : 0;
                 good = good && nonfin < T;
             }
-            if (wave_any(good)) finish_fast_column<NP, T, CALIB, PLO, PHI>(v, good, p, plo, CALIB ? phi : nonfin);
+            if (wave_any(good)) finish_fast_column<NP, T, CALIB, PLO, PHI, PLUS>(v, good, p, plo, CALIB ? phi : nonfin);
         }
     }
     redo_push(!good && p < late_params()->P, p);
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
 
 // The pixels stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, FULL> does for a
 // pixel), one list entry per lane, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
-template <int NP, typename RawT, bool CALIB, bool FULL = true>
+template <int NP, typename RawT, bool CALIB, bool FULL = true, bool PLUS = false>
 __global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
 {
     constexpr int MINN = padded_minn(NP, FULL);
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
             // (prm.fast32 is 0: no split pads - pad_low is 0 -, the complete network, the float64 clip; a gather: base 0, the
             // lane's own pixel as the offset)
             const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, 0, pix, v);
-            reduce_and_store<NP, MINN, false>(prm, v, n, (int64_t)pix);
+            reduce_and_store<NP, MINN, PLUS>(prm, v, n, (int64_t)pix);
         }
     }
 }
@@ -782,7 +819,9 @@ inline void keep_pool_memory()
     (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
 }
 
-// fast(prm) launches the fast kernel, redo(prm, workgroups) the kernel that walks the list.
+// fast(prm) launches the fast kernel, redo(prm, workgroups) the kernel that walks the list.  Returns kNoRedoList (> 0, nothing
+// launched) when the list cannot be allocated: the caller goes on to the complete kernels.
+constexpr int kNoRedoList = 1;
 template <typename FastLaunch, typename RedoLaunch>
 int launch_with_redo(const StackParams &prm0, hipStream_t st, FastLaunch fast, RedoLaunch redo_launch)
 {
@@ -792,7 +831,10 @@ int launch_with_redo(const StackParams &prm0, hipStream_t st, FastLaunch fast, R
     keep_pool_memory();
     int32_t *redo = nullptr;
     hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), words * sizeof(int32_t), st);
-    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): cannot allocate the redo list: %s", hipGetErrorString(e));
+    if (e != hipSuccess) {                                  // no room for the list (4 bytes per pixel): the complete kernel needs none
+        (void)hipGetLastError();
+        return kNoRedoList;
+    }
     e = hipMemsetAsync(redo, 0, (size_t)kRedoSegs * 16 * sizeof(int32_t), st);
     if (e != hipSuccess) {
         (void)hipFreeAsync(redo, st);
@@ -826,12 +868,12 @@ int launch_with_redo(const StackParams &prm0, hipStream_t st, FastLaunch fast, R
     return rc;
 }
 
-template <int NP, typename RawT, bool CALIB, bool FULL, int D = 0>
+template <int NP, typename RawT, bool CALIB, bool FULL, int D = 0, bool PLUS = false>
 int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
 {
     return launch_with_redo(
-        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL, D>), grid, dim3(256), 0, st, q); },
-        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL>), dim3(wgs), dim3(256), 0, st, q); });
+        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL, D, PLUS>), grid, dim3(256), 0, st, q); },
+        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL, PLUS>), dim3(wgs), dim3(256), 0, st, q); });
 }
 
 template <int NP, bool CALIB, bool FULL, int D = 0>
@@ -881,14 +923,16 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
                 else snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
                 return APGPU_OK;
             }
+            int frc = kNoRedoList;
             if constexpr (kFastPairsFull) {
-                if (fastp && prm.N == NP) return launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP) frc = launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
             }
             if constexpr (kFastPairsPadded) {                // (slot counts up to 64: 1 .. 3 pads, one instantiation each)
-                if (fastp && prm.N == NP - 1) return launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
-                if (fastp && prm.N == NP - 2) return launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
-                if (fastp && prm.N == NP - 3) return launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP - 1) frc = launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP - 2) frc = launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
+                if (fastp && prm.N == NP - 3) frc = launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
             }
+            if (frc != kNoRedoList) return frc;
             if constexpr (kPairsFit) {
                 if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
                 else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
@@ -927,11 +971,13 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     // (uint16 frames: only the cases of `wide_fast` above - everything else went to the pair kernels)
     constexpr bool kFastSlots = (sizeof(RawT) == 4 || (CALIB && NP > 64)) && fast_kernel_slots(NP);
     constexpr int kMaxPads = NP - prev_slots(NP) - 1;                // (the next smaller slot count serves fewer frames)
-    constexpr bool kStaticPads = true;                      // one instantiation per pad count (run-time pads: 225 VGPRs at 128 slots)
-    const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus) &&
+    constexpr bool kStaticPads = true;                      // (one instantiation per pad count; with run-time pads: 225 VGPRs at 128 slots)
+    // mean + median + std planes (PLUS): full float32 stacks up to 96 slots have their fast kernel too
+    const bool fastplus = plus && full && sizeof(RawT) == 4 && NP <= 96;
+    const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus && !fastplus) &&
                        (sizeof(RawT) == 4 || !full || NP > 112);
     if (describe) {
-        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d>", NP, rawname, tf[CALIB], tf[full], kStaticPads ? NP - prm.N : 0);
+        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d, %s>", NP, rawname, tf[CALIB], tf[full], kStaticPads ? NP - prm.N : 0, tf[fastplus]);
         else if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
         else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
         else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
@@ -939,19 +985,20 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     }
     const dim3 g((unsigned)grid), b(block);
     if constexpr (kFastSlots) {
-        if (fastk && full) return launch_fast<NP, RawT, CALIB, true>(prm, g, st);
-        if constexpr (kStaticPads) {
-            const int pads = NP - prm.N;
-            if constexpr (kMaxPads >= 1) if (fastk && pads == 1) return launch_fast<NP, RawT, CALIB, false, 1>(prm, g, st);
-            if constexpr (kMaxPads >= 2) if (fastk && pads == 2) return launch_fast<NP, RawT, CALIB, false, 2>(prm, g, st);
-            if constexpr (kMaxPads >= 3) if (fastk && pads == 3) return launch_fast<NP, RawT, CALIB, false, 3>(prm, g, st);
-            if constexpr (kMaxPads >= 4) if (fastk && pads == 4) return launch_fast<NP, RawT, CALIB, false, 4>(prm, g, st);
-            if constexpr (kMaxPads >= 5) if (fastk && pads == 5) return launch_fast<NP, RawT, CALIB, false, 5>(prm, g, st);
-            if constexpr (kMaxPads >= 6) if (fastk && pads == 6) return launch_fast<NP, RawT, CALIB, false, 6>(prm, g, st);
-            if constexpr (kMaxPads >= 7) if (fastk && pads == 7) return launch_fast<NP, RawT, CALIB, false, 7>(prm, g, st);
-        } else if constexpr (kMaxPads > 0) {
-            if (fastk && !full) return launch_fast<NP, RawT, CALIB, false>(prm, g, st);
+        int frc = kNoRedoList;
+        const int pads = NP - prm.N;
+        if constexpr (sizeof(RawT) == 4 && NP <= 96) {
+            if (fastk && fastplus) frc = launch_fast<NP, RawT, CALIB, true, 0, true>(prm, g, st);
         }
+        if (fastk && full && !fastplus) frc = launch_fast<NP, RawT, CALIB, true>(prm, g, st);
+        if constexpr (kMaxPads >= 1) if (fastk && pads == 1) frc = launch_fast<NP, RawT, CALIB, false, 1>(prm, g, st);
+        if constexpr (kMaxPads >= 2) if (fastk && pads == 2) frc = launch_fast<NP, RawT, CALIB, false, 2>(prm, g, st);
+        if constexpr (kMaxPads >= 3) if (fastk && pads == 3) frc = launch_fast<NP, RawT, CALIB, false, 3>(prm, g, st);
+        if constexpr (kMaxPads >= 4) if (fastk && pads == 4) frc = launch_fast<NP, RawT, CALIB, false, 4>(prm, g, st);
+        if constexpr (kMaxPads >= 5) if (fastk && pads == 5) frc = launch_fast<NP, RawT, CALIB, false, 5>(prm, g, st);
+        if constexpr (kMaxPads >= 6) if (fastk && pads == 6) frc = launch_fast<NP, RawT, CALIB, false, 6>(prm, g, st);
+        if constexpr (kMaxPads >= 7) if (fastk && pads == 7) frc = launch_fast<NP, RawT, CALIB, false, 7>(prm, g, st);
+        if (frc != kNoRedoList) return frc;
     }
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);

@@ -31,7 +31,7 @@ def test_default_workload_line():
     rf = d['roofline']
     assert rf['bound'] == 'hbm' and rf['unit'] == 'GB/s' and rf['peak'] == 8000.0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     assert rf['algorithmic_bytes'] == 4 * 16 * 256 * 512 + 16 * 256 * 512 and rf['avg_launch_ms'] > 0
-    assert rf['kernel'] == 'stack_fast_kernel<16, float, true, true, 0>'      # reported by the library's dispatch (the fast kernel + redo list)
+    assert rf['kernel'] == 'stack_fast_kernel<16, float, true, true, 0, false>'      # reported by the library's dispatch (the fast kernel + redo list)
     assert d['rccl_world_size'] == 1 and len(d['per_rank_ms']) == 1
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0 and 'sample' in cb

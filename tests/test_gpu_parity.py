@@ -771,6 +771,13 @@ def test_fast32_path_guards_on_adversarial_columns(ops, apref):
             assert np.array_equal(host(exact['count']), ref['count']), what
             assert_ulp(host(exact['mean']), ref['mean'].astype(np.float32), 1, what + ' float64 path')
             assert_ulp(host(fast['mean']), ref['mean'].astype(np.float32), 1, what + ' float32 fast path')
+            if N <= 96:
+                # the three planes of sigma_clipped_stats on the fast kernel (PLUS): one float64 pass about the fast path's mean
+                plus = ops.stack_sigclip(d, sigma=sigma, maxiters=maxiters, outputs=('mean', 'median', 'std', 'count'))
+                assert np.array_equal(host(plus['count']), ref['count']), what
+                assert_ulp(host(plus['mean']), ref['mean'].astype(np.float32), 1, what + ' planes: mean')
+                assert_ulp(host(plus['median']), ref['median'].astype(np.float32), 1, what + ' planes: median')
+                assert_ulp(host(plus['std']), ref['std'].astype(np.float32), 2, what + ' planes: std')
 
 
 def test_unfused_stacks_with_nonfinite_values(ops, apref):

@@ -453,3 +453,61 @@ def test_sort_networks_pass_the_zero_one_principle(tmp_path):
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and 'ALL OK' in r.stdout, r.stdout[-3000:]
     assert 'NP  64 T 4:  750 instructions' in r.stdout          # the headline kernel's network (890 with sort4 + Batcher)
+
+
+def test_mad_window_crossing_equals_scan():
+    """stack_reduce.h:mad_std_window (round 4) finds the minimum over the windows [L, L + k1] of max(|x_L - med|, |x_(L+k1) - med|)
+    by a binary search for the crossing of the two end deviations instead of scanning every window.  The same two procedures in
+    NumPy on random sorted columns (ties, constant runs, outliers, every count 1 .. 64): identical values, and equal to
+    astropy's definition median(|x - median(x)|)."""
+    rng = np.random.default_rng(77)
+
+    def scan(x):
+        n = len(x)
+        k1 = (n - 1) >> 1
+        med = 0.5 * (float(x[(n - 1) >> 1]) + float(x[n >> 1]))
+        dl = np.abs(x.astype(np.float64) - med)
+        f = [max(dl[L], dl[L + k1]) for L in range(0, n - k1)]
+        g = [max(dl[L - 1], dl[L + k1]) for L in range(1, n - k1)]
+        return min(f), (min(g) if g else np.inf)
+
+    def search(x):
+        n = len(x)
+        k1 = (n - 1) >> 1
+        bk = n - k1
+        med = 0.5 * (float(x[(n - 1) >> 1]) + float(x[n >> 1]))
+        d = lambda i: abs(float(x[min(max(i, 0), n - 1)]) - med)
+        lo, hi = 0, bk - 1
+        while lo < hi:
+            mid = (lo + hi) >> 1
+            if d(mid + k1) >= d(mid):
+                hi = mid
+            else:
+                lo = mid + 1
+        DL = lambda L: d(L) if L >= 0 else np.inf
+        DR = lambda L: d(L + k1) if L < bk else np.inf
+        m1 = min(max(DL(lo - 1), DR(lo - 1)), max(DL(lo), DR(lo)))
+        m2 = min(max(DL(lo - 2), DR(lo - 1)), max(DL(lo - 1), DR(lo)), max(DL(lo), DR(lo + 1)))
+        return m1, m2
+
+    for trial in range(4000):
+        n = int(rng.integers(1, 65))
+        kind = trial % 4
+        if kind == 0:
+            x = rng.normal(500, 20, n)
+        elif kind == 1:
+            x = rng.integers(0, 4, n).astype(np.float64)     # heavy ties
+        elif kind == 2:
+            x = np.concatenate([rng.normal(0, 1, n - n // 3), rng.normal(0, 1, n // 3) * 1e6])
+        else:
+            x = np.full(n, 7.0)
+        x = np.sort(x.astype(np.float32))
+        s1, s2 = scan(x)
+        b1, b2 = search(x)
+        assert b1 == s1, (trial, n)
+        if n % 2 == 0:
+            assert b2 == s2, (trial, n)
+            mad = 0.5 * (b1 + b2)
+        else:
+            mad = b1
+        assert mad == np.median(np.abs(x.astype(np.float64) - np.median(x.astype(np.float64)))), (trial, n)

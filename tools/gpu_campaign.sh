@@ -13,7 +13,7 @@ python tools/bench_kernels.py > gpurun_out/r04k/bench_kernels.txt 2>&1
 python tools/bench_f32_sizes.py > gpurun_out/r04k/bench_f32_sizes.txt 2>&1
 python tools/bench_f32_sizes.py --u16 > gpurun_out/r04k/bench_u16_sizes.txt 2>&1
 python tools/bench_u16_64.py 2>&1 | tail -2
-tail -1 gpurun_out/r04k/bench_f32_sizes.txt gpurun_out/r04k/bench_u16_sizes.txt
+tail -q -n 1 gpurun_out/r04k/bench_f32_sizes.txt gpurun_out/r04k/bench_u16_sizes.txt
 grep -- "<--" gpurun_out/r04k/bench_f32_sizes.txt | cut -c1-12,100-140 | tr '\n' ';'
 echo
 grep -- "<--" gpurun_out/r04k/bench_u16_sizes.txt | cut -c1-12,100-140 | tr '\n' ';'
