@@ -444,26 +444,36 @@ __device__ __forceinline__ int mask_list_reserve(int c, int *ctl)
     return base + incl - c;
 }
 
+// number of non-zero bytes of a word
+__device__ __forceinline__ int nonzero_bytes(unsigned w)
+{
+    const unsigned t = (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+    return __builtin_popcount(t);
+}
+
 __global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restrict__ mask, int64_t n, int cap, int *__restrict__ ctl,
                                                        int *__restrict__ list)
 {
     // 16 mask bytes per lane and load (the frames' masks are 16-byte aligned like every plane here; a misaligned one takes the
-    // byte loop); a zero quad - almost all of them - costs one compare
+    // byte loop).  TWO passes over the wavefront's share - count, ONE reservation (mask_list_reserve: a scan and one atomicAdd),
+    // fill: with one reservation per loop trip the 65,000 atomics of an 8192 x 8192 mask (0.2 % bad pixels: nearly every
+    // 1024-pixel trip holds one) serialised on the one counter and cost 0.21 ms where reading the mask takes 13 us; the second
+    // read of the share comes from the cache.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const bool vec = (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
     const int64_t n16 = vec ? n / 16 : 0;
-    const int64_t n16r = (n16 + 63) / 64 * 64;              // whole wavefronts walk the loop together (the scan needs all lanes)
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n16r; q += stride) {
-        uint4 w = make_uint4(0u, 0u, 0u, 0u);
-        if (q < n16) w = reinterpret_cast<const uint4 *>(mask)[q];
-        const bool any = (w.x | w.y | w.z | w.w) != 0;
-        if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
-        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
-        int c = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) c += ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1 : 0;
+    const int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    for (int64_t q = q0; q < n16; q += stride) {
+        const uint4 w = reinterpret_cast<const uint4 *>(mask)[q];
+        if ((w.x | w.y | w.z | w.w) != 0) c += nonzero_bytes(w.x) + nonzero_bytes(w.y) + nonzero_bytes(w.z) + nonzero_bytes(w.w);
+    }
+    if (__builtin_amdgcn_ballot_w64(c != 0) != 0) {         // (wave-uniform: the scan needs all lanes)
         int i = mask_list_reserve(c, ctl);
-        if (c) {
+        for (int64_t q = q0; q < n16 && c; q += stride) {
+            const uint4 w = reinterpret_cast<const uint4 *>(mask)[q];
+            if ((w.x | w.y | w.z | w.w) == 0) continue;
+            const unsigned ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 if ((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) {
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(256) void mask_list_kernel(const uint8_t *__restric
             }
         }
     }
-    for (int64_t p = n16 * 16 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    for (int64_t p = n16 * 16 + q0; p < n; p += stride) {
         if (mask[p]) {
             const int i = atomicAdd(&ctl[0], 1);
             if (i < cap) list[i] = (int)p;
@@ -843,7 +853,7 @@ int launch_resample(const float *frames, int32_t n_frames, int64_t h_in, int64_t
             return fail(APGPU_ELAUNCH, "%s: cannot allocate the mask list: %s", who, hipGetErrorString(e));
         }
         if (mask_scatter) {
-            int64_t g = (h_in * w_in / 16 + 255) / 256;
+            int64_t g = (h_in * w_in / 16 / 16 + 255) / 256;    // ~16 loads of 16 bytes per lane: few reservations, enough wavefronts
             if (g < 1) g = 1;
             if (g > kNumCU * 32) g = kNumCU * 32;
             hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)g), dim3(256), 0, st, mask, h_in * w_in, kMaskListCap, mctl, mctl + 2);
