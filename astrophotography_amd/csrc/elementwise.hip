@@ -396,10 +396,19 @@ __global__ __launch_bounds__(kBlock) void threshold_mask_kernel(const float *__r
         mask[i] = b;
         cnt += b;
     }
-    // wave reduction, one atomic per wave
+    // wave reduction, then ONE atomic per workgroup (every atomic lands on the same counter: 8192 of them cost more than
+    // reading the image)
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) cnt += __shfl_down(cnt, d);
-    if ((threadIdx.x % kWave) == 0 && cnt) atomicAdd(nbad, (unsigned long long)cnt);
+    __shared__ unsigned s_cnt[kBlock / kWave];
+    if ((threadIdx.x % kWave) == 0) s_cnt[threadIdx.x / kWave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; w++) tot += s_cnt[w];
+        if (tot) atomicAdd(nbad, (unsigned long long)tot);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void mask_add_rects_kernel(uint8_t *mask, int64_t W, const int32_t *__restrict__ rects,
