@@ -969,15 +969,18 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     // the fast kernel + redo list (see stack_fast_kernel): float32 stacks on the float32 fast path, lean outputs, no pedestals
     // (uint16 frames: only the cases of `wide_fast` above - everything else went to the pair kernels)
-    constexpr bool kFastSlots = (sizeof(RawT) == 4 || (CALIB && NP > 64)) && fast_kernel_slots(NP);
+    constexpr bool kFastSlots = (sizeof(RawT) == 4 || CALIB) && fast_kernel_slots(NP);
     constexpr int kMaxPads = NP - prev_slots(NP) - 1;                // (the next smaller slot count serves fewer frames)
-    constexpr bool kStaticPads = true;                      // (one instantiation per pad count; with run-time pads: 225 VGPRs at 128 slots)
-    // mean + median + std planes (PLUS): full float32 stacks up to 96 slots have their fast kernel too
-    const bool fastplus = plus && full && sizeof(RawT) == 4 && NP <= 96;
+    // mean + median + std planes (PLUS, up to 96 slots) have their fast kernel too: float32 stacks of any frame count, uint16
+    // stacks (fused calibration, one pixel per lane) when full
+    constexpr bool kPlusSlots = NP <= 96 && (sizeof(RawT) == 4 || CALIB);
+    const bool fastplus = kPlusSlots && plus && (sizeof(RawT) == 4 || full);
+    // lean uint16 stacks come here only as `wide_fast` (above): padded beyond 64 slots, or 120 / 128 slots
+    const bool u16_lean_ok = !full ? NP > 64 : NP > 112;
     const bool fastk = kFastSlots && (full || kMaxPads > 0) && fast_kernel_eligible(prm, median_only, rich, plus && !fastplus) &&
-                       (sizeof(RawT) == 4 || !full || NP > 112);
+                       (sizeof(RawT) == 4 || fastplus || u16_lean_ok);
     if (describe) {
-        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d, %s>", NP, rawname, tf[CALIB], tf[full], kStaticPads ? NP - prm.N : 0, tf[fastplus]);
+        if (fastk) snprintf(describe, 256, "stack_fast_kernel<%d, %s, %s, %s, %d, %s>", NP, rawname, tf[CALIB], tf[full], NP - prm.N, tf[fastplus]);
         else if (median_only) snprintf(describe, 256, "stack_median_kernel<%d, %s, %s, %s>", NP, rawname, tf[CALIB], tf[full]);
         else if (plus) snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, false, %s, true>", NP, rawname, tf[CALIB], tf[full]);
         else snprintf(describe, 256, "stack_sigclip_kernel<%d, %s, %s, %s, %s, false>", NP, rawname, tf[CALIB], tf[rich], tf[full]);
@@ -987,17 +990,33 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     if constexpr (kFastSlots) {
         int frc = kNoRedoList;
         const int pads = NP - prm.N;
-        if constexpr (sizeof(RawT) == 4 && NP <= 96) {
-            if (fastk && fastplus) frc = launch_fast<NP, RawT, CALIB, true, 0, true>(prm, g, st);
+        if (fastk && fastplus) {
+            if constexpr (kPlusSlots) {
+                if (pads == 0) frc = launch_fast<NP, RawT, CALIB, true, 0, true>(prm, g, st);
+                if constexpr (sizeof(RawT) == 4) {
+                    if constexpr (kMaxPads >= 1) if (pads == 1) frc = launch_fast<NP, RawT, CALIB, false, 1, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 2) if (pads == 2) frc = launch_fast<NP, RawT, CALIB, false, 2, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 3) if (pads == 3) frc = launch_fast<NP, RawT, CALIB, false, 3, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 4) if (pads == 4) frc = launch_fast<NP, RawT, CALIB, false, 4, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 5) if (pads == 5) frc = launch_fast<NP, RawT, CALIB, false, 5, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 6) if (pads == 6) frc = launch_fast<NP, RawT, CALIB, false, 6, true>(prm, g, st);
+                    if constexpr (kMaxPads >= 7) if (pads == 7) frc = launch_fast<NP, RawT, CALIB, false, 7, true>(prm, g, st);
+                }
+            }
+        } else if (fastk) {
+            if constexpr (sizeof(RawT) == 4 || NP > 112) {
+                if (pads == 0) frc = launch_fast<NP, RawT, CALIB, true>(prm, g, st);
+            }
+            if constexpr (sizeof(RawT) == 4 || NP > 64) {
+                if constexpr (kMaxPads >= 1) if (pads == 1) frc = launch_fast<NP, RawT, CALIB, false, 1>(prm, g, st);
+                if constexpr (kMaxPads >= 2) if (pads == 2) frc = launch_fast<NP, RawT, CALIB, false, 2>(prm, g, st);
+                if constexpr (kMaxPads >= 3) if (pads == 3) frc = launch_fast<NP, RawT, CALIB, false, 3>(prm, g, st);
+                if constexpr (kMaxPads >= 4) if (pads == 4) frc = launch_fast<NP, RawT, CALIB, false, 4>(prm, g, st);
+                if constexpr (kMaxPads >= 5) if (pads == 5) frc = launch_fast<NP, RawT, CALIB, false, 5>(prm, g, st);
+                if constexpr (kMaxPads >= 6) if (pads == 6) frc = launch_fast<NP, RawT, CALIB, false, 6>(prm, g, st);
+                if constexpr (kMaxPads >= 7) if (pads == 7) frc = launch_fast<NP, RawT, CALIB, false, 7>(prm, g, st);
+            }
         }
-        if (fastk && full && !fastplus) frc = launch_fast<NP, RawT, CALIB, true>(prm, g, st);
-        if constexpr (kMaxPads >= 1) if (fastk && pads == 1) frc = launch_fast<NP, RawT, CALIB, false, 1>(prm, g, st);
-        if constexpr (kMaxPads >= 2) if (fastk && pads == 2) frc = launch_fast<NP, RawT, CALIB, false, 2>(prm, g, st);
-        if constexpr (kMaxPads >= 3) if (fastk && pads == 3) frc = launch_fast<NP, RawT, CALIB, false, 3>(prm, g, st);
-        if constexpr (kMaxPads >= 4) if (fastk && pads == 4) frc = launch_fast<NP, RawT, CALIB, false, 4>(prm, g, st);
-        if constexpr (kMaxPads >= 5) if (fastk && pads == 5) frc = launch_fast<NP, RawT, CALIB, false, 5>(prm, g, st);
-        if constexpr (kMaxPads >= 6) if (fastk && pads == 6) frc = launch_fast<NP, RawT, CALIB, false, 6>(prm, g, st);
-        if constexpr (kMaxPads >= 7) if (fastk && pads == 7) frc = launch_fast<NP, RawT, CALIB, false, 7>(prm, g, st);
         if (frc != kNoRedoList) return frc;
     }
     if (median_only) {

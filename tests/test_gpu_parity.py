@@ -657,7 +657,7 @@ def test_stack_sigclip_u16_pairs_paths(ops, apref):
         assert_biteq(host(ro['mean']), host(rfo['mean']), f'odd-P u16 N={N}')
 
 
-@pytest.mark.parametrize('N', [9, 12, 20, 24, 36, 40, 48, 52, 56, 70, 80, 96, 100, 112])
+@pytest.mark.parametrize('N', [9, 12, 14, 20, 24, 30, 36, 40, 45, 48, 52, 56, 61, 70, 77, 80, 93, 96, 100, 112])
 def test_stack_three_quarter_slot_sizes(ops, apref, N):
     """Slot counts 12 / 24 / 40 / 48 / 56 / 80 / 96 / 112 use Batcher networks pruned to their first NP wires and non-power-of-two
     multiplexer trees: full (N = NP) and padded stacks, lean and rich outputs, median, float32 and uint16."""
@@ -680,6 +680,13 @@ def test_stack_three_quarter_slot_sizes(ops, apref, N):
         if 'median' in r:
             assert_ulp(host(r['median']), ref['median'].astype(np.float32), 1, what + ' median plane')
             assert_ulp(host(r['std']), ref['std'].astype(np.float32), 2, what + ' std plane')
+        elif cen == 'median':
+            # the three planes of a padded stack on the fast kernel (one instantiation per pad count)
+            r3 = ops.stack_sigclip(dev(cube, ops), sigma=sig, maxiters=mi, calib=calib, outputs=('mean', 'median', 'std', 'count'))
+            assert np.array_equal(host(r3['count']), ref['count']), what + ' planes'
+            assert_ulp(host(r3['mean']), ref['mean'].astype(np.float32), 1, what + ' planes: mean')
+            assert_ulp(host(r3['median']), ref['median'].astype(np.float32), 1, what + ' planes: median')
+            assert_ulp(host(r3['std']), ref['std'].astype(np.float32), 2, what + ' planes: std')
     med = ops.stack_median(dev(cube, ops), calib=calib)
     assert_ulp(host(med), apref.stack_median(cal).astype(np.float32), 0 if N % 2 else 1, f'median N={N}')
     u16 = synth_cube(rng, N, shape, dtype=np.uint16)
@@ -689,6 +696,11 @@ def test_stack_three_quarter_slot_sizes(ops, apref, N):
     r = ops.stack_sigclip(dev(u16, ops), sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
     assert np.array_equal(host(r['count']), ref['count']), f'u16 N={N}'
     assert_ulp(host(r['mean']), ref['mean'].astype(np.float32), 1, f'u16 N={N}')
+    r3 = ops.stack_sigclip(dev(u16, ops), sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'median', 'std', 'count'))
+    assert np.array_equal(host(r3['count']), ref['count']), f'u16 planes N={N}'
+    assert_ulp(host(r3['mean']), ref['mean'].astype(np.float32), 1, f'u16 planes: mean N={N}')
+    assert_ulp(host(r3['median']), ref['median'].astype(np.float32), 1, f'u16 planes: median N={N}')
+    assert_ulp(host(r3['std']), ref['std'].astype(np.float32), 2, f'u16 planes: std N={N}')
     assert_ulp(host(ops.stack_median(dev(u16, ops), calib=calib)), apref.stack_median(calu).astype(np.float32),
                0 if N % 2 else 1, f'u16 median N={N}')
 

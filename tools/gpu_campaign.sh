@@ -20,3 +20,4 @@ grep -- "<--" gpurun_out/r04k/bench_u16_sizes.txt | cut -c1-12,100-140 | tr '\n'
 echo
 for t in r04 r04_c5 r04_c4 r04_c3n1; do echo "== $t"; cat gpurun_out/prof_$t/bench_line.json | cut -c1-300; done
 head -30 gpurun_out/r04k/bench_kernels.txt | cut -c1-120
+python bench.py --force-collective --no-cpu-baseline --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('force-collective (one rank, 4 stripes):', d['ms_per_step'], 'ms')"
