@@ -102,9 +102,9 @@ __device__ __forceinline__ void lds_bitonic_sort(float *col, int lo, int len)
     }
 }
 
-// redo == nullptr: workgroup b reduces the 64 pixels [64 b, 64 b + 64).  redo != nullptr: the wavefronts the chunked fast
-// kernel (stack_chunks.hip) was not sure about - redo[0] entries redo[1 ..], each a 64-pixel block index - are shared out
-// over the grid.
+// redo == nullptr: workgroup b reduces the 64 pixels [64 b, 64 b + 64).  redo != nullptr: the PIXELS the chunked fast
+// kernel (stack_chunks.hip) was not sure about - redo[0] entries redo[1 ..], pixel indices - are shared out over the grid,
+// 64 listed pixels per workgroup and trip (a gather: every lane loads its own pixel's column).
 template <int NP, typename RawT, bool CALIB, bool MEDIAN>
 __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm, const int32_t *redo)
 {
@@ -112,12 +112,16 @@ __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackPara
     __shared__ FrameScalars<128> fs;
     const int lane = threadIdx.x;
     float *const col = col_all + lane;
-    const int64_t nitems = redo ? redo[0] : (int64_t)gridDim.x;
+    const int64_t nlisted = redo ? redo[0] : 0;
+    const int64_t nitems = redo ? (nlisted + kBigLanes - 1) / kBigLanes : (int64_t)gridDim.x;
 #pragma unroll 1
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int64_t base = (redo ? (int64_t)redo[1 + item] : item) * kBigLanes;
-    const int64_t p = base + lane;
-    const bool live = p < prm.P;                            // dead lanes of the last workgroup still stage and vote
+    // (list mode: base 0 and the lane's own pixel as its offset; pixel indices fit an int - chunks_eligible)
+    const int64_t base = redo ? 0 : item * kBigLanes;
+    const bool listed = redo && item * kBigLanes + lane < nlisted;
+    const int plane = redo ? (listed ? redo[1 + item * kBigLanes + lane] : 0) : lane;
+    const int64_t p = base + plane;
+    const bool live = redo ? listed : p < prm.P;            // dead lanes of the last workgroup still stage and vote
     __syncthreads();                                        // (redo loop) the previous item is done with LDS
     int n = 0;
 #pragma unroll 1
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackPara
         if (q.N > 0) {
             __syncthreads();                                // the previous chunk is done with the staged scalars
             stage_frame_scalars<128>(q, fs);
-            if (live) nc = load_sorted_column<128, RawT, CALIB, !MEDIAN, false, 0>(q, fs, base, lane, v);   // a chunk may hold 1..128 frames
+            if (live) nc = load_sorted_column<128, RawT, CALIB, !MEDIAN, false, 0>(q, fs, base, plane, v);   // a chunk may hold 1..128 frames
         }
         if (!(q.N > 0 && live)) {
 #pragma unroll

@@ -23,8 +23,8 @@
 //     partial sums added to running totals: the error budget of clip_fast32 holds with the same rho, see below).
 // The clip then runs exactly as clip_fast32 does, with tails of 8 (7 usable: the value after the tail is not known) and
 // the median picked from the merged window.  Lanes that are not sure - a comparison inside the error margin, a tail used
-// up, non-finite values, a masked pixel, a median outside the zone - put their wave on a redo list, and
-// stack_big_kernel (the exact LDS-resident kernel, stack_big.hip) recomputes exactly those waves afterwards.
+// up, non-finite values, a masked pixel, a median outside the zone - put their pixel on a redo list, and
+// stack_big_kernel (the exact LDS-resident kernel, stack_big.hip) recomputes exactly those pixels afterwards.
 // Survivor sets are therefore those of the exact path; the mean carries the float32 rounding of its sum like the
 // 64-frame kernel's.
 //
@@ -458,13 +458,21 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     Q = (Qtot + f.Qlo) + f.Qhi;
     const int cnt = N - f.ta - f.tb;
     f.unsure = f.unsure || !(4.f * Q <= (float)cnt * (c0 * c0));           // mean-accuracy guard, see clip_fast32
-    if (wave_any(f.unsure)) {
-        // the whole wave is redone by the exact kernel (stack_big_kernel over the redo list); nothing is written here
-        if (__builtin_amdgcn_readfirstlane(lane) == lane) {
-            const int slot = atomicAdd(&redo[0], 1);
-            redo[1 + slot] = (int32_t)(p >> 6);
+    {
+        // the lanes that are not sure are redone by the exact kernel (stack_big_kernel over the redo list, one listed PIXEL per
+        // lane - round 4; rounds 2-3 listed whole wavefronts: 2.3 % of them at 256 frames for a handful of lanes each); they
+        // write nothing here.  One atomic per wavefront that has any.
+        const uint64_t m = __builtin_amdgcn_ballot_w64(f.unsure);
+        if (m != 0) {
+            int first = 0;
+            if (__builtin_amdgcn_readfirstlane(lane) == lane) first = atomicAdd(&redo[0], (int)__builtin_popcountll(m));
+            first = __builtin_amdgcn_readfirstlane(first);
+            const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (f.unsure) {
+                redo[1 + first + mine] = (int32_t)p;
+                return;
+            }
         }
-        return;
     }
     const float nf32 = (float)cnt;
     const float y = __builtin_amdgcn_rcpf(nf32);
@@ -485,6 +493,7 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
     // (97 .. 128 frames as two chunks were measured too: 2.8 - 3.1 ms for 128 frames against 2.7 ms for the 128-slot
     // register kernel - a chunk costs what the whole 64-frame kernel costs - so the register kernels keep that range)
     if (median_only || prm.N <= 128 || prm.N > 4 * kChunkSlots) return false;
+    if (prm.P >= 0x7fffffffLL) return false;                 // the redo list holds pixel indices as int32
     if (prm.median || prm.std || prm.mean64 || prm.std64) return false;
     if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (prm.fast32 == 0) return false;
@@ -504,10 +513,9 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     }
     const int64_t grid = (prm.P + 255) / 256;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-    // redo list: count + one entry per wavefront, a stream-ordered temporary (nothing persistent is allocated)
-    const int64_t nwaves = (prm.P + 63) / 64;
+    // redo list: count + one entry per pixel, a stream-ordered temporary (nothing persistent is allocated)
     int32_t *redo = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), (size_t)(nwaves + 1) * sizeof(int32_t), st);
+    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), (size_t)(prm.P + 1) * sizeof(int32_t), st);
     if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot allocate the redo list: %s", hipGetErrorString(e));
     e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
     if (e != hipSuccess) {
@@ -533,7 +541,7 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
         int32_t cnt = -1;
         (void)hipMemcpyAsync(&cnt, redo, sizeof(cnt), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
-        fprintf(stderr, "stack_chunks: %d of %lld wavefronts on the redo list\n", cnt, (long long)nwaves);
+        fprintf(stderr, "stack_chunks: %d of %lld pixels on the redo list\n", cnt, (long long)prm.P);
     }
 #endif
     if (rc == APGPU_OK) rc = launch_big_exact(prm, u16, CALIB, false, st, nullptr, redo);
