@@ -124,54 +124,48 @@ class ApCalcReadNoise:
         self._logger.debug(f'Initialized an ApCalcReadNoise instance with biasfile1={biasfile1}, biasfile1={biasfile2}, '
                            f'gain={gain}, and loglevel={loglevel}')
 
-    @staticmethod
-    def _isfloat(value_str):
-        try:
-            float(value_str)
-            return True
-        except (TypeError, ValueError):
-            return False
+    _GAIN_TOLERANCE = 0.001          # e/ADU: the two headers must agree this well (ap_calc_read_noise.py:634-688)
 
-    def _select_gain(self, hdr1, hdr2):
-        """A number given at construction wins; otherwise the keyword must exist in both headers and agree
-        to 0.001 e/ADU (ap_calc_read_noise.py:634-688)."""
-        if self._isfloat(self._gaininfo):
-            return float(self._gaininfo)
-        gain1 = float(hdr1[self._gaininfo]) if self._gaininfo in hdr1 else None
-        gain2 = float(hdr2[self._gaininfo]) if self._gaininfo in hdr2 else None
-        if gain1 is None or gain2 is None:
-            err_msg = f'Error, {self._gaininfo} gain keyword not found in'
-            if gain1 is None and gain2 is None:
-                err_msg += ' both FITS files.'
-            elif gain1 is None:
-                err_msg += ' the first FITS file.'
-            else:
-                err_msg += ' the second FITS file.'
-            self._logger.error(err_msg)
-            raise RuntimeError(err_msg)
-        tolerance = 0.001
-        if math.fabs(gain1 - gain2) > tolerance:
-            err_msg = f'Error, gains differ by more than {tolerance:.3f} e/ADU, where gain1={gain1:.3f}, gain2={gain2:.3f}.'
-            self._logger.error(err_msg)
-            raise RuntimeError(err_msg)
-        return gain1
+    def _fail(self, err_msg):
+        self._logger.error(err_msg)
+        raise RuntimeError(err_msg)
+
+    def _gain_from(self, headers):
+        """The gain in e/ADU: a number passed at construction is taken as it is; anything else names a header keyword,
+        which both bias frames must carry with the same value (to _GAIN_TOLERANCE)."""
+        spec = self._gaininfo
+        try:
+            return float(spec)
+        except (TypeError, ValueError):
+            pass
+        found = [float(h[spec]) if spec in h else None for h in headers]
+        absent = tuple(g is None for g in found)
+        if any(absent):
+            where = {(True, True): 'both FITS files.', (True, False): 'the first FITS file.',
+                     (False, True): 'the second FITS file.'}[absent]
+            self._fail(f'Error, {spec} gain keyword not found in {where}')
+        spread = abs(found[0] - found[1])
+        if spread > self._GAIN_TOLERANCE:
+            self._fail(f'Error, gains differ by more than {self._GAIN_TOLERANCE:.3f} e/ADU, '
+                       f'where gain1={found[0]:.3f}, gain2={found[1]:.3f}.')
+        return found[0]
 
     def estimate_rn(self, sigmaclip, histplot=None):
+        """Read noise in e/pixel = gain * std(bias1 - bias2 over the good pixels) / sqrt(2) (ap_calc_read_noise.py:507-556)."""
         if histplot is not None:
             raise RuntimeError('Histogram plotting (matplotlib) is outside the scope of the MI355X path; pass histplot=None.')
-        data1, hdr1, _ = _common.read_fits(self._logger, self._biasfile1)
-        data2, hdr2, _ = _common.read_fits(self._logger, self._biasfile2)
+        frames = [_common.read_fits(self._logger, f)[:2] for f in (self._biasfile1, self._biasfile2)]
+        (data1, hdr1), (data2, hdr2) = frames
         if data1.shape != data2.shape:
-            err_msg = f'Error, data array shapes do not match: First file={data1.shape}, second file={data2.shape}'
-            self._logger.error(err_msg)
-            raise RuntimeError(err_msg)
-        self._gain = self._select_gain(hdr1, hdr2)
+            self._fail(f'Error, data array shapes do not match: First file={data1.shape}, second file={data2.shape}')
+        self._gain = self._gain_from((hdr1, hdr2))
         self._logger.info(f'Adopted gain is {self._gain:.2f} electrons/ADU.')
-        im_diff = ApImageDifference(data1, data2, sigmaclip, self._loglevel, mask1=None, mask2=None)
-        stddev = im_diff.stddev()
-        npix_good, npix_total = im_diff.numpix()
-        pct_bad = 100 * (npix_total - npix_good) / npix_total
-        self._logger.info(f'Standard deviation={stddev:.2f} ADU using {npix_good}/{npix_total} pixels ({pct_bad:.3f} % bad).')
-        read_noise = self._gain * stddev / math.sqrt(2)
+        # everything numeric happens on the device inside ApImageDifference
+        diff = ApImageDifference(data1, data2, sigmaclip, self._loglevel, mask1=None, mask2=None)
+        sigma_adu = diff.stddev()
+        good, total = diff.numpix()
+        self._logger.info(f'Standard deviation={sigma_adu:.2f} ADU using {good}/{total} pixels '
+                          f'({100 * (total - good) / total:.3f} % bad).')
+        read_noise = self._gain * sigma_adu / math.sqrt(2)
         self._logger.info(f'Estimated read noise is {read_noise:.2f} e/pixel')
         return read_noise

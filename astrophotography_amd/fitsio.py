@@ -533,6 +533,21 @@ def _device_layout(hdr):
     return shape, bitpix, unsigned16, int(np.prod(shape)) * abs(bitpix) // 8
 
 
+def _host_read_is_float64(h):
+    """Whether read() returns float64 for this header: BITPIX -64, or BITPIX 32 / 64 integers scaled by a BSCALE / BZERO pair
+    that is neither 1 / 0 nor the unsigned-integer convention (those stay integers)."""
+    bitpix = int(h['BITPIX'])
+    if bitpix == -64:
+        return True
+    if bitpix not in (32, 64):
+        return False
+    bscale, bzero = float(h.get('BSCALE', 1.0)), float(h.get('BZERO', 0.0))
+    if bscale == 1.0 and bzero == 0.0:
+        return False
+    unsigned = bscale == 1.0 and bzero == float(2 ** (bitpix - 1))
+    return not unsigned
+
+
 def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
     """N FITS files of one shape -> ONE contiguous [N, H, W] device slab + their Headers: the ingest of the stackers
     (the reference reads N files per combine: scripts/ap_combine_darks.py:411-420, core/ApCalibrate.py:260-328).
@@ -573,10 +588,11 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
     if dtype == 'auto':
         if all(lay is not None and lay[2] for lay in lays):
             sdt = torch.uint16
-        elif any((lay is not None and lay[1] == -64) or (lay is None and int(h['BITPIX']) == -64)
+        elif any((lay is not None and lay[1] == -64) or (lay is None and _host_read_is_float64(h))
                  for lay, h in zip(lays, hdrs)):
-            # float64 only for BITPIX -64: the reference converts every NON-float raw frame to float32 whatever its
-            # integer width (core/ApCalibrate.py:301-305), so BITPIX 8 / 16 / 32 / 64 integers go to float32 like there
+            # float64 for BITPIX -64 and for 32 / 64-bit integers with a real BSCALE / BZERO (read() - like astropy - hands
+            # those over as float64, and the reference keeps floating data as it is); UNSCALED integers of any width go to
+            # float32 like there (core/ApCalibrate.py:301-305 converts every non-float raw frame to float32)
             sdt = torch.float64
         else:
             sdt = torch.float32
