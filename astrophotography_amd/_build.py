@@ -94,13 +94,18 @@ def _newest(paths):
     return max(os.path.getmtime(p if os.path.isabs(p) else os.path.join(CSRC, p)) for p in paths)
 
 
+# The stack kernels' translation units: machine LICM off - the complete lean kernel is one loop (plain launch and redo pass share
+# its body) and hoisted loop-invariant values cost it 5-10 VGPRs, the difference between three and two wavefronts per SIMD.
+STACK_TU_FLAGS = ['-mllvm', '-disable-machine-licm']
+
+
 def _compile(src):
     obj = os.path.join(OBJ, src.replace('.hip', '.o'))
     srcp = os.path.join(CSRC, src)
     dep_time = max(os.path.getmtime(srcp), _newest(HEADERS))
     if os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
         return obj, False
-    cmd = [_hipcc()] + HIPCC_FLAGS + ['-c', srcp, '-o', obj]
+    cmd = [_hipcc()] + HIPCC_FLAGS + (STACK_TU_FLAGS if src.startswith('stack_inst_') else []) + ['-c', srcp, '-o', obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout[-4000:]))

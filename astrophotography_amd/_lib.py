@@ -14,7 +14,8 @@ OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
 CENTER = {'median': 0, 'mean': 1}
 DEV = {'std': 0, 'mad_std': 1}
 MAX_STACK = 512
-STACK_EXACT_MOMENTS, STACK_MOMENTS_MEAN = 1, 2          # apgpu_stack_args.flags
+STACK_EXACT_MOMENTS, STACK_MOMENTS_MEAN, STACK_SINGLE_KERNEL = 1, 2, 4          # apgpu_stack_args.flags
+STACK_WS_STATS_OFFSET = 16384                           # APGPU_STACK_WS_STATS_OFFSET: int64 calls, pixels, pixels listed, 64-pixel blocks given up
 
 E_INVAL, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4
 
@@ -35,6 +36,7 @@ class StackArgs(C.Structure):
         ('pixmask', C.c_void_p), ('mean', C.c_void_p), ('median', C.c_void_p), ('std', C.c_void_p),
         ('count', C.c_void_p), ('moments', C.c_void_p), ('frame_stride', C.c_int64),
         ('mean_f64', C.c_void_p), ('std_f64', C.c_void_p), ('moments_f64', C.c_int32), ('flags', C.c_int32),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
     ]
 
 
@@ -50,6 +52,7 @@ SIGNATURES = {
     'apgpu_flat_normalize_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_calibrate_mixed': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    'apgpu_stack_ws_bytes': (C.c_size_t, [C.c_int64, C.POINTER(C.c_size_t)]),
     'apgpu_stack_sigclip': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     'apgpu_stack_median': (C.c_int, [C.POINTER(StackArgs), C.c_void_p]),
     'apgpu_stack_kernel_name': (C.c_int, [C.POINTER(StackArgs), C.c_int, C.c_char_p, C.c_size_t]),

@@ -52,6 +52,10 @@ constexpr int kFastPitch = 80;                       // fast path: fixed pitch (
 // TH = output rows per workgroup: 16 (one API tile: the only choice with one transform per tile) or 32 (two vertically
 // adjacent tiles of a frame that has ONE transform: half the workgroup launches and tile set-up, 42 instead of 2 x 26
 // footprint rows).  The fast path takes footprints of up to TH + 10 rows (rotations up to ~2.5 degrees).
+// (Round 5, measured and dropped: ONE copy of the footprint, odd-start windows read with 4-byte aligned pairs - ds_read2_b32 -
+// for half the LDS per workgroup and half the fill's stores: 9.0 against 4.0 ms per 16 x 8192^2.)
+// (and: a wavefront shaped 16 columns x 4 row groups instead of 64 x 1 - a third of the distinct table rows per weight load, LDS
+// pitch 84 and copy B at 16 mod 64 banks to keep the reads conflict-free - no change: 3.94-4.00 against 3.95-3.96 ms.)
 template <int TH>
 struct FastGeom {
     static constexpr int kRows = TH + 10;
@@ -304,6 +308,118 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
             if (want_w) apgpu_buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
             ooff += ostep;
         }
+    }
+}
+
+// ---- FAST tiles, rolling window (round 5) ------------------------------------------------------------------------------
+// A lane produces TH / 4 CONSECUTIVE output rows of one column and keeps its 6 x 6 window in registers between them.  For a
+// registration-sized transform the next output row's window is the same six columns one input row further down - then five
+// of its six rows are already in registers and only ONE row (three ds_read_b64) is read; otherwise (the column or the copy
+// changed: every 1 / |sin(rotation)| rows; or the row step was not exactly one) the lane re-reads its whole window.  The test
+// is one compare - the window's LDS index went up by exactly the row pitch - and the re-read sits behind a wave vote, so a
+// wave pays for it only in the steps in which one of its lanes needs it (0.2 degrees: one step in five).  The window rows
+// live in six register triples in a STATIC rotation (step k keeps window row j in triple (j + k) % 6: the loop is unrolled,
+// nothing is ever moved - round 3's first attempt at this shuffled registers around the vote and lost more VALU work than
+// the LDS reads saved).  LDS reads per pixel: 18 -> 3 + (18 + 15 x re-reads) / (TH / 4), e.g. ~7 at 0.2 degrees.  Same
+// arithmetic in the same order as eval_fast: the oracle is untouched.
+#ifndef APGPU_RESAMPLE_ROLLING
+#define APGPU_RESAMPLE_ROLLING 1
+#endif
+
+
+// The per-pixel table rows (four buffer loads) are fetched kAhead pixels AHEAD of their use: a pixel's wait for its weights was
+// a memory round trip behind the previous pixel's output store (one in-order counter for both), eight of them in a row per
+// wavefront - with 72 registers in use and the LDS holding the kernel at five wavefronts per SIMD, the 12 registers per pixel in
+// flight are free.  The first kAhead pixels are prepared BEFORE the footprint's barrier (their loads overlap the fill's).
+#ifndef APGPU_RESAMPLE_AHEAD
+#define APGPU_RESAMPLE_AHEAD 2
+#endif
+template <int TH>
+struct Rolling {
+    static constexpr int R = TH / 4;                         // consecutive rows per lane
+    static constexpr int kAhead = APGPU_RESAMPLE_AHEAD < R ? APGPU_RESAMPLE_AHEAD : R - 1;
+    unsigned long long X, Y;                                 // coordinates of the next pixel to prepare
+    FastPrep nxt[kAhead > 0 ? kAhead : 1];
+};
+
+template <int TH, typename LutT>
+__device__ __forceinline__ void rolling_begin(Rolling<TH> &ro, const TileCtx &tc, LutT lut, int sh, int x0, int y0, int lx, int ly)
+{
+    constexpr int R = Rolling<TH>::R;
+    const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
+    const unsigned long long us = (unsigned long long)(long long)x0, vs = (unsigned long long)(long long)y0;
+    const unsigned long long Xs = F0 * us + F1 * vs + F2 - ((unsigned long long)(unsigned)(tc.bx0 + 2) << 32);
+    const unsigned long long Ys = F3 * us + F4 * vs + F5 - ((unsigned long long)(unsigned)(tc.by0 + 2) << 32);
+    const unsigned long long ul = (unsigned long long)(unsigned)lx, vl = (unsigned long long)(unsigned)(ly * R);
+    ro.X = Xs + F0 * ul + F1 * vl;
+    ro.Y = Ys + F3 * ul + F4 * vl;
+#pragma unroll
+    for (int k = 0; k < Rolling<TH>::kAhead; k++) {
+        ro.nxt[k] = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+        ro.X += F1;
+        ro.Y += F4;
+    }
+}
+
+template <int TH, typename LutT>
+__device__ __forceinline__ void pixels_fast_rolling(Rolling<TH> &ro, const TileCtx &tc, const float *tile, LutT lut, int sh, int lx, int ly,
+                                                    v4i orsrc, v4i wrsrc, bool want_w, int w_out)
+{
+    constexpr int R = Rolling<TH>::R, A = Rolling<TH>::kAhead;
+    const unsigned long long F1 = tc.F[1], F4 = tc.F[4];
+    const float fs = tc.fs;
+    int ooff = (ly * R * w_out + lx) * 4;
+    const int ostep = 4 * w_out;
+    v2f win[6][3];
+    int prev = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        FastPrep cur;
+        if constexpr (A > 0) {
+            cur = ro.nxt[k % A];
+            if (k + A < R) {
+                ro.nxt[k % A] = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+                ro.X += F1;
+                ro.Y += F4;
+            }
+        } else {
+            cur = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+            ro.X += F1;
+            ro.Y += F4;
+        }
+        lds_pair_p t = (lds_pair_p)(tile + cur.idx);
+        const bool reread = (k == 0) || (cur.idx != prev + kFastPitch);
+        prev = cur.idx;
+        if (k == 0 || __builtin_amdgcn_ballot_w64(reread) != 0) {
+            if (reread) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    win[(j + k) % 6][0] = t[j * (kFastPitch / 2) + 0];
+                    win[(j + k) % 6][1] = t[j * (kFastPitch / 2) + 1];
+                    win[(j + k) % 6][2] = t[j * (kFastPitch / 2) + 2];
+                }
+            }
+        }
+        win[(5 + k) % 6][0] = t[5 * (kFastPitch / 2) + 0];
+        win[(5 + k) % 6][1] = t[5 * (kFastPitch / 2) + 1];
+        win[(5 + k) % 6][2] = t[5 * (kFastPitch / 2) + 2];
+        const Weights &w = cur.w;
+        const float wy[6] = {w.wy01.x, w.wy01.y, w.wy23.x, w.wy23.y, w.wy45.x, w.wy45.y};
+        v2f V = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const v2f(&row)[3] = win[(j + k) % 6];
+            v2f acc = w.wx01 * row[0];
+            acc = __builtin_elementwise_fma(w.wx23, row[1], acc);
+            acc = __builtin_elementwise_fma(w.wx45, row[2], acc);
+            const v2f wyj = {wy[j], wy[j]};
+            V = (j == 0) ? wyj * acc : __builtin_elementwise_fma(wyj, acc, V);
+        }
+        const float v = V.x + V.y;
+        const float res = (v == v) ? v * fs : __builtin_nanf("");
+        apgpu_buffer_store_f32(res, orsrc, ooff, 0, 0);
+        if (want_w) apgpu_buffer_store_i8((char)((res == res) ? 1 : 0), wrsrc, ooff >> 2, 0, 0);
+        ooff += ostep;
     }
 }
 
@@ -716,6 +832,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
                                                              int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
                                                              int h_in, int w_in, int h_out, int w_out, const int *__restrict__ mask_ctl, int mask_cap)
 {
+    constexpr bool kRolling = !OVERSAMPLED && APGPU_RESAMPLE_ROLLING;
     using G = FastGeom<TH>;
     __shared__ __attribute__((aligned(16))) float tile[G::kLdsFloats];
     // Tile order: grid = (tiles per frame rounded up to 8, frames).  Workgroups are dispatched round-robin over the 8 XCDs
@@ -777,22 +894,33 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         if (inline_mask) general_fill<true>(tc, fv, tile, tid);
         else general_fill<false>(tc, fv, tile, tid);
     }
+    // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12 (rolling fast path: the rows y0 + R ly .. + R - 1)
+    const int lx = tid % kTileW, ly = tid / kTileW;
+    const int sh = 32 - log2_phases;
+    Rolling<TH> ro;
+    if constexpr (kRolling) {
+        if (fast) {                                            // the first pixels' table rows are on their way during the fill
+            const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
+            rolling_begin<TH>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
+        }
+    }
     __syncthreads();
 
-    // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12
-    const int lx = tid % kTileW, ly = tid / kTileW;
     const int x = x0 + lx;
     if (x >= w_out) return;
     const int yb0 = y0 + ly;
-    const int sh = 32 - log2_phases;
     if (fast) {
         // stores through a buffer resource based at the tile's first pixel: 32-bit offsets (w_out < 2^26, checked by the launcher)
         const int64_t t0 = (f * h_out + y0) * (int64_t)w_out + x0;
         const v4i orsrc = make_rsrc(out + t0, 0xffffffffu);
         const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
-        const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
-        pixels_fast<OVERSAMPLED, TH, 1>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        if constexpr (kRolling) {
+            pixels_fast_rolling<TH>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
+        } else {
+            const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
+            pixels_fast<OVERSAMPLED, TH, 1>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
+        }
         return;
     }
     const int64_t o0 = (f * h_out + yb0) * (int64_t)w_out + x;

@@ -94,8 +94,14 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
         if (args->moments_f64 < 0 || args->moments_f64 > 4) return fail(APGPU_EINVAL, "stack: bad moments_f64 %d", args->moments_f64);
         if (args->moments && args->moments_f64 && (reinterpret_cast<uintptr_t>(args->moments) & 7))
             return fail(APGPU_EINVAL, "stack: float64 moments must be 8-byte aligned");
-        if (args->flags & ~(APGPU_STACK_EXACT_MOMENTS | APGPU_STACK_MOMENTS_MEAN))
+        if (args->flags & ~(APGPU_STACK_EXACT_MOMENTS | APGPU_STACK_MOMENTS_MEAN | APGPU_STACK_SINGLE_KERNEL))
             return fail(APGPU_EINVAL, "stack: unknown flags 0x%x", args->flags);
+        if (args->workspace) {
+            if (reinterpret_cast<uintptr_t>(args->workspace) & 15) return fail(APGPU_EINVAL, "stack: the workspace must be 16-byte aligned");
+            if (args->workspace_bytes < apgpu_stack_ws_bytes(args->n_pixels, nullptr))
+                return fail(APGPU_EWORKSPACE, "stack: workspace of %zu bytes, %lld pixels need %zu (apgpu_stack_ws_bytes)",
+                            args->workspace_bytes, (long long)args->n_pixels, apgpu_stack_ws_bytes(args->n_pixels, nullptr));
+        }
     } else if (!args->median) {
         return fail(APGPU_EINVAL, "stack_median: median output is NULL");
     }
@@ -124,6 +130,8 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     prm.moments64 = median_only ? 0 : args->moments_f64;
     prm.mean64 = median_only ? nullptr : args->mean_f64;
     prm.std64 = median_only ? nullptr : args->std_f64;
+    prm.redo = median_only ? nullptr : static_cast<int32_t *>(args->workspace);
+    prm.single_kernel = (args->flags & APGPU_STACK_SINGLE_KERNEL) ? 1 : 0;
     prm.fast32 = (median_only || (args->flags & APGPU_STACK_EXACT_MOMENTS)) ? 0 : ((args->flags & APGPU_STACK_MOMENTS_MEAN) ? 2 : 1);
 #ifdef APGPU_DEVELOPMENT                                     // measurement knobs, never in a release build
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;      // all frames alias frame 0: compute-only timing
@@ -140,6 +148,18 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
 }
 
 }  // namespace
+
+static_assert(APGPU_STACK_WS_STATS_OFFSET == kWsStats * sizeof(int32_t), "include/apgpu.h names the statistics' place in the workspace");
+
+extern "C" size_t apgpu_stack_ws_bytes(int64_t n_pixels, size_t *zero_bytes)
+{
+    if (n_pixels <= 0) {
+        if (zero_bytes) *zero_bytes = 0;
+        return 0;
+    }
+    if (zero_bytes) *zero_bytes = (size_t)ws_list_off(n_pixels) * sizeof(int32_t);
+    return (size_t)ws_total_words(n_pixels) * sizeof(int32_t);
+}
 
 extern "C" int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream)
 {

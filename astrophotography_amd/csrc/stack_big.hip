@@ -102,24 +102,27 @@ __device__ __forceinline__ void lds_bitonic_sort(float *col, int lo, int len)
     }
 }
 
-// redo == nullptr: workgroup b reduces the 64 pixels [64 b, 64 b + 64).  redo != nullptr: the PIXELS the chunked fast
-// kernel (stack_chunks.hip) was not sure about - redo[0] entries redo[1 ..], pixel indices - are shared out over the grid,
-// 64 listed pixels per workgroup and trip (a gather: every lane loads its own pixel's column).
+// redo_count == nullptr: workgroup b reduces the 64 pixels [64 b, 64 b + 64).  Otherwise: the PIXELS the chunked fast
+// kernel (stack_chunks.hip) was not sure about - *redo_count entries of redo_list, pixel indices - are shared out over the grid,
+// 64 listed pixels per workgroup and trip (a gather: every lane loads its own pixel's column).  ws != nullptr: count and list
+// live in the caller's workspace (stack_kernels.h, "workspace"): the last workgroup to finish clears the counter it used and
+// books the statistics.
 template <int NP, typename RawT, bool CALIB, bool MEDIAN>
-__global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm, const int32_t *redo)
+__global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackParams prm, int32_t *redo_count, const int32_t *redo_list, int32_t *ws)
 {
     extern __shared__ float col_all[];                      // [NP][64]
     __shared__ FrameScalars<128> fs;
     const int lane = threadIdx.x;
     float *const col = col_all + lane;
-    const int64_t nlisted = redo ? redo[0] : 0;
+    const bool redo = redo_count != nullptr;
+    const int64_t nlisted = redo ? __builtin_amdgcn_readfirstlane(ws_load(redo_count)) : 0;
     const int64_t nitems = redo ? (nlisted + kBigLanes - 1) / kBigLanes : (int64_t)gridDim.x;
 #pragma unroll 1
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
     // (list mode: base 0 and the lane's own pixel as its offset; pixel indices fit an int - chunks_eligible)
     const int64_t base = redo ? 0 : item * kBigLanes;
     const bool listed = redo && item * kBigLanes + lane < nlisted;
-    const int plane = redo ? (listed ? redo[1 + item * kBigLanes + lane] : 0) : lane;
+    const int plane = redo ? (listed ? redo_list[item * kBigLanes + lane] : 0) : lane;
     const int64_t p = base + plane;
     const bool live = redo ? listed : p < prm.P;            // dead lanes of the last workgroup still stage and vote
     __syncthreads();                                        // (redo loop) the previous item is done with LDS
@@ -166,10 +169,22 @@ __global__ __launch_bounds__(kBigLanes, 1) void stack_big_kernel(const StackPara
         }
     }
     }
+    if (ws && lane == 0) {
+        // (one wavefront per workgroup: no barrier needed) every workgroup has read the count before it arrives here
+        const int arrived = __hip_atomic_fetch_add(ws + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (int)gridDim.x - 1) {
+            unsigned long long *const stats = reinterpret_cast<unsigned long long *>(ws + kWsStats);
+            atomicAdd(stats + 0, 1ull);
+            atomicAdd(stats + 1, (unsigned long long)prm.P);
+            atomicAdd(stats + 2, (unsigned long long)nlisted);
+            ws[0] = 0;
+            ws[2] = 0;
+        }
+    }
 }
 
 template <int NP, typename RawT, bool CALIB, bool MEDIAN>
-static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe, const int32_t *redo)
+static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe, int32_t *redo, const int32_t *list, int32_t *ws)
 {
     if (describe) {
         snprintf(describe, 256, "stack_big_kernel<%d, %s, %s, %s>", NP, sizeof(RawT) == 2 ? "unsigned short" : "float",
@@ -185,23 +200,24 @@ static int launch_big_one(const StackParams &prm, hipStream_t st, char *describe
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (big): cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBigLanes), lds, st, prm, redo);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBigLanes), lds, st, prm, redo, list, ws);
     return check_launch("stack kernel (129..512 frames)");
 }
 
 template <typename RawT, bool CALIB>
-static int launch_big_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe, const int32_t *redo)
+static int launch_big_np(const StackParams &prm, bool median_only, hipStream_t st, char *describe, int32_t *redo, const int32_t *list, int32_t *ws)
 {
     if (prm.N <= 256)
-        return median_only ? launch_big_one<256, RawT, CALIB, true>(prm, st, describe, redo) : launch_big_one<256, RawT, CALIB, false>(prm, st, describe, redo);
-    return median_only ? launch_big_one<512, RawT, CALIB, true>(prm, st, describe, redo) : launch_big_one<512, RawT, CALIB, false>(prm, st, describe, redo);
+        return median_only ? launch_big_one<256, RawT, CALIB, true>(prm, st, describe, redo, list, ws) : launch_big_one<256, RawT, CALIB, false>(prm, st, describe, redo, list, ws);
+    return median_only ? launch_big_one<512, RawT, CALIB, true>(prm, st, describe, redo, list, ws) : launch_big_one<512, RawT, CALIB, false>(prm, st, describe, redo, list, ws);
 }
 
 // The exact LDS-resident kernel, on every pixel (redo == nullptr) or on the wavefronts of a redo list.
-int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, const int32_t *redo)
+int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, int32_t *redo,
+                     const int32_t *list, int32_t *ws)
 {
-    if (u16) return calib ? launch_big_np<uint16_t, true>(prm, median_only, st, describe, redo) : launch_big_np<uint16_t, false>(prm, median_only, st, describe, redo);
-    return calib ? launch_big_np<float, true>(prm, median_only, st, describe, redo) : launch_big_np<float, false>(prm, median_only, st, describe, redo);
+    if (u16) return calib ? launch_big_np<uint16_t, true>(prm, median_only, st, describe, redo, list, ws) : launch_big_np<uint16_t, false>(prm, median_only, st, describe, redo, list, ws);
+    return calib ? launch_big_np<float, true>(prm, median_only, st, describe, redo, list, ws) : launch_big_np<float, false>(prm, median_only, st, describe, redo, list, ws);
 }
 
 bool chunks_eligible(const StackParams &prm, bool median_only);                                        // stack_chunks.hip
@@ -211,7 +227,9 @@ int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, 
 int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
     if (chunks_eligible(prm, median_only)) return launch_chunks(prm, u16, calib, st, describe);
-    return launch_big_exact(prm, u16, calib, median_only, st, describe, nullptr);
+    StackParams q = prm;
+    q.redo = nullptr;
+    return launch_big_exact(q, u16, calib, median_only, st, describe, nullptr, nullptr, nullptr);
 }
 
 }  // namespace apgpu_stack

@@ -23,8 +23,11 @@ struct StackParams {
     int maxiters;           // < 0: until convergence
     int moments64;          // layout of `moments` (see above)
     double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
+    int single_kernel;      // host side only: never the fast kernel + redo pass pair (APGPU_STACK_SINGLE_KERNEL)
     int fast32;             // 0: float64 clip only; 1: float32 fast path for mean / count / float32 moments; 2: also float64-layout moments
-    int32_t *redo;          // stack_fast_kernel: [0] = number of entries, [1 ..] = 64-pixel block indices it could not finish
+    int32_t *redo;          // the workspace of the two-kernel scheme (stack_kernels.h, "workspace layout"): segment counters,
+                            // tile flags and per-segment lists of the PIXELS the fast kernel could not finish.  NULL in a
+                            // plain launch of the complete kernels (stack_sigclip_kernel: non-NULL = redo pass)
 };
 
 // The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a
@@ -541,13 +544,15 @@ __device__ __forceinline__ int pad_low(const StackParams &prm)
 template <int NP, typename RawT, bool CALIB, bool FINITE_ONLY, bool FULL, int MINN = padded_minn(NP, FULL), int PRUNE_T = 0,
           bool FORCE_HALVES = false, bool SPLIT_PADS = false, bool PRE = false>
 __device__ __forceinline__ int load_sorted_column(const StackParams &prm, const FrameScalars<NP> &fs, int64_t base,
-                                                  int lane, float (&v)[NP], bool *pruned = nullptr, const EarlyLoads<NP, RawT> &pre = EarlyLoads<NP, RawT>())
+                                                  int lane, float (&v)[NP], bool *pruned = nullptr, const EarlyLoads<NP, RawT> &pre = EarlyLoads<NP, RawT>(),
+                                                  const bool allow_fast = true)
 {
     ColumnCtx cx;
     // SPLIT_PADS (padded stacks headed for the float32 fast path, fast32_possible_padded): the first plo padding slots become
-    // -inf, the rest +inf; the caller (reduce_and_store) knows - from the same arguments - and undoes it for the exact path
+    // -inf, the rest +inf; the caller (reduce_and_store) knows - from the same arguments - and undoes it for the exact path.
+    // allow_fast (wave-uniform; false in the list pass of the redo kernel, which is exact only): no split, every pad +inf.
     int plo = 0;
-    if constexpr (SPLIT_PADS) plo = pad_low<NP>(prm);
+    if constexpr (SPLIT_PADS) plo = allow_fast ? pad_low<NP>(prm) : 0;
     int n = load_column<NP, RawT, CALIB, FINITE_ONLY, FULL, MINN, FORCE_HALVES, PRE>(prm, fs, base, lane, v, cx, plo, pre);
     bool prune = false;
     if constexpr (PRUNE_T > 0) prune = *pruned && wave_all(n == (FULL ? NP : prm.N));

@@ -305,7 +305,7 @@ __device__ __forceinline__ void trim_high_t(const float (&GH)[kChunkTail], FastT
 }
 
 template <int K, typename RawT, bool CALIB, bool FULLCH>
-__global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo)
+__global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo_count, int32_t *redo_list)
 {
     constexpr int T = kChunkTail, W = kChunkWin;
     __shared__ FrameScalars<kChunkSlots> fs[K];
@@ -465,11 +465,11 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
         const uint64_t m = __builtin_amdgcn_ballot_w64(f.unsure);
         if (m != 0) {
             int first = 0;
-            if (__builtin_amdgcn_readfirstlane(lane) == lane) first = atomicAdd(&redo[0], (int)__builtin_popcountll(m));
+            if (__builtin_amdgcn_readfirstlane(lane) == lane) first = atomicAdd(redo_count, (int)__builtin_popcountll(m));
             first = __builtin_amdgcn_readfirstlane(first);
             const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             if (f.unsure) {
-                redo[1 + first + mine] = (int32_t)p;
+                redo_list[first + mine] = (int32_t)p;
                 return;
             }
         }
@@ -484,7 +484,9 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------------------------
-int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, const int32_t *redo);   // stack_big.hip
+// stack_big.hip; redo_count != nullptr: only the listed pixels; ws != nullptr: the list lives in the caller's workspace - clear its counter afterwards
+int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, int32_t *redo_count = nullptr,
+                     const int32_t *redo_list = nullptr, int32_t *ws = nullptr);
 
 // Whether a stack of 129 .. 256 frames can take the chunked fast path: lean outputs, median centre / std deviation, the
 // float32 path not switched off, float64-layout moments only when they are for a mean.
@@ -513,40 +515,47 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     }
     const int64_t grid = (prm.P + 255) / 256;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-    // redo list: count + one entry per pixel, a stream-ordered temporary (nothing persistent is allocated)
-    int32_t *redo = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), (size_t)(prm.P + 1) * sizeof(int32_t), st);
-    if (e != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): cannot allocate the redo list: %s", hipGetErrorString(e));
-    e = hipMemsetAsync(redo, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) {
-        (void)hipFreeAsync(redo, st);
-        return fail(APGPU_ELAUNCH, "stack (chunks): memset: %s", hipGetErrorString(e));
+    // redo list: a count + up to one entry per pixel.  In the caller's workspace (apgpu_stack_args.workspace: the count is word 0
+    // of its first counter line - zero between calls -, the entries its list area, which holds more than P words) or, without
+    // one, a stream-ordered temporary; if that cannot be had either, the exact kernel reduces the whole stack (it needs no list).
+    int32_t *ws = prm.redo, *cnt = nullptr, *list = nullptr, *own = nullptr;
+    StackParams q = prm;
+    q.redo = nullptr;
+    if (ws) {
+        cnt = ws;
+        list = ws + ws_list_off(prm.P);
+    } else {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&own), (size_t)(prm.P + 1) * sizeof(int32_t), st);
+        if (e == hipSuccess) {
+            e = hipMemsetAsync(own, 0, sizeof(int32_t), st);
+            if (e != hipSuccess) (void)hipFreeAsync(own, st);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return launch_big_exact(q, u16, CALIB, false, st, nullptr);
+        }
+        cnt = own;
+        list = own + 1;
     }
     const size_t lds = (size_t)(K - 2) * kChunkWin * 256 * sizeof(float);
     if (lds > 48 * 1024) {
         const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, true>)
                                   : reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, false>);
-        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {                              // no room for the parked windows: the exact kernel does the whole stack
             (void)hipGetLastError();
-            (void)hipFreeAsync(redo, st);
-            return launch_big_exact(prm, u16, CALIB, false, st, nullptr, nullptr);
+            if (own) (void)hipFreeAsync(own, st);
+            return launch_big_exact(q, u16, CALIB, false, st, nullptr);
         }
     }
-    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);
-    else hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, prm, redo);
+    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
+    else hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
     int rc = check_launch("stack kernel (chunked, 129..256 frames)");
-#ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
-    if (getenv("APGPU_DEBUG_REDO")) {
-        int32_t cnt = -1;
-        (void)hipMemcpyAsync(&cnt, redo, sizeof(cnt), hipMemcpyDeviceToHost, st);
-        (void)hipStreamSynchronize(st);
-        fprintf(stderr, "stack_chunks: %d of %lld pixels on the redo list\n", cnt, (long long)prm.P);
+    if (rc == APGPU_OK) rc = launch_big_exact(q, u16, CALIB, false, st, nullptr, cnt, list, ws);
+    if (own) {
+        const hipError_t ef = hipFreeAsync(own, st);
+        if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
     }
-#endif
-    if (rc == APGPU_OK) rc = launch_big_exact(prm, u16, CALIB, false, st, nullptr, redo);
-    const hipError_t ef = hipFreeAsync(redo, st);
-    if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
     return rc;
 }
 

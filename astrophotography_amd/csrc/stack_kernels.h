@@ -37,11 +37,15 @@ using namespace apgpu;
 // (Round 4, measured and dropped: workgroups of 64 lanes, and persistent workgroups walking the tiles with stride gridDim.x
 // so that a finished wavefront's slot is refilled by its own next tile - either pushes the 64-slot kernel over 168 VGPRs,
 // i.e. to two wavefronts per SIMD: 1.09 / 1.24 ms against 1.02 on the same box.)
+// (round 5: the complete lean kernels - plain launch and redo pass in one loop - are held at the three-wavefront budget of 168
+// VGPRs: left alone the loop costs them 174-183 (loop-invariant values kept in registers across the body), i.e. two wavefronts
+// per SIMD and 10-14 % of their speed; with machine LICM off for these translation units (_build.py) the cap costs the full
+// 64-slot kernel nothing and the padded / PLUS ones 2-4 spilled registers)
 #ifndef APGPU_LEAN_MIN_BLOCKS
-#define APGPU_LEAN_MIN_BLOCKS 2
+#define APGPU_LEAN_MIN_BLOCKS 3
 #endif
-#ifndef APGPU_LEAN_BLOCK
-#define APGPU_LEAN_BLOCK 256
+#ifndef APGPU_PLUS_MIN_BLOCKS
+#define APGPU_PLUS_MIN_BLOCKS 3
 #endif
 // (lean kernels of 72 .. 128 slots: two wavefronts per SIMD = at most 256 VGPRs; left alone the padded 112- and 120-slot
 // kernels take 258 - ONE wavefront per SIMD, 4.0 ms where the full 112-slot kernel takes 2.2)
@@ -49,17 +53,83 @@ using namespace apgpu;
 #define APGPU_WIDE_MIN_BLOCKS 2
 #endif
 #ifndef APGPU_PADDED_MIN_BLOCKS
-#define APGPU_PADDED_MIN_BLOCKS 2
+#define APGPU_PADDED_MIN_BLOCKS 3
 #endif
 
+// -------------------------------------------------------------------------------------------------
+// Workspace of the two-kernel scheme (apgpu_stack_args.workspace, include/apgpu.h; int32 words; StackParams.redo points at it):
+//   [0, 4096)                 256 segment lines of 16 words (64 bytes apart, so that their atomics do not share a cache line):
+//                             [0] pixels listed, [2] arrivals of the redo pass, [3] "blocks of tiles with tile % 256 == this
+//                             segment were given up", [4] / [5] the guard's window (alert mode only): pixels listed and
+//                             (window number << 16 | 64-pixel blocks finished) by the window's wavefronts - fast_block_bails
+//   [4096, 4112)              int64 statistics, cumulative over the calls that used this workspace (never reset by the library):
+//                             calls, pixels, pixels listed, 64-pixel blocks given up (APGPU_STACK_WS_STATS_OFFSET = 4 * 4096)
+//   [4112, 4128)              the call line: [0] segments the redo pass has finished, [1] pixels listed by this call, [2] blocks
+//                             given up by this call, [3] the MODE the next call's fast kernel starts in (0 = alert: every
+//                             wavefront checks its segment's counter before it loads anything; 1 = quiet: the previous call on
+//                             this workspace listed under 1 % of its pixels and gave nothing up, no check - fast_block_bails)
+//   [4128, list_off)          one int32 flag per 64-pixel block (four per 256-pixel tile): the fast kernel's wavefront gave the
+//                             block up, the redo pass does it whole
+//   [list_off, ...)           256 segments of redo_seg_capacity(P) pixel indices (segment = workgroup % 256)
+// Everything below list_off is ZERO between calls, the statistics and the mode word excepted: the caller zeroes it once, the redo
+// pass leaves it zero again (its last workgroup per segment clears what the call used).  The layout depends on P: a workspace
+// serves one image size at a time.
+// -------------------------------------------------------------------------------------------------
+constexpr int kRedoSegs = 256;
+constexpr int kWsLine = 16;
+constexpr int kWsStats = kRedoSegs * kWsLine;
+constexpr int kWsCall = kWsStats + 16;
+constexpr int kWsFlags = kWsCall + 16;
+constexpr int kModeAlert = 0, kModeQuiet = 1;
+// entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles; one tile more for
+// the pair kernels, whose workgroups cover 512 pixels)
+__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs + 1) * 256; }
+__host__ __device__ inline int64_t ws_flag_words(int64_t P) { return ((4 * ((P + 255) / 256 + 2) + 15) / 16) * 16; }
+__host__ __device__ inline int64_t ws_list_off(int64_t P) { return kWsFlags + ws_flag_words(P); }
+__host__ __device__ inline int64_t ws_total_words(int64_t P) { return ws_list_off(P) + (int64_t)kRedoSegs * redo_seg_capacity(P); }
+
+// The kernel's argument block as a value, every field by its own scalar load from the kernarg segment (late_params: opaque,
+// so the loads happen where this is called).
+__device__ __forceinline__ StackParams read_params(LateParams *kp)
+{
+    StackParams q;
+    q.frames = kp->frames; q.bias = kp->bias; q.dark = kp->dark; q.nflat = kp->nflat; q.exp_ratio = kp->exp_ratio;
+    q.pedestal = kp->pedestal; q.pixmask = kp->pixmask; q.mean = kp->mean; q.median = kp->median; q.std = kp->std;
+    q.moments = kp->moments; q.count = kp->count; q.P = kp->P; q.stride = kp->stride; q.sl2 = kp->sl2; q.su2 = kp->su2;
+    q.N = kp->N; q.still_biased = kp->still_biased; q.center = kp->center; q.dev = kp->dev; q.maxiters = kp->maxiters;
+    q.moments64 = kp->moments64; q.mean64 = kp->mean64; q.std64 = kp->std64; q.single_kernel = kp->single_kernel;
+    q.fast32 = kp->fast32; q.redo = kp->redo;
+    return q;
+}
+
+// A coherent read of a counter other workgroups bump with atomics (agent scope: past the non-coherent vector / scalar caches).
+__device__ __forceinline__ int ws_load(const int32_t *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The complete kernels.  EXTRA: the rich kernel (sorted column parked in LDS: mad_std, float64 planes), one tile per workgroup.
+// Otherwise the lean kernel (float32 fast path with the exact path behind it, wavefront by wavefront), in one of two roles:
+//   prm.redo == nullptr   the whole stack, workgroup b reduces the tile [256 b, 256 b + 256);
+//   prm.redo != nullptr   the REDO PASS behind stack_fast_kernel / stack_fast_u16_pairs_kernel (round 5; round 4 had a separate
+//                         stack_redo_kernel family - a third of the library's code): a fixed grid of kRedoSegs * k workgroups;
+//                         workgroup b serves segment b % kRedoSegs with the k - 1 others of that segment:
+//                         (1) the segment's LISTED PIXELS, one per lane (a gather: base 0, the pixel index as the lane offset),
+//                             exact clip only - a listed pixel has failed the float32 path already;
+//                         (2) if the segment's word [3] is set, the FLAGGED 64-PIXEL BLOCKS of its tiles (tile % 256 ==
+//                             segment; wavefront w of the workgroup looks at block w of each tile), whole and coalesced, fast
+//                             path allowed - what the fast kernel's wavefronts gave up without trying (fast_block_bails:
+//                             more than an eighth of the segment's pixels were failing, or the frames of a uint16 pair stack
+//                             do not share one exposure ratio).  This is the guard against the two-kernel scheme's worst
+//                             case: a stack whose pixels mostly fail costs one pass of THIS kernel plus a few rounds of the
+//                             fast one, not both in full.  A wavefront reads the flags of its next 64 tiles with ONE load
+//                             and walks the set bits: one flag per load left a memory round trip in front of every block.
+//                         (3) the last workgroup of a segment to finish clears the segment's counters and flags and adds to
+//                             the statistics; the last segment to finish sets the mode of the next call's fast kernel.
+// One body serves all three item kinds (one copy of the code): a small wave-uniform state machine picks the next item.
 template <int NP, typename RawT, bool CALIB, bool EXTRA, bool FULL, bool PLUS = false>
 // (padded lean kernels: capped at the three-wavefront register budget - 172 VGPRs uncapped -, the spills land in the
 // exact-fallback blocks; full ones need 166 by themselves)
-__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN_BLOCK), NP <= 64 ? (EXTRA || PLUS ? 2 : (FULL ? APGPU_LEAN_MIN_BLOCKS : APGPU_PADDED_MIN_BLOCKS)) : ((EXTRA || PLUS) ? 1 : APGPU_WIDE_MIN_BLOCKS)) void stack_sigclip_kernel(const StackParams prm)
+__global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ? 2 : (PLUS ? APGPU_PLUS_MIN_BLOCKS : (FULL ? APGPU_LEAN_MIN_BLOCKS : APGPU_PADDED_MIN_BLOCKS))) : ((EXTRA || PLUS) ? 1 : APGPU_WIDE_MIN_BLOCKS)) void stack_sigclip_kernel(const StackParams prm)
 {
-    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int lane = threadIdx.x;
-    const int64_t p = base + lane;
     __shared__ FrameScalars<NP> fs;
     __shared__ ColumnLds<NP, EXTRA> cols;        // lane-private columns: no barrier around their use
     // Full calibrated stacks without pedestals read the exposure ratios with scalar loads and stage nothing: no barrier before
@@ -67,47 +137,145 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
     // wavefront's wait for its ratios is an in-order vmcnt(0) that then covers its 67 column loads as well - worse.)
     constexpr int MINN = padded_minn(NP, FULL);
     if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
-    if (p >= prm.P) return;
-
-    float v[NP];
-    APGPU_MARK("load_calibrate_sort");
-#ifdef APGPU_VARIANT_STRIP
-    // measurement only (tools/variant_lib.sh): the kernel WITHOUT its clip (1: load + calibrate + pruned sort, the sorted
-    // column's needed outputs summed; 2: load + calibrate, the column summed) - the instruction floor of DESIGN 4.1
-    if constexpr (!EXTRA && !PLUS && fast32_possible(NP, MINN)) {
-        float acc = 0.f;
-        if (APGPU_VARIANT_STRIP == 1) {
-            bool pruned = true;
-            load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTail>(prm, fs, base, lane, v, &pruned);
-#pragma unroll
-            for (int i = 0; i < NP; i++) acc += v[i];
-        } else {
-            ColumnCtx cx;
-            load_column<NP, RawT, CALIB, true, FULL, MINN>(prm, fs, base, lane, v, cx);
-#pragma unroll
-            for (int i = 0; i < NP; i++) acc += v[i];
-        }
-        if (prm.mean) prm.mean[p] = acc;
-        return;
-    }
-#endif
     if constexpr (EXTRA) {
+        const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+        const int64_t p = base + lane;
+        if (p >= prm.P) return;
+        float v[NP];
+        APGPU_MARK("load_calibrate_sort");
         const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
         reduce_and_store_rich<NP>(prm, v, n, p, cols.lane_ptr(lane));
-    } else if constexpr (fast32_possible(NP, MINN)) {
-        // full stacks headed for the float32 fast path only sort what it reads (pruned network); `pruned` tells the reduction
-        // to complete the sort should it have to fall back to the exact path
-        bool pruned = fast32_wanted(prm);
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTail>(prm, fs, base, lane, v, &pruned);
-        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p, pruned);
-    } else if constexpr (fast32_possible_padded(NP, MINN)) {
-        // padded stacks: split pads (-inf below, +inf above the real values) and tails of 8 - see fast32_possible_padded
-        bool pruned = fast32_wanted(prm);
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, fast_tail_padded(NP), false, true>(prm, fs, base, lane, v, &pruned);
-        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p, pruned);
     } else {
-        const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, base, lane, v);
-        reduce_and_store<NP, MINN, PLUS>(prm, v, n, p);
+        enum { kPlain = 0, kList = 1, kTiles = 2, kDone = 3 };
+        const bool redo_pass = prm.redo != nullptr;
+        const int seg = blockIdx.x % kRedoSegs, rank = blockIdx.x / kRedoSegs, wv = __builtin_amdgcn_readfirstlane(lane >> 6);
+        int nitems = 0, flagged = 0, phase = kPlain, cursor = 0, nblocks_done = 0;
+        uint64_t pending = 0;                                // kTiles: the flagged ones among the 64 tiles before `cursor`
+        if (redo_pass) {
+            nitems = __builtin_amdgcn_readfirstlane(ws_load(prm.redo + seg * kWsLine));
+            flagged = __builtin_amdgcn_readfirstlane(ws_load(prm.redo + seg * kWsLine + 3));      // blocks of tiles with tile % 256 == seg were given up
+            phase = kList;
+            cursor = rank * 256;
+        }
+#pragma unroll 1
+        for (;;) {
+            int64_t base = 0;
+            int off = 0;
+            bool valid = false, fastok = true;
+            if (phase == kPlain) {
+                base = (int64_t)blockIdx.x * 256;
+                off = lane;
+                valid = base + off < prm.P;
+                phase = kDone;
+            } else if (phase == kList) {
+                if (cursor >= nitems) {
+                    phase = flagged ? kTiles : kDone;
+                    cursor = rank;
+                    continue;
+                }
+                LateParams *const kp = late_params();
+                const int32_t *const list = kp->redo + ws_list_off(kp->P) + (int64_t)seg * redo_seg_capacity(kp->P);
+                valid = cursor + lane < nitems;
+                off = valid ? list[cursor + lane] : 0;
+                fastok = false;
+                cursor += (int)(gridDim.x / kRedoSegs) * 256;
+            } else if (phase == kTiles) {
+                // this workgroup's tiles of the segment: tile(c) = seg + c * kRedoSegs, c = rank, rank + per_seg, ...
+                LateParams *const kp = late_params();
+                const int per_seg = (int)(gridDim.x / kRedoSegs);
+                const int64_t ntiles = (kp->P + 255) / 256;
+                if (pending == 0) {
+                    if (seg + (int64_t)cursor * kRedoSegs >= ntiles) {
+                        phase = kDone;
+                        continue;
+                    }
+                    // lane i: the flag of this wavefront's block in the i-th of the next 64 tiles
+                    const int64_t t = seg + ((int64_t)cursor + (int64_t)(lane & 63) * per_seg) * kRedoSegs;
+                    const int f = t < ntiles ? kp->redo[kWsFlags + 4 * t + wv] : 0;
+                    pending = __builtin_amdgcn_ballot_w64(f != 0);
+                    cursor += 64 * per_seg;
+                    continue;
+                }
+                const int i = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const int64_t tile = seg + ((int64_t)cursor - (int64_t)(64 - i) * per_seg) * kRedoSegs;
+                nblocks_done++;
+                base = tile * 256 + wv * 64;
+                off = lane & 63;
+                valid = base + off < kp->P;
+            } else {
+                break;
+            }
+            if (valid) {
+                const int64_t p = base + off;
+                float v[NP];
+                APGPU_MARK("load_calibrate_sort");
+                // the arguments are read from the kernarg segment HERE, once per item: as values that live across the loop they
+                // cost ~40 SGPRs that the body then spills to VGPR lanes (175 instead of 166 VGPRs: two wavefronts per SIMD)
+                const StackParams q = read_params(late_params());
+                if constexpr (fast32_possible(NP, MINN)) {
+                    // full stacks headed for the float32 fast path only sort what it reads (pruned network); `pruned` tells the
+                    // reduction to complete the sort should it have to fall back to the exact path
+                    bool pruned = fastok && fast32_wanted(q);
+                    const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, kFastTail>(q, fs, base, off, v, &pruned);
+                    reduce_and_store<NP, MINN, PLUS>(q, v, n, p, pruned, fastok);
+                } else if constexpr (fast32_possible_padded(NP, MINN)) {
+                    // padded stacks: split pads (-inf below, +inf above the real values) and tails of 8 - see fast32_possible_padded
+                    bool pruned = fastok && fast32_wanted(q);
+                    const int n = load_sorted_column<NP, RawT, CALIB, true, FULL, MINN, fast_tail_padded(NP), false, true>(q, fs, base, off, v, &pruned, EarlyLoads<NP, RawT>(), fastok);
+                    reduce_and_store<NP, MINN, PLUS>(q, v, n, p, pruned, fastok);
+                } else {
+                    const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(q, fs, base, off, v);
+                    reduce_and_store<NP, MINN, PLUS>(q, v, n, p, false, fastok);
+                }
+            }
+        }
+        if (redo_pass) {
+            // The segment's last workgroup to get here clears what the call used and books the call's statistics; the last
+            // segment sets the next call's mode.  Every workgroup of the segment has read the counters by then (at its start);
+            // the block flags are read during the walk, so a workgroup that walked tiles waits for all its wavefronts before it
+            // reports in.  (The common case - nothing flagged - is one atomic by one lane and no barrier: with a barrier pair here
+            // the 4096 mostly idle workgroups of the benchmark's redo pass took 80 us where its one busy wavefront per segment
+            // needs 20.)
+            LateParams *const kp = late_params();
+            int32_t *const ws = kp->redo;
+            unsigned long long *const stats = reinterpret_cast<unsigned long long *>(ws + kWsStats);
+            if (nblocks_done && (lane & 63) == 0) {
+                atomicAdd(stats + 3, (unsigned long long)nblocks_done);
+                atomicAdd(ws + kWsCall + 2, nblocks_done);
+            }
+            if (flagged) __syncthreads();
+            if (lane == 0) {
+                const int per_seg = (int)(gridDim.x / kRedoSegs);
+                const int arrived = __hip_atomic_fetch_add(ws + seg * kWsLine + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (arrived == per_seg - 1) {
+                    if (nitems) {
+                        atomicAdd(stats + 2, (unsigned long long)nitems);
+                        atomicAdd(ws + kWsCall + 1, nitems);
+                    }
+                    if (flagged) {
+                        const int64_t ntiles = (kp->P + 255) / 256;
+                        for (int64_t t = seg; t < ntiles + 1; t += kRedoSegs) *reinterpret_cast<int4 *>(ws + kWsFlags + 4 * t) = make_int4(0, 0, 0, 0);
+                    }
+                    ws[seg * kWsLine] = 0;
+                    ws[seg * kWsLine + 1] = 0;
+                    ws[seg * kWsLine + 2] = 0;
+                    ws[seg * kWsLine + 3] = 0;
+                    ws[seg * kWsLine + 4] = 0;
+                    ws[seg * kWsLine + 5] = 0;
+                    const int segs_done = __hip_atomic_fetch_add(ws + kWsCall, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                    if (segs_done == kRedoSegs - 1) {        // the call is complete: totals -> statistics, and the next call's mode
+                        const long long listed = ws_load(ws + kWsCall + 1), blocks = ws_load(ws + kWsCall + 2);
+                        atomicAdd(stats + 0, 1ull);
+                        atomicAdd(stats + 1, (unsigned long long)kp->P);
+                        ws[kWsCall + 3] = (blocks == 0 && listed * 100 < kp->P) ? kModeQuiet : kModeAlert;
+                        ws[kWsCall] = 0;
+                        ws[kWsCall + 1] = 0;
+                        ws[kWsCall + 2] = 0;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -134,15 +302,11 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : (PLUS ? 256 : APGPU_LEAN
 #ifndef APGPU_FAST_MIN_BLOCKS
 #define APGPU_FAST_MIN_BLOCKS 4
 #endif
-constexpr int kRedoSegs = 256;
-// entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles; one tile more for
-// the pair kernels, whose workgroups cover 512 pixels)
-__host__ __device__ inline int64_t redo_seg_capacity(int64_t P) { return (((P + 255) / 256 + kRedoSegs - 1) / kRedoSegs + 1) * 256; }
 
 // Appends the failing lanes' pixels to the list: one atomic per wavefront that has any.  kRedoSegs counters, one cache line
 // apart, each with its own stretch of the list (segment = workgroup % kRedoSegs, so a segment can never overflow its share):
 // a stack whose every pixel fails would otherwise serialise on one address.
-__device__ __forceinline__ void redo_push(bool fail, int64_t p)
+__device__ __forceinline__ void redo_push(bool fail, int64_t p, bool alert)
 {
     const uint64_t m = __builtin_amdgcn_ballot_w64(fail);
     if (m == 0) return;
@@ -150,10 +314,103 @@ __device__ __forceinline__ void redo_push(bool fail, int64_t p)
     int32_t *const redo = kp->redo;
     const int seg = blockIdx.x % kRedoSegs;
     int first = 0;
-    if ((threadIdx.x & 63) == 0) first = atomicAdd(&redo[seg * 16], (int)__builtin_popcountll(m));
+    if (alert && (threadIdx.x & 63) == 0) atomicAdd(&redo[seg * kWsLine + 4], (int)__builtin_popcountll(m));      // the guard's window
+    if ((threadIdx.x & 63) == 0) first = atomicAdd(&redo[seg * kWsLine], (int)__builtin_popcountll(m));
     first = __builtin_amdgcn_readfirstlane(first);
     const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-    if (fail) redo[kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(kp->P) + first + mine] = (int32_t)p;
+    if (fail) redo[ws_list_off(kp->P) + (int64_t)seg * redo_seg_capacity(kp->P) + first + mine] = (int32_t)p;
+}
+
+// The guard against the two-kernel scheme's worst case (round 5).  A listed pixel is paid for twice - the fast kernel's work on
+// it is lost, and the redo pass gathers it through a list - which is a bargain at the benchmark's 0.007 % and a loss when most
+// pixels fail (5 or more values to trim per side, frames full of NaNs, pedestal-free data outside the division's guards ...):
+// measured on 64 x 4096^2 with a share f of the columns forced off the fast path (profiles/r05/redo_sweep.txt), the list route
+// costs 1.65 + 0.8 f ms against 1.70 for the complete kernel alone - 1.4 x at f = 1.  So a WAVEFRONT first looks at how its
+// segment has fared: the segment's line holds, for the current WINDOW of kBailWindow consecutive workgroups of the segment, the
+// pixels its wavefronts listed and the 64-pixel blocks they finished; once more than kBailNum / kBailDen of the finished pixels
+// were listed (and at least kBailMinBlocks blocks are in) this and every later wavefront of the window GIVES ITS BLOCK UP at
+// once - one flag store, no loads, no arithmetic - and the redo pass reduces the flagged blocks whole and coalesced with the
+// complete kernel's body.  A window's first workgroup starts its counters afresh, so every window begins with kBailMinBlocks
+// blocks of honest attempts: a bad REGION (the NaN border of resampled frames, a satellite-free corner of a mosaic) costs its
+// own windows, not the image - a first version with one cumulative count and a sticky flag per segment gave up C5's whole
+// 8192^2 share because its first 30 rows are the frames' NaN border (8.2 against 5.6 ms per step).  Segments interleave the
+// image's tiles (segment = tile % 256), so each samples its window's rows evenly and they tip together.  Flags are per
+// wavefront (a 64-pixel block; two for a pair kernel's wavefront): the four wavefronts of a workgroup decide on their own -
+// they read the line at different moments and there is no barrier to agree behind.
+// The look costs one coherent 8-byte load and its round trip to L2 BEFORE the wavefront's frame loads can be issued: measured
+// on the benchmark, +1.5 % (profiles/r05/ab_bail.txt) - for a guard that data like the benchmark's never needs.  Hence the MODE
+// word (workspace layout above): the redo pass of every call leaves behind whether the NEXT call on this workspace may skip
+// the look (quiet: under 1 % listed, nothing given up) or must take it (alert; also the state of a fresh, zeroed workspace
+// and of the temporary a call without workspace makes).  The word is read with a scalar load - written by an earlier
+// kernel, never during this one - so a quiet call pays nothing (and counts no finished blocks).  The price: the FIRST call
+// after the data turned bad runs unguarded (both kernels in full); from the second on the guard holds.
+#ifndef APGPU_BAIL_MIN_BLOCKS
+#define APGPU_BAIL_MIN_BLOCKS 16
+#define APGPU_BAIL_NUM 2
+#define APGPU_BAIL_DEN 5
+#define APGPU_BAIL_WINDOW_LOG2 7
+#endif
+constexpr int kBailMinBlocks = APGPU_BAIL_MIN_BLOCKS, kBailNum = APGPU_BAIL_NUM, kBailDen = APGPU_BAIL_DEN;
+constexpr int kBailWindowLog2 = APGPU_BAIL_WINDOW_LOG2;    // workgroups of a segment per window (128: 32768 tiles of the image)
+
+// the mode the previous call left behind: a scalar load (constant address space: nothing writes it while this kernel runs)
+__device__ __forceinline__ bool fast_kernel_alert()
+{
+#ifdef APGPU_VARIANT_NO_BAIL
+    return false;
+#endif
+    typedef const int __attribute__((address_space(4))) cint;
+    return ((cint *)(uintptr_t)late_params()->redo)[kWsCall + 3] != kModeQuiet;
+}
+
+// a wavefront that ran the fast path reports its blocks as finished (alert mode only: the guard's denominator)
+template <int TILE>
+__device__ __forceinline__ void fast_blocks_done(bool alert, int32_t *ws)
+{
+    if (alert && (threadIdx.x & 63) == 0) atomicAdd(ws + (blockIdx.x % kRedoSegs) * kWsLine + 5, TILE / 256);
+}
+
+// TILE: pixels per workgroup (256; 512 in the pair kernels, whose wavefront covers two blocks).  Block b = pixels [64 b, 64 b + 64);
+// its tile (b / 4) belongs to the tile walk of segment (b / 4) % 256 - hence word [3], "this segment has flagged blocks", next to
+// word [1], "this segment's wavefronts give up" (segment = workgroup % 256: the same thing only for the 256-pixel kernels).
+template <int TILE>
+__device__ __forceinline__ void give_blocks_up()
+{
+    if ((threadIdx.x & 63) != 0) return;
+    LateParams *const kp = late_params();
+    int32_t *const ws = kp->redo;
+    constexpr int BPW = TILE / 256;                          // blocks per wavefront
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * BPW;
+    const int64_t nblocks = (kp->P + 63) / 64;
+#pragma unroll
+    for (int k = 0; k < BPW; k++) {
+        if (b0 + k < nblocks) {
+            ws[kWsFlags + b0 + k] = 1;
+            ws[(int)(((b0 + k) >> 2) % kRedoSegs) * kWsLine + 3] = 1;
+        }
+    }
+}
+
+template <int TILE>
+__device__ __forceinline__ bool fast_block_bails(bool alert, int32_t *ws)
+{
+    if (!alert) return false;                                // (scalar: a quiet call loads nothing)
+    const int j = blockIdx.x / kRedoSegs;                    // this workgroup's ordinal within its segment
+    const int window = j >> kBailWindowLog2;
+    int32_t *const line = ws + (blockIdx.x % kRedoSegs) * kWsLine;
+    if ((j & ((1 << kBailWindowLog2) - 1)) == 0) {           // a window's first workgroup starts the counters afresh
+        if (threadIdx.x == 0) {
+            line[4] = 0;
+            line[5] = window << 16;
+        }
+        return false;
+    }
+    const uint64_t wc = __hip_atomic_load(reinterpret_cast<const uint64_t *>(line + 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int listed = __builtin_amdgcn_readfirstlane((int)(uint32_t)wc);
+    const int w5 = __builtin_amdgcn_readfirstlane((int)(uint32_t)(wc >> 32));
+    const int done = w5 & 0xffff;
+    // (counts of another window - its first workgroup has not got here yet, or stragglers of the last one - say nothing)
+    return (w5 >> 16) == window && done >= kBailMinBlocks && (int64_t)listed * kBailDen > (int64_t)done * 64 * kBailNum;
 }
 
 // clip_fast32 + the outputs of reduce_and_store's fast branch for the lanes that complete; `good` is cleared for the others.
@@ -238,6 +495,11 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
     __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
     const int N = FULL ? NP : (PADS > 0 ? NP - PADS : prm.N);
     const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
+    const bool alert = fast_kernel_alert();
+    if (fast_block_bails<256>(alert, prm.redo)) {           // the segment's pixels mostly fail: the redo pass takes the block whole
+        give_blocks_up<256>();
+        return;
+    }
     bool good = false;
     if (base + 256 <= prm.P) {                              // the last, partial tile goes to the redo list whole
         float v[NP];
@@ -289,6 +551,24 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
                 }
             }
         }
+#ifdef APGPU_VARIANT_STRIP
+        // measurement only (tools/variant_lib.sh): THIS kernel without its clip - 2: loads + calibration, the column summed; 1: the
+        // pruned sort and the range test as well, then the column summed - the floor rows of DESIGN 4.1 (round 5: measured on the
+        // kernel that ships, same control flow up to the cut, same residency: the LDS block below holds it at four workgroups per CU)
+        if (wave_any(good)) {
+            if (APGPU_VARIANT_STRIP == 1) {
+                sort_column<NP, T>(v);
+                if constexpr (CALIB) good = good && range_ok_sorted<NP, MINN>(v, dodiv, N, plo);
+            }
+            float acc[4] = {good ? 0.f : 1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NP; i++) acc[i & 3] += v[i];
+            if (prm.mean) prm.mean[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        __shared__ char geometry[40 * 1024];
+        if (prm.N < 0) geometry[lane] = 1;
+        return;
+#endif
         if (wave_any(good)) {
             sort_column<NP, T>(v);
             if constexpr (CALIB) good = good && range_ok_sorted<NP, MINN>(v, dodiv, N, plo);
@@ -301,33 +581,9 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
             if (wave_any(good)) finish_fast_column<NP, T, CALIB, PLO, PHI, PLUS>(v, good, p, plo, CALIB ? phi : nonfin);
         }
     }
-    redo_push(!good && p < late_params()->P, p);
-}
-
-// The pixels stack_fast_kernel left: the complete path (what stack_sigclip_kernel<NP, RawT, CALIB, false, FULL> does for a
-// pixel), one list entry per lane, a fixed grid walking the list.  prm.fast32 is 0 here (the launcher clears it).
-template <int NP, typename RawT, bool CALIB, bool FULL = true, bool PLUS = false>
-__global__ __launch_bounds__(256) void stack_redo_kernel(const StackParams prm)
-{
-    constexpr int MINN = padded_minn(NP, FULL);
-    __shared__ FrameScalars<NP> fs;
-    if (needs_staging<CALIB, FULL, NP>(prm)) stage_frame_scalars<NP>(prm, fs);
-    // workgroup b walks segment b % kRedoSegs together with the other workgroups of that segment (gridDim.x / kRedoSegs of them)
-    const int seg = blockIdx.x % kRedoSegs, per_seg = gridDim.x / kRedoSegs;
-    const int nitems = prm.redo[seg * 16];
-    const int32_t *const list = prm.redo + kRedoSegs * 16 + (int64_t)seg * redo_seg_capacity(prm.P);
-#pragma unroll 1
-    for (int item0 = (blockIdx.x / kRedoSegs) * 256; item0 < nitems; item0 += per_seg * 256) {
-        const int item = item0 + (int)threadIdx.x;
-        if (item < nitems) {
-            const int pix = list[item];
-            float v[NP];
-            // (prm.fast32 is 0: no split pads - pad_low is 0 -, the complete network, the float64 clip; a gather: base 0, the
-            // lane's own pixel as the offset)
-            const int n = load_sorted_column<NP, RawT, CALIB, true, FULL>(prm, fs, 0, pix, v);
-            reduce_and_store<NP, MINN, PLUS>(prm, v, n, (int64_t)pix);
-        }
-    }
+    // (finished blocks are counted BEFORE their pixels are listed: whoever reads the line in between underestimates the rate)
+    fast_blocks_done<256>(alert, prm.redo);
+    redo_push(!good && p < late_params()->P, p, alert);
 }
 
 // np.nanmedian(axis=0): NaNs dropped, +/-inf are ordinary values.
@@ -732,8 +988,18 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
     const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;
     const int64_t p2 = ((int64_t)blockIdx.x * 256 + lane) * 2;         // this lane's pixel pair (P is even here)
     bool good0 = false, good1 = false;
-    bool tile_ok = ((int64_t)blockIdx.x + 1) * 512 <= prm.P;
-    if constexpr (CALIB) tile_ok = tile_ok && ratios_uniform<NP>(prm.exp_ratio, N);
+    const bool tile_ok = ((int64_t)blockIdx.x + 1) * 512 <= prm.P;
+    // Frames that do not share one exposure ratio (a wave-uniform scalar test) cannot take the pair scheme at all, and a segment
+    // whose pixels mostly fail should not try: either way the workgroup gives its two tiles up and the redo pass reduces them
+    // whole with the complete one-pixel-per-lane body, float32 fast path included (round 4 listed every pixel of such a stack
+    // and redid it through the gather with the float64 clip only - the advisor's "performance cliff").
+    const bool alert = fast_kernel_alert();
+    bool give_up = fast_block_bails<512>(alert, prm.redo);
+    if constexpr (CALIB) give_up = give_up || !ratios_uniform<NP>(prm.exp_ratio, N);
+    if (give_up) {
+        give_blocks_up<512>();
+        return;
+    }
     if (tile_ok) {
         float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
         bool dodiv[2] = {false, false};
@@ -785,9 +1051,10 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void sta
         for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
         good1 = fast_raw_column<NP, CALIB, FULL, T, MINN, PLO, PHI>(fs, cur, bb[1], dd[1], nn[1], dodiv[1], skip[1], prm.exp_ratio, p2 + 1, N, plo, phi);
     }
+    fast_blocks_done<512>(alert, prm.redo);                  // (before the pushes: see stack_fast_kernel)
     const int64_t P = late_params()->P;
-    redo_push(!good0 && p2 < P, p2);
-    redo_push(!good1 && p2 + 1 < P, p2 + 1);
+    redo_push(!good0 && p2 < P, p2, alert);
+    redo_push(!good1 && p2 + 1 < P, p2 + 1, alert);
 }
 
 // Whether a call takes stack_fast_kernel + stack_redo_kernel (host side; the same conditions as fast32_wanted, plus: lean
@@ -797,74 +1064,73 @@ inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool 
 #ifdef APGPU_VARIANT_NO_FAST_KERNEL
     return false;
 #endif
-    if (median_only || rich || plus) return false;
+    if (median_only || rich || plus || prm.single_kernel) return false;
     if (prm.fast32 == 0 || prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (!(prm.moments == nullptr || prm.moments64 == 0 || prm.fast32 == 2)) return false;
     if (prm.pedestal) return false;
     return prm.P < 0x7fffffffLL;
 }
 
-// The redo list is a stream-ordered temporary of P + 4096 words.  The device's default pool returns freed memory to the
-// system at the next synchronisation unless told otherwise - a fresh 64 .. 270 MB allocation per call; keep up to 1 GiB.
-inline void keep_pool_memory()
+// fast(prm) launches the fast kernel, redo(prm, workgroups) the redo pass (the complete kernel with prm.redo set).  The
+// workspace is the caller's (apgpu_stack_args.workspace, checked by stack_dispatch: large enough, its prefix zero) - then the
+// call is exactly these two dispatches; without one the list is a stream-ordered temporary (allocate, clear the prefix,
+// free: three more runtime calls, and whatever the pool does with 4 bytes per pixel - the library no longer touches the
+// pool's settings).  Returns kNoRedoList (> 0, nothing launched) when neither can be had: the caller goes on to the
+// complete kernels, which need no list.
+constexpr int kNoRedoList = 1;
+
+// Workgroups of 256 threads of `Kernel` that fit a CU (2 or 3 for the complete kernels, by their register count): the redo pass
+// launches exactly one residency round of them.  Asked once per kernel.
+template <auto Kernel>
+int blocks_per_cu()
 {
-    static bool done[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || done[dev]) return;
-    done[dev] = true;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess) return;
-    uint64_t keep = 1ull << 30, cur = 0;
-    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur >= keep) return;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    static int cached = 0;
+    if (cached == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, Kernel, 256, 0) != hipSuccess || n < 1) {
+            (void)hipGetLastError();
+            n = 2;
+        }
+        cached = n > 4 ? 4 : n;
+    }
+    return cached;
 }
 
-// fast(prm) launches the fast kernel, redo(prm, workgroups) the kernel that walks the list.  Returns kNoRedoList (> 0, nothing
-// launched) when the list cannot be allocated: the caller goes on to the complete kernels.
-constexpr int kNoRedoList = 1;
 template <typename FastLaunch, typename RedoLaunch>
-int launch_with_redo(const StackParams &prm0, hipStream_t st, FastLaunch fast, RedoLaunch redo_launch)
+int launch_with_redo(const StackParams &prm0, hipStream_t st, int redo_blocks_per_cu, FastLaunch fast, RedoLaunch redo_launch)
 {
-    // redo list: kRedoSegs counters (64 bytes apart) + kRedoSegs segments of entries, a stream-ordered temporary
     const int64_t ntiles = (prm0.P + 255) / 256;
-    const size_t words = (size_t)kRedoSegs * 16 + (size_t)kRedoSegs * (size_t)redo_seg_capacity(prm0.P);
-    keep_pool_memory();
-    int32_t *redo = nullptr;
-    hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&redo), words * sizeof(int32_t), st);
-    if (e != hipSuccess) {                                  // no room for the list (4 bytes per pixel): the complete kernel needs none
-        (void)hipGetLastError();
-        return kNoRedoList;
-    }
-    e = hipMemsetAsync(redo, 0, (size_t)kRedoSegs * 16 * sizeof(int32_t), st);
-    if (e != hipSuccess) {
-        (void)hipFreeAsync(redo, st);
-        return fail(APGPU_ELAUNCH, "stack (fast): memset: %s", hipGetErrorString(e));
+    int32_t *ws = prm0.redo;
+    const bool own = ws == nullptr;
+    if (own) {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&ws), (size_t)ws_total_words(prm0.P) * sizeof(int32_t), st);
+        if (e != hipSuccess) {                              // no room for the list (4 bytes per pixel): the complete kernel needs none
+            (void)hipGetLastError();
+            return kNoRedoList;
+        }
+        e = hipMemsetAsync(ws, 0, (size_t)ws_list_off(prm0.P) * sizeof(int32_t), st);
+        if (e != hipSuccess) {
+            (void)hipFreeAsync(ws, st);
+            return fail(APGPU_ELAUNCH, "stack (fast): memset: %s", hipGetErrorString(e));
+        }
     }
     StackParams prm = prm0;
-    prm.redo = redo;
+    prm.redo = ws;
     fast(prm);
     int rc = check_launch("stack kernel (fast)");
     if (rc == APGPU_OK) {
-        prm.fast32 = 0;                                     // the list is redone by the exact clip
-        // kRedoSegs .. 16 kRedoSegs workgroups (a multiple of the segment count), by the size of the image; workgroups beyond
-        // their segment's count leave at once
-        int64_t per_seg = ntiles / (kRedoSegs * 8);
-        per_seg = per_seg < 1 ? 1 : (per_seg > 16 ? 16 : per_seg);
+        // One residency round of the complete kernel: as many workgroups per segment as fit a CU (256 CUs = 256 segments; one
+        // per segment for small images), so a pass with every block flagged walks them at full width, while a pass with next to
+        // nothing to do - the usual one - is over as soon as its one busy wavefront per segment is (round 4 launched up to
+        // 4096 workgroups: several rounds that only look at a counter and leave)
+        const int64_t per_seg = ntiles >= 4 * kRedoSegs ? redo_blocks_per_cu : 1;
         redo_launch(prm, (unsigned)(kRedoSegs * per_seg));
-        rc = check_launch("stack kernel (redo list)");
+        rc = check_launch("stack kernel (redo pass)");
     }
-#ifdef APGPU_DEVELOPMENT                                     // measurement knob, never in a release build
-    if (getenv("APGPU_DEBUG_REDO")) {
-        int32_t cnts[kRedoSegs * 16];
-        (void)hipMemcpyAsync(cnts, redo, sizeof(cnts), hipMemcpyDeviceToHost, st);
-        (void)hipStreamSynchronize(st);
-        long cnt = 0;
-        for (int sg = 0; sg < kRedoSegs; sg++) cnt += cnts[sg * 16];
-        fprintf(stderr, "stack_fast: %ld of %lld pixels on the redo list\n", cnt, (long long)prm0.P);
+    if (own) {
+        const hipError_t ef = hipFreeAsync(ws, st);
+        if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): free: %s", hipGetErrorString(ef));
     }
-#endif
-    const hipError_t ef = hipFreeAsync(redo, st);
-    if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (fast): free: %s", hipGetErrorString(ef));
     return rc;
 }
 
@@ -872,16 +1138,18 @@ template <int NP, typename RawT, bool CALIB, bool FULL, int D = 0, bool PLUS = f
 int launch_fast(const StackParams &prm0, dim3 grid, hipStream_t st)
 {
     return launch_with_redo(
-        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL, D, PLUS>), grid, dim3(256), 0, st, q); },
-        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, RawT, CALIB, FULL, PLUS>), dim3(wgs), dim3(256), 0, st, q); });
+        prm0, st, blocks_per_cu<stack_sigclip_kernel<NP, RawT, CALIB, false, FULL, PLUS>>(),
+        [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_kernel<NP, RawT, CALIB, FULL, D, PLUS>), grid, dim3(256), 0, st, q); },
+        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, FULL, PLUS>), dim3(wgs), dim3(256), 0, st, q); });
 }
 
 template <int NP, bool CALIB, bool FULL, int D = 0>
 int launch_fast_u16_pairs(const StackParams &prm0, dim3 grid, hipStream_t st)
 {
     return launch_with_redo(
-        prm0, st, [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_u16_pairs_kernel<NP, CALIB, FULL, D>), grid, dim3(256), 0, st, q); },
-        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_redo_kernel<NP, uint16_t, CALIB, FULL>), dim3(wgs), dim3(256), 0, st, q); });
+        prm0, st, blocks_per_cu<stack_sigclip_kernel<NP, uint16_t, CALIB, false, FULL, false>>(),
+        [&](const StackParams &q) { hipLaunchKernelGGL((stack_fast_u16_pairs_kernel<NP, CALIB, FULL, D>), grid, dim3(256), 0, st, q); },
+        [&](const StackParams &q, unsigned wgs) { hipLaunchKernelGGL((stack_sigclip_kernel<NP, uint16_t, CALIB, false, FULL, false>), dim3(wgs), dim3(256), 0, st, q); });
 }
 
 // `describe` != nullptr: write the name of the kernel variant this call would launch (as rocprofv3 prints it, without
@@ -914,30 +1182,38 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         if (!wide_fast && kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-            // the fast kernel of the pair scheme + redo list (stack_fast_u16_pairs_kernel)
+            // the fast kernel of the pair scheme + redo pass (stack_fast_u16_pairs_kernel)
             constexpr bool kFastPairsFull = NP <= 64 && fast32_possible(NP, NP);
             constexpr bool kFastPairsPadded = NP <= 64 && fast32_possible_padded(NP, padded_minn(NP, false));
             const bool fastp = (prm.N == NP ? kFastPairsFull : kFastPairsPadded) && fast_kernel_eligible(prm, false, false, false);
-            if (describe) {
+            // The COMPLETE pair kernel exists beyond 64 slots only (round 5): up to 64 a stack that does not take the fast pair
+            // kernel (exact = True, mean centre, no list to be had) runs the one-pixel-per-lane complete kernel below - rare
+            // configurations that no longer justify 88 kernels of 165 KB.
+            constexpr bool kCompletePairs = NP > 64 && kPairsFit;
+            if (describe && (fastp || kCompletePairs)) {
                 if (fastp) snprintf(describe, 256, "stack_fast_u16_pairs_kernel<%d, %s, %s, %d>", NP, tf[CALIB], tf[prm.N == NP], NP - prm.N);
                 else snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
                 return APGPU_OK;
             }
             int frc = kNoRedoList;
-            if constexpr (kFastPairsFull) {
-                if (fastp && prm.N == NP) frc = launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
+            if (!describe) {
+                if constexpr (kFastPairsFull) {
+                    if (fastp && prm.N == NP) frc = launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
+                }
+                if constexpr (kFastPairsPadded) {            // (slot counts up to 64: 1 .. 3 pads, one instantiation each)
+                    if (fastp && prm.N == NP - 1) frc = launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
+                    if (fastp && prm.N == NP - 2) frc = launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
+                    if (fastp && prm.N == NP - 3) frc = launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
+                }
+                if (frc != kNoRedoList) return frc;
             }
-            if constexpr (kFastPairsPadded) {                // (slot counts up to 64: 1 .. 3 pads, one instantiation each)
-                if (fastp && prm.N == NP - 1) frc = launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
-                if (fastp && prm.N == NP - 2) frc = launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
-                if (fastp && prm.N == NP - 3) frc = launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
+            if constexpr (kCompletePairs) {
+                StackParams q = prm;
+                q.redo = nullptr;
+                if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, q);
+                else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, q);
+                return check_launch("stack kernel (uint16 pairs)");
             }
-            if (frc != kNoRedoList) return frc;
-            if constexpr (kPairsFit) {
-                if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, prm);
-                else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, prm);
-            }
-            return check_launch("stack kernel (uint16 pairs)");
         }
         if (pairs) {
             const int64_t grid = (prm.P + 511) / 512;
@@ -964,7 +1240,7 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
     const bool rich = needs_lds || (wants_planes && !plus);
 #endif
     const bool full = prm.N == NP;
-    const int block = rich ? rich_block<NP>() : ((plus || median_only) ? 256 : APGPU_LEAN_BLOCK);
+    const int block = rich ? rich_block<NP>() : 256;
     const int64_t grid = (prm.P + block - 1) / block;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     // the fast kernel + redo list (see stack_fast_kernel): float32 stacks on the float32 fast path, lean outputs, no pedestals
@@ -987,6 +1263,8 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         return APGPU_OK;
     }
     const dim3 g((unsigned)grid), b(block);
+    StackParams plain = prm;                                 // the complete kernels' plain launches: no workspace = not a redo pass
+    plain.redo = nullptr;
     if constexpr (kFastSlots) {
         int frc = kNoRedoList;
         const int pads = NP - prm.N;
@@ -1020,20 +1298,20 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         if (frc != kNoRedoList) return frc;
     }
     if (median_only) {
-        if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, prm);
-        else hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, false>), g, b, 0, st, prm);
+        if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, plain);
+        else hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, false>), g, b, 0, st, plain);
     } else if (rich) {
-        if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, prm);
-        else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, prm);
+        if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, plain);
+        else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, plain);
     } else if (plus) {
         if constexpr (NP <= 96) {
-            if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true, true>), g, b, 0, st, prm);
-            else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false, true>), g, b, 0, st, prm);
+            if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true, true>), g, b, 0, st, plain);
+            else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false, true>), g, b, 0, st, plain);
         }
     } else if (full) {
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), g, b, 0, st, prm);
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, true>), g, b, 0, st, plain);
     } else {
-        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), g, b, 0, st, prm);
+        hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, false, false>), g, b, 0, st, plain);
     }
     return check_launch("stack kernel");
 }

@@ -690,9 +690,11 @@ __device__ __forceinline__ void shift_down(float (&v)[NP], int P)
 // the column load is in registers: sort, moments, clipping iterations, outputs.
 // pruned (wave-uniform): the column came out of the pruned network (load_sorted_column) - the caller has established
 // fast32_wanted(prm) and n == NP for the whole wave; before the exact path may read it the sort is completed.
+// allow_fast (wave-uniform): false = the exact clip whatever the arguments say (the list pass of the redo kernel; the column
+// was then loaded without split pads - load_sorted_column got the same flag).
 template <int NP, int MINN = NP, bool PLUS = false>
 __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (&v)[NP], const int n, const int64_t p,
-                                                 const bool pruned = false)
+                                                 const bool pruned = false, const bool allow_fast = true)
 {
     const int ns = MINN < NP ? prm.N : NP;                  // wave-uniform number of real frames (slots >= ns: padding)
     // everything the loop and the epilogue need from the kernel arguments: read from the argument block HERE, after the sort
@@ -726,8 +728,8 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     if constexpr (fast32_possible_padded(NP, MINN)) {
         // padded stack with split pads (the kernel loaded the column with SPLIT_PADS, same decision from the same arguments):
         // the fast path starts with the pads trimmed; for the exact path the column is moved down onto the -inf pads first
-        const int plo = pad_low<NP>(prm);
-        if (fast32_wanted(prm)) {
+        const int plo = allow_fast ? pad_low<NP>(prm) : 0;
+        if (allow_fast && fast32_wanted(prm)) {
             if (pruned) {                                    // (load_sorted_column: every lane of the wave holds all N values)
                 float Qf;
                 done = clip_fast32<NP, fast_tail_padded(NP)>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf, plo, NP - ns - plo);
@@ -742,7 +744,7 @@ __device__ __forceinline__ void reduce_and_store(const StackParams &prm, float (
     if constexpr (fast32_possible(NP, MINN)) {
         // float32 fast path (see clip_fast32): full columns, median centre; float64-layout moments carry a sum of squares
         // that callers turn into a std, so they stay on the exact path (the float32 layout is refused a std anyway)
-        if (pruned || (use_median && fast32 && (out_moments == nullptr || mom64 == 0 || fast32 == 2) && wave_all(n == NP))) {
+        if (pruned || (allow_fast && use_median && fast32 && (out_moments == nullptr || mom64 == 0 || fast32 == 2) && wave_all(n == NP))) {
             float Qf;
             done = clip_fast32<NP>(v, (float)sl2, (float)su2, maxiters, a, b, cf, Sf, Qf);
             S = (double)Sf;

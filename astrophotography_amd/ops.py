@@ -208,8 +208,53 @@ def _stack_args(frames, calib, pixmask, keep):
     return a, N, P, shp, frames.device
 
 
+# Workspaces of the stack's two-kernel scheme (apgpu_stack_args.workspace): one per (device, stream, pixel count), zeroed once
+# - the library leaves the part that must be zero as it found it.  Keyed by the stream because a workspace must not be shared
+# by calls that may run concurrently (parallel.stack_nshard alternates two compute streams).
+_stack_ws = {}
+
+
+def stack_workspace(n_pixels, device):
+    lib = _lib.load()
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, int(n_pixels))
+    ws = _stack_ws.get(key)
+    if ws is None:
+        zero = C.c_size_t(0)
+        nbytes = lib.apgpu_stack_ws_bytes(int(n_pixels), C.byref(zero))
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=dev)
+        ws[:(zero.value + 7) // 8].zero_()
+        if len(_stack_ws) >= 32:                             # many image sizes in one process: forget the oldest
+            _stack_ws.pop(next(iter(_stack_ws)))
+        _stack_ws[key] = ws
+    return ws
+
+
+def _attach_workspace(a, P, dev):
+    ws = stack_workspace(P, dev)
+    a.workspace = ws.data_ptr()
+    a.workspace_bytes = ws.numel() * 8
+    return ws
+
+
+def stack_redo_stats(reset=False):
+    """What the fast kernels of the stack left to the redo pass, summed over this process's workspaces: dict(calls, pixels,
+    pixels_listed, blocks_given_up (64-pixel blocks), fraction = share of the pixels that did not finish on the fast path).  Synchronises."""
+    tot = np.zeros(4, dtype=np.int64)
+    for ws in _stack_ws.values():
+        torch.cuda.synchronize(ws.device)
+        o = _lib.STACK_WS_STATS_OFFSET // 8
+        tot += ws[o:o + 4].cpu().numpy()
+        if reset:
+            ws[o:o + 4].zero_()
+    calls, pixels, listed, blocks = (int(x) for x in tot)
+    return dict(calls=calls, pixels=pixels, pixels_listed=listed, blocks_given_up=blocks,
+                fraction=((listed + 64 * blocks) / pixels if pixels else 0.0))
+
+
 def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
-                  stdfunc='std', calib=None, pixmask=None, outputs=('mean',), exact=False, moments_mean_only=False):
+                  stdfunc='std', calib=None, pixmask=None, outputs=('mean',), exact=False, moments_mean_only=False,
+                  single_kernel=False, workspace=True):
     """Per-pixel sigma-clipped reduction along N = astropy sigma_clipped_stats(cube, axis=0)
     (sigma_clipping.py:298-383, 924-937), optionally fused with the calibration of each value.
 
@@ -222,6 +267,9 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
     -> dict of device tensors.
     exact: APGPU_STACK_EXACT_MOMENTS (float64 clip only: the mean is the float64 mean of the survivors rounded once);
     moments_mean_only: APGPU_STACK_MOMENTS_MEAN (the float64 moments will only be turned into a mean).
+    single_kernel: APGPU_STACK_SINGLE_KERNEL (one complete kernel instead of the fast kernel + redo pass pair);
+    workspace: True = this module's cached workspace for the two-kernel scheme (stack_workspace), False = none (the
+    library then allocates a stream-ordered temporary per call), or a tensor from stack_workspace().
     """
     _need_cuda(frames)
     lib = _lib.load()
@@ -256,7 +304,12 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
         else:
             raise ValueError('unknown output %r' % (k,))
         setattr(a, k, res[k].data_ptr())
-    a.flags = (_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0)
+    a.flags = ((_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0) |
+               (_lib.STACK_SINGLE_KERNEL if single_kernel else 0))
+    if workspace is True:
+        keep.append(_attach_workspace(a, P, dev))
+    elif workspace is not False and workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
     return res
 
@@ -303,6 +356,7 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, fina
         a.moments = mom['buffer'].data_ptr()
         a.moments_f64 = (3 if k == 0 else 4) if packed else (1 if k == 0 else 2)
         a.flags = (0 if want_std else _lib.STACK_MOMENTS_MEAN) | (_lib.STACK_EXACT_MOMENTS if exact else 0)   # exact: float64 clip only
+        keep.append(_attach_workspace(a, P, dev))
         check(lib.apgpu_stack_sigclip(C.byref(a), _stream()))
     if not finalize:
         return mom

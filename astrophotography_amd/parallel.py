@@ -13,11 +13,15 @@ Two partitionings of a stack job:
   instead of following it.
 
   Exchange forms (``exchange=``):
-    'rs'  (default for world > 1 when a stripe's rows divide by the world size; round 4)  the same packed float64 planes,
-                     but REDUCE-SCATTERED by rows - every rank receives the combined (sum, count[, sumsq]) of its own
+    'rs'  (default for world > 1 when a stripe's rows divide by the world size; round 4, slimmed in round 5)  the moment planes
+                     are REDUCE-SCATTERED by rows - every rank receives the combined (sum, count[, sumsq]) of its own
                      1/world of the stripe's rows, finalises those rows, and the float32 mean (and std) rows are
-                     ALL-GATHERED: per pixel (world-1)/world x (16 + 4) bytes leave a rank instead of the all-reduce's
-                     2 (world-1)/world x 16 (17.5 against 28 bytes at 8 ranks), and a rank finalises 1/world of the
+                     ALL-GATHERED.  Round 5: the count no longer rides as a float64 plane - the kernels write the float64
+                     sum + INT32 count layout (include/apgpu.h, moments_f64 = 1) and the count is exchanged as its own
+                     4-byte plane, or as a 2-byte float16 plane (`count_dtype=torch.float16`: exact while the whole job has at
+                     most 2048 frames - integers up to 2048 are float16 numbers and so are all their partial sums): per pixel
+                     (world-1)/world x (8 + 4 + 4) = 14 bytes leave a rank at 8 ranks (12.25 with the float16 count) where
+                     round 4's float64 count made it 17.5 and the all-reduce form sends 28; a rank finalises 1/world of the
                      pixels.  Same float64 combine rounded once (the ranks' sums are added in float64 either way; the
                      order of the additions is the collective's).  Stripes whose rows do not divide fall back to 'f64'.
     'f64'            ONE all-reduce per stripe (the north star's literal form) of the packed float64 moment planes (sum, count[, sumsq]) of include/apgpu.h's layout 3 - 16 bytes per
@@ -98,9 +102,11 @@ def _default_local_moments(frames, calib, r0, r1, clip, exchange, want_std=False
             raise ValueError("hierarchical chunks accumulate float64 moments: use exchange='f64'")
         m = ops.stack_sigclip(sub, calib=c, outputs=('moments',), exact=exact, **clip)['moments']
         return dict(sum=m[0], count=m[1], prefix=m[:2])         # (sum, count) is one contiguous float32 block
+    packed = exchange != 'f64i'                              # 'f64': packed float64 planes (one all-reduce); 'f64i': float64 sums + int32 count ('rs')
     if chunked:
-        return ops.stack_sigclip_chunked(sub, chunk=hier_chunk, want_std=want_std, packed=True, finalize=False, calib=c, exact=exact, **clip)
-    return ops.stack_sigclip(sub, calib=c, outputs=('moments_f64p',), moments_mean_only=not want_std, exact=exact, **clip)['moments_f64p']
+        return ops.stack_sigclip_chunked(sub, chunk=hier_chunk, want_std=want_std, packed=packed, finalize=False, calib=c, exact=exact, **clip)
+    key = 'moments_f64p' if packed else 'moments_f64'
+    return ops.stack_sigclip(sub, calib=c, outputs=(key,), moments_mean_only=not want_std, exact=exact, **clip)[key]
 
 
 def _default_finalize(m, out_mean, out_std, exchange):
@@ -118,25 +124,37 @@ def _default_finalize(m, out_mean, out_std, exchange):
 def _exchange(m, exchange, want_std, group):
     """THE all-reduce of one stripe: the contiguous (sum, count) planes - float32 or float64 - or, with a std, the whole
     packed float64 buffer (sum, count, sumsq)."""
+    if exchange == 'f64i':
+        # (the float64 sum + int32 count layout of 'rs' has no single-dtype block: a stripe that cannot be reduce-scattered
+        # - rows not divisible by the world size - all-reduces its planes one by one)
+        for k in (('sum', 'count', 'sumsq') if want_std else ('sum', 'count')):
+            dist.all_reduce(m[k], op=dist.ReduceOp.SUM, group=group)
+        return
     dist.all_reduce(m['buffer'] if (want_std and exchange == 'f64') else m['prefix'], op=dist.ReduceOp.SUM, group=group)
 
 
-def _exchange_rs(m, want_std, group, finalize, out_mean, out_std):
-    """The reduce-scatter form of one stripe (rows divisible by the world size): every packed float64 plane [h, W] is
-    reduce-scattered by rows, the rank finalises ITS rows, the float32 result rows are all-gathered into out_mean
-    (out_std).  Returns the rank's combined moment rows (dict(sum, count[, sumsq], rows=(a, b)))."""
+def _exchange_rs(m, want_std, group, finalize, out_mean, out_std, count_dtype=torch.int32):
+    """The reduce-scatter form of one stripe (rows divisible by the world size): the float64 sum plane [h, W] (and sumsq,
+    with a std) and the count plane - int32 as the kernels write it, or narrowed to float16 - are reduce-scattered by rows,
+    the rank finalises ITS rows, the float32 result rows are all-gathered into out_mean (out_std).  Returns the rank's
+    combined moment rows (dict(sum, count (int32)[, sumsq], rows=(a, b)))."""
     world, rank = _world(group)
-    names = ('sum', 'count', 'sumsq') if want_std else ('sum', 'count')
     h, W = m['sum'].shape
     hb = h // world
     own = {}
-    for k in names:
+    for k in (('sum', 'sumsq') if want_std else ('sum',)):
         plane = m[k]
         own[k] = torch.empty((hb, W), dtype=plane.dtype, device=plane.device)
         dist.reduce_scatter_tensor(own[k], plane, op=dist.ReduceOp.SUM, group=group)
+    cnt = m['count']
+    if cnt.dtype != count_dtype:
+        cnt = cnt.to(count_dtype)                            # (the packed layout's float64 plane, or int32 -> float16)
+    got = torch.empty((hb, W), dtype=count_dtype, device=cnt.device)
+    dist.reduce_scatter_tensor(got, cnt.contiguous(), op=dist.ReduceOp.SUM, group=group)
+    own['count'] = got if got.dtype == torch.int32 else got.to(torch.int32)
     my_mean = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device)
     my_std = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device) if want_std else None
-    finalize(own, my_mean, my_std, 'f64')
+    finalize(own, my_mean, my_std, 'f64i')
     dist.all_gather_into_tensor(out_mean, my_mean, group=group)
     if want_std:
         dist.all_gather_into_tensor(out_std, my_std, group=group)
@@ -145,20 +163,23 @@ def _exchange_rs(m, want_std, group, finalize, out_mean, out_std):
     return own
 
 
-def exchange_bytes_per_pixel(exchange='f64', want_std=False):
-    """Bytes per output pixel of the moment planes each rank contributes to the exchange."""
+def exchange_bytes_per_pixel(exchange='f64', want_std=False, count_bytes=4):
+    """Bytes per output pixel of the moment planes each rank contributes to the exchange ('rs' / 'f64i': float64 sum[, sumsq] +
+    a count plane of count_bytes)."""
     if exchange == 'f32':
         return 8
+    if exchange in ('rs', 'f64i'):
+        return (16 if want_std else 8) + count_bytes
     return 24 if want_std else 16
 
 
-def exchange_bytes_on_wire(exchange, world, n_pixels, want_std=False):
+def exchange_bytes_on_wire(exchange, world, n_pixels, want_std=False, count_bytes=4):
     """Bytes one rank SENDS per step for n_pixels output pixels (ring collectives): all-reduce = 2 (w-1)/w x payload;
     'rs' = (w-1)/w x (payload + the float32 result planes that are all-gathered)."""
     if world <= 1:
         return 0
     f = (world - 1) / world
-    payload = exchange_bytes_per_pixel('f64' if exchange == 'rs' else exchange, want_std)
+    payload = exchange_bytes_per_pixel(exchange, want_std, count_bytes)
     if exchange == 'rs':
         return int(f * (payload + (8 if want_std else 4)) * n_pixels)
     return int(2 * f * payload * n_pixels)
@@ -168,6 +189,10 @@ def default_stripes(H, W, exchange='f64', want_std=False):
     """Row stripes per step: enough to overlap the exchange with the reduction, few enough that every all-reduce stays a
     large transfer (>= 64 MB) - 4 for a 4096 x 4096 image, never more than 8."""
     payload = H * W * exchange_bytes_per_pixel(exchange, want_std)
+    if exchange in ('rs', 'f64i'):
+        # a power of two (rows stay divisible by the world size, or the stripe falls back to all-reduces), >= 48 MB per stripe
+        n = int(max(1, min(8, payload // (48 << 20))))
+        return 1 << (n.bit_length() - 1)
     return int(max(1, min(8, payload // (64 << 20))))
 
 
@@ -190,7 +215,7 @@ def _record(m, stream):
 
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
                  n_stripes=None, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
-                 exchange=None, want_std=False, hier_chunk=None, timings=None, exact=False):
+                 exchange=None, want_std=False, hier_chunk=None, timings=None, exact=False, count_dtype=torch.int32):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank
     (want_std: (mean, std)).
 
@@ -198,7 +223,8 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     selects the payload (module docstring); want_std needs 'f64'.  return_moments appends the combined per-stripe
     moment dicts (sum, count[, sumsq]) for inspection.  n_stripes None = default_stripes().  hier_chunk: see the module
     docstring.  timings: a list that receives one (start, end) pair of CUDA events per stripe around its all-reduce on the
-    communication stream (bench.py's exchange_ms).
+    communication stream (bench.py's exchange_ms).  count_dtype ('rs'): torch.int32, or torch.float16 when the WHOLE job has
+    at most 2048 frames (the caller's knowledge: a rank only sees its own).
     """
     if exchange is None:
         exchange = 'rs'
@@ -212,7 +238,9 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     finalize = finalize or _default_finalize
     world, _ = _world(group)
     n_local, H, W = frames_local.shape
-    payload = 'f64' if exchange == 'rs' else exchange        # the moment layout the kernels write
+    if count_dtype not in (torch.int32, torch.float16):
+        raise ValueError('count_dtype must be torch.int32 or torch.float16')
+    payload = 'f64i' if exchange == 'rs' else exchange       # the moment layout the kernels write
     if n_stripes is None:
         n_stripes = default_stripes(H, W, payload, want_std)
     clip = dict(sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc)
@@ -245,7 +273,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
                     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     t0.record(comm)
                 if exchange == 'rs' and (r1 - r0) % world == 0:
-                    own = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None)
+                    own = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype)
                     _record(own, comm)
                     if timings is not None:
                         t1.record(comm)
@@ -266,7 +294,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip, payload)
             if collective and exchange == 'rs' and (r1 - r0) % world == 0:
-                m = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None)
+                m = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype)
             else:
                 if collective:
                     _exchange(m, payload, want_std, group)

@@ -60,6 +60,9 @@ def parse(argv=None):
                          'finalises its rows, float32 mean rows all-gathered (17.5 B/pixel on the wire at 8 ranks); f64 = ONE '
                          'all-reduce per stripe of the same planes (16 B/pixel payload, 28 on the wire; the north star\'s literal '
                          'form); f32 = one all-reduce of float32 sum + count (8 B/pixel payload)')
+    ap.add_argument('--rs-count', default='auto', choices=['auto', 'f16', 'i32'],
+                    help="exchange rs: the count plane's type on the wire - f16 (2 bytes, exact up to 2048 frames in the whole job), "
+                         'i32, or auto = f16 when the job has at most 2048 frames')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c4', 'c5'],
                     help='c2 (default, the BASELINE metric): fused calibrate + clipped mean, 64 x 4096 x 4096 f32; c4: uint16 Bayer '
                          'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
@@ -343,7 +346,10 @@ def main(argv=None):
             return 2
         hier_chunk = args.total_frames // args.hier_shards
     single_launch = (world == 1 and not args.force_collective and hier_chunk is None) or rowshard
-    payload = 'f64' if args.exchange == 'rs' else args.exchange      # the moment layout the kernels write
+    payload = 'f64i' if args.exchange == 'rs' else args.exchange     # the moment layout the kernels write ('rs': float64 sum + int32 count)
+    # 'rs' sends the count as a float16 plane while that is exact (<= 2048 frames in the whole job), else as int32
+    count_dtype = torch.float16 if (args.rs_count == 'f16' or (args.rs_count == 'auto' and n_total <= 2048)) else torch.int32
+    count_bytes = 2 if count_dtype == torch.float16 else 4
     n_stripes = args.stripes or parallel.default_stripes(H, W, payload)
     timings = []                                             # (start, end) events around every stripe's all-reduce
 
@@ -355,17 +361,18 @@ def main(argv=None):
             if world == 1:
                 return ops.stack_sigclip(resampled, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
             return parallel.stack_nshard(resampled, None, sigma=3.0, maxiters=5, n_stripes=n_stripes, exchange=args.exchange,
-                                         timings=timings)
+                                         timings=timings, count_dtype=count_dtype)
         if single_launch:
             return ops.stack_sigclip(frames, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std', calib=calib,
                                      outputs=('mean',), exact=args.exact_moments)['mean']
         return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=n_stripes,
                                      force_collective=args.force_collective, exchange=args.exchange, hier_chunk=hier_chunk,
-                                     timings=timings)
+                                     timings=timings, count_dtype=count_dtype)
 
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    ops.stack_redo_stats(reset=True)                         # count the timed steps only
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -393,6 +400,8 @@ def main(argv=None):
         dist.all_gather(allt, mine)
         per_rank_ms = [1e3 * float(v.item()) / args.steps for v in allt]
     ms_per_step = 1e3 * elapsed / args.steps
+    # what the stack's fast kernels left to the redo pass over the timed steps (counters in the workspace, read after the clock)
+    redo = ops.stack_redo_stats()
     job_pixels = float(N) * P                                  # input frame pixels of ALL ranks (ragged blocks: summed, not
     if world > 1:                                              # rank 0's share times the world size)
         t = torch.tensor([job_pixels], dtype=torch.float64, device=dev)
@@ -462,11 +471,11 @@ def main(argv=None):
     avg_kernel_ms = sum(kern_ms) / len(kern_ms)
     esize = 4 if args.dtype == 'f32' else 2
     nshard_multi = not single_launch
-    out_bytes = 4 if single_launch else (24 if payload == 'f64' else 12)           # mean plane | moment planes written
+    out_bytes = 4 if single_launch else {'f64': 24, 'f64i': 20, 'f32': 12}[payload]           # mean plane | moment planes written
     algo_bytes = esize * N * P + 12 * P + out_bytes * P       # frames + bias/dark/nflat read, outputs written
     kernel_name = ops.stack_kernel_name(min(N, hier_chunk) if hier_chunk else N, args.dtype, calibrated=True,
-                                        outputs=('mean',) if single_launch else (('moments_f64p',) if payload == 'f64' else ('moments',)),
-                                        moments_mean_only=not single_launch and payload == 'f64', exact=args.exact_moments and single_launch)
+                                        outputs=('mean',) if single_launch else ({'f64': ('moments_f64p',), 'f64i': ('moments_f64',), 'f32': ('moments',)}[payload]),
+                                        moments_mean_only=not single_launch and payload != 'f32', exact=args.exact_moments and single_launch)
     metric = 'Mpixels/sec calibrate+sigma-clip-stack'
     cfg_name = 'C3' if strong else 'C2'
     if not strong and not (N == 64 and H_glob == 4096 and W == 4096 and args.dtype == 'f32'):
@@ -538,8 +547,8 @@ def main(argv=None):
                 world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes,
                 'float64 sum + count (16 B/pixel)' if args.exchange == 'f64' else 'float32 sum + count (8 B/pixel)')
             if args.exchange == 'rs':
-                par = 'N-shard x%d (%d of %d frames per rank%s), %d stripes, per stripe: reduce-scatter of the float64 sum + count planes by rows, every rank finalises its rows, all-gather of the float32 mean rows' % (
-                    world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes)
+                par = 'N-shard x%d (%d of %d frames per rank%s), %d stripes, per stripe: reduce-scatter by rows of the float64 sum plane and the %s count plane, every rank finalises its rows, all-gather of the float32 mean rows' % (
+                    world, N, n_total, ', clipped in shards of %d' % hier_chunk if hier_chunk else '', n_stripes, 'float16' if count_bytes == 2 else 'int32')
         if world == 1 and hier_chunk:
             par = 'single GPU, hierarchical: %d shards of %d frames clipped per shard, float64 moments added' % (N // hier_chunk, hier_chunk)
         line = {
@@ -550,6 +559,10 @@ def main(argv=None):
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': workload, 'frames_per_gpu': N, 'frames_total': n_total if not rowshard else N,
                        'height': H, 'width': W, 'parallelism': par},
+            # share of the output pixels of the timed steps' stack calls that did not finish on the fast kernel (listed pixels +
+            # 64 x blocks given up, over pixels; rank 0's calls) - the data-dependent part of the two-kernel scheme's cost
+            'redo_fraction': redo['fraction'] if redo['calls'] else None,
+            'redo': redo if redo['calls'] else None,
             # `bound`: the roofline the kernel is PRICED against (bytes / HBM peak, the contract's fields); `limiter`: what the
             # counters say holds it back today - the fused float32 clip kernels issue VALU instructions ~90 % of the time
             # (roofline.valu, measured), the uint16 median kernel streams.
@@ -567,8 +580,10 @@ def main(argv=None):
                                             n_stripes if world > 1 or args.force_collective else 1,
                                             ' x %d shards' % (N // hier_chunk) if hier_chunk and N > hier_chunk else ''))
             line['exchange'] = args.exchange
-            line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(payload)
-            line['exchange_bytes_on_wire'] = parallel.exchange_bytes_on_wire(args.exchange, world, P)
+            line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(payload, count_bytes=count_bytes)
+            line['exchange_bytes_on_wire'] = parallel.exchange_bytes_on_wire(args.exchange, world, P, count_bytes=count_bytes)
+            if args.exchange == 'rs':
+                line['exchange_count_dtype'] = 'float16' if count_bytes == 2 else 'int32'
             line['exchange_ms'] = exchange_ms
             line['stripes'] = n_stripes
             if hier_chunk:

@@ -10,7 +10,8 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer (HBM) unless its name ends in _host;
- *  - the caller owns every buffer; the library allocates nothing and keeps no state;
+ *  - the caller owns every buffer; the library allocates nothing and keeps no state (one exception, stated at
+ *    apgpu_stack_args.workspace: a stack call WITHOUT a workspace makes a stream-ordered temporary allocation);
  *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is asynchronous
  *    with respect to the host, no call synchronises;
  *  - functions return 0 on success or a negative APGPU_E* code; apgpu_last_error() returns a
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGPU_VERSION 111           /* 0.1.1 */
+#define APGPU_VERSION 120           /* 0.1.2: apgpu_stack_args.workspace, apgpu_stack_ws_bytes */
 
 /* error codes */
 #define APGPU_OK            0
@@ -155,6 +156,8 @@ typedef struct apgpu_stack_args {
     double *std_f64;             /* [P] or NULL */
     int32_t moments_f64;         /* layout of `moments`, see above */
     int32_t flags;               /* APGPU_STACK_* bits below; 0 = defaults (was reserved0) */
+    void *workspace;             /* NULL, or apgpu_stack_ws_bytes(n_pixels, ..) bytes for the two-kernel scheme (below) */
+    size_t workspace_bytes;
 } apgpu_stack_args;
 
 /* apgpu_stack_args.flags.  The lean kernels (mean / count / moments outputs, median centre, std deviation, full slot
@@ -168,6 +171,37 @@ typedef struct apgpu_stack_args {
  *                               Without it float64-layout moments always come from the float64 path. */
 #define APGPU_STACK_EXACT_MOMENTS 1
 #define APGPU_STACK_MOMENTS_MEAN 2
+#define APGPU_STACK_SINGLE_KERNEL 4   /* never the fast kernel + redo pass pair described below: one complete kernel, no workspace used */
+
+/* The two-kernel scheme and its workspace.  A clipped stack of up to 128 frames (and the chunked kernel for 129 .. 256) with
+ * lean outputs runs as a FAST kernel - the float32 fast path alone, four wavefronts per SIMD - followed by a REDO PASS of the
+ * complete kernel over what the fast kernel could not finish: single pixels (unsure comparisons, non-finite values, masked
+ * pixels, operands outside the guards of the fast division) gathered from per-segment lists, and whole 256-pixel tiles that
+ * (in 64-pixel blocks) the fast kernel gave up without trying once more than an eighth of the pixels it had seen were failing - so that a stack
+ * whose pixels mostly fail costs about one pass of the complete kernel, not both kernels in full.  The lists, counters and
+ * tile flags live in `workspace`:
+ *   - size: apgpu_stack_ws_bytes(n_pixels, &zero_bytes) bytes (about 4 bytes per pixel), 16-byte aligned;
+ *   - its first zero_bytes bytes must be ZERO at the first call (hipMemsetAsync once; zeroing all of it is fine); every call
+ *     leaves them zero again (the statistics and one mode word excepted, below).  After a call that returned an error, zero
+ *     them again;
+ *   - the layout depends on n_pixels: a workspace serves calls of ONE n_pixels (re-zero the prefix before using it for
+ *     another image size) and must not be shared by calls that may run concurrently (two streams);
+ *   - the 32 bytes at APGPU_STACK_WS_STATS_OFFSET hold four int64 counters, cumulative over the calls that used this
+ *     workspace and never reset by the library: calls, pixels, pixels listed, 64-pixel blocks given up (apgpu_stack_ws_stats) -
+ *     the caller may copy them out (after the stream has been synchronised) to see which fraction of its data leaves the fast
+ *     path: (pixels_listed + 64 * blocks_given_up) / pixels;
+ *   - the workspace also remembers, from one call to the next, whether the guard is needed: a call whose data listed under 1 %
+ *     of its pixels and gave nothing up lets the next call on the same workspace skip the fast kernel's look at the counters
+ *     (it costs 1.5 % of the benchmark); the first call after the data has turned bad therefore runs unguarded - both
+ *     kernels in full, about twice the complete kernel's time in the worst case - and sets the guard for the calls after it.
+ * workspace == NULL: the call allocates and frees a stream-ordered temporary of the same size itself (hipMallocAsync /
+ * hipMemsetAsync / hipFreeAsync on `stream` - three more runtime calls per stack; the only place where the library
+ * allocates); if that fails too, or with APGPU_STACK_SINGLE_KERNEL, the complete kernel reduces the whole stack in one launch. */
+#define APGPU_STACK_WS_STATS_OFFSET 16384
+typedef struct apgpu_stack_ws_stats {
+    int64_t calls, pixels, pixels_listed, blocks_given_up;
+} apgpu_stack_ws_stats;
+size_t apgpu_stack_ws_bytes(int64_t n_pixels, size_t *zero_bytes);
 
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 

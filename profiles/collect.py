@@ -36,7 +36,8 @@ if 'hbm_bytes_per_launch' in s and cfg:
         td = {'workloads': {}}
     td['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench command (profiles/run_profile.sh); KiB '
                   'units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request)')
-    td['workloads'][key] = {'tag': tag, 'kernel': s.get('dominant_kernel'), 'hbm_bytes_per_launch': s['hbm_bytes_per_launch'],
+    # (the dominant kernel as the library names it: bench.py reports the traffic only for a step that IS one launch of it)
+    td['workloads'][key] = {'tag': tag, 'kernel': (s.get('dominant_kernel') or '').replace('apgpu_stack::', ''), 'hbm_bytes_per_launch': s['hbm_bytes_per_launch'],
                             'read_bytes_fetch_size_x2': s['hbm_read_bytes_corrected'], 'write_bytes': s['hbm_write_bytes']}
     if 'valu_insts_per_wave' in s:
         td['workloads'][key]['valu'] = {'insts_per_wave': round(s['valu_insts_per_wave'], 1),

@@ -39,6 +39,9 @@ def _oracle_local_moments(frames, calib, r0, r1, clip, exchange):
     if exchange == 'f32':
         mom = torch.from_numpy(np.stack([kept.sum(0), r['count'].astype(np.float64)]).astype(np.float32))
         return dict(sum=mom[0], count=mom[1], prefix=mom)
+    if exchange == 'f64i':                                     # the layout of 'rs': float64 sum / sumsq planes + an int32 count plane
+        return dict(sum=torch.from_numpy(kept.sum(0)), sumsq=torch.from_numpy((kept * kept).sum(0)),
+                    count=torch.from_numpy(r['count'].astype(np.int32)))
     # the packed float64 layout: planes sum, count, sumsq in ONE buffer; a mean-only exchange sends the [2] prefix
     buf = torch.from_numpy(np.stack([kept.sum(0), r['count'].astype(np.float64), (kept * kept).sum(0)]))
     return dict(sum=buf[0], count=buf[1], sumsq=buf[2], buffer=buf, prefix=buf[:2])
@@ -185,12 +188,20 @@ def _rs_worker(rank, world, port, n_total, shape, out_dir):
     h = H // n_stripes
     # the default exchange IS 'rs'
     mean_rs, parts = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, return_moments=True, **kw)
-    # per stripe: one reduce-scatter per float64 plane (sum, count) of [h, W], one all-gather of the float32 mean rows
+    # per stripe: a reduce-scatter of the float64 sum plane [h, W] and one of the INT32 count plane, one all-gather of the float32 mean rows
     exp = []
     for _ in range(n_stripes):
-        exp += [('reduce_scatter', (h, W), torch.float64, 8 * h * W)] * 2 + [('all_gather', (h, W), torch.float32, 4 * h * W)]
+        exp += [('reduce_scatter', (h, W), torch.float64, 8 * h * W), ('reduce_scatter', (h, W), torch.int32, 4 * h * W),
+                ('all_gather', (h, W), torch.float32, 4 * h * W)]
     assert calls == exp, calls
-    assert all(p['sum'].shape == (h // world, W) and p['rows'] == (rank * (h // world), (rank + 1) * (h // world)) for p in parts)
+    assert all(p['sum'].shape == (h // world, W) and p['count'].dtype == torch.int32 and
+               p['rows'] == (rank * (h // world), (rank + 1) * (h // world)) for p in parts)
+    del calls[:]
+    # the count as a float16 plane (exact up to 2048 frames in the whole job): 2 bytes per pixel, the same result bit for bit
+    mean_h = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, count_dtype=torch.float16, **kw)
+    assert [c[2] for c in calls if c[0] == 'reduce_scatter'] == [torch.float64, torch.float16] * n_stripes, calls
+    assert sum(c[3] for c in calls) == n_stripes * (8 + 2 + 4) * h * W
+    assert torch.equal(mean_h, mean_rs)
     del calls[:]
     (mean_s, std_s), _ = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, exchange='rs', want_std=True, return_moments=True, **kw)
     assert [c[0] for c in calls] == (['reduce_scatter'] * 3 + ['all_gather'] * 2) * n_stripes, calls
@@ -205,7 +216,10 @@ def _rs_worker(rank, world, port, n_total, shape, out_dir):
     parallel.dist.all_reduce, parallel.dist.reduce_scatter_tensor, parallel.dist.all_gather_into_tensor = real['ar'], real['rs'], real['ag']
     # bytes a rank sends per step (ring collectives)
     f = (world - 1) / world
-    assert parallel.exchange_bytes_on_wire('rs', world, H * W) == int(f * 20 * H * W)
+    assert parallel.exchange_bytes_on_wire('rs', world, H * W) == int(f * 16 * H * W)                   # 14 bytes per pixel at 8 ranks
+    assert parallel.exchange_bytes_on_wire('rs', world, H * W, count_bytes=2) == int(f * 14 * H * W)    # 12.25 with the float16 count
+    assert parallel.exchange_bytes_on_wire('rs', world, H * W, want_std=True) == int(f * 28 * H * W)
+    assert parallel.default_stripes(4096, 4096, 'rs') == 4 and parallel.default_stripes(8192, 8192, 'rs') == 8
     assert parallel.exchange_bytes_on_wire('f64', world, H * W) == int(2 * f * 16 * H * W)
     assert parallel.exchange_bytes_on_wire('f32', world, H * W) == int(2 * f * 8 * H * W)
     np.savez(os.path.join(out_dir, f'rs{rank}.npz'), mean_rs=mean_rs.numpy(), mean_s=mean_s.numpy(), std_s=std_s.numpy(),

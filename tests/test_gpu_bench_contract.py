@@ -77,10 +77,12 @@ def test_multi_rank_paths_on_one_gpu():
         if '--parallelism' not in extra:
             assert d['exchange_ms'] is not None and d['exchange_ms'] >= 0 and d['stripes'] >= 1
             assert d['rowshard']['value'] > 0 and d['rowshard']['ms_per_step'] > 0
-            assert d['exchange_bytes_per_pixel'] == (8 if 'f32' in extra else 16)
             assert d['exchange'] == (extra[1] if '--exchange' in extra else 'rs')
+            # 'rs': float64 sum + float16 count (the job has at most 2048 frames) reduce-scattered, float32 mean rows all-gathered
+            assert d['exchange_bytes_per_pixel'] == {'rs': 10, 'f64': 16, 'f32': 8}[d['exchange']]
+            assert d.get('exchange_count_dtype') == ('float16' if d['exchange'] == 'rs' else None)
             px = 128 * 512
-            assert d['exchange_bytes_on_wire'] == {'rs': int(0.5 * 20 * px), 'f64': int(2 * 0.5 * 16 * px), 'f32': int(2 * 0.5 * 8 * px)}[d['exchange']]
+            assert d['exchange_bytes_on_wire'] == {'rs': int(0.5 * 14 * px), 'f64': int(2 * 0.5 * 16 * px), 'f32': int(2 * 0.5 * 8 * px)}[d['exchange']]
         if '--scaling' in extra and '--parallelism' not in extra:
             assert d['hier_shards'] == 4 and d['config']['frames_per_gpu'] == 32 and d['config']['frames_total'] == 64
             assert d['roofline']['kernel'].startswith('stack_fast_kernel<16,')        # shards of 16 frames

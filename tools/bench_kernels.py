@@ -113,6 +113,14 @@ def main():
     rec('stack_sigclip fused, mean+median+std (EXTRA)', 4 * N * P + 24 * P, lambda: ops.stack_sigclip(frames, calib=calib, outputs=('mean', 'median', 'std')), reps=5)
     rec('stack_sigclip plain f32 (A7, no calibration)', 4 * N * P + 4 * P, lambda: ops.stack_sigclip(frames, outputs=('mean',)))
     rec('stack ccdproc config: 1 pass, median/mad_std 5s (A6)', 4 * N * P + 4 * P, lambda: ops.stack_sigclip(frames, sigma=5.0, maxiters=1, stdfunc='mad_std', outputs=('mean',)), reps=3, warm=1)
+    # what ApMasterCal.make_master really runs (ap_combine_darks.py:394-420): the frames as stored - float32, or raw uint16 darks /
+    # biases -, no calibration, one pass median / mad_std 5 sigma, float64 mean + std planes + count (bytes: frames + 20 per pixel)
+    rec('ApMasterCal A6: f32 frames -> mean_f64, std_f64, count', 4 * N * P + 20 * P,
+        lambda: ops.stack_sigclip(frames, sigma=5.0, maxiters=1, stdfunc='mad_std', outputs=('mean_f64', 'count', 'std_f64')), reps=3, warm=1)
+    raw16 = synth.make_frames(N, masters, nflat, config_id=2, dtype=torch.uint16)
+    rec('ApMasterCal A6: uint16 frames -> mean_f64, std_f64, count', 2 * N * P + 20 * P,
+        lambda: ops.stack_sigclip(raw16, sigma=5.0, maxiters=1, stdfunc='mad_std', outputs=('mean_f64', 'count', 'std_f64')), reps=3, warm=1)
+    del raw16
     rec('stack_sigclip fused, 48 of 64 slots (non-FULL lean)', 4 * 48 * P + 16 * P, lambda: ops.stack_sigclip(frames[:48], calib=calib, outputs=('mean',)))
     rec('stack_median fused (C4-style, f32)', 4 * N * P + 16 * P, lambda: ops.stack_median(frames, calib=calib))
     f16 = synth.make_frames(N, masters, nflat, config_id=2, dtype=torch.uint16)

@@ -7,7 +7,8 @@ TMP=$(mktemp -d)
 echo "translation_unit,kernel,vgpr,sgpr_spill,vgpr_spill,scratch_bytes,lds_bytes"
 for src in $CS/*.hip; do
   b=$(basename $src .hip)
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -S --cuda-device-only -I$CS -I$REPO/include $src -o $TMP/$b.s 2>/dev/null &
+  EXTRA=""; case $b in stack_inst_*) EXTRA="-mllvm -disable-machine-licm";; esac     # as _build.py's STACK_TU_FLAGS
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math $EXTRA -S --cuda-device-only -I$CS -I$REPO/include $src -o $TMP/$b.s 2>/dev/null &
 done
 wait
 for src in $CS/*.hip; do
@@ -20,7 +21,7 @@ for blk in txt.split('  - .agpr_count:')[1:]:
     name=g('name')
     try:
         import subprocess
-        dem=subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', name],capture_output=True,text=True).stdout.strip()
+        dem=subprocess.run(['c++filt', name],capture_output=True,text=True).stdout.strip()
     except Exception:
         dem=name
     dem=dem.replace(',',';')

@@ -18,8 +18,9 @@ for o in $CS/_obj/*.o; do
 done
 for tu in "$@"; do
   b=$(basename $tu .hip)
+  EXTRA=""; case $b in stack_inst_*) EXTRA="-mllvm -disable-machine-licm";; esac     # as _build.py's STACK_TU_FLAGS
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
-    -I$ROOT/include -I$CS $FLAGS -c $CS/$b.hip -o $OUT/$b.o &
+    -I$ROOT/include -I$CS $EXTRA $FLAGS -c $CS/$b.hip -o $OUT/$b.o &
 done
 wait
 for tu in "$@"; do OBJS="$OBJS $OUT/$(basename $tu .hip).o"; done
