@@ -190,12 +190,13 @@ struct DigitPick {
 };
 
 // Wavefront 0 finds the bin of rank k in hist[0 .. kBoxBins) (32 bins per lane + a wavefront scan) and publishes it.
-__device__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *shared_pick)
+__device__ __forceinline__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *shared_pick)
 {
     if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
         constexpr int per = kBoxBins / kWave;
         unsigned tot = 0;
+#pragma unroll 4
         for (int j = 0; j < per; j++) tot += hist[lane * per + j];
         unsigned inc = tot;
 #pragma unroll
@@ -207,6 +208,7 @@ __device__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *sha
         int dlow = -1;
         if (k >= exc && k < inc) {
             unsigned run = exc;
+#pragma unroll 1
             for (int j = 0; j < per; j++) {
                 const unsigned c = hist[lane * per + j];
                 if (k < run + c) { shared_pick->digit = lane * per + j; shared_pick->cum = run; break; }
@@ -214,6 +216,7 @@ __device__ DigitPick pick_digit(const unsigned *hist, unsigned k, DigitPick *sha
                 run += c;
             }
         } else if (k >= inc) {
+#pragma unroll 1
             for (int j = per - 1; j >= 0; j--)
                 if (hist[lane * per + j]) { dlow = lane * per + j; break; }
         }

@@ -183,14 +183,15 @@ __device__ T leaf_sum(const T *a, int n, int &nans)
     return res;
 }
 
+struct PairwiseItem { int off, len; };
+
+// (one thread; its explicit stack lives in the caller's LDS: as local arrays with run-time indices it was 272 / 528 bytes of
+// scratch per thread of the kernel - round 5)
 template <typename T>
-__device__ T pairwise_generic(const T *a, int n, int &nans)
+__device__ T pairwise_generic(const T *a, int n, int &nans, PairwiseItem *stack, T *vals, int *state)
 {
     // iterative form of numpy's recursion for the ragged last piece (n < 8192): explicit stack
-    struct Item { int off, len; };
-    Item stack[32];
-    T vals[32];
-    int state[32];
+    typedef PairwiseItem Item;
     int sp = 0, vp = 0;
     stack[sp] = {0, n}; state[sp] = 0; sp++;
     // post-order evaluation
@@ -284,9 +285,12 @@ __global__ __launch_bounds__(kBlock) void flat_norm_kernel(const T *__restrict__
     const int rem = (int)(n - npieces_full * kPiece);
     for (int t = threadIdx.x; t < rem; t += blockDim.x) stage[t] = flat[npieces_full * kPiece + t];
     __syncthreads();
+    __shared__ PairwiseItem pw_stack[32];
+    __shared__ T pw_vals[32];
+    __shared__ int pw_state[32];
     if (threadIdx.x != 0) return;
     int nans = 0;
-    if (rem > 0) res = res + pairwise_generic(stage, rem, nans);
+    if (rem > 0) res = res + pairwise_generic(stage, rem, nans, pw_stack, pw_vals, pw_state);
     const unsigned long long bad = *nan_count + (unsigned long long)nans;
     const double cnt = (double)(n - (int64_t)bad);
     norm_out[0] = (T)((double)res / cnt);              // numpy 1.26: float32 / int -> float64 -> float32; float64 / int -> float64

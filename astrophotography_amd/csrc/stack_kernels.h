@@ -720,217 +720,16 @@ __global__ __launch_bounds__(256) void stack_median_u16_kernel(const StackParams
     }
 }
 
-// One pixel of the uint16 pair kernel: its sorted raw column arrives packed two values per register.
-// pruned (wave-uniform): the raw columns came out of the pruned network (the caller wants the float32 fast path).
-template <int NP, bool CALIB, bool FULL>
-__device__ __forceinline__ void reduce_sorted_raw_column(const StackParams &prm, const FrameScalars<NP> &fs,
-                                                         const uint32_t (&cur)[NP >= 2 ? NP / 2 : 1], float b, float D, float nf,
-                                                         bool dv, int64_t p, bool pruned = false)
-{
-    constexpr int HP = NP >= 2 ? NP / 2 : 1;
-    const int N = prm.N;
-    const bool skip = prm.pixmask && prm.pixmask[p];
-    float v[NP];
-    int n = N;
-    bool fast = !skip;
-    float rawf[NP];
-    if constexpr (NP >= 2) {
-#pragma unroll
-        for (int k = 0; k < HP; k++) {
-            rawf[2 * k] = (float)(cur[k] & 0xffffu);
-            rawf[2 * k + 1] = (float)(cur[k] >> 16);
-        }
-    } else {
-        rawf[0] = (float)cur[0];
-    }
-    // Padded stacks on the float32 fast path (round 4; the one-pixel-per-lane kernels have it since round 3): SPLIT PADS - the
-    // kernel wrote the first plo padding slots as raw 0 and the others as raw 65535, so that after the packed sort they sit at
-    // the two ends of the column; here they become -inf / +inf and clip_fast32's padded form starts with them trimmed.
-    constexpr int MINNP = padded_minn(NP, false);
-    constexpr bool SPLIT = !FULL && fast32_possible_padded(NP, MINNP);
-    const int plo = SPLIT ? pad_low<NP>(prm) : 0;
-    const int phi = FULL ? 0 : NP - N - plo;
-    if constexpr (CALIB) {
-        // non-decreasing map: finite masters and a positive (or unused) flat
-        const bool increasing = (fabsf(b) < __builtin_inff()) && (fabsf(D) < __builtin_inff()) && (!dv || (nf > 0.f && nf < __builtin_inff()));
-        // the columns come out sorted (non-decreasing map of a sorted raw column), so their range guards are read off the ends
-        // (of the real values: the pads' own quotients mean nothing)
-        bool good = calibrate_fast<NP, float, false, 0, NP, false, NP, true>(fs, rawf, b, D, nf, dv, v);   // (one exposure ratio: the workgroup's precondition)
-        if constexpr (!FULL) {
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                if (i < NP - MINNP && i < plo) v[i] = -__builtin_inff();                  // (wave-uniform tests, the end slots only)
-                if (i >= MINNP && i >= NP - phi) v[i] = __builtin_inff();
-            }
-        }
-        if constexpr (FULL) good = good && (!increasing || range_ok_sorted<NP>(v, dv));
-        else good = good && (!increasing || range_ok_sorted<NP, (MINNP < NP ? MINNP : 0)>(v, dv, N, plo));
-        fast = fast && good && increasing;
-    } else {
-#pragma unroll
-        for (int f = 0; f < NP; f++) v[f] = rawf[f];
-        if constexpr (!FULL) {
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                if (i < NP - MINNP && i < plo) v[i] = -__builtin_inff();
-                if (i >= MINNP && i >= NP - phi) v[i] = __builtin_inff();
-            }
-        }
-    }
-    if (wave_all(fast)) {
-        if constexpr (!FULL) pruned = SPLIT && fast32_wanted(prm);      // complete, sorted, every lane holds all N values
-    } else {
-        pruned = false;                                     // (the column below is sorted completely)
-        // rare: exact IEEE calibration of every value (frame order is irrelevant: the per-frame scalars are
-        // uniform), non-finite results and padding become sentinels, and the column is sorted the ordinary way.
-        // The raw values are re-read from memory: the sorted copy has left the registers.
-        n = 0;
-        const float e = CALIB ? fs.e[0] : 0.f;
-        const uint16_t *fp = static_cast<const uint16_t *>(prm.frames) + p;
-#pragma unroll
-        for (int f = 0; f < NP; f++) {
-            const float x = calibrate_exact_u16<CALIB>(*fp, b, D, e, nf, dv);
-            if (FULL || f + 1 < N) fp += prm.stride;
-            const bool ok = (fabsf(x) < __builtin_inff()) && (FULL || f < N) && !skip;
-            n += ok ? 1 : 0;
-            v[f] = ok ? x : __builtin_inff();
-            if (SPLIT && f >= N && f < N + plo) v[f] = -__builtin_inff();       // split pads (wave-uniform test), as load_column_exact
-        }
-        sort_column<NP>(v);
-    }
-    if constexpr (SPLIT) reduce_and_store<NP, MINNP>(prm, v, n, p, pruned);
-    else
-    reduce_and_store<NP>(prm, v, n, p, pruned);
-}
-
 // -------------------------------------------------------------------------------------------------
-// uint16 clipped stacks, two pixels per lane.  Same observation as for the median kernel: with one exposure
-// ratio for all frames, no pedestal and a positive flat, calibration is one non-decreasing function per pixel,
-// so sorting the RAW uint16 column sorts the calibrated column.  The raw columns of two neighbouring pixels
-// are sorted together with packed 16-bit compare-exchanges (543 v_pk_min_u16 + 543 v_pk_max_u16 for BOTH
-// pixels - half the sort cost per pixel, and one 4-byte load per lane per frame); each pixel's sorted raw
-// column is then calibrated (same packed fast path and guards as the lean kernel) and reduced WITHOUT a
-// second sort.  Lanes that do not meet the precondition (flat <= 0 / non-finite masters / guard hit) take the
-// exact per-value path followed by the ordinary sort; workgroups whose per-frame scalars are not uniform run
-// the ordinary kernel body on their 512 pixels.  Results are bit-identical to the one-pixel-per-lane kernel:
-// the survivors are summed in sorted order in both.
-// -------------------------------------------------------------------------------------------------
-template <int NP, bool CALIB, bool FULL>
-#ifndef APGPU_U16PAIRS_MIN_BLOCKS
-#define APGPU_U16PAIRS_MIN_BLOCKS 3
-#endif
-__global__ __launch_bounds__(256, NP <= 64 ? APGPU_U16PAIRS_MIN_BLOCKS : 1) void stack_sigclip_u16_pairs_kernel(const StackParams prm)
-{
-    __shared__ FrameScalars<NP> fs;
-    const int lane = threadIdx.x;
-    bool monotone = true;
-    if constexpr (CALIB) {
-        stage_frame_scalars<NP>(prm, fs);
-        const bool differs = lane < NP && (!(fs.e[lane] == fs.e[0]) || fs.ped[lane] != 0.f);
-        monotone = !__syncthreads_or(differs);
-    } else if constexpr (!FULL) {
-        stage_frame_scalars<NP>(prm, fs);
-    }
-    const int N = prm.N;
-    if (!monotone) {
-        // per-frame exposure ratios / pedestals: the ordinary path, two 256-pixel tiles per workgroup
-#pragma unroll 1
-        for (int half = 0; half < 2; half++) {
-            const int64_t base = ((int64_t)blockIdx.x * 2 + half) * 256;
-            const int64_t p = base + lane;
-            if (p >= prm.P) break;
-            float v[NP];
-            StackParams q = prm;
-            asm volatile("" : "+s"(q.N));                  // keeps the NP (f < N) masks of this rare path inside the loop
-            const int n = load_sorted_column<NP, uint16_t, CALIB, true, FULL>(q, fs, base, lane, v);
-            reduce_and_store<NP>(prm, v, n, p);
-        }
-        return;
-    }
-    const int64_t p2 = ((int64_t)blockIdx.x * 256 + lane) * 2;         // this lane's pixel pair (P is even here)
-    if (p2 >= prm.P) return;
-    uint32_t w[NP];
-    {
-        const uint32_t *fp = reinterpret_cast<const uint32_t *>(static_cast<const uint16_t *>(prm.frames) + (int64_t)blockIdx.x * 512);
-        const int64_t step = prm.stride / 2;
-        int nframes = N;
-        if constexpr (!FULL) asm volatile("" : "+s"(nframes));         // see load_raw
-#pragma unroll
-        for (int f = 0; f < NP; f++) {
-            w[f] = fp[lane];
-            if (FULL || f + 1 < nframes) fp += step;        // padded slots re-read the last frame
-            if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (!FULL) {
-            // padding slots: all ones (sorts to the top); with split pads (reduce_sorted_raw_column) the first plo of them zero
-            constexpr int MINNP = padded_minn(NP, false);
-            const int plo = fast32_possible_padded(NP, MINNP) ? pad_low<NP>(prm) : 0;
-#pragma unroll
-            for (int f = 0; f < NP; f++) {
-                if (f >= MINNP || MINNP >= NP) {
-                    if (f >= N) w[f] = (f < N + plo) ? 0u : 0xffffffffu;           // (wave-uniform tests)
-                }
-            }
-        }
-    }
-    // full stacks headed for the float32 fast path only sort what it reads (both pixels at once); a wave that falls back to
-    // the exact path completes the sort of its calibrated column there (reduce_and_store)
-    bool pruned = false;
-    if constexpr (FULL && fast32_possible(NP, NP)) pruned = fast32_wanted(prm);
-    if constexpr (NP > 1) {
-        if constexpr (FULL && fast32_possible(NP, NP)) {
-            if (pruned) pruned_net_pk16<NP, kFastTail>(w);
-            else net_from_pk16<NP, 0>(w);
-        } else {
-            net_from_pk16<NP, 0>(w);
-        }
-    }
-
-    // Re-pack the two sorted columns: cur[k] = (raw[2k], raw[2k+1]) of the first pixel stays in registers, the
-    // second pixel's column is parked in LDS (NP/2 dwords per lane, bank = lane) while the first is reduced, so
-    // only one column is register-resident at a time.
-    constexpr int HP = NP >= 2 ? NP / 2 : 1;
-    __shared__ uint32_t parked[HP][256];
-    uint32_t cur[HP];
-    if constexpr (NP >= 2) {
-#pragma unroll
-        for (int k = 0; k < HP; k++) {
-            cur[k] = (w[2 * k] & 0xffffu) | (w[2 * k + 1] << 16);
-            parked[k][lane] = (w[2 * k] >> 16) | (w[2 * k + 1] & 0xffff0000u);
-        }
-    } else {
-        cur[0] = w[0] & 0xffffu;
-        parked[0][lane] = w[0] >> 16;
-    }
-
-    float bb[2] = {0.f, 0.f}, dd[2] = {0.f, 0.f}, nn[2] = {1.f, 1.f};
-    bool dodiv[2] = {false, false};
-    if constexpr (CALIB) {
-        const float2 b2 = *reinterpret_cast<const float2 *>(prm.bias + p2);
-        const float2 d2 = *reinterpret_cast<const float2 *>(prm.dark + p2);
-        bb[0] = b2.x; bb[1] = b2.y;
-        dd[0] = prm.still_biased ? d2.x - b2.x : d2.x;      // ApCalibrate.py:440-445
-        dd[1] = prm.still_biased ? d2.y - b2.y : d2.y;
-        if (prm.nflat) {
-            const float2 n2 = *reinterpret_cast<const float2 *>(prm.nflat + p2);
-            nn[0] = n2.x; nn[1] = n2.y;
-            dodiv[0] = n2.x != 0.f;                         // ApCalibrate.py:462 (NaN != 0 is True)
-            dodiv[1] = n2.y != 0.f;
-        }
-    }
-    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[0], dd[0], nn[0], dodiv[0], p2, pruned);
-    // the parked column takes over the registers (through an opaque pointer: otherwise the compiler forwards the
-    // stored values to these loads, i.e. keeps the column in NP/2 registers across the whole first reduction)
-    int slot = lane;
-    asm volatile("" : "+v"(slot) : : "memory");             // opaque index: no store-to-load forwarding in registers
-#pragma unroll
-    for (int k = 0; k < HP; k++) cur[k] = parked[k][slot];
-    reduce_sorted_raw_column<NP, CALIB, FULL>(prm, fs, cur, bb[1], dd[1], nn[1], dodiv[1], p2 + 1, pruned);
-}
-
-// -------------------------------------------------------------------------------------------------
-// The FAST kernel of the uint16 pair scheme (round 4): what stack_fast_kernel is to stack_sigclip_kernel.  Only the common
-// path of stack_sigclip_u16_pairs_kernel - packed sort of two raw columns (pruned to what the clip reads), one column parked in
+// uint16 clipped stacks, two pixels per lane (the pair scheme).  With one exposure ratio for all frames, no pedestal and a
+// positive flat, calibration is one non-decreasing function per pixel, so sorting the RAW uint16 column sorts the calibrated
+// column: the raw columns of two neighbouring pixels are sorted together with packed 16-bit compare-exchanges (v_pk_min_u16 /
+// v_pk_max_u16 on both pixels at once - half the sort cost per pixel, and one 4-byte load per lane per frame), and each pixel's
+// sorted raw column is then calibrated and clipped WITHOUT a second sort.
+// This is the FAST kernel of that scheme (round 4; since round 5 the only one, for every full slot count up to 128: the complete
+// pair kernel of rounds 2-4, stack_sigclip_u16_pairs_kernel, is gone - whatever this kernel cannot take or finish runs one pixel
+// per lane on the complete lean kernel): what stack_fast_kernel is to stack_sigclip_kernel.  Only the common
+// path - packed sort of two raw columns (pruned to what the clip reads), one column parked in
 // LDS, packed calibration with one scalar-load exposure ratio, range guards off the ends of the sorted column, clip_fast32 per
 // lane, outputs; no staging pass, no barrier, no exact calibration, no second sort, no float64 clip: four wavefronts per SIMD
 // without spills where the complete kernel holds three with 2-8 spilled registers.  A workgroup whose frames do not share one
@@ -972,13 +771,16 @@ __device__ __forceinline__ bool fast_raw_column(const FrameScalars<NP> &fs, cons
     return good;
 }
 
+// padded stacks on the pair kernel: split pads, tails of 6 / 8 (fast32_possible_padded), and 104 slots as well (97 .. 103 frames)
+constexpr bool pairs_padded_slots(int np) { return fast32_possible_padded(np, padded_minn(np, false)) || np == 104; }
+
 template <int NP, bool CALIB, bool FULL, int PADS = 0>
-__global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : 2) void stack_fast_u16_pairs_kernel(const StackParams prm)
+__global__ __launch_bounds__(256, NP <= 80 ? APGPU_FAST_MIN_BLOCKS : (NP <= 104 ? 3 : 2)) void stack_fast_u16_pairs_kernel(const StackParams prm)
 {
     static_assert(PADS == 0 || (!FULL && PADS <= NP - padded_minn(NP, false)), "static pads: a padded stack");
     constexpr int MINN = padded_minn(NP, FULL);
     constexpr int PLO = PADS > 0 ? (PADS >> 1) : -1, PHI = PADS > 0 ? PADS - (PADS >> 1) : -1;
-    static_assert(FULL ? fast32_possible(NP, NP) : fast32_possible_padded(NP, MINN), "the fast kernel is the float32 fast path");
+    static_assert(FULL ? fast_kernel_slots(NP) : pairs_padded_slots(NP), "the fast kernel is the float32 fast path");
     constexpr int T = FULL ? kFastTail : fast_tail_padded(NP);
     constexpr int HP = NP / 2;
     __shared__ uint32_t parked[HP][256];
@@ -1172,47 +974,40 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
                                 ((reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0) &&
                                 ((reinterpret_cast<uintptr_t>(prm.bias) | reinterpret_cast<uintptr_t>(prm.dark) |
                                   reinterpret_cast<uintptr_t>(prm.nflat)) & 7) == 0;
-        // register budget: two sorted columns + a calibrated one fit two wavefronts per SIMD up to 96 slots (and 112 full
-        // slots); beyond that the one-pixel-per-lane kernel with half-column loads is the faster one
-        constexpr bool kPairsFit = NP <= 112;
-        // beyond 64 slots a PADDED uint16 stack - and any of 120 / 128 slots - is fastest one pixel per lane on the fast kernel
-        // (static pads, half-column loads; measured: N = 89 .. 95 as pairs 2.6-2.9 ms against 1.4-1.5 for float32 frames there)
-        const bool wide_fast = CALIB && NP > 64 && fast_kernel_slots(NP) && (prm.N != NP || NP > 112) &&
-                               fast_kernel_eligible(prm, median_only, rich_out, false);
-        if (!wide_fast && kPairsFit && pairs_clip && (NP <= 96 || prm.N == NP)) {
+        // FULL stacks of every slot count, and padded ones up to 104 slots (one instantiation per pad count), take the fast pair
+        // kernel (round 5: 72 .. 128 slots too - 101 .. 174 VGPRs, 36 .. 64 KB of LDS, no spills: 72 frames 1.08 -> 0.85 ms, 128:
+        // 1.91 -> 1.68); a PADDED stack of 112 .. 128 slots runs one pixel per lane on stack_fast_kernel (static pads, half-column
+        // loads)
+        const bool wide_fast = CALIB && NP > 104 && fast_kernel_slots(NP) && prm.N != NP && fast_kernel_eligible(prm, median_only, rich_out, false);
+        if (!wide_fast && pairs_clip) {
             const int64_t grid = (prm.P + 511) / 512;
             if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
-            // the fast kernel of the pair scheme + redo pass (stack_fast_u16_pairs_kernel)
-            constexpr bool kFastPairsFull = NP <= 64 && fast32_possible(NP, NP);
-            constexpr bool kFastPairsPadded = NP <= 64 && fast32_possible_padded(NP, padded_minn(NP, false));
+            // the fast kernel of the pair scheme + redo pass (stack_fast_u16_pairs_kernel).  A stack that does not take it (exact =
+            // True, mean centre, rich outputs, no list to be had) runs the one-pixel-per-lane kernels below.
+            constexpr bool kFastPairsFull = fast_kernel_slots(NP);
+            constexpr bool kFastPairsPadded = pairs_padded_slots(NP);
             const bool fastp = (prm.N == NP ? kFastPairsFull : kFastPairsPadded) && fast_kernel_eligible(prm, false, false, false);
-            // The COMPLETE pair kernel exists beyond 64 slots only (round 5): up to 64 a stack that does not take the fast pair
-            // kernel (exact = True, mean centre, no list to be had) runs the one-pixel-per-lane complete kernel below - rare
-            // configurations that no longer justify 88 kernels of 165 KB.
-            constexpr bool kCompletePairs = NP > 64 && kPairsFit;
-            if (describe && (fastp || kCompletePairs)) {
-                if (fastp) snprintf(describe, 256, "stack_fast_u16_pairs_kernel<%d, %s, %s, %d>", NP, tf[CALIB], tf[prm.N == NP], NP - prm.N);
-                else snprintf(describe, 256, "stack_sigclip_u16_pairs_kernel<%d, %s, %s>", NP, tf[CALIB], tf[prm.N == NP]);
+            if (describe && fastp) {
+                snprintf(describe, 256, "stack_fast_u16_pairs_kernel<%d, %s, %s, %d>", NP, tf[CALIB], tf[prm.N == NP], NP - prm.N);
                 return APGPU_OK;
             }
-            int frc = kNoRedoList;
-            if (!describe) {
+            if (!describe && fastp) {
+                int frc = kNoRedoList;
                 if constexpr (kFastPairsFull) {
-                    if (fastp && prm.N == NP) frc = launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
+                    if (prm.N == NP) frc = launch_fast_u16_pairs<NP, CALIB, true>(prm, dim3((unsigned)grid), st);
                 }
-                if constexpr (kFastPairsPadded) {            // (slot counts up to 64: 1 .. 3 pads, one instantiation each)
-                    if (fastp && prm.N == NP - 1) frc = launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
-                    if (fastp && prm.N == NP - 2) frc = launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
-                    if (fastp && prm.N == NP - 3) frc = launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
+                if constexpr (kFastPairsPadded) {            // (1 .. 3 pads up to 64 slots, 1 .. 7 beyond: one instantiation each)
+                    if (prm.N == NP - 1) frc = launch_fast_u16_pairs<NP, CALIB, false, 1>(prm, dim3((unsigned)grid), st);
+                    if (prm.N == NP - 2) frc = launch_fast_u16_pairs<NP, CALIB, false, 2>(prm, dim3((unsigned)grid), st);
+                    if (prm.N == NP - 3) frc = launch_fast_u16_pairs<NP, CALIB, false, 3>(prm, dim3((unsigned)grid), st);
+                    if constexpr (NP > 64) {
+                        if (prm.N == NP - 4) frc = launch_fast_u16_pairs<NP, CALIB, false, 4>(prm, dim3((unsigned)grid), st);
+                        if (prm.N == NP - 5) frc = launch_fast_u16_pairs<NP, CALIB, false, 5>(prm, dim3((unsigned)grid), st);
+                        if (prm.N == NP - 6) frc = launch_fast_u16_pairs<NP, CALIB, false, 6>(prm, dim3((unsigned)grid), st);
+                        if (prm.N == NP - 7) frc = launch_fast_u16_pairs<NP, CALIB, false, 7>(prm, dim3((unsigned)grid), st);
+                    }
                 }
                 if (frc != kNoRedoList) return frc;
-            }
-            if constexpr (kCompletePairs) {
-                StackParams q = prm;
-                q.redo = nullptr;
-                if (prm.N == NP) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, true>), dim3((unsigned)grid), dim3(256), 0, st, q);
-                else if constexpr (NP <= 96) hipLaunchKernelGGL((stack_sigclip_u16_pairs_kernel<NP, CALIB, false>), dim3((unsigned)grid), dim3(256), 0, st, q);
-                return check_launch("stack kernel (uint16 pairs)");
             }
         }
         if (pairs) {
