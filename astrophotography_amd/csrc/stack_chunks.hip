@@ -47,6 +47,10 @@ using namespace apgpu;
 
 constexpr int kChunkSlots = 64;
 constexpr int kChunkTail = 8;
+#ifndef APGPU_CHUNKS_PAIR_TAIL
+#define APGPU_CHUNKS_PAIR_TAIL 16
+#endif
+constexpr int kChunkTailPairs = APGPU_CHUNKS_PAIR_TAIL;     // 257 .. 512 frames
 constexpr int kChunkWin = 32;
 constexpr int kChunkMinFrames = 33;                          // a chunk holds its whole window: c_k >= 33
 #ifndef APGPU_CHUNKS_HALVES
@@ -77,12 +81,16 @@ __device__ __forceinline__ void uniform_slice(const float (&v)[NV], int s, float
     for (int j = 0; j < LEN; j++) out[j] = w[j];
 }
 
-// Sorts a bitonic sequence of 8 ascending (3 layers of 4 compare-exchanges).
-__device__ __forceinline__ void bitonic8(float (&t)[8])
+// Sorts a bitonic sequence of T = 8 or 16 values ascending (log2 T layers of T / 2 compare-exchanges).
+template <int T>
+__device__ __forceinline__ void bitonic_sort(float (&t)[T])
 {
-    cmpx(t[0], t[4]); cmpx(t[1], t[5]); cmpx(t[2], t[6]); cmpx(t[3], t[7]);
-    cmpx(t[0], t[2]); cmpx(t[1], t[3]); cmpx(t[4], t[6]); cmpx(t[5], t[7]);
-    cmpx(t[0], t[1]); cmpx(t[2], t[3]); cmpx(t[4], t[5]); cmpx(t[6], t[7]);
+#pragma unroll
+    for (int d = T / 2; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < T; i++)
+            if ((i & d) == 0) cmpx(t[i], t[i + d]);
+    }
 }
 
 struct ChunkSums {
@@ -165,12 +173,12 @@ __device__ __forceinline__ bool load_chunk(const StackParams &q, const FrameScal
 // stride-NCH sample of the whole sequence: a stack that drifts in acquisition order (sky background over a night, dark
 // current with temperature) no longer separates the chunk medians, which would empty the zone the windows vouch for and
 // send every wavefront to the redo list (correct, but the chunk pass AND the exact pass were paid).
-template <typename RawT, bool CALIB, bool FULLCH, int KIDX, int NCH>
+template <typename RawT, bool CALIB, bool FULLCH, bool FIRST, int NCH, int T>
 __device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameScalars<kChunkSlots> &fs, int kchunk, int c, int64_t base,
-                                           int lane, float (&GL)[kChunkTail], float (&GH)[kChunkTail], float (&win)[kChunkWin],
+                                           int lane, float (&GL)[T], float (&GH)[T], float (&win)[kChunkWin],
                                            float &c0, float &Stot, float &Qtot, float &Lmax, float &Umin)
 {
-    constexpr int NP = kChunkSlots, T = kChunkTail;
+    constexpr int NP = kChunkSlots;
     __builtin_amdgcn_sched_barrier(0);                      // chunks do not overlap: the scheduler otherwise stretches live ranges across them
     StackParams q = prm;                                    // the chunk as a stack of its own
     q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)kchunk * prm.stride;
@@ -190,9 +198,9 @@ __device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameSc
         uniform_slice<T, NP - kChunkMinFrames, kChunkMinFrames - T, NP>(v, c - kChunkMinFrames, hi);          // v[c - 8 .. c)
         uniform_slice<kChunkWin, (NP - kChunkWin) / 2, 0, NP>(v, c / 2 - kChunkWin / 2, win);                  // v[c/2 - 16 .. c/2 + 16)
     }
-    if constexpr (KIDX == 0) c0 = win[kChunkWin / 2];       // the first chunk's (upper) median: the pivot of every sum
-    Lmax = KIDX == 0 ? win[0] : fmaxf(Lmax, win[0]);
-    Umin = KIDX == 0 ? win[kChunkWin - 1] : fminf(Umin, win[kChunkWin - 1]);
+    if constexpr (FIRST) c0 = win[kChunkWin / 2];       // the first chunk's (upper) median: the pivot of every sum
+    Lmax = FIRST ? win[0] : fmaxf(Lmax, win[0]);
+    Umin = FIRST ? win[kChunkWin - 1] : fminf(Umin, win[kChunkWin - 1]);
     // the chunk's own sums: everything between its tails, in mirror pairs (clip_fast32)
     ChunkSums cs = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if constexpr (FULLCH) {
@@ -212,8 +220,8 @@ __device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameSc
             add_value(cs, i, v[i], c0);
         }
     }
-    // tails: 8 + 8 -> 8 (bitonic), the values pushed out join the sums
-    if constexpr (KIDX == 0) {
+    // tails: T + T -> T (bitonic), the values pushed out join the sums
+    if constexpr (FIRST) {
 #pragma unroll
         for (int j = 0; j < T; j++) { GL[j] = lo[j]; GH[j] = hi[j]; }
     } else {
@@ -225,7 +233,7 @@ __device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameSc
             GL[j] = a;
             out[j] = b;
         }
-        bitonic8(GL);
+        bitonic_sort<T>(GL);
 #pragma unroll
         for (int j = 0; j < T; j++) add_value(cs, j, out[j], c0);
 #pragma unroll
@@ -235,14 +243,14 @@ __device__ __forceinline__ bool chunk_step(const StackParams &prm, const FrameSc
             GH[j] = b;
             out[j] = a;
         }
-        bitonic8(GH);
+        bitonic_sort<T>(GH);
 #pragma unroll
         for (int j = 0; j < T; j++) add_value(cs, j + 2, out[j], c0);
     }
     const float Sk = (cs.S[0] + cs.S[1]) + (cs.S[2] + cs.S[3]);
     const float Qk = (cs.Q[0] + cs.Q[1]) + (cs.Q[2] + cs.Q[3]);
-    Stot = KIDX == 0 ? Sk : Stot + Sk;
-    Qtot = KIDX == 0 ? Qk : Qtot + Qk;
+    Stot = FIRST ? Sk : Stot + Sk;
+    Qtot = FIRST ? Qk : Qtot + Qk;
     // pin the sums HERE: their only use is the clip at the end, inside the region the `ok` flags guard, and LLVM sinks the
     // whole summation down there - keeping every chunk's values alive (132 spilled registers, measured)
     asm volatile("" : "+v"(Stot), "+v"(Qtot));
@@ -264,10 +272,10 @@ __device__ __forceinline__ float fast_t(const FastT &f, float x)
     return w * w;
 }
 
-template <int I>
-__device__ __forceinline__ void trim_low_t(const float (&GL)[kChunkTail], FastT &f, const float (&SL)[kChunkTail + 1], const float (&QL)[kChunkTail + 1])
+template <int I, int T>
+__device__ __forceinline__ void trim_low_t(const float (&GL)[T], FastT &f, const float (&SL)[T + 1], const float (&QL)[T + 1])
 {
-    if constexpr (I < kChunkTail) {
+    if constexpr (I < T) {
         const float t = fast_t(f, GL[I]);
         const bool at = f.ta == I;
         const bool rej = at && (t > f.tl_hi);
@@ -278,36 +286,88 @@ __device__ __forceinline__ void trim_low_t(const float (&GL)[kChunkTail], FastT 
             f.Slo = SL[I + 1];
             f.Qlo = QL[I + 1];
         }
-        if (wave_any(f.ta > I)) trim_low_t<I + 1>(GL, f, SL, QL);
+        if (wave_any(f.ta > I)) trim_low_t<I + 1, T>(GL, f, SL, QL);
     } else {
-        f.unsure = f.unsure || (f.ta == kChunkTail);        // the tail is used up: the next value is not known here
+        f.unsure = f.unsure || (f.ta == T);        // the tail is used up: the next value is not known here
     }
 }
 
-template <int I>                                             // GH ascending: GH[7] is the column's maximum; I counts from the top
-__device__ __forceinline__ void trim_high_t(const float (&GH)[kChunkTail], FastT &f, const float (&SH)[kChunkTail + 1], const float (&QH)[kChunkTail + 1])
+template <int I, int T>                                      // GH ascending: GH[T - 1] is the column's maximum; I counts from the top
+__device__ __forceinline__ void trim_high_t(const float (&GH)[T], FastT &f, const float (&SH)[T + 1], const float (&QH)[T + 1])
 {
-    if constexpr (I < kChunkTail) {
-        const float t = fast_t(f, GH[kChunkTail - 1 - I]);
+    if constexpr (I < T) {
+        const float t = fast_t(f, GH[T - 1 - I]);
         const bool at = f.tb == I;
         const bool rej = at && (t > f.th_hi);
         const bool maybe = at && (t > f.th_lo);
         f.unsure = f.unsure || (maybe != rej);
         if (rej) {
             f.tb = I + 1;
-            f.Shi = SH[kChunkTail - 1 - I];
-            f.Qhi = QH[kChunkTail - 1 - I];
+            f.Shi = SH[T - 1 - I];
+            f.Qhi = QH[T - 1 - I];
         }
-        if (wave_any(f.tb > I)) trim_high_t<I + 1>(GH, f, SH, QH);
+        if (wave_any(f.tb > I)) trim_high_t<I + 1, T>(GH, f, SH, QH);
     } else {
-        f.unsure = f.unsure || (f.tb == kChunkTail);
+        f.unsure = f.unsure || (f.tb == T);
     }
 }
 
-template <int K, typename RawT, bool CALIB, bool FULLCH>
+// One WINDOW of the final merge.  129 .. 256 frames (PAIR = false): the window of chunk SIDX.  257 .. 512 frames (PAIR = true,
+// round 5): chunks 2 SIDX and 2 SIDX + 1 are reduced one after the other - tails and sums exactly as before - and their two
+// windows are merged (Batcher's 32 + 32 merge pruned to the 32 middle outputs) into ONE window of 32: the 16 lowest and 16
+// highest of the 64 are dropped (they are already part of the sums, which cover everything between the tails).  The pair is a
+// stride-KS sample of 66 .. 128 frames in which the column's middle order statistics have local rank c / 2 +- 5 (one sigma;
+// hypergeometric), i.e. position 32 +- 5 in the merged list of 64: the kept 16 on either side are 3 sigma, and the pixels
+// whose median falls outside (~1 % of them at 512 frames, measured) fail the zone test below and are redone exactly.  The zone
+// the windows vouch for shrinks accordingly: a value x is at merged index (rank - below) iff everything that was left out is
+// known to lie on its proper side of x - the chunk values below / above the chunk windows (Lmax / Umin as before) AND the
+// dropped 16 + 16, which are <= P[0] / >= P[31]: Lmax = max(.., P[0]), Umin = min(.., P[31]), below += 16 per pair.
+template <typename RawT, bool CALIB, bool FULLCH, int SIDX, int KS, bool PAIR, int T>
+__device__ __forceinline__ bool window_step(const StackParams &prm, const FrameScalars<kChunkSlots> *fs, int cbase, int cextra, int64_t base,
+                                            int lane, float (&GL)[T], float (&GH)[T], float (&win)[kChunkWin], float &c0, float &Stot,
+                                            float &Qtot, float &Lmax, float &Umin, int &below)
+{
+    constexpr int W = kChunkWin;
+    if constexpr (!PAIR) {
+        const int c = cbase + (SIDX < cextra ? 1 : 0);
+        below += c / 2 - W / 2;
+        return chunk_step<RawT, CALIB, FULLCH, SIDX == 0, KS, T>(prm, fs[SIDX], SIDX, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin);
+    } else {
+        constexpr int ka = 2 * SIDX, kb = 2 * SIDX + 1;
+        const int ca = cbase + (ka < cextra ? 1 : 0), cb = cbase + (kb < cextra ? 1 : 0);
+        float Y[2 * W];
+        bool ok;
+        {
+            float wa[W];
+            ok = chunk_step<RawT, CALIB, FULLCH, SIDX == 0, 2 * KS, T>(prm, fs[ka], ka, ca, base, lane, GL, GH, wa, c0, Stot, Qtot, Lmax, Umin);
+#pragma unroll
+            for (int j = 0; j < W; j++) Y[j] = wa[j];
+        }
+        {
+            float wb[W];
+            ok = chunk_step<RawT, CALIB, FULLCH, false, 2 * KS, T>(prm, fs[kb], kb, cb, base, lane, GL, GH, wb, c0, Stot, Qtot, Lmax, Umin) && ok;
+#pragma unroll
+            for (int j = 0; j < W; j++) Y[W + j] = wb[j];
+        }
+        window_net_from<2 * W, W, W / 2, W / 2 + W>(Y);
+#pragma unroll
+        for (int j = 0; j < W; j++) win[j] = Y[W / 2 + j];
+        Lmax = fmaxf(Lmax, win[0]);
+        Umin = fminf(Umin, win[W - 1]);
+        below += (ca / 2 - W / 2) + (cb / 2 - W / 2) + W / 2;
+        __builtin_amdgcn_sched_barrier(0);
+        return ok;
+    }
+}
+
+// KS windows reach the final merge (3 or 4; the template also takes 2).  PAIR: every window is made of two chunks, K = 2 KS
+// chunks in all (6: 257 .. 384 frames, 8: 385 .. 512), and the tails hold 16 values (a 512-frame column loses twice as many
+// values to the same clip as a 256-frame one).
+template <int KS, bool PAIR, typename RawT, bool CALIB, bool FULLCH>
 __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo_count, int32_t *redo_list)
 {
-    constexpr int T = kChunkTail, W = kChunkWin;
+    constexpr int K = PAIR ? 2 * KS : KS;
+    constexpr int T = PAIR ? kChunkTailPairs : kChunkTail, W = kChunkWin;
     __shared__ FrameScalars<kChunkSlots> fs[K];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -327,60 +387,46 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     __syncthreads();
     if (p >= prm.P) return;
 
-    // the windows of the first K - 2 chunks wait in LDS ([slot][lane]: bank = lane), the last two stay in registers: with all
+    // the first KS - 2 windows wait in LDS ([slot][lane]: bank = lane), the last two stay in registers: with all
     // four in registers next to a 64-slot chunk the kernel spills (256 VGPRs, 142 spilled); 64 KB of LDS per workgroup still
     // leaves two workgroups (8 wavefronts) per CU
-    extern __shared__ float parked[];                       // [(K - 2) * W][256]
+    extern __shared__ float parked[];                       // [(KS - 2) * W][256]
     float R0[W], R1[W];
     float GL[T], GH[T];
     float c0 = 0.f, Stot = 0.f, Qtot = 0.f, Lmax = 0.f, Umin = 0.f;
     bool ok = !(prm.pixmask && prm.pixmask[p]);
     int below = 0;                                          // values below the windows (wave-uniform)
-    if constexpr (K >= 3) {
+    if constexpr (KS >= 3) {
         float win[W];
-        const int c = cbase + (0 < cextra ? 1 : 0);
-        ok = chunk_step<RawT, CALIB, FULLCH, 0, K>(prm, fs[0], 0, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
-        below += c / 2 - W / 2;
+        ok = window_step<RawT, CALIB, FULLCH, 0, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
     }
-    if constexpr (K == 4) {
+    if constexpr (KS == 4) {
         float win[W];
-        const int c = cbase + (1 < cextra ? 1 : 0);
-        ok = chunk_step<RawT, CALIB, FULLCH, 1, K>(prm, fs[1], 1, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin) && ok;
-        below += c / 2 - W / 2;
+        ok = window_step<RawT, CALIB, FULLCH, 1, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
     }
-    {
-        constexpr int k = K - 2;                            // (K = 2: this is the first chunk)
-        const int c = cbase + (k < cextra ? 1 : 0);
-        ok = chunk_step<RawT, CALIB, FULLCH, (k == 0 ? 0 : 2), K>(prm, fs[k], k, c, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin) && ok;
-        below += c / 2 - W / 2;
-    }
-    {
-        constexpr int k = K - 1;
-        const int c = cbase;                                // the last chunk never gets an extra frame
-        ok = chunk_step<RawT, CALIB, FULLCH, 3, K>(prm, fs[k], k, c, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin) && ok;
-        below += c / 2 - W / 2;
-    }
-    float X[4 * W];                                         // the K windows side by side, +inf beyond them
+    ok = window_step<RawT, CALIB, FULLCH, KS - 2, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+    ok = window_step<RawT, CALIB, FULLCH, KS - 1, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+    float X[4 * W];                                         // the KS windows side by side, +inf beyond them
     {
         int slot = lane;
         asm volatile("" : "+v"(slot) : : "memory");         // opaque index: no store-to-load forwarding through registers
 #pragma unroll
-        for (int j = 0; j < (K - 2) * W; j++) X[j] = parked[j * 256 + slot];
+        for (int j = 0; j < (KS - 2) * W; j++) X[j] = parked[j * 256 + slot];
 #pragma unroll
         for (int j = 0; j < W; j++) {
-            X[(K - 2) * W + j] = R0[j];
-            X[(K - 1) * W + j] = R1[j];
+            X[(KS - 2) * W + j] = R0[j];
+            X[(KS - 1) * W + j] = R1[j];
         }
 #pragma unroll
-        for (int j = K * W; j < 4 * W; j++) X[j] = __builtin_inff();
+        for (int j = KS * W; j < 4 * W; j++) X[j] = __builtin_inff();
     }
     APGPU_MARK("chunks_merge");
     // merge the windows: [0,32)+[32,64) and [64,96)+[96,128), then the two halves - only the 16 middle outputs are read
-    constexpr int MLO = 16 * K - 8;
+    constexpr int MLO = 16 * KS - 8;
 #ifndef APGPU_EXP_NOMERGE
     window_net_from<4 * W, W, MLO, MLO + 16>(X);
 #endif
@@ -437,8 +483,8 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
         f.th_hi = __builtin_fmaf(th, rho, th);
         f.th_lo = __builtin_fmaf(th, -rho, th);
 #ifndef APGPU_EXP_NOTRIM
-        trim_low_t<0>(GL, f, SL, QL);
-        trim_high_t<0>(GH, f, SH, QH);
+        trim_low_t<0, T>(GL, f, SL, QL);
+        trim_high_t<0, T>(GH, f, SH, QH);
 #endif
         it++;
         const bool changed = (f.ta != ta0) || (f.tb != tb0);
@@ -494,7 +540,7 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
 {
     // (97 .. 128 frames as two chunks were measured too: 2.8 - 3.1 ms for 128 frames against 2.7 ms for the 128-slot
     // register kernel - a chunk costs what the whole 64-frame kernel costs - so the register kernels keep that range)
-    if (median_only || prm.N <= 128 || prm.N > 4 * kChunkSlots) return false;
+    if (median_only || prm.N <= 128 || prm.N > 8 * kChunkSlots) return false;
     if (prm.P >= 0x7fffffffLL) return false;                 // the redo list holds pixel indices as int32
     if (prm.median || prm.std || prm.mean64 || prm.std64) return false;
     if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
@@ -504,12 +550,12 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
     return true;
 }
 
-template <int K, typename RawT, bool CALIB>
+template <int KS, bool PAIR, typename RawT, bool CALIB>
 static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, char *describe)
 {
-    const bool fullch = prm.N == K * kChunkSlots;
+    const bool fullch = prm.N == (PAIR ? 2 : 1) * KS * kChunkSlots;
     if (describe) {
-        snprintf(describe, 256, "stack_chunks_kernel<%d, %s, %s, %s>", K, sizeof(RawT) == 2 ? "unsigned short" : "float",
+        snprintf(describe, 256, "stack_chunks_kernel<%d, %s, %s, %s, %s>", KS, PAIR ? "true" : "false", sizeof(RawT) == 2 ? "unsigned short" : "float",
                  CALIB ? "true" : "false", fullch ? "true" : "false");
         return APGPU_OK;
     }
@@ -537,10 +583,10 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
         cnt = own;
         list = own + 1;
     }
-    const size_t lds = (size_t)(K - 2) * kChunkWin * 256 * sizeof(float);
+    const size_t lds = (size_t)(KS - 2) * kChunkWin * 256 * sizeof(float);
     if (lds > 48 * 1024) {
-        const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, true>)
-                                  : reinterpret_cast<const void *>(stack_chunks_kernel<K, RawT, CALIB, false>);
+        const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>)
+                                  : reinterpret_cast<const void *>(stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>);
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {                              // no room for the parked windows: the exact kernel does the whole stack
             (void)hipGetLastError();
@@ -548,9 +594,9 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
             return launch_big_exact(q, u16, CALIB, false, st, nullptr);
         }
     }
-    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
-    else hipLaunchKernelGGL((stack_chunks_kernel<K, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
-    int rc = check_launch("stack kernel (chunked, 129..256 frames)");
+    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
+    else hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
+    int rc = check_launch("stack kernel (chunked, 129..512 frames)");
     if (rc == APGPU_OK) rc = launch_big_exact(q, u16, CALIB, false, st, nullptr, cnt, list, ws);
     if (own) {
         const hipError_t ef = hipFreeAsync(own, st);
@@ -559,15 +605,20 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     return rc;
 }
 
+template <int KS, bool PAIR>
+static int launch_chunks_t(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
+{
+    if (u16) return calib ? launch_chunks_k<KS, PAIR, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<KS, PAIR, uint16_t, false>(prm, u16, st, describe);
+    return calib ? launch_chunks_k<KS, PAIR, float, true>(prm, u16, st, describe) : launch_chunks_k<KS, PAIR, float, false>(prm, u16, st, describe);
+}
+
 int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
 {
-    const int K = (prm.N + kChunkSlots - 1) / kChunkSlots;  // 3 or 4 (the kernel template also takes K = 2)
-    if (K == 3) {
-        if (u16) return calib ? launch_chunks_k<3, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<3, uint16_t, false>(prm, u16, st, describe);
-        return calib ? launch_chunks_k<3, float, true>(prm, u16, st, describe) : launch_chunks_k<3, float, false>(prm, u16, st, describe);
-    }
-    if (u16) return calib ? launch_chunks_k<4, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<4, uint16_t, false>(prm, u16, st, describe);
-    return calib ? launch_chunks_k<4, float, true>(prm, u16, st, describe) : launch_chunks_k<4, float, false>(prm, u16, st, describe);
+    // 129 .. 256 frames: 3 or 4 chunks, one window each; 257 .. 512: 3 or 4 PAIRS of chunks (6 or 8 chunks of 42 .. 64 frames)
+    const bool pair = prm.N > 4 * kChunkSlots;
+    const int KS = (prm.N + (pair ? 2 : 1) * kChunkSlots - 1) / ((pair ? 2 : 1) * kChunkSlots);
+    if (pair) return KS == 3 ? launch_chunks_t<3, true>(prm, u16, calib, st, describe) : launch_chunks_t<4, true>(prm, u16, calib, st, describe);
+    return KS == 3 ? launch_chunks_t<3, false>(prm, u16, calib, st, describe) : launch_chunks_t<4, false>(prm, u16, calib, st, describe);
 }
 
 }  // namespace apgpu_stack

@@ -750,15 +750,16 @@ def test_fast32_path_guards_on_adversarial_columns(ops, apref):
     counts must be identical everywhere, means within 1 ulp."""
     rng = np.random.default_rng(2025)
     H, W = 16, 256
-    for N in (13, 16, 30, 32, 37, 52, 58, 64, 75, 96, 100, 119, 128, 160, 256):       # 13, 30, 37, 52, 58, 75, 100, 119: padded stacks (split pads)
+    # 13, 30, 37, 52, 58, 75, 100, 119: padded stacks (split pads); 160, 256: chunked kernel; 257 .. 512: chunked kernel, pairs of chunks
+    for N in (13, 16, 30, 32, 37, 52, 58, 64, 75, 96, 100, 119, 128, 160, 256, 257, 300, 384, 385, 449, 512):
         cols = []
         base = rng.normal(0.0, 1.0, (N, H, W))
         level = np.array([0.0, 1e-3, 1.0, 50.0, 500.0, 5e4, -300.0, 1e-20])[rng.integers(0, 8, (H, W))]
         spread = np.array([1e-6, 1e-3, 1.0, 30.0, 300.0])[rng.integers(0, 5, (H, W))]
         cube = level[None] + spread[None] * base
         kind = rng.integers(0, 8, (H, W))
-        k = min(N // 3, 9)
-        for f in range(k):                                                          # up to nine outliers on one side
+        k = min(N // 3, 9 if N <= 256 else 20)
+        for f in range(k):                                                          # up to nine (twenty) outliers on one side
             m = (kind == 1) & (rng.random((H, W)) < 0.7)
             cube[f][m] += (10.0 ** rng.uniform(1, 30, m.sum())) * spread[m]
         m = kind == 2

@@ -175,3 +175,41 @@ def test_workspace_contract(ops, apref):
     assert np.array_equal(r['count'].cpu().numpy(), c2)
     assert_ulp(r['mean'].cpu().numpy(), m2, 1, '160 frames, chunked kernel')
     assert ws[o:o + 8].view(torch.int64)[0].item() == before + 1 and _zero_prefix_is_zero(ops, ws, H * W)
+
+
+@pytest.mark.parametrize('N,dtype', [(257, np.float32), (320, np.uint16), (384, np.float32), (385, np.uint16), (470, np.float32), (512, np.float32),
+                                     (512, np.uint16)])
+def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
+    """257 .. 512 frames on the chunked kernel (round 5: pairs of chunks, tails of 16): fused calibration, a sky level that drifts
+    in acquisition order, 1 % outliers per frame (five per column on average: some columns use the tails up), a dead column,
+    a NaN in the flat, per-frame exposure ratios - against the oracle; and the fast pass must really carry the stack (the
+    exact kernel redoes a small share), with its list in the caller's workspace."""
+    rng = np.random.default_rng(600 + N)
+    H, W = 24, 512
+    bias, dark, flat = synth_masters(rng, (H, W))
+    nf = (flat / np.float32(flat.mean())).astype(np.float32)
+    nf[3, 5] = np.nan
+    e = (0.4 + 0.0005 * np.arange(N)).astype(np.float32)
+    sky = rng.normal(400, 15, (N, H, W)) + np.linspace(0.0, 60.0, N)[:, None, None]       # four sigma of drift over the sequence
+    hits = rng.random(sky.shape) < 0.01
+    sky[hits] += rng.uniform(200, 4000, hits.sum())
+    sky[:, 7, 9] = 123.0
+    raw = bias + e[:, None, None] * dark + np.where(np.isnan(nf), 1.0, nf) * sky
+    raw = np.clip(np.rint(raw), 0, 65535).astype(np.uint16) if dtype == np.uint16 else raw.astype(np.float32)
+    el = [float(x) for x in e]
+    with np.errstate(all='ignore'):
+        mean_ref, cnt_ref = apref.calibrate_stack(raw, bias, dark, nf, el, sigma=3.0, maxiters=5)
+    calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nf, ops), exp_ratio=el)
+    name = ops.stack_kernel_name(N, 'u16' if dtype == np.uint16 else 'f32', calibrated=True)
+    assert name.startswith('stack_chunks_kernel<%d, true' % (3 if N <= 384 else 4)), name
+    d = dev(raw, ops)
+    ops.stack_redo_stats(reset=True)
+    r = ops.stack_sigclip(d, sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
+    st = ops.stack_redo_stats()
+    assert np.array_equal(r['count'].cpu().numpy(), cnt_ref), N
+    assert_ulp(r['mean'].cpu().numpy(), mean_ref, 1, '%d frames, chunked pairs' % N)
+    assert st['calls'] == 1 and 0 < st['pixels_listed'] < 0.25 * H * W, st
+    x = ops.stack_sigclip(d, sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'), exact=True)
+    assert np.array_equal(x['count'].cpu().numpy(), cnt_ref), N
+    assert_ulp(x['mean'].cpu().numpy(), mean_ref, 1, '%d frames, exact kernel' % N)
+    assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W)
