@@ -825,6 +825,13 @@ __device__ __forceinline__ void general_fill(const TileCtx &tc, const FrameView 
     }
 }
 
+// (Round 5, measured and dropped: PERSISTENT workgroups - a grid of what the chip holds at once, 5 x 256 workgroups, each walking
+// tiles w, w + G, .. in the same XCD-aware order, the next tile's record touched ahead so that its load hits the scalar cache.
+// 4.27 ms against 3.83 ms for one workgroup per tile on the same box (16 x 8192^2, +-0.2 degrees; 4.57 ms before the workgroups
+// per XCD were made an odd number: with 160 a workgroup met the same few tile columns again and again - 160 k mod 128 - and the
+// ones that drew the frame's edge columns, which take the general path, finished long after the rest).  The dispatcher's 0.6 ms
+// for 524,288 workgroups is not on the critical path - it runs ahead of the workgroups - and its dynamic assignment balances
+// the slow edge tiles, which a static walk cannot; the loop also cost 20 - 40 spilled SGPRs.  profiles/r05_c5/ab_resample.txt.)
 template <bool HAS_MASK, bool OVERSAMPLED, int TH>
 __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,

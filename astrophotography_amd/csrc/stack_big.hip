@@ -223,7 +223,7 @@ int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_o
 bool chunks_eligible(const StackParams &prm, bool median_only);                                        // stack_chunks.hip
 int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe);
 
-// 129 .. 512 frames: the chunked float32 fast path where it applies (129 .. 256 frames, lean outputs), else the exact kernel.
+// 129 .. 512 frames: the chunked float32 fast path where it applies (lean outputs), else the exact kernel.
 int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
     if (chunks_eligible(prm, median_only)) return launch_chunks(prm, u16, calib, st, describe);

@@ -1,4 +1,5 @@
-// stack_chunks.hip - 129 .. 256 frames on the float32 fast path (round 3): the column never exists as a whole.
+// stack_chunks.hip - 129 .. 256 frames (round 3) and 257 .. 512 frames (round 5: window_step, pairs of chunks) on the float32
+// fast path: the column never exists as a whole.
 //
 // Same semantics and outputs as the lean register kernels (stack_kernels.h / stack_reduce.h): the sigma-clipped mean /
 // count / partial moments of astropy.stats.sigma_clipped_stats(cube, axis=0) (sigma_clipping.py:298-383, 924-937) with the
@@ -31,6 +32,9 @@
 // Error budget: per chunk 4 chains of <= 12 terms + 2 (+ <= 16 pushed-out values in 4 chains + 2), K <= 4 chunk totals
 // + 3, tails 8 + 2: every partial sum at most ~24 roundings deep -> |dQ| <= 26u Q, |dS| <= 25u sqrt(n Q), |dV| <=
 // (27 + 50 + 1)u nQ <= 312u V under the guard V >= nQ / 4, + 10u for the test itself: rho = 2^-15 = 512u covers it.
+// 257 .. 512 frames (8 chunks, tails of 16): per chunk 4 chains of <= 8 terms + 2 and <= 32 pushed-out values in 4 chains
+// + 2, 8 chunk totals + 7, tails 16 + 2, the final three-term sum + 2: at most ~30 roundings -> |dQ| <= 32u Q, |dS| <=
+// 31u sqrt(n Q), |dV| <= (33 + 62 + 1)u nQ <= 384u V, + 10u for the test: still inside rho = 512u.
 //
 // Registers / LDS: 64 (chunk) + 32 (half of its raw values) + the last two windows + 16 (tails) + sums in registers; the
 // windows of the first K - 2 chunks are parked in LDS (64 KB per 256-pixel workgroup for K = 4): two workgroups = eight
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
 int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe, int32_t *redo_count = nullptr,
                      const int32_t *redo_list = nullptr, int32_t *ws = nullptr);
 
-// Whether a stack of 129 .. 256 frames can take the chunked fast path: lean outputs, median centre / std deviation, the
+// Whether a stack of 129 .. 512 frames can take the chunked fast path: lean outputs, median centre / std deviation, the
 // float32 path not switched off, float64-layout moments only when they are for a mean.
 bool chunks_eligible(const StackParams &prm, bool median_only)
 {

@@ -173,7 +173,7 @@ typedef struct apgpu_stack_args {
 #define APGPU_STACK_MOMENTS_MEAN 2
 #define APGPU_STACK_SINGLE_KERNEL 4   /* never the fast kernel + redo pass pair described below: one complete kernel, no workspace used */
 
-/* The two-kernel scheme and its workspace.  A clipped stack of up to 128 frames (and the chunked kernel for 129 .. 256) with
+/* The two-kernel scheme and its workspace.  A clipped stack of up to 128 frames (and the chunked kernel for 129 .. 512) with
  * lean outputs runs as a FAST kernel - the float32 fast path alone, four wavefronts per SIMD - followed by a REDO PASS of the
  * complete kernel over what the fast kernel could not finish: single pixels (unsure comparisons, non-finite values, masked
  * pixels, operands outside the guards of the fast division) gathered from per-segment lists, and whole 256-pixel tiles that

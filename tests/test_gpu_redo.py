@@ -166,7 +166,7 @@ def test_workspace_contract(ops, apref):
     with pytest.raises(_lib.ApGpuError) as ei:
         ops.stack_sigclip(d, sigma=3.0, maxiters=5, calib=calib, workspace=ws[1:])
     assert ei.value.code == _lib.E_INVAL
-    # chunked kernel (129 .. 256 frames): its redo list lives in the same workspace
+    # chunked kernel (129 .. 512 frames): its redo list lives in the same workspace
     raw2 = _raw_frames(rng, 160, (H, W), bias, dark, nf, 0.4, np.float32)
     calib2 = dict(calib, exp_ratio=0.4)
     m2, c2 = apref.calibrate_stack(raw2, bias, dark, nf, 0.4, sigma=3.0, maxiters=5)
