@@ -212,6 +212,10 @@ __device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned lo
 {
     int js, jr, px, py;
     phases(Xr, Yr, sh, js, jr, px, py);
+#ifdef APGPU_EXP_PHASE_MASK                                  /* timing experiment only (wrong weights): how much the table gathers cost */
+    px &= APGPU_EXP_PHASE_MASK;
+    py &= APGPU_EXP_PHASE_MASK;
+#endif
     FastPrep p;
     p.w = load_weights(lut, px, py);
     const unsigned s = (unsigned)js, r = (unsigned)jr;
@@ -334,18 +338,83 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 #ifndef APGPU_RESAMPLE_AHEAD
 #define APGPU_RESAMPLE_AHEAD 2
 #endif
-template <int TH>
-struct Rolling {
-    static constexpr int R = TH / 4;                         // consecutive rows per lane
-    static constexpr int kAhead = APGPU_RESAMPLE_AHEAD < R ? APGPU_RESAMPLE_AHEAD : R - 1;
-    unsigned long long X, Y;                                 // coordinates of the next pixel to prepare
-    FastPrep nxt[kAhead > 0 ? kAhead : 1];
+#ifndef APGPU_RESAMPLE_ONE_LDS_WAIT
+#define APGPU_RESAMPLE_ONE_LDS_WAIT 0
+#endif
+#ifndef APGPU_RESAMPLE_REREAD_VOTE
+#define APGPU_RESAMPLE_REREAD_VOTE 0
+#endif
+// Round 5, second step - the table rows are what the kernel waits for: with every lane reading row 0 (wrong weights, timing only)
+// the same launch takes 2.92 instead of 3.75 ms, with 16 distinct rows the full 3.75 (profiles/r05_c5/ab_resample.txt) - a
+// divergent buffer load is paid per lane, however few cache lines it touches, and there were four of them per pixel.  A lane's
+// consecutive output rows differ in Y by F4 = cos(rotation) x scale, i.e. by an integer plus a few millionths: the y PHASE of the
+// next row is the same one (it moves by one table row every ~100 output rows at 0.2 degrees), so the lane keeps its y weights and
+// reloads them only when its phase changed - behind a wave vote, with its own full wait inside the rare block so that the
+// compiler's wait counters at the join stay those of the prefetched x rows.  Two gathers per pixel instead of four.
+#ifndef APGPU_RESAMPLE_KEEP_WY
+#define APGPU_RESAMPLE_KEEP_WY 1
+#endif
+
+struct RowsY {
+    v2f wy01, wy23, wy45;
 };
 
-template <int TH, typename LutT>
-__device__ __forceinline__ void rolling_begin(Rolling<TH> &ro, const TileCtx &tc, LutT lut, int sh, int x0, int y0, int lx, int ly)
+struct RollPrep {
+    v2f wx01, wx23, wx45;       // x taps as (even, odd) pairs
+    RowsY y;                    // !KEEP: the y rows travel with the x rows (KEEP: not used)
+    int py;                     // y phase (table row)
+    int idx;                    // float index of the window's first pair (even)
+};
+
+__device__ __forceinline__ RowsY load_rows_y(v4i lut, int py)
 {
-    constexpr int R = Rolling<TH>::R;
+    const int oy = (int)__umul24((unsigned)py, 24u);
+    const v4f c = apgpu_buffer_load_v4f32(lut, oy, 0, 0);
+    const v2f d = apgpu_buffer_load_v2f32(lut, oy + 16, 0, 0);
+    RowsY r;
+    r.wy01 = v2f{c.x, c.y};
+    r.wy23 = v2f{c.z, c.w};
+    r.wy45 = d;
+    return r;
+}
+
+template <int OFFB, bool KEEP>
+__device__ __forceinline__ RollPrep prep_roll(unsigned long long Xr, unsigned long long Yr, int sh, v4i lut)
+{
+    int js, jr, px, py;
+    phases(Xr, Yr, sh, js, jr, px, py);
+#ifdef APGPU_EXP_PHASE_MASK
+    px &= APGPU_EXP_PHASE_MASK;
+    py &= APGPU_EXP_PHASE_MASK;
+#endif
+    RollPrep p;
+    const int ox = (int)__umul24((unsigned)px, 24u);
+    const v4f a = apgpu_buffer_load_v4f32(lut, ox, 0, 0);
+    const v2f b = apgpu_buffer_load_v2f32(lut, ox + 16, 0, 0);
+    p.wx01 = v2f{a.x, a.y};
+    p.wx23 = v2f{a.z, a.w};
+    p.wx45 = b;
+    if constexpr (!KEEP) p.y = load_rows_y(lut, py);
+    p.py = py;
+    const unsigned sx = (unsigned)js, r = (unsigned)jr;
+    p.idx = (int)mad_u24(sx & 1u, (unsigned)(OFFB - 1), mad_u24(r, (unsigned)kFastPitch, sx));
+    return p;
+}
+
+template <int TH, int AHEAD>
+struct Rolling {
+    static constexpr int R = TH / 4;                         // consecutive rows per lane
+    static constexpr int kAhead = AHEAD < R ? AHEAD : R - 1;
+    unsigned long long X, Y;                                 // coordinates of the next pixel to prepare
+    RollPrep nxt[kAhead > 0 ? kAhead : 1];
+    RowsY wy;                                                // the y weights in use, and their phase
+    int py;
+};
+
+template <int TH, bool KEEP, int AHEAD, int AS, typename LutT>          // AHEAD <= AS: pixels prepared ahead / slots in the state
+__device__ __forceinline__ void rolling_begin(Rolling<TH, AS> &ro, const TileCtx &tc, LutT lut, int sh, int x0, int y0, int lx, int ly)
+{
+    constexpr int R = Rolling<TH, AHEAD>::R;
     const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
     const unsigned long long us = (unsigned long long)(long long)x0, vs = (unsigned long long)(long long)y0;
     const unsigned long long Xs = F0 * us + F1 * vs + F2 - ((unsigned long long)(unsigned)(tc.bx0 + 2) << 32);
@@ -353,19 +422,24 @@ __device__ __forceinline__ void rolling_begin(Rolling<TH> &ro, const TileCtx &tc
     const unsigned long long ul = (unsigned long long)(unsigned)lx, vl = (unsigned long long)(unsigned)(ly * R);
     ro.X = Xs + F0 * ul + F1 * vl;
     ro.Y = Ys + F3 * ul + F4 * vl;
+    ro.py = -1;
 #pragma unroll
-    for (int k = 0; k < Rolling<TH>::kAhead; k++) {
-        ro.nxt[k] = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+    for (int k = 0; k < Rolling<TH, AHEAD>::kAhead; k++) {
+        ro.nxt[k] = prep_roll<FastGeom<TH>::kOffB, KEEP>(ro.X, ro.Y, sh, lut);
+        if (KEEP && k == 0) {                                  // the first pixel's y rows travel with its x rows, during the fill
+            ro.wy = load_rows_y(lut, ro.nxt[0].py);
+            ro.py = ro.nxt[0].py;
+        }
         ro.X += F1;
         ro.Y += F4;
     }
 }
 
-template <int TH, typename LutT>
-__device__ __forceinline__ void pixels_fast_rolling(Rolling<TH> &ro, const TileCtx &tc, const float *tile, LutT lut, int sh, int lx, int ly,
+template <int TH, bool KEEP, int AHEAD, int AS, typename LutT>
+__device__ __forceinline__ void pixels_fast_rolling(Rolling<TH, AS> &ro, const TileCtx &tc, const float *tile, LutT lut, int sh, int lx, int ly,
                                                     v4i orsrc, v4i wrsrc, bool want_w, int w_out)
 {
-    constexpr int R = Rolling<TH>::R, A = Rolling<TH>::kAhead;
+    constexpr int R = Rolling<TH, AHEAD>::R, A = Rolling<TH, AHEAD>::kAhead;
     const unsigned long long F1 = tc.F[1], F4 = tc.F[4];
     const float fs = tc.fs;
     int ooff = (ly * R * w_out + lx) * 4;
@@ -374,24 +448,41 @@ __device__ __forceinline__ void pixels_fast_rolling(Rolling<TH> &ro, const TileC
     int prev = 0;
 #pragma unroll
     for (int k = 0; k < R; k++) {
-        FastPrep cur;
+        RollPrep cur;
         if constexpr (A > 0) {
             cur = ro.nxt[k % A];
             if (k + A < R) {
-                ro.nxt[k % A] = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+                ro.nxt[k % A] = prep_roll<FastGeom<TH>::kOffB, KEEP>(ro.X, ro.Y, sh, lut);
                 ro.X += F1;
                 ro.Y += F4;
             }
         } else {
-            cur = prep_fast<FastGeom<TH>::kOffB>(ro.X, ro.Y, sh, lut);
+            cur = prep_roll<FastGeom<TH>::kOffB, KEEP>(ro.X, ro.Y, sh, lut);
             ro.X += F1;
             ro.Y += F4;
+        }
+        RowsY wyr;
+        if constexpr (KEEP) {
+            const bool changed = cur.py != ro.py;
+            if (__builtin_amdgcn_ballot_w64(changed) != 0) {   // rare: some lane's y phase moved on (or kAhead = 0: the first pixel)
+                if (changed) {
+                    ro.wy = load_rows_y(lut, cur.py);
+                    ro.py = cur.py;
+                }
+                __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0), here, so that the join keeps the counters of the prefetched x rows
+            }
+            wyr = ro.wy;
+        } else {
+            wyr = cur.y;
         }
         lds_pair_p t = (lds_pair_p)(tile + cur.idx);
         const bool reread = (k == 0) || (cur.idx != prev + kFastPitch);
         prev = cur.idx;
-        if (k == 0 || __builtin_amdgcn_ballot_w64(reread) != 0) {
-            if (reread) {
+#if APGPU_RESAMPLE_REREAD_VOTE
+        if (k == 0 || __builtin_amdgcn_ballot_w64(reread) != 0)
+#endif
+        {
+            if (reread) {                                         // (divergent branch: skipped by the wave when no lane takes it)
 #pragma unroll
                 for (int j = 0; j < 5; j++) {
                     win[(j + k) % 6][0] = t[j * (kFastPitch / 2) + 0];
@@ -403,15 +494,17 @@ __device__ __forceinline__ void pixels_fast_rolling(Rolling<TH> &ro, const TileC
         win[(5 + k) % 6][0] = t[5 * (kFastPitch / 2) + 0];
         win[(5 + k) % 6][1] = t[5 * (kFastPitch / 2) + 1];
         win[(5 + k) % 6][2] = t[5 * (kFastPitch / 2) + 2];
-        const Weights &w = cur.w;
-        const float wy[6] = {w.wy01.x, w.wy01.y, w.wy23.x, w.wy23.y, w.wy45.x, w.wy45.y};
+#if APGPU_RESAMPLE_ONE_LDS_WAIT
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): one wait for the window instead of one per read
+#endif
+        const float wy[6] = {wyr.wy01.x, wyr.wy01.y, wyr.wy23.x, wyr.wy23.y, wyr.wy45.x, wyr.wy45.y};
         v2f V = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const v2f(&row)[3] = win[(j + k) % 6];
-            v2f acc = w.wx01 * row[0];
-            acc = __builtin_elementwise_fma(w.wx23, row[1], acc);
-            acc = __builtin_elementwise_fma(w.wx45, row[2], acc);
+            v2f acc = cur.wx01 * row[0];
+            acc = __builtin_elementwise_fma(cur.wx23, row[1], acc);
+            acc = __builtin_elementwise_fma(cur.wx45, row[2], acc);
             const v2f wyj = {wy[j], wy[j]};
             V = (j == 0) ? wyj * acc : __builtin_elementwise_fma(wyj, acc, V);
         }
@@ -904,11 +997,22 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12 (rolling fast path: the rows y0 + R ly .. + R - 1)
     const int lx = tid % kTileW, ly = tid / kTileW;
     const int sh = 32 - log2_phases;
-    Rolling<TH> ro;
+    // steady: over a lane's TH / 4 consecutive rows the y phase moves by at most one table row (F4 within 1 / (rows x phases) of
+    // an integer: rotations up to ~0.9 degrees at unit scale, scale errors up to 1e-4) - the lane keeps its y weights; otherwise
+    // both table rows are fetched per pixel, in the trip that uses them (fetching them ahead as well would put this path at 94
+    // VGPRs and the whole kernel at five wavefronts per SIMD instead of six; it bought 2 % when it was measured)
+    Rolling<TH, APGPU_RESAMPLE_AHEAD> ro;
+    bool steady = false;
     if constexpr (kRolling) {
+        const unsigned fr4 = (unsigned)tc.F[4];
+        const unsigned dist = fr4 < 0x80000000u ? fr4 : 0u - fr4;
+#if APGPU_RESAMPLE_KEEP_WY
+        steady = (unsigned long long)dist * (TH / 4) <= (1ull << sh);
+#endif
         if (fast) {                                            // the first pixels' table rows are on their way during the fill
             const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
-            rolling_begin<TH>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
+            if (steady) rolling_begin<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
+            else rolling_begin<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
         }
     }
     __syncthreads();
@@ -923,7 +1027,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const v4i wrsrc = make_rsrc(wout + t0, 0xffffffffu);            // (not used when wout is NULL)
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
         if constexpr (kRolling) {
-            pixels_fast_rolling<TH>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
+            if (steady) pixels_fast_rolling<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
+            else pixels_fast_rolling<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
         } else {
             const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
             pixels_fast<OVERSAMPLED, TH, 1>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);

@@ -17,6 +17,7 @@ def main():
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--rot', type=float, default=0.2, help='rotations drawn from +-rot degrees')
     ap.add_argument('--os', type=int, default=1)
+    ap.add_argument('--scale', type=float, default=1.0, help='input pixels per output pixel')
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--two-step', action='store_true')
     ap.add_argument('--weight', action='store_true')
@@ -26,7 +27,8 @@ def main():
     frames = torch.rand((N, H, H), device='cuda', generator=g) * 1000.0
     rng = np.random.default_rng(5)
     th = np.deg2rad(rng.uniform(-a.rot, a.rot, N))
-    A = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, N), np.sin(th), np.cos(th), rng.uniform(-3, 3, N)], 1)
+    sc = a.scale
+    A = np.stack([sc * np.cos(th), -sc * np.sin(th), rng.uniform(-3, 3, N), sc * np.sin(th), sc * np.cos(th), rng.uniform(-3, 3, N)], 1)
     if a.os > 1:
         fn = (ops.resample_oversampled_two_step if a.two_step else ops.resample_oversampled)
         call = lambda: fn(frames, A, a.os)
