@@ -350,7 +350,12 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 // consecutive output rows differ in Y by F4 = cos(rotation) x scale, i.e. by an integer plus a few millionths: the y PHASE of the
 // next row is the same one (it moves by one table row every ~100 output rows at 0.2 degrees), so the lane keeps its y weights and
 // reloads them only when its phase changed - behind a wave vote, with its own full wait inside the rare block so that the
-// compiler's wait counters at the join stay those of the prefetched x rows.  Two gathers per pixel instead of four.
+// compiler's wait counters at the join stay those of the prefetched x rows.  Two gathers per pixel instead of four: 3.80 -> 3.41 ms.
+// Measured beside it and dropped (same file): (a) the reload issued two pixels ahead into per-stage copies of the y rows, so that
+// nothing waits - 3.50 against 3.41 ms at 0.2 degrees, 3.83 against 3.89 at scale 1.0001 (a gather with a tenth of its lanes
+// active costs what a full one costs), 92 VGPRs; (b) the x row through the scalar unit when a wavefront's 64 columns share one x
+// phase (s_buffer_load + six moves) - 3.50 against 3.40 ms, and 3.42 against 3.20 for pure translations: a gather whose lanes all
+// read ONE address is already cheap, the scalar load only adds its wait.
 #ifndef APGPU_RESAMPLE_KEEP_WY
 #define APGPU_RESAMPLE_KEEP_WY 1
 #endif
@@ -388,12 +393,14 @@ __device__ __forceinline__ RollPrep prep_roll(unsigned long long Xr, unsigned lo
     py &= APGPU_EXP_PHASE_MASK;
 #endif
     RollPrep p;
-    const int ox = (int)__umul24((unsigned)px, 24u);
-    const v4f a = apgpu_buffer_load_v4f32(lut, ox, 0, 0);
-    const v2f b = apgpu_buffer_load_v2f32(lut, ox + 16, 0, 0);
-    p.wx01 = v2f{a.x, a.y};
-    p.wx23 = v2f{a.z, a.w};
-    p.wx45 = b;
+    {
+        const int ox = (int)__umul24((unsigned)px, 24u);
+        const v4f a = apgpu_buffer_load_v4f32(lut, ox, 0, 0);
+        const v2f b = apgpu_buffer_load_v2f32(lut, ox + 16, 0, 0);
+        p.wx01 = v2f{a.x, a.y};
+        p.wx23 = v2f{a.z, a.w};
+        p.wx45 = b;
+    }
     if constexpr (!KEEP) p.y = load_rows_y(lut, py);
     p.py = py;
     const unsigned sx = (unsigned)js, r = (unsigned)jr;
@@ -426,7 +433,7 @@ __device__ __forceinline__ void rolling_begin(Rolling<TH, AS> &ro, const TileCtx
 #pragma unroll
     for (int k = 0; k < Rolling<TH, AHEAD>::kAhead; k++) {
         ro.nxt[k] = prep_roll<FastGeom<TH>::kOffB, KEEP>(ro.X, ro.Y, sh, lut);
-        if (KEEP && k == 0) {                                  // the first pixel's y rows travel with its x rows, during the fill
+        if (KEEP && k == 0) {   // the first pixel's y rows travel with its x rows, during the fill
             ro.wy = load_rows_y(lut, ro.nxt[0].py);
             ro.py = ro.nxt[0].py;
         }
