@@ -336,7 +336,7 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 // wavefront - with 72 registers in use and the LDS holding the kernel at five wavefronts per SIMD, the 12 registers per pixel in
 // flight are free.  The first kAhead pixels are prepared BEFORE the footprint's barrier (their loads overlap the fill's).
 #ifndef APGPU_RESAMPLE_AHEAD
-#define APGPU_RESAMPLE_AHEAD 2
+#define APGPU_RESAMPLE_AHEAD 1
 #endif
 #ifndef APGPU_RESAMPLE_ONE_LDS_WAIT
 #define APGPU_RESAMPLE_ONE_LDS_WAIT 0
@@ -345,17 +345,22 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 #define APGPU_RESAMPLE_REREAD_VOTE 0
 #endif
 // Round 5, second step - the table rows are what the kernel waits for: with every lane reading row 0 (wrong weights, timing only)
-// the same launch takes 2.92 instead of 3.75 ms, with 16 distinct rows the full 3.75 (profiles/r05_c5/ab_resample.txt) - a
-// divergent buffer load is paid per lane, however few cache lines it touches, and there were four of them per pixel.  A lane's
-// consecutive output rows differ in Y by F4 = cos(rotation) x scale, i.e. by an integer plus a few millionths: the y PHASE of the
-// next row is the same one (it moves by one table row every ~100 output rows at 0.2 degrees), so the lane keeps its y weights and
-// reloads them only when its phase changed - behind a wave vote, with its own full wait inside the rare block so that the
-// compiler's wait counters at the join stay those of the prefetched x rows.  Two gathers per pixel instead of four: 3.80 -> 3.41 ms.
-// Measured beside it and dropped (same file): (a) the reload issued two pixels ahead into per-stage copies of the y rows, so that
-// nothing waits - 3.50 against 3.41 ms at 0.2 degrees, 3.83 against 3.89 at scale 1.0001 (a gather with a tenth of its lanes
-// active costs what a full one costs), 92 VGPRs; (b) the x row through the scalar unit when a wavefront's 64 columns share one x
-// phase (s_buffer_load + six moves) - 3.50 against 3.40 ms, and 3.42 against 3.20 for pure translations: a gather whose lanes all
-// read ONE address is already cheap, the scalar load only adds its wait.
+// the same launch takes 2.92 instead of 3.75 ms, with 16 distinct rows the full 3.75, and without the second (8-byte) load of
+// each row nothing changes (profiles/r05_c5/ab_resample.txt): a gather is paid per distinct row its lanes address, and the y rows
+// of a wavefront's 64 columns are 64 different ones (the y phase moves by sin(rotation) x phases per column), fetched for
+// every pixel.  But a lane's CONSECUTIVE output rows differ in Y by F4 = cos(rotation) x scale - an integer plus a few millionths:
+// on a "steady" tile (the phase drifts by less than one table row over the lane's R rows; rotations up to ~0.9 degrees at unit
+// scale, scale errors up to ~1.4e-4) the y phase is monotonic and takes the value of the lane's first row, then that of its last.
+// Both rows are fetched once per tile, during the footprint fill, and a pixel picks one (six selects): 2 y gathers per tile instead
+// of 8.  Where the fraction wraps, a third value can appear (.. 1023, 1024 | 0, 1 ..: rows 1024 and 0 are half a phase wide): that
+// lane fetches on the spot, behind a wave vote.  3.80 -> 3.45 ms at +-0.2 degrees, and the same 3.5 ms at 0.1 / 0.6 degrees and at
+// scale 1.0001.
+// Measured beside it and dropped (same file): (a) ONE kept row per lane, re-fetched behind a vote when the phase moves on, with
+// its own full wait: 3.41 / 3.28 ms at 0.2 / 0.1 degrees but 3.73 at 0.6 and 3.9 at scale 1.0001 - some lane of the 64 moves
+// on in 40 % of the steps at 0.2 degrees and in all of them at scale 1.0001; (b) that re-fetch issued two pixels ahead into
+// per-stage copies, nothing waits: 3.50 / 3.83 ms, 92 VGPRs (a gather with a tenth of its lanes active costs what a full one
+// costs); (c) the x row through the scalar unit when a wavefront's 64 columns share one x phase (s_buffer_load + six moves):
+// 3.50 against 3.40 ms, 3.42 against 3.20 for pure translations - a gather whose lanes all read ONE address is already cheap.
 #ifndef APGPU_RESAMPLE_KEEP_WY
 #define APGPU_RESAMPLE_KEEP_WY 1
 #endif
@@ -414,8 +419,8 @@ struct Rolling {
     static constexpr int kAhead = AHEAD < R ? AHEAD : R - 1;
     unsigned long long X, Y;                                 // coordinates of the next pixel to prepare
     RollPrep nxt[kAhead > 0 ? kAhead : 1];
-    RowsY wy;                                                // the y weights in use, and their phase
-    int py;
+    RowsY wyA, wyB;                                          // KEEP: the y rows of the lane's first and last output row, and their phases
+    int pyA, pyB;
 };
 
 template <int TH, bool KEEP, int AHEAD, int AS, typename LutT>          // AHEAD <= AS: pixels prepared ahead / slots in the state
@@ -429,14 +434,24 @@ __device__ __forceinline__ void rolling_begin(Rolling<TH, AS> &ro, const TileCtx
     const unsigned long long ul = (unsigned long long)(unsigned)lx, vl = (unsigned long long)(unsigned)(ly * R);
     ro.X = Xs + F0 * ul + F1 * vl;
     ro.Y = Ys + F3 * ul + F4 * vl;
-    ro.py = -1;
+    if constexpr (KEEP) {
+        // steady tiles: the y phase moves by less than one table row over the lane's R rows, and monotonically - it takes at most
+        // TWO values, those of the first and of the last row.  Both rows are fetched here, during the fill; a pixel picks one.
+        int js, jr, px, py;
+        phases(ro.X, ro.Y, sh, js, jr, px, py);
+        ro.pyA = py;
+        phases(ro.X + F1 * (unsigned long long)(R - 1), ro.Y + F4 * (unsigned long long)(R - 1), sh, js, jr, px, py);
+        ro.pyB = py;
+#ifdef APGPU_EXP_PHASE_MASK
+        ro.pyA &= APGPU_EXP_PHASE_MASK;
+        ro.pyB &= APGPU_EXP_PHASE_MASK;
+#endif
+        ro.wyA = load_rows_y(lut, ro.pyA);
+        ro.wyB = load_rows_y(lut, ro.pyB);
+    }
 #pragma unroll
     for (int k = 0; k < Rolling<TH, AHEAD>::kAhead; k++) {
         ro.nxt[k] = prep_roll<FastGeom<TH>::kOffB, KEEP>(ro.X, ro.Y, sh, lut);
-        if (KEEP && k == 0) {   // the first pixel's y rows travel with its x rows, during the fill
-            ro.wy = load_rows_y(lut, ro.nxt[0].py);
-            ro.py = ro.nxt[0].py;
-        }
         ro.X += F1;
         ro.Y += F4;
     }
@@ -470,15 +485,18 @@ __device__ __forceinline__ void pixels_fast_rolling(Rolling<TH, AS> &ro, const T
         }
         RowsY wyr;
         if constexpr (KEEP) {
-            const bool changed = cur.py != ro.py;
-            if (__builtin_amdgcn_ballot_w64(changed) != 0) {   // rare: some lane's y phase moved on (or kAhead = 0: the first pixel)
-                if (changed) {
-                    ro.wy = load_rows_y(lut, cur.py);
-                    ro.py = cur.py;
-                }
-                __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0), here, so that the join keeps the counters of the prefetched x rows
+            const bool isA = cur.py == ro.pyA;
+            wyr.wy01 = isA ? ro.wyA.wy01 : ro.wyB.wy01;
+            wyr.wy23 = isA ? ro.wyA.wy23 : ro.wyB.wy23;
+            wyr.wy45 = isA ? ro.wyA.wy45 : ro.wyB.wy45;
+            // a third value is possible only where the fraction wraps (.. 1023, 1024 | 0, 1 ..: rows 1024 and 0 are half a phase
+            // wide each): such a lane fetches its rows on the spot, with its own full wait inside the rare block so that the
+            // compiler's wait counters at the join stay those of the prefetched x rows
+            const bool other = !isA && cur.py != ro.pyB;
+            if (__builtin_amdgcn_ballot_w64(other) != 0) {
+                if (other) wyr = load_rows_y(lut, cur.py);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
             }
-            wyr = ro.wy;
         } else {
             wyr = cur.y;
         }
@@ -933,7 +951,7 @@ __device__ __forceinline__ void general_fill(const TileCtx &tc, const FrameView 
 // for 524,288 workgroups is not on the critical path - it runs ahead of the workgroups - and its dynamic assignment balances
 // the slow edge tiles, which a static walk cannot; the loop also cost 20 - 40 spilled SGPRs.  profiles/r05_c5/ab_resample.txt.)
 template <bool HAS_MASK, bool OVERSAMPLED, int TH>
-__global__ __launch_bounds__(256) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
                                                              const float *__restrict__ lut,
                                                              int log2_phases, int os, float *__restrict__ out, uint8_t *__restrict__ wout,
@@ -1004,8 +1022,8 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
     // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12 (rolling fast path: the rows y0 + R ly .. + R - 1)
     const int lx = tid % kTileW, ly = tid / kTileW;
     const int sh = 32 - log2_phases;
-    // steady: over a lane's TH / 4 consecutive rows the y phase moves by at most one table row (F4 within 1 / (rows x phases) of
-    // an integer: rotations up to ~0.9 degrees at unit scale, scale errors up to 1e-4) - the lane keeps its y weights; otherwise
+    // steady: over a lane's TH / 4 consecutive rows the y phase moves by less than one table row (F4 within 1 / (rows x phases) of
+    // an integer: rotations up to ~0.9 degrees at unit scale, scale errors up to 1.4e-4) - the lane keeps two y rows; otherwise
     // both table rows are fetched per pixel, in the trip that uses them (fetching them ahead as well would put this path at 94
     // VGPRs and the whole kernel at five wavefronts per SIMD instead of six; it bought 2 % when it was measured)
     Rolling<TH, APGPU_RESAMPLE_AHEAD> ro;
@@ -1014,7 +1032,7 @@ __global__ __launch_bounds__(256) void resample_affine_kernel(const float *__res
         const unsigned fr4 = (unsigned)tc.F[4];
         const unsigned dist = fr4 < 0x80000000u ? fr4 : 0u - fr4;
 #if APGPU_RESAMPLE_KEEP_WY
-        steady = (unsigned long long)dist * (TH / 4) <= (1ull << sh);
+        steady = (unsigned long long)dist * (TH / 4 - 1) < (1ull << sh);
 #endif
         if (fast) {                                            // the first pixels' table rows are on their way during the fill
             const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
