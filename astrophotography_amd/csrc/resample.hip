@@ -212,10 +212,6 @@ __device__ __forceinline__ FastPrep prep_fast(unsigned long long Xr, unsigned lo
 {
     int js, jr, px, py;
     phases(Xr, Yr, sh, js, jr, px, py);
-#ifdef APGPU_EXP_PHASE_MASK                                  /* timing experiment only (wrong weights): how much the table gathers cost */
-    px &= APGPU_EXP_PHASE_MASK;
-    py &= APGPU_EXP_PHASE_MASK;
-#endif
     FastPrep p;
     p.w = load_weights(lut, px, py);
     const unsigned s = (unsigned)js, r = (unsigned)jr;
@@ -393,10 +389,6 @@ __device__ __forceinline__ RollPrep prep_roll(unsigned long long Xr, unsigned lo
 {
     int js, jr, px, py;
     phases(Xr, Yr, sh, js, jr, px, py);
-#ifdef APGPU_EXP_PHASE_MASK
-    px &= APGPU_EXP_PHASE_MASK;
-    py &= APGPU_EXP_PHASE_MASK;
-#endif
     RollPrep p;
     {
         const int ox = (int)__umul24((unsigned)px, 24u);
@@ -442,10 +434,6 @@ __device__ __forceinline__ void rolling_begin(Rolling<TH, AS> &ro, const TileCtx
         ro.pyA = py;
         phases(ro.X + F1 * (unsigned long long)(R - 1), ro.Y + F4 * (unsigned long long)(R - 1), sh, js, jr, px, py);
         ro.pyB = py;
-#ifdef APGPU_EXP_PHASE_MASK
-        ro.pyA &= APGPU_EXP_PHASE_MASK;
-        ro.pyB &= APGPU_EXP_PHASE_MASK;
-#endif
         ro.wyA = load_rows_y(lut, ro.pyA);
         ro.wyB = load_rows_y(lut, ro.pyB);
     }
