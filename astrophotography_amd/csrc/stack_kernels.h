@@ -102,6 +102,10 @@ __device__ __forceinline__ StackParams read_params(LateParams *kp)
     return q;
 }
 
+#ifndef APGPU_REDO_RELAXED
+#define APGPU_REDO_RELAXED 1
+#endif
+
 // A coherent read of a counter other workgroups bump with atomics (agent scope: past the non-coherent vector / scalar caches).
 __device__ __forceinline__ int ws_load(const int32_t *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -242,16 +246,33 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
             unsigned long long *const stats = reinterpret_cast<unsigned long long *>(ws + kWsStats);
             if (nblocks_done && (lane & 63) == 0) {
                 atomicAdd(stats + 3, (unsigned long long)nblocks_done);
-                atomicAdd(ws + kWsCall + 2, nblocks_done);
+                int got = atomicAdd(ws + kWsCall + 2, nblocks_done);
+                asm volatile("" : "+v"(got));                    // performed before the barrier below
             }
             if (flagged) __syncthreads();
             if (lane == 0) {
                 const int per_seg = (int)(gridDim.x / kRedoSegs);
+#if APGPU_REDO_RELAXED
+                // Relaxed atomics, ordered by their RETURN VALUES where order matters (an atomic whose result has arrived has been
+                // performed at the memory side): a release / acquire pair here is an L2 write-back + invalidate per workgroup on this
+                // chip - 768 of them per call for counters that only other atomics and the next kernel ever read.  What has to hold:
+                // a workgroup has READ its segment's counters and flags before it reports in (it has used their values), every
+                // wavefront's block totals are performed before the workgroup reports in (the barrier above waits for them), and a
+                // segment's totals are performed before the segment counts itself as done (`sync` below).
+                const int arrived = atomicAdd(ws + seg * kWsLine + 2, 1);
+                int sync = 1;
+#else
                 const int arrived = __hip_atomic_fetch_add(ws + seg * kWsLine + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 if (arrived == per_seg - 1) {
                     if (nitems) {
                         atomicAdd(stats + 2, (unsigned long long)nitems);
+#if APGPU_REDO_RELAXED
+                        int got = atomicAdd(ws + kWsCall + 1, nitems);
+                        asm volatile("" : "+v"(sync), "+v"(got));   // `sync` exists only after the total has been performed
+#else
                         atomicAdd(ws + kWsCall + 1, nitems);
+#endif
                     }
                     if (flagged) {
                         const int64_t ntiles = (kp->P + 255) / 256;
@@ -263,7 +284,11 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
                     ws[seg * kWsLine + 3] = 0;
                     ws[seg * kWsLine + 4] = 0;
                     ws[seg * kWsLine + 5] = 0;
+#if APGPU_REDO_RELAXED
+                    const int segs_done = atomicAdd(ws + kWsCall, sync);
+#else
                     const int segs_done = __hip_atomic_fetch_add(ws + kWsCall, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                     if (segs_done == kRedoSegs - 1) {        // the call is complete: totals -> statistics, and the next call's mode
                         const long long listed = ws_load(ws + kWsCall + 1), blocks = ws_load(ws + kWsCall + 2);
                         atomicAdd(stats + 0, 1ull);
