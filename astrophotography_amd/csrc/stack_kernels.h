@@ -67,7 +67,7 @@ using namespace apgpu;
 //   [4112, 4128)              the call line: [0] segments the redo pass has finished, [1] pixels listed by this call, [2] blocks
 //                             given up by this call, [3] the MODE the next call's fast kernel starts in (0 = alert: every
 //                             wavefront checks its segment's counter before it loads anything; 1 = quiet: the previous call on
-//                             this workspace listed under 1 % of its pixels and gave nothing up, no check - fast_block_bails)
+//                             this workspace sent under an eighth of its pixels to the redo pass, no check - fast_block_bails)
 //   [4128, list_off)          one int32 flag per 64-pixel block (four per 256-pixel tile): the fast kernel's wavefront gave the
 //                             block up, the redo pass does it whole
 //   [list_off, ...)           256 segments of redo_seg_capacity(P) pixel indices (segment = workgroup % 256)
@@ -102,6 +102,9 @@ __device__ __forceinline__ StackParams read_params(LateParams *kp)
     return q;
 }
 
+#ifndef APGPU_QUIET_DEN
+#define APGPU_QUIET_DEN 8
+#endif
 #ifndef APGPU_REDO_RELAXED
 #define APGPU_REDO_RELAXED 1
 #endif
@@ -293,7 +296,11 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
                         const long long listed = ws_load(ws + kWsCall + 1), blocks = ws_load(ws + kWsCall + 2);
                         atomicAdd(stats + 0, 1ull);
                         atomicAdd(stats + 1, (unsigned long long)kp->P);
-                        ws[kWsCall + 3] = (blocks == 0 && listed * 100 < kp->P) ? kModeQuiet : kModeAlert;
+                        // quiet: under an eighth of the pixels went to the redo pass, listed or in blocks given up - below that the
+                        // list route costs within 2 % of the complete kernel (profiles/r05/redo_sweep.txt) and the guard has nothing
+                        // to save, while its look costs every wavefront of a short kernel a memory round trip (C5's 16-frame stacks
+                        // list 6 % of their pixels, the NaN blocks around bad pixels, in every call)
+                        ws[kWsCall + 3] = ((blocks * 64 + listed) * APGPU_QUIET_DEN < kp->P) ? kModeQuiet : kModeAlert;
                         ws[kWsCall] = 0;
                         ws[kWsCall + 1] = 0;
                         ws[kWsCall + 2] = 0;
@@ -365,7 +372,7 @@ __device__ __forceinline__ void redo_push(bool fail, int64_t p, bool alert)
 // The look costs one coherent 8-byte load and its round trip to L2 BEFORE the wavefront's frame loads can be issued: measured
 // on the benchmark, +1.5 % (profiles/r05/ab_bail.txt) - for a guard that data like the benchmark's never needs.  Hence the MODE
 // word (workspace layout above): the redo pass of every call leaves behind whether the NEXT call on this workspace may skip
-// the look (quiet: under 1 % listed, nothing given up) or must take it (alert; also the state of a fresh, zeroed workspace
+// the look (quiet: under an eighth of the pixels redone) or must take it (alert; also the state of a fresh, zeroed workspace
 // and of the temporary a call without workspace makes).  The word is read with a scalar load - written by an earlier
 // kernel, never during this one - so a quiet call pays nothing (and counts no finished blocks).  The price: the FIRST call
 // after the data turned bad runs unguarded (both kernels in full); from the second on the guard holds.

@@ -190,9 +190,9 @@ typedef struct apgpu_stack_args {
  *     workspace and never reset by the library: calls, pixels, pixels listed, 64-pixel blocks given up (apgpu_stack_ws_stats) -
  *     the caller may copy them out (after the stream has been synchronised) to see which fraction of its data leaves the fast
  *     path: (pixels_listed + 64 * blocks_given_up) / pixels;
- *   - the workspace also remembers, from one call to the next, whether the guard is needed: a call whose data listed under 1 %
- *     of its pixels and gave nothing up lets the next call on the same workspace skip the fast kernel's look at the counters
- *     (it costs 1.5 % of the benchmark); the first call after the data has turned bad therefore runs unguarded - both
+ *   - the workspace also remembers, from one call to the next, whether the guard is needed: a call that sent under an eighth
+ *     of its pixels to the redo pass (listed, or in blocks given up) lets the next call on the same workspace skip the fast
+ *     kernel's look at the counters (it costs 1.5 % of the benchmark, 6 % of a 16-frame stack); the first call after the data has turned bad therefore runs unguarded - both
  *     kernels in full, about twice the complete kernel's time in the worst case - and sets the guard for the calls after it.
  * workspace == NULL: the call allocates and frees a stream-ordered temporary of the same size itself (hipMallocAsync /
  * hipMemsetAsync / hipFreeAsync on `stream` - three more runtime calls per stack; the only place where the library
