@@ -454,3 +454,54 @@ def test_coadd_files_oversampled_weighted_wcs(tmp_path, ops):
         wgt = np.clip(co[sel] - bg, 0, None)
         cx, cy = (wgt * ox[sel]).sum() / wgt.sum(), (wgt * oy[sel]).sum() / wgt.sum()
         assert abs(cx - x0) < 0.1 and abs(cy - y0) < 0.1, (x0, y0, cx, cy)
+
+
+def test_steady_tiles_keep_two_weight_rows_bitexact(ops, apref):
+    """The fast path's steady tiles (round 5): when the y phase drifts by less than one table row over a lane's consecutive output
+    rows, the lane fetches the rows of its first and last output row once and every pixel picks one.  Transforms built to sit on
+    the edges of that: unit scale with rotations of a few hundredths of a degree, scale errors just inside and just outside the
+    steady band (drift of 0.99 / 1.01 table rows over seven steps), drift in both directions, and offsets that put the y
+    fraction across its wrap inside the image - phases .. 1023, 1024 | 0, 1 .., where rows 1024 and 0 are half a phase wide and a
+    lane can meet three values.  Frames with NaN / inf and a mask; 1024 and 4096 phases; one transform per frame (32-row
+    workgroups) and one per 16 x 64 tile.  Bit for bit against the oracle."""
+    rng = np.random.default_rng(77)
+    H, W = 300, 520
+    out_shape = (256, 512)
+    cases = []
+    for n_phases in (1024, 4096):
+        band = 1.0 / (7 * n_phases)                          # scale error at which the drift over seven steps is one table row
+        for eps in (0.0, 3e-5, 0.7 * band, 0.99 * band, 1.01 * band, -0.7 * band, -0.99 * band):
+            for th_deg in (0.0, 0.03, -0.11):
+                th = np.deg2rad(th_deg)
+                s = (1.0 + eps) / max(np.cos(th), 1e-12)     # F4 = s cos(th) = 1 + eps exactly up to rounding
+                # y offset: the fraction of Y crosses 1.0 somewhere inside the output rows (and starts just below it)
+                ty = 2.0 + (1.0 - abs(eps) * rng.uniform(20, 230) - rng.uniform(0, 1e-4))
+                cases.append((n_phases, [s * np.cos(th), -s * np.sin(th), rng.uniform(1, 3), s * np.sin(th), s * np.cos(th), ty]))
+    frames = rng.normal(300, 30, (len(cases), H, W)).astype(np.float32)
+    frames[:, 100, 200] = np.nan
+    frames[:, 17, 300] = np.inf
+    mask = (rng.random((H, W)) < 0.002).astype(np.uint8)
+    for n_phases in (1024, 4096):
+        idx = [i for i, c in enumerate(cases) if c[0] == n_phases]
+        A = np.array([cases[i][1] for i in idx], np.float64)
+        fr = np.ascontiguousarray(frames[idx])
+        ref, wref = apref.resample_affine(fr, A, mask=mask, out_shape=out_shape, n_phases=n_phases)
+        got, wgot = _run(ops, fr, A, mask=mask, out_shape=out_shape, n_phases=n_phases)
+        assert_biteq(got, ref, 'steady / nearly steady tiles, %d phases' % n_phases)
+        assert np.array_equal(wgot, wref)
+    # one transform per 16 x 64 tile (16-row workgroups): the same frames' transforms, perturbed per tile by a few 1e-6
+    gy, gx = (out_shape[0] + 15) // 16, (out_shape[1] + 63) // 64
+    idx = [i for i, c in enumerate(cases) if c[0] == 1024][:6]
+    tiles = np.empty((len(idx), gy, gx, 6), np.float64)
+    for k, i in enumerate(idx):
+        a = np.array(cases[i][1])
+        for ty_ in range(gy):
+            for tx_ in range(gx):
+                p = a.copy()
+                p[[0, 4]] += rng.uniform(-2e-6, 2e-6)
+                tiles[k, ty_, tx_] = p
+    fr = np.ascontiguousarray(frames[idx])
+    ref, wref = apref.resample_affine(fr, tiles, mask=mask, out_shape=out_shape)
+    got, wgot = _run(ops, fr, tiles, mask=mask, out_shape=out_shape)
+    assert_biteq(got, ref, 'steady tiles, one transform per tile')
+    assert np.array_equal(wgot, wref)
