@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
     'stack_inst_f32_calib_h.hip',
     'stack_inst_f32_plain_h.hip',
     'stack_inst_u16_calib_h.hip',

@@ -25,6 +25,8 @@ struct StackParams {
     double *mean64, *std64; // float64 output planes (rich kernels only): ccdproc.combine writes float64 (ap_combine_darks.py:437)
     int single_kernel;      // host side only: never the fast kernel + redo pass pair (APGPU_STACK_SINGLE_KERNEL)
     int fast32;             // 0: float64 clip only; 1: float32 fast path for mean / count / float32 moments; 2: also float64-layout moments
+    int flag_mode;          // rich kernels only (EXTRA): 1 = behind stack_mad_fast_kernel - a wavefront reduces its 64-pixel block only if
+                            // the block's flag in `redo` is set, and clears it (stack_mad.hip)
     int32_t *redo;          // the workspace of the two-kernel scheme (stack_kernels.h, "workspace layout"): segment counters,
                             // tile flags and per-segment lists of the PIXELS the fast kernel could not finish.  NULL in a
                             // plain launch of the complete kernels (stack_sigclip_kernel: non-NULL = redo pass)

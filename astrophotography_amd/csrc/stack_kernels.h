@@ -147,6 +147,13 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
     if constexpr (EXTRA) {
         const int64_t base = (int64_t)blockIdx.x * blockDim.x;
         const int64_t p = base + lane;
+        if constexpr (rich_block<NP>() == 256) {
+            if (prm.flag_mode) {                                 // behind stack_mad_fast_kernel: only the blocks it could not finish
+                int32_t *const fl = prm.redo + kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6);
+                if (*fl == 0) return;
+                if ((lane & 63) == 0) *fl = 0;
+            }
+        }
         if (p >= prm.P) return;
         float v[NP];
         APGPU_MARK("load_calibrate_sort");
@@ -912,6 +919,8 @@ inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool 
 // pool's settings).  Returns kNoRedoList (> 0, nothing launched) when neither can be had: the caller goes on to the
 // complete kernels, which need no list.
 constexpr int kNoRedoList = 1;
+bool mad_fast_eligible(const StackParams &prm, bool calib, int np);                          // stack_mad.hip
+int launch_mad_fast(const StackParams &prm, int np, bool u16, hipStream_t st);
 
 // Workgroups of 256 threads of `Kernel` that fit a CU (2 or 3 for the complete kernels, by their register count): the redo pass
 // launches exactly one residency round of them.  Asked once per kernel.
@@ -1123,6 +1132,20 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
             }
         }
         if (frc != kNoRedoList) return frc;
+    }
+    if constexpr (!CALIB && NP <= 64) {
+        // the ccdproc.combine configuration (one pass of median / mad_std) on full stacks: register-resident fast kernel, then the
+        // rich kernel for the 64-pixel blocks it flagged (stack_mad.hip)
+        if (rich && full && mad_fast_eligible(prm, CALIB, NP)) {
+            const int frc = launch_mad_fast(prm, NP, sizeof(RawT) == 2, st);
+            if (frc == APGPU_OK) {
+                StackParams fl = prm;
+                fl.flag_mode = 1;
+                hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, fl);
+                return check_launch("stack kernel (flagged blocks)");
+            }
+            if (frc != kNoRedoList) return frc;
+        }
     }
     if (median_only) {
         if (full) hipLaunchKernelGGL((stack_median_kernel<NP, RawT, CALIB, true>), g, b, 0, st, plain);

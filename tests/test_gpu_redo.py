@@ -213,3 +213,56 @@ def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
     assert np.array_equal(x['count'].cpu().numpy(), cnt_ref), N
     assert_ulp(x['mean'].cpu().numpy(), mean_ref, 1, '%d frames, exact kernel' % N)
     assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W)
+
+
+@pytest.mark.parametrize('N,dtype', [(8, np.float32), (16, np.uint16), (24, np.float32), (32, np.uint16), (48, np.float32), (64, np.float32),
+                                     (64, np.uint16)])
+def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
+    """A6 on the register-resident fast kernel (stack_mad.hip, round 5): one pass of median / mad_std with 5-sigma bounds on
+    full stacks, float64 mean / std + count, against the oracle's restatement of ccdproc.combine.  Columns built for its edges:
+    plain noise, 1 % outliers, columns with 3 .. 12 outliers on one side (more than the tails of 8 hold), low-noise integer data
+    (ties; more than half of the values equal: MAD = 0), values planted next to the bound, NaN / inf (float32), and a pixel count
+    that leaves a partial last block.  Unsure blocks go to the rich kernel: the results must equal the oracle either way, the
+    workspace's flags must be clear afterwards, and the fast kernel must carry most of the blocks."""
+    rng = np.random.default_rng(700 + N + (1 if dtype == np.uint16 else 0))
+    H, W = 41, 389                                           # 15949 pixels: 62 full tiles + a partial one
+    cube = rng.normal(1000.0, 12.0, (N, H, W))
+    hits = rng.random(cube.shape) < 0.01
+    cube[hits] += rng.uniform(100, 5000, hits.sum())
+    for k in range(3, 13):                                   # columns with k outliers on one side
+        sgn = 1.0 if k % 2 else -0.4
+        cube[:min(k, N - 2), 2, k] += sgn * 2000.0
+    cube[:, 3, :] = np.rint(rng.normal(500.0, 0.6, (N, W)))  # a few distinct integer values: ties, often MAD = 0
+    cube[:, 4, :] = 777.0                                     # constant columns
+    cube[:, 5, :] = np.rint(rng.normal(300.0, 2.0, (N, W)))
+    # a value next to the upper bound: base + 5 * 1.4826 * MAD (+- a few ulp) computed from the column as it stands
+    for x in range(0, W, 3):
+        col = np.sort(cube[1:, 6, x].astype(np.float32).astype(np.float64))
+        base = np.median(col)
+        mad = np.median(np.abs(col - base))
+        cube[0, 6, x] = base + 5 * 1.482602218505602 * mad * (1 + rng.integers(-3, 4) * 2.0 ** -23)
+    if dtype == np.uint16:
+        cube = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
+    else:
+        cube = cube.astype(np.float32)
+        cube[1, 7, 10:40] = np.nan
+        cube[2, 7, 50] = np.inf
+        cube[:, 7, 60] = np.nan
+    ref = apref.combine_ccdproc(cube.astype(np.float32) if dtype == np.uint16 else cube)
+    d = dev(cube, ops)
+    ops.stack_redo_stats(reset=True)
+    r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count', 'mean_f64', 'std_f64'))
+    st = ops.stack_redo_stats()
+    what = '%d frames %s' % (N, np.dtype(dtype).name)
+    assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
+    np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+    assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
+    np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=what)
+    nblocks = (H * W + 63) // 64
+    assert st['calls'] == 1 and st['pixels'] == H * W and 0 < st['blocks_given_up'] < 0.5 * nblocks, (what, st)
+    assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W), what
+    # the same call on the rich kernel alone, and without a workspace: same numbers
+    for kw in (dict(single_kernel=True), dict(workspace=False)):
+        r2 = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean_f64', 'count'), **kw)
+        assert np.array_equal(r2['count'].cpu().numpy(), ref['count']), (what, kw)
+        np.testing.assert_allclose(r2['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
