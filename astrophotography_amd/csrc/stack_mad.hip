@@ -111,21 +111,50 @@ __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams 
         }
         return;
     }
-    // float64 sums of the survivors about m1
-    const double c = (double)m1;
-    double S[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool want_std = q.std64 != nullptr;
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-        double d = (double)v[i] - c;
-        if (i < T) d = (i >= na) ? d : 0.0;
-        if (i >= NP - T) d = (NP - 1 - i >= nb) ? d : 0.0;
-        S[i & 3] += d;
-        if (want_std) Q[i & 3] = fma(d, d, Q[i & 3]);
-    }
-    const double Ss = (S[0] + S[1]) + (S[2] + S[3]), Qs = (Q[0] + Q[1]) + (Q[2] + Q[3]);
     const int n = NP - na - nb;
     const double nn = (double)n;
+    const double c = (double)m1;
+    const bool want_std = q.std64 != nullptr;
+    double Ss = 0.0, Qs = 0.0;                                // sums of (x - m1), (x - m1)^2 over the survivors
+    bool summed = false;
+    if constexpr (sizeof(RawT) == 2) {
+        // uint16 frames: x - m1 is an integer below 2^16 in magnitude - exact in float32, and so are its partial sums (< 2^22);
+        // the squares are summed as integers (v_mad_i32_i24), exact while every survivor lies within 4096 of m1 (64 x 2^24 < 2^31):
+        // the survivors lie within half the bound of the median, so the bound says whether that holds (one wave vote)
+        const float reach = 0.5f * __builtin_fmaxf(tl_hi, th_hi) + (m2 - m1);
+        if (__builtin_amdgcn_ballot_w64(!(reach < 4000.f)) == 0) {
+            float Sf[4] = {0.f, 0.f, 0.f, 0.f};
+            int Qi[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                float d = v[i] - m1;
+                if (i < T) d = (i >= na) ? d : 0.f;
+                if (i >= NP - T) d = (NP - 1 - i >= nb) ? d : 0.f;
+                Sf[i & 3] += d;
+                if (want_std) {
+                    const int di = (int)d;
+                    Qi[i & 3] = __mul24(di, di) + Qi[i & 3];
+                }
+            }
+            Ss = (double)((Sf[0] + Sf[1]) + (Sf[2] + Sf[3]));
+            Qs = (double)((Qi[0] + Qi[1]) + (Qi[2] + Qi[3]));
+            summed = true;
+        }
+    }
+    if (!summed) {
+        // float64 sums about m1 (middle values unconditionally, the tails by select)
+        double S[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            double d = (double)v[i] - c;
+            if (i < T) d = (i >= na) ? d : 0.0;
+            if (i >= NP - T) d = (NP - 1 - i >= nb) ? d : 0.0;
+            S[i & 3] += d;
+            if (want_std) Q[i & 3] = fma(d, d, Q[i & 3]);
+        }
+        Ss = (S[0] + S[1]) + (S[2] + S[3]);
+        Qs = (Q[0] + Q[1]) + (Q[2] + Q[3]);
+    }
     const double mean = c + Ss / nn;
     if (q.mean) q.mean[p] = (float)mean;
     if (q.count) q.count[p] = n;
