@@ -919,8 +919,8 @@ inline bool fast_kernel_eligible(const StackParams &prm, bool median_only, bool 
 // pool's settings).  Returns kNoRedoList (> 0, nothing launched) when neither can be had: the caller goes on to the
 // complete kernels, which need no list.
 constexpr int kNoRedoList = 1;
-bool mad_fast_eligible(const StackParams &prm, bool calib, int np);                          // stack_mad.hip
-int launch_mad_fast(const StackParams &prm, int np, bool u16, hipStream_t st);
+bool mad_fast_eligible(const StackParams &prm, bool calib);                                  // stack_mad.hip
+int launch_mad_fast(const StackParams &prm, bool u16, hipStream_t st);
 
 // Workgroups of 256 threads of `Kernel` that fit a CU (2 or 3 for the complete kernels, by their register count): the redo pass
 // launches exactly one residency round of them.  Asked once per kernel.
@@ -1134,14 +1134,15 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         if (frc != kNoRedoList) return frc;
     }
     if constexpr (!CALIB && NP <= 64) {
-        // the ccdproc.combine configuration (one pass of median / mad_std) on full stacks: register-resident fast kernel, then the
+        // the ccdproc.combine configuration (one pass of median / mad_std): register-resident fast kernel, then the
         // rich kernel for the 64-pixel blocks it flagged (stack_mad.hip)
-        if (rich && full && mad_fast_eligible(prm, CALIB, NP)) {
-            const int frc = launch_mad_fast(prm, NP, sizeof(RawT) == 2, st);
+        if (rich && mad_fast_eligible(prm, CALIB)) {
+            const int frc = launch_mad_fast(prm, sizeof(RawT) == 2, st);
             if (frc == APGPU_OK) {
                 StackParams fl = prm;
                 fl.flag_mode = 1;
-                hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, fl);
+                if (full) hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, true>), g, b, 0, st, fl);
+                else hipLaunchKernelGGL((stack_sigclip_kernel<NP, RawT, CALIB, true, false>), g, b, 0, st, fl);
                 return check_launch("stack kernel (flagged blocks)");
             }
             if (frc != kNoRedoList) return frc;

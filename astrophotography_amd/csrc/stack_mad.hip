@@ -23,11 +23,13 @@
 // of the two-kernel scheme, stack_kernels.h); the rich kernel follows in FLAG MODE - a wavefront whose flag is clear leaves at
 // once, the others reduce their block exactly and clear the flag.  Results are the rich kernel's wherever the two could
 // differ; elsewhere the same survivors by construction and float64 sums of the same values.
-// No guard: a stack whose every block holds an unsure pixel (float32 frames full of NaN) pays both kernels, 1.7 x the rich one;
-// APGPU_STACK_SINGLE_KERNEL (or no workspace) keeps the call on the rich kernel alone.
+// No guard: a stack whose every block holds an unsure pixel pays both kernels - for blocks with a non-finite value this one gives up
+// right after its loads (1.3 x the rich kernel for float32 frames full of NaN), for blocks that use a tail up or sit on a bound only
+// at its end (1.6 x); APGPU_STACK_SINGLE_KERNEL (or no workspace) keeps the call on the rich kernel alone.
 #include "stack_kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <utility>
 
 namespace apgpu_stack {
 
@@ -47,10 +49,13 @@ struct MadParams {
 
 constexpr int kMadTail = 8;
 
+// NP = the number of frames itself (one instantiation per count, 3 .. 64: no padding slots, every index a compile-time fact).
+// Odd counts: the median is the middle element (m1 = m2), its own deviation is the smallest, and the MAD is the lower middle of
+// the other NP - 1 - the same half-cleaner over the column without its vertex, E = twice the maximum of the lower outputs.
 template <int NP, typename RawT>
 __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams q)
 {
-    constexpr int H = NP / 2, T = kMadTail < H ? kMadTail : H;
+    constexpr int H = NP / 2, UP = (NP + 1) / 2, T = kMadTail < H ? kMadTail : H;
     const int lane = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * 256 + lane;
     const bool inside = p < q.P;
@@ -68,18 +73,33 @@ __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams 
 #pragma unroll
         for (int f = 0; f < NP; f++) v[f] = (v[f] == v[f]) ? v[f] : __builtin_inff();      // the network is for NaN-free columns
     }
+    const int wv = lane >> 6;
+    auto give_up = [&]() {                                    // the block goes to the rich kernel whole
+        if ((lane & 63) == 0) {
+            q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + wv] = 1;
+            atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 3, 1ull);
+        }
+    };
+    if (blockIdx.x == 0 && lane == 0) {                       // the call's share of the workspace's cumulative statistics
+        atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 0, 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 1, (unsigned long long)q.P);
+    }
+    if (__builtin_amdgcn_ballot_w64(unsure) != 0) {           // a non-finite value (or the image's partial last block): before the sort,
+        give_up();                                            // so that frames full of NaN cost this kernel its loads only
+        return;
+    }
     sort_column<NP>(v);
-    const float m1 = v[H - 1], m2 = v[H];
+    const float m1 = v[(NP - 1) / 2], m2 = v[NP / 2];
     auto dev2 = [&](float x) { return (x - m1) + (x - m2); };                               // 2 (x - base)
     // the two middle order statistics of |e|: one half-cleaner layer of the bitonic (V-shaped) sequence
     float maxlo = 0.f, minhi = __builtin_inff();
 #pragma unroll
     for (int i = 0; i < H; i++) {
-        const float a = __builtin_fabsf(dev2(v[i])), b = __builtin_fabsf(dev2(v[i + H]));
+        const float a = __builtin_fabsf(dev2(v[i])), b = __builtin_fabsf(dev2(v[i + UP]));
         maxlo = __builtin_fmaxf(maxlo, __builtin_fminf(a, b));
         minhi = __builtin_fminf(minhi, __builtin_fmaxf(a, b));
     }
-    const float E = maxlo + minhi;                                                          // 4 MAD
+    const float E = (NP & 1) ? 2.f * maxlo : maxlo + minhi;                                  // 4 MAD
     const float dmax = __builtin_fmaxf(-dev2(v[0]), dev2(v[NP - 1]));
     unsure = unsure || !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
     const float rho = 0x1p-20f;
@@ -98,17 +118,9 @@ __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams 
         unsure = unsure || !(rejb || keepb);
         nb += rejb ? 1 : 0;
     }
-    unsure = unsure || na == T || nb == T;                    // the tail is used up: the next value is not tested here
-    const int wv = lane >> 6;
-    if (blockIdx.x == 0 && lane == 0) {                       // the call's share of the workspace's cumulative statistics
-        atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 0, 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 1, (unsigned long long)q.P);
-    }
+    if constexpr (T < H) unsure = unsure || na == T || nb == T;   // the tail is used up: the next value is not tested here (T = H: every value is)
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) {
-        if ((lane & 63) == 0) {
-            q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + wv] = 1;
-            atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 3, 1ull);
-        }
+        give_up();
         return;
     }
     const int n = NP - na - nb;
@@ -173,29 +185,29 @@ int launch_mad_np(const MadParams &q, hipStream_t st)
     return check_launch("stack kernel (median / mad_std fast path)");
 }
 
+constexpr int kMadMin = 3, kMadMax = 64;
+
+template <typename RawT, int... I>
+int launch_mad_seq(const MadParams &q, int np, hipStream_t st, std::integer_sequence<int, I...>)
+{
+    int rc = kNoRedoList;
+    (void)((np == kMadMin + I ? (rc = launch_mad_np<kMadMin + I, RawT>(q, st), true) : false) || ...);
+    return rc;
+}
+
 template <typename RawT>
 int launch_mad_t(const MadParams &q, int np, hipStream_t st)
 {
-    switch (np) {
-    case 8: return launch_mad_np<8, RawT>(q, st);
-    case 16: return launch_mad_np<16, RawT>(q, st);
-    case 24: return launch_mad_np<24, RawT>(q, st);
-    case 32: return launch_mad_np<32, RawT>(q, st);
-    case 40: return launch_mad_np<40, RawT>(q, st);
-    case 48: return launch_mad_np<48, RawT>(q, st);
-    case 56: return launch_mad_np<56, RawT>(q, st);
-    case 64: return launch_mad_np<64, RawT>(q, st);
-    default: return kNoRedoList;
-    }
+    return launch_mad_seq<RawT>(q, np, st, std::make_integer_sequence<int, kMadMax - kMadMin + 1>{});
 }
 
 }  // namespace
 
-// Whether a call is the configuration this kernel implements: unfused full stack of 8 .. 64 frames (a multiple of 8), one pass of
-// median / mad_std, outputs among mean / count / float64 mean / float64 std, the caller's workspace for the block flags.
-bool mad_fast_eligible(const StackParams &prm, bool calib, int np)
+// Whether a call is the configuration this kernel implements: unfused stack of 3 .. 64 frames, one pass of median / mad_std,
+// outputs among mean / count / float64 mean / float64 std, the caller's workspace for the block flags.
+bool mad_fast_eligible(const StackParams &prm, bool calib)
 {
-    if (calib || prm.N != np || np > 64 || np < 8 || (np & 7)) return false;
+    if (calib || prm.N < kMadMin || prm.N > kMadMax) return false;
     if (prm.dev != APGPU_DEV_MAD_STD || prm.center != APGPU_CENTER_MEDIAN || prm.maxiters != 1) return false;
     if (prm.pixmask || prm.pedestal || prm.median || prm.std || prm.moments) return false;
     if (!prm.redo || prm.single_kernel || prm.fast32 == 0) return false;
@@ -206,7 +218,7 @@ bool mad_fast_eligible(const StackParams &prm, bool calib, int np)
 
 // Launches the fast kernel (kNoRedoList: not this configuration - nothing launched).  The caller follows with the rich kernel
 // in flag mode.
-int launch_mad_fast(const StackParams &prm, int np, bool u16, hipStream_t st)
+int launch_mad_fast(const StackParams &prm, bool u16, hipStream_t st)
 {
     MadParams q;
     q.frames = prm.frames;
@@ -219,7 +231,7 @@ int launch_mad_fast(const StackParams &prm, int np, bool u16, hipStream_t st)
     q.ws = prm.redo;
     q.cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5);
     q.cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
-    return u16 ? launch_mad_t<uint16_t>(q, np, st) : launch_mad_t<float>(q, np, st);
+    return u16 ? launch_mad_t<uint16_t>(q, prm.N, st) : launch_mad_t<float>(q, prm.N, st);
 }
 
 }  // namespace apgpu_stack

@@ -215,11 +215,11 @@ def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
     assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W)
 
 
-@pytest.mark.parametrize('N,dtype', [(8, np.float32), (16, np.uint16), (24, np.float32), (32, np.uint16), (48, np.float32), (64, np.float32),
-                                     (64, np.uint16)])
+@pytest.mark.parametrize('N,dtype', [(3, np.float32), (4, np.uint16), (5, np.uint16), (10, np.float32), (16, np.uint16), (25, np.float32),
+                                     (32, np.uint16), (33, np.uint16), (47, np.float32), (63, np.uint16), (64, np.float32), (64, np.uint16)])
 def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     """A6 on the register-resident fast kernel (stack_mad.hip, round 5): one pass of median / mad_std with 5-sigma bounds on
-    full stacks, float64 mean / std + count, against the oracle's restatement of ccdproc.combine.  Columns built for its edges:
+    stacks of 3 .. 64 frames (odd and even counts), float64 mean / std + count, against the oracle's restatement of ccdproc.combine.  Columns built for its edges:
     plain noise, 1 % outliers, columns with 3 .. 12 outliers on one side (more than the tails of 8 hold), low-noise integer data
     (ties; more than half of the values equal: MAD = 0), values planted next to the bound, NaN / inf (float32), and a pixel count
     that leaves a partial last block.  Unsure blocks go to the rich kernel: the results must equal the oracle either way, the
@@ -231,7 +231,7 @@ def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     cube[hits] += rng.uniform(100, 5000, hits.sum())
     for k in range(3, 13):                                   # columns with k outliers on one side
         sgn = 1.0 if k % 2 else -0.4
-        cube[:min(k, N - 2), 2, k] += sgn * 2000.0
+        cube[:max(min(k, N - 2), 1), 2, k] += sgn * 2000.0
     cube[:, 3, :] = np.rint(rng.normal(500.0, 0.6, (N, W)))  # a few distinct integer values: ties, often MAD = 0
     cube[:, 4, :] = 777.0                                     # constant columns
     cube[:, 5, :] = np.rint(rng.normal(300.0, 2.0, (N, W)))
@@ -259,7 +259,7 @@ def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
     np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=what)
     nblocks = (H * W + 63) // 64
-    assert st['calls'] == 1 and st['pixels'] == H * W and 0 < st['blocks_given_up'] < 0.5 * nblocks, (what, st)
+    assert st['calls'] == 1 and st['pixels'] == H * W and 0 < st['blocks_given_up'] < (0.5 if N >= 8 else 0.9) * nblocks, (what, st)
     assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W), what
     # the same call on the rich kernel alone, and without a workspace: same numbers
     for kw in (dict(single_kernel=True), dict(workspace=False)):
