@@ -356,7 +356,11 @@ __device__ __forceinline__ void pixels_fast(const TileCtx &tc, const float *tile
 // on in 40 % of the steps at 0.2 degrees and in all of them at scale 1.0001; (b) that re-fetch issued two pixels ahead into
 // per-stage copies, nothing waits: 3.50 / 3.83 ms, 92 VGPRs (a gather with a tenth of its lanes active costs what a full one
 // costs); (c) the x row through the scalar unit when a wavefront's 64 columns share one x phase (s_buffer_load + six moves):
-// 3.50 against 3.40 ms, 3.42 against 3.20 for pure translations - a gather whose lanes all read ONE address is already cheap.
+// 3.50 against 3.40 ms, 3.42 against 3.20 for pure translations - a gather whose lanes all read ONE address is already cheap;
+// (d) the x rows of a steady tile staged in LDS - its range of (cyclic) table rows from the tile's four corners, up to 224 rows =
+// 5.4 KB copied with coalesced loads during the fill, a pixel reading its row with three ds_read_b64: bit-identical, and 4.4 ms
+// (3.9 with room for 96 or 160 rows) against 3.45 - also for tiles that did not stage: the copy's registers and the larger LDS
+// block cost every tile more than the gathers cost the staged ones.
 #ifndef APGPU_RESAMPLE_KEEP_WY
 #define APGPU_RESAMPLE_KEEP_WY 1
 #endif
