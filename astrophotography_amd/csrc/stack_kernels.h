@@ -79,6 +79,10 @@ constexpr int kRedoSegs = 256;
 constexpr int kWsLine = 16;
 constexpr int kWsStats = kRedoSegs * kWsLine;
 constexpr int kWsCall = kWsStats + 16;
+// words of the workspace's call line that belong to the median / mad_std pair (stack_mad.hip): the blocks given up among the sampled
+// tiles of this call (zero between calls), and the mode the next call starts in (0: the fast kernel runs on every tile; 1: the last
+// call gave up more than an eighth of its sampled blocks - the fast kernel runs on every 16th tile only and hands the rest over)
+constexpr int kWsMadCount = 8, kWsMadMode = 10, kMadSample = 16;
 constexpr int kWsFlags = kWsCall + 16;
 constexpr int kModeAlert = 0, kModeQuiet = 1;
 // entries a segment can receive: the pixels of its workgroups (every kRedoSegs-th of the P / 256 tiles; one tile more for
@@ -149,6 +153,15 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
         const int64_t p = base + lane;
         if constexpr (rich_block<NP>() == 256) {
             if (prm.flag_mode) {                                 // behind stack_mad_fast_kernel: only the blocks it could not finish
+                if (blockIdx.x == 0 && lane == 0) {
+                    // the guard of that pair (stack_mad.hip): the fast kernel counted the blocks it gave up among every 16th tile;
+                    // more than an eighth of them -> the next call's fast kernel only samples (mode 1), else it runs in full
+                    const int64_t ntiles = (prm.P + 255) / 256;
+                    const int64_t sampled = 4 * ((ntiles + kMadSample - 1) / kMadSample);
+                    const int given = prm.redo[kWsCall + kWsMadCount];
+                    prm.redo[kWsCall + kWsMadMode] = ((int64_t)given * 8 > sampled) ? 1 : 0;
+                    prm.redo[kWsCall + kWsMadCount] = 0;
+                }
                 int32_t *const fl = prm.redo + kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6);
                 if (*fl == 0) return;
                 if ((lane & 63) == 0) *fl = 0;

@@ -23,9 +23,12 @@
 // of the two-kernel scheme, stack_kernels.h); the rich kernel follows in FLAG MODE - a wavefront whose flag is clear leaves at
 // once, the others reduce their block exactly and clear the flag.  Results are the rich kernel's wherever the two could
 // differ; elsewhere the same survivors by construction and float64 sums of the same values.
-// No guard: a stack whose every block holds an unsure pixel pays both kernels - for blocks with a non-finite value this one gives up
-// right after its loads (1.3 x the rich kernel for float32 frames full of NaN), for blocks that use a tail up or sit on a bound only
-// at its end (1.6 x); APGPU_STACK_SINGLE_KERNEL (or no workspace) keeps the call on the rich kernel alone.
+// The guard: a stack whose every block holds an unsure pixel would pay both kernels (for blocks with a non-finite value this one
+// gives up right after its loads: 1.3 x the rich kernel for float32 frames full of NaN; for blocks that use a tail up only at its
+// end: 1.6 x).  So the rich kernel's first workgroup leaves a mode word behind - the blocks given up among every 16th tile against an
+// eighth of them - and in mode 1 the next call's fast kernel tries only those sampled tiles and hands the others over at once:
+// the steady state on bad data is the rich kernel + a sixteenth of this one, the first call after the data turned bad pays in full.
+// APGPU_STACK_SINGLE_KERNEL (or no workspace) keeps the call on the rich kernel alone.
 #include "stack_kernels.h"
 
 #include <hip/hip_runtime.h>
@@ -60,6 +63,14 @@ __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams 
     const int64_t p = (int64_t)blockIdx.x * 256 + lane;
     const bool inside = p < q.P;
     const int64_t pc = inside ? p : q.P - 1;
+    // the guard: in mode 1 (the previous call on this workspace gave up more than an eighth of its sampled blocks) only every
+    // 16th tile is tried - enough to see the data turn good again - and the others go to the rich kernel at once
+    typedef const int __attribute__((address_space(4))) cint;
+    const bool sampled = (blockIdx.x % kMadSample) == 0;
+    if (!sampled && ((cint *)(uintptr_t)q.ws)[kWsCall + kWsMadMode] != 0) {
+        if ((lane & 63) == 0) q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6)] = 1;
+        return;
+    }
     float v[NP];
     const RawT *src = static_cast<const RawT *>(q.frames) + pc;
 #pragma unroll
@@ -78,11 +89,17 @@ __global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams 
         if ((lane & 63) == 0) {
             q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + wv] = 1;
             atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 3, 1ull);
+            if (sampled) atomicAdd(q.ws + kWsCall + kWsMadCount, 1);
         }
     };
     if (blockIdx.x == 0 && lane == 0) {                       // the call's share of the workspace's cumulative statistics
         atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 0, 1ull);
         atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 1, (unsigned long long)q.P);
+        if (((cint *)(uintptr_t)q.ws)[kWsCall + kWsMadMode] != 0) {      // mode 1: the tiles handed over without a try
+            const int64_t ntiles = (q.P + 255) / 256;
+            atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 3,
+                      (unsigned long long)(4 * (ntiles - (ntiles + kMadSample - 1) / kMadSample)));
+        }
     }
     if (__builtin_amdgcn_ballot_w64(unsure) != 0) {           // a non-finite value (or the image's partial last block): before the sort,
         give_up();                                            // so that frames full of NaN cost this kernel its loads only

@@ -194,6 +194,8 @@ typedef struct apgpu_stack_args {
  *     of its pixels to the redo pass (listed, or in blocks given up) lets the next call on the same workspace skip the fast
  *     kernel's look at the counters (it costs 1.5 % of the benchmark, 6 % of a 16-frame stack); the first call after the data has turned bad therefore runs unguarded - both
  *     kernels in full, about twice the complete kernel's time in the worst case - and sets the guard for the calls after it.
+ *     The ccdproc.combine configuration (one pass of median / mad_std) keeps a mode word of its own in the same line: after a call
+ *     that gave up more than an eighth of its sampled 64-pixel blocks, the next call tries only every 16th tile on the fast kernel.
  * workspace == NULL: the call allocates and frees a stream-ordered temporary of the same size itself (hipMallocAsync /
  * hipMemsetAsync / hipFreeAsync on `stream` - three more runtime calls per stack; the only place where the library
  * allocates); if that fails too, or with APGPU_STACK_SINGLE_KERNEL, the complete kernel reduces the whole stack in one launch. */

@@ -53,7 +53,8 @@ def _zero_prefix_is_zero(ops, ws, P):
     pre = ws.view(torch.int32)[:zero.value // 4].clone()
     o = _lib.STACK_WS_STATS_OFFSET // 4
     pre[o:o + 8] = 0                                         # the statistics are cumulative by design,
-    pre[o + 16 + 3] = 0                                      # and the mode word is the workspace's memory of the last call
+    pre[o + 16 + 3] = 0                                      # and the mode words are the workspace's memory of the last call
+    pre[o + 16 + 10] = 0                                     # (the median / mad_std pair's)
     return int(pre.abs().max().item()) == 0
 
 
@@ -266,3 +267,33 @@ def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
         r2 = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean_f64', 'count'), **kw)
         assert np.array_equal(r2['count'].cpu().numpy(), ref['count']), (what, kw)
         np.testing.assert_allclose(r2['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+
+
+def test_ccdproc_configuration_guard(ops, apref):
+    """The median / mad_std pair's guard: float32 frames with a NaN in every 64-pixel block send every block to the rich kernel; the
+    call after that tries only every 16th tile (mode 1) and hands the rest over untried; clean data bring the fast kernel back
+    one call later.  Results against the oracle in every mode."""
+    rng = np.random.default_rng(801)
+    N, H, W = 32, 128, 512                                   # 256 tiles, 1024 blocks, 16 sampled tiles
+    clean = rng.normal(1000.0, 12.0, (N, H, W)).astype(np.float32)
+    bad = clean.copy()
+    bad[3].reshape(-1)[::61] = np.nan                        # at least one NaN per 64-pixel block
+    nblocks = H * W // 64
+    ref = {id(clean): apref.combine_ccdproc(clean), id(bad): apref.combine_ccdproc(bad)}
+    dc, db = dev(clean, ops), dev(bad, ops)
+
+    def call(d, cube):
+        ops.stack_redo_stats(reset=True)
+        r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('count', 'mean_f64', 'std_f64'))
+        st = ops.stack_redo_stats()
+        assert np.array_equal(r['count'].cpu().numpy(), ref[id(cube)]['count'])
+        np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref[id(cube)]['mean'], rtol=4e-16, atol=0, equal_nan=True)
+        np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref[id(cube)]['std'], rtol=1e-12, atol=1e-12, equal_nan=True)
+        assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W)
+        return st['blocks_given_up']
+
+    assert call(dc, clean) < nblocks // 8                     # mode 0, clean: the fast kernel carries it
+    assert call(db, bad) == nblocks                          # mode 0, bad: every block tried and given up -> mode 1
+    assert call(db, bad) == nblocks                          # mode 1: sampled tiles tried (and given up), the others handed over
+    assert call(dc, clean) >= nblocks - nblocks // 16         # still mode 1 (the decision is the previous call's): mostly handed over
+    assert call(dc, clean) < nblocks // 8                     # the sampled tiles were clean: mode 0 again
