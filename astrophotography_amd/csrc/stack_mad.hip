@@ -56,7 +56,8 @@ constexpr int kMadTail = 8;
 // Odd counts: the median is the middle element (m1 = m2), its own deviation is the smallest, and the MAD is the lower middle of
 // the other NP - 1 - the same half-cleaner over the column without its vertex, E = twice the maximum of the lower outputs.
 template <int NP, typename RawT>
-__global__ __launch_bounds__(256, 3) void stack_mad_fast_kernel(const MadParams q)
+// (uint16 frames: the 64-frame kernel fits the four-wavefront budget without spills; float32 frames need 146 registers)
+__global__ __launch_bounds__(256, sizeof(RawT) == 2 ? 4 : 3) void stack_mad_fast_kernel(const MadParams q)
 {
     constexpr int H = NP / 2, UP = (NP + 1) / 2, T = kMadTail < H ? kMadTail : H;
     const int lane = threadIdx.x;
