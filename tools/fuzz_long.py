@@ -310,11 +310,51 @@ def chunked_case(seed):
     np.testing.assert_allclose(got[ok] ** 2, np.maximum(var[ok], 0), rtol=1e-4, atol=1e-3, err_msg=what)
 
 
+def a6_case(seed):
+    """The ccdproc.combine configuration (one pass of median / mad_std, float64 planes) on its fast kernel + rich kernel pair
+    (stack_mad.hip): 3 .. 64 frames, float32 / uint16, thresholds, noise levels from a few distinct integers (ties, MAD = 0) to
+    wide, outliers on one or both sides, NaN / inf, constant columns, any image size - against the oracle's restatement."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(3, 65))
+    H, W = int(rng.integers(1, 6)), int(rng.integers(1, 400))
+    u16 = bool(rng.integers(0, 2))
+    sig = float(rng.choice([0.3, 1.0, 3.0, 40.0]))
+    cube = rng.normal(float(rng.choice([50.0, 1000.0, 30000.0])), sig, (N, H, W))
+    if rng.integers(0, 2):
+        cube = np.rint(cube)
+    frac = float(rng.choice([0.0, 0.01, 0.1, 0.3]))
+    hits = rng.random(cube.shape) < frac
+    cube[hits] += rng.uniform(-1, 1, hits.sum()) * float(rng.choice([5.0, 100.0, 5000.0])) * sig
+    if W > 3:
+        cube[:, :, 0] = cube[0, 0, 0]
+        k = int(rng.integers(1, N))
+        cube[:k, :, 1] += 50 * sig
+    lo, hi = float(rng.choice([1.0, 3.0, 5.0])), float(rng.choice([2.0, 5.0]))
+    if u16:
+        cube = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
+        ref = apref.combine_ccdproc(cube.astype(np.float32), lo, hi)
+    else:
+        cube = cube.astype(np.float32)
+        bad = rng.random(cube.shape) < float(rng.choice([0.0, 0.0, 0.002, 0.05]))
+        cube[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), bad.sum())
+        with np.errstate(all='ignore'):
+            ref = apref.combine_ccdproc(cube, lo, hi)
+    what = f'a6 seed={seed} N={N} {H}x{W} u16={u16} lo={lo} hi={hi}'
+    r = ops.stack_sigclip(dev(cube), sigma_lower=lo, sigma_upper=hi, maxiters=1, cenfunc='median', stdfunc='mad_std',
+                          outputs=('mean', 'count', 'mean_f64', 'std_f64'))
+    assert np.array_equal(r['count'].cpu().numpy(), ref['count']), 'count ' + what
+    # (the oracle sums in frame order: its own rounding is up to n eps max|x|, which is all there is to a mean near zero)
+    fin = np.abs(cube[np.isfinite(cube)].astype(np.float64))
+    scale = float(fin.max()) if fin.size else 1.0
+    np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=1e-14 * scale, equal_nan=True, err_msg=what)
+    np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12 * scale, equal_nan=True, err_msg=what)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=5.0)
     ap.add_argument('--seed0', type=int, default=100000)
-    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith,fits,chunked')
+    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith,fits,chunked,a6')
     a = ap.parse_args()
     t_end = time.time() + 60.0 * a.minutes
     fails, runs = [], {}
@@ -323,7 +363,7 @@ def main():
     while time.time() < t_end:
         for name, fn in (('big', big_case), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
                          ('image', lambda s: tf.test_random_image_kernels(ops, apref, s)), ('global', global_case),
-                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case), ('fits', fits_case), ('chunked', chunked_case)):
+                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case), ('fits', fits_case), ('chunked', chunked_case), ('a6', a6_case)):
             if only and name not in only:
                 continue
             try:
