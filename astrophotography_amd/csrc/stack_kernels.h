@@ -151,7 +151,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
     if constexpr (EXTRA) {
         const int64_t base = (int64_t)blockIdx.x * blockDim.x;
         const int64_t p = base + lane;
-        if constexpr (rich_block<NP>() == 256) {
+        {
             if (prm.flag_mode) {                                 // behind stack_mad_fast_kernel: only the blocks it could not finish
                 if (blockIdx.x == 0 && lane == 0) {
                     // the guard of that pair (stack_mad.hip): the fast kernel counted the blocks it gave up among every 16th tile;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(EXTRA ? rich_block<NP>() : 256, NP <= 64 ? (EXTRA ?
                     prm.redo[kWsCall + kWsMadMode] = ((int64_t)given * 8 > sampled) ? 1 : 0;
                     prm.redo[kWsCall + kWsMadCount] = 0;
                 }
-                int32_t *const fl = prm.redo + kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6);
+                int32_t *const fl = prm.redo + kWsFlags + (base >> 6) + (lane >> 6);      // one flag per 64 pixels, whatever the workgroup's size
                 if (*fl == 0) return;
                 if ((lane & 63) == 0) *fl = 0;
             }
@@ -1146,7 +1146,7 @@ int launch_one(const StackParams &prm, bool median_only, hipStream_t st, char *d
         }
         if (frc != kNoRedoList) return frc;
     }
-    if constexpr (!CALIB && NP <= 64) {
+    if constexpr (!CALIB) {
         // the ccdproc.combine configuration (one pass of median / mad_std): register-resident fast kernel, then the
         // rich kernel for the 64-pixel blocks it flagged (stack_mad.hip)
         if (rich && mad_fast_eligible(prm, CALIB)) {

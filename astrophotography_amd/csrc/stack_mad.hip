@@ -52,18 +52,21 @@ struct MadParams {
 
 constexpr int kMadTail = 8;
 
-// NP = the number of frames itself (one instantiation per count, 3 .. 64: no padding slots, every index a compile-time fact).
+// NP = the number of frames itself (one instantiation per count, 3 .. 128: no padding slots, every index a compile-time fact).
 // Odd counts: the median is the middle element (m1 = m2), its own deviation is the smallest, and the MAD is the lower middle of
 // the other NP - 1 - the same half-cleaner over the column without its vertex, E = twice the maximum of the lower outputs.
 template <int NP, typename RawT>
-// (uint16 frames: the 64-frame kernel fits the four-wavefront budget without spills; float32 frames need 146 registers)
-__global__ __launch_bounds__(256, sizeof(RawT) == 2 ? 4 : 3) void stack_mad_fast_kernel(const MadParams q)
+// (uint16 frames: the 64-frame kernel fits the four-wavefront budget without spills; float32 frames need 146 registers.  65 .. 128
+// frames: two wavefronts per SIMD - 216 registers at 96 frames; at 128 the float32 kernel spills 28, the uint16 one 2 - where the
+// rich kernel, its column in LDS, runs ONE)
+__global__ __launch_bounds__(256, NP > 64 ? 2 : (sizeof(RawT) == 2 ? 4 : 3)) void stack_mad_fast_kernel(const MadParams q)
 {
     constexpr int H = NP / 2, UP = (NP + 1) / 2, T = kMadTail < H ? kMadTail : H;
     const int lane = threadIdx.x;
     const int64_t p = (int64_t)blockIdx.x * 256 + lane;
     const bool inside = p < q.P;
     const int64_t pc = inside ? p : q.P - 1;
+    if ((int64_t)blockIdx.x * 256 + (lane & ~63) >= q.P) return;   // a wavefront wholly behind the image: no block, no flag
     // the guard: in mode 1 (the previous call on this workspace gave up more than an eighth of its sampled blocks) only every
     // 16th tile is tried - enough to see the data turn good again - and the others go to the rich kernel at once
     typedef const int __attribute__((address_space(4))) cint;
@@ -203,7 +206,7 @@ int launch_mad_np(const MadParams &q, hipStream_t st)
     return check_launch("stack kernel (median / mad_std fast path)");
 }
 
-constexpr int kMadMin = 3, kMadMax = 64;
+constexpr int kMadMin = 3, kMadMax = 128;
 
 template <typename RawT, int... I>
 int launch_mad_seq(const MadParams &q, int np, hipStream_t st, std::integer_sequence<int, I...>)
@@ -221,7 +224,7 @@ int launch_mad_t(const MadParams &q, int np, hipStream_t st)
 
 }  // namespace
 
-// Whether a call is the configuration this kernel implements: unfused stack of 3 .. 64 frames, one pass of median / mad_std,
+// Whether a call is the configuration this kernel implements: unfused stack of 3 .. 128 frames, one pass of median / mad_std,
 // outputs among mean / count / float64 mean / float64 std, the caller's workspace for the block flags.
 bool mad_fast_eligible(const StackParams &prm, bool calib)
 {

@@ -217,10 +217,11 @@ def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
 
 
 @pytest.mark.parametrize('N,dtype', [(3, np.float32), (4, np.uint16), (5, np.uint16), (10, np.float32), (16, np.uint16), (25, np.float32),
-                                     (32, np.uint16), (33, np.uint16), (47, np.float32), (63, np.uint16), (64, np.float32), (64, np.uint16)])
+                                     (32, np.uint16), (33, np.uint16), (47, np.float32), (63, np.uint16), (64, np.float32), (64, np.uint16),
+                                     (65, np.float32), (96, np.uint16), (101, np.float32), (127, np.uint16), (128, np.float32), (128, np.uint16)])
 def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     """A6 on the register-resident fast kernel (stack_mad.hip, round 5): one pass of median / mad_std with 5-sigma bounds on
-    stacks of 3 .. 64 frames (odd and even counts), float64 mean / std + count, against the oracle's restatement of ccdproc.combine.  Columns built for its edges:
+    stacks of 3 .. 128 frames (odd and even counts), float64 mean / std + count, against the oracle's restatement of ccdproc.combine.  Columns built for its edges:
     plain noise, 1 % outliers, columns with 3 .. 12 outliers on one side (more than the tails of 8 hold), low-noise integer data
     (ties; more than half of the values equal: MAD = 0), values planted next to the bound, NaN / inf (float32), and a pixel count
     that leaves a partial last block.  Unsure blocks go to the rich kernel: the results must equal the oracle either way, the

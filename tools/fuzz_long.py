@@ -312,10 +312,10 @@ def chunked_case(seed):
 
 def a6_case(seed):
     """The ccdproc.combine configuration (one pass of median / mad_std, float64 planes) on its fast kernel + rich kernel pair
-    (stack_mad.hip): 3 .. 64 frames, float32 / uint16, thresholds, noise levels from a few distinct integers (ties, MAD = 0) to
+    (stack_mad.hip): 3 .. 128 frames, float32 / uint16, thresholds, noise levels from a few distinct integers (ties, MAD = 0) to
     wide, outliers on one or both sides, NaN / inf, constant columns, any image size - against the oracle's restatement."""
     rng = np.random.default_rng(seed)
-    N = int(rng.integers(3, 65))
+    N = int(rng.integers(3, 129))
     H, W = int(rng.integers(1, 6)), int(rng.integers(1, 400))
     u16 = bool(rng.integers(0, 2))
     sig = float(rng.choice([0.3, 1.0, 3.0, 40.0]))
