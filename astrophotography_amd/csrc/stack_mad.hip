@@ -38,8 +38,6 @@ namespace apgpu_stack {
 
 using namespace apgpu;
 
-namespace {
-
 struct MadParams {
     const void *frames;
     int64_t stride, P;
@@ -49,6 +47,8 @@ struct MadParams {
     int32_t *ws;
     float cl, cu;               // thresh x 1.482602218505602 / 2 for the lower / upper bound
 };
+
+namespace {
 
 constexpr int kMadTail = 8;
 
@@ -66,13 +66,12 @@ __global__ __launch_bounds__(256, NP > 64 ? 2 : (sizeof(RawT) == 2 ? 4 : 3)) voi
     const int64_t p = (int64_t)blockIdx.x * 256 + lane;
     const bool inside = p < q.P;
     const int64_t pc = inside ? p : q.P - 1;
-    if ((int64_t)blockIdx.x * 256 + (lane & ~63) >= q.P) return;   // a wavefront wholly behind the image: no block, no flag
     // the guard: in mode 1 (the previous call on this workspace gave up more than an eighth of its sampled blocks) only every
     // 16th tile is tried - enough to see the data turn good again - and the others go to the rich kernel at once
     typedef const int __attribute__((address_space(4))) cint;
     const bool sampled = (blockIdx.x % kMadSample) == 0;
     if (!sampled && ((cint *)(uintptr_t)q.ws)[kWsCall + kWsMadMode] != 0) {
-        if ((lane & 63) == 0) q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6)] = 1;
+        if ((lane & 63) == 0 && inside) q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + (lane >> 6)] = 1;
         return;
     }
     float v[NP];
@@ -90,7 +89,8 @@ __global__ __launch_bounds__(256, NP > 64 ? 2 : (sizeof(RawT) == 2 ? 4 : 3)) voi
     }
     const int wv = lane >> 6;
     auto give_up = [&]() {                                    // the block goes to the rich kernel whole
-        if ((lane & 63) == 0) {
+        if ((lane & 63) == 0 && inside) {                     // (a wavefront wholly behind the image has no block: no flag - an early
+                                                              // return for it at the top cost the float32 kernel 5-10 %)
             q.ws[kWsFlags + 4 * (int64_t)blockIdx.x + wv] = 1;
             atomicAdd(reinterpret_cast<unsigned long long *>(q.ws + kWsStats) + 3, 1ull);
             if (sampled) atomicAdd(q.ws + kWsCall + kWsMadCount, 1);
@@ -206,7 +206,14 @@ int launch_mad_np(const MadParams &q, hipStream_t st)
     return check_launch("stack kernel (median / mad_std fast path)");
 }
 
-constexpr int kMadMin = 3, kMadMax = 128;
+// Two translation units: this file as it stands holds the kernels of 3 .. 64 frames; stack_mad_wide.hip includes it with
+// APGPU_MAD_WIDE for 65 .. 128.  In ONE code object the 126 wider kernels cost the 64-frame float32 kernel 8 % (0.95 -> 1.04 ms,
+// same box, identical instructions: only its place in a 4.7 MB text section differs).
+#ifdef APGPU_MAD_WIDE
+constexpr int kMadMin = 65, kMadMax = 128;
+#else
+constexpr int kMadMin = 3, kMadMax = 64;
+#endif
 
 template <typename RawT, int... I>
 int launch_mad_seq(const MadParams &q, int np, hipStream_t st, std::integer_sequence<int, I...>)
@@ -224,11 +231,19 @@ int launch_mad_t(const MadParams &q, int np, hipStream_t st)
 
 }  // namespace
 
+int launch_mad_wide(const MadParams &q, int np, bool u16, hipStream_t st);       // stack_mad_wide.hip: 65 .. 128 frames
+
+#ifdef APGPU_MAD_WIDE
+int launch_mad_wide(const MadParams &q, int np, bool u16, hipStream_t st)
+{
+    return u16 ? launch_mad_t<uint16_t>(q, np, st) : launch_mad_t<float>(q, np, st);
+}
+#else
 // Whether a call is the configuration this kernel implements: unfused stack of 3 .. 128 frames, one pass of median / mad_std,
 // outputs among mean / count / float64 mean / float64 std, the caller's workspace for the block flags.
 bool mad_fast_eligible(const StackParams &prm, bool calib)
 {
-    if (calib || prm.N < kMadMin || prm.N > kMadMax) return false;
+    if (calib || prm.N < 3 || prm.N > 128) return false;
     if (prm.dev != APGPU_DEV_MAD_STD || prm.center != APGPU_CENTER_MEDIAN || prm.maxiters != 1) return false;
     if (prm.pixmask || prm.pedestal || prm.median || prm.std || prm.moments) return false;
     if (!prm.redo || prm.single_kernel || prm.fast32 == 0) return false;
@@ -252,7 +267,9 @@ int launch_mad_fast(const StackParams &prm, bool u16, hipStream_t st)
     q.ws = prm.redo;
     q.cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5);
     q.cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
+    if (prm.N > 64) return launch_mad_wide(q, prm.N, u16, st);
     return u16 ? launch_mad_t<uint16_t>(q, prm.N, st) : launch_mad_t<float>(q, prm.N, st);
 }
+#endif
 
 }  // namespace apgpu_stack
