@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'stack_mad_pairs.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
     'stack_inst_f32_calib_h.hip',
     'stack_inst_f32_plain_h.hip',
     'stack_inst_u16_calib_h.hip',
@@ -102,7 +102,10 @@ STACK_TU_FLAGS = ['-mllvm', '-disable-machine-licm']
 def _compile(src):
     obj = os.path.join(OBJ, src.replace('.hip', '.o'))
     srcp = os.path.join(CSRC, src)
-    dep_time = max(os.path.getmtime(srcp), _newest(HEADERS + (['stack_mad.hip'] if src == 'stack_mad_wide.hip' else [])))   # (the wide unit includes the narrow one)
+    extra = ['stack_mad.h'] if src.startswith('stack_mad') else []
+    if src == 'stack_mad_wide.hip':
+        extra.append('stack_mad.hip')                        # (the wide unit includes the narrow one)
+    dep_time = max(os.path.getmtime(srcp), _newest(HEADERS + extra))
     if os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
         return obj, False
     cmd = [_hipcc()] + HIPCC_FLAGS + (STACK_TU_FLAGS if src.startswith('stack_inst_') else []) + ['-c', srcp, '-o', obj]

@@ -29,7 +29,7 @@
 // eighth of them - and in mode 1 the next call's fast kernel tries only those sampled tiles and hands the others over at once:
 // the steady state on bad data is the rich kernel + a sixteenth of this one, the first call after the data turned bad pays in full.
 // APGPU_STACK_SINGLE_KERNEL (or no workspace) keeps the call on the rich kernel alone.
-#include "stack_kernels.h"
+#include "stack_mad.h"
 
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -37,16 +37,6 @@
 namespace apgpu_stack {
 
 using namespace apgpu;
-
-struct MadParams {
-    const void *frames;
-    int64_t stride, P;
-    float *mean;
-    int32_t *count;
-    double *mean64, *std64;
-    int32_t *ws;
-    float cl, cu;               // thresh x 1.482602218505602 / 2 for the lower / upper bound
-};
 
 namespace {
 
@@ -231,8 +221,6 @@ int launch_mad_t(const MadParams &q, int np, hipStream_t st)
 
 }  // namespace
 
-int launch_mad_wide(const MadParams &q, int np, bool u16, hipStream_t st);       // stack_mad_wide.hip: 65 .. 128 frames
-
 #ifdef APGPU_MAD_WIDE
 int launch_mad_wide(const MadParams &q, int np, bool u16, hipStream_t st)
 {
@@ -268,6 +256,11 @@ int launch_mad_fast(const StackParams &prm, bool u16, hipStream_t st)
     q.cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5);
     q.cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
     if (prm.N > 64) return launch_mad_wide(q, prm.N, u16, st);
+    // uint16 frames, two pixels per lane on the packed sorting network (stack_mad_pairs.hip): pixel pairs must be whole words
+    if (u16 && (prm.P % 2) == 0 && (prm.stride % 2) == 0 && (reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0 &&
+        (!prm.mean64 || (reinterpret_cast<uintptr_t>(prm.mean64) & 15) == 0) && (!prm.std64 || (reinterpret_cast<uintptr_t>(prm.std64) & 15) == 0) &&
+        (!prm.mean || (reinterpret_cast<uintptr_t>(prm.mean) & 7) == 0) && (!prm.count || (reinterpret_cast<uintptr_t>(prm.count) & 7) == 0))
+        return launch_mad_pairs(q, prm.N, st);
     return u16 ? launch_mad_t<uint16_t>(q, prm.N, st) : launch_mad_t<float>(q, prm.N, st);
 }
 #endif

@@ -227,7 +227,14 @@ def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     that leaves a partial last block.  Unsure blocks go to the rich kernel: the results must equal the oracle either way, the
     workspace's flags must be clear afterwards, and the fast kernel must carry most of the blocks."""
     rng = np.random.default_rng(700 + N + (1 if dtype == np.uint16 else 0))
-    H, W = 41, 389                                           # 15949 pixels: 62 full tiles + a partial one
+    # 15949 pixels: 62 full tiles + a partial one (odd: one pixel per lane); uint16 stacks of up to 64 frames also with an even
+    # pixel count - two pixels per lane on the packed network (stack_mad_pairs.hip), 30 full 512-pixel tiles + a partial one
+    for H, W in ((41, 389),) + (((40, 390),) if dtype == np.uint16 and N <= 64 else ()):
+        _ccdproc_fast_case(ops, apref, N, dtype, H, W)
+
+
+def _ccdproc_fast_case(ops, apref, N, dtype, H, W):
+    rng = np.random.default_rng(700 + N + (1 if dtype == np.uint16 else 0) + W)
     cube = rng.normal(1000.0, 12.0, (N, H, W))
     hits = rng.random(cube.shape) < 0.01
     cube[hits] += rng.uniform(100, 5000, hits.sum())
