@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'stack_mad_pairs.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'stack_mad_pairs.hip', 'stack_mad_pairs_wide.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
     'stack_inst_f32_calib_h.hip',
     'stack_inst_f32_plain_h.hip',
     'stack_inst_u16_calib_h.hip',
@@ -104,7 +104,9 @@ def _compile(src):
     srcp = os.path.join(CSRC, src)
     extra = ['stack_mad.h'] if src.startswith('stack_mad') else []
     if src == 'stack_mad_wide.hip':
-        extra.append('stack_mad.hip')                        # (the wide unit includes the narrow one)
+        extra.append('stack_mad.hip')                        # (the wide units include the narrow ones)
+    if src == 'stack_mad_pairs_wide.hip':
+        extra.append('stack_mad_pairs.hip')
     dep_time = max(os.path.getmtime(srcp), _newest(HEADERS + extra))
     if os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
         return obj, False

@@ -16,6 +16,7 @@ struct MadParams {
 };
 
 int launch_mad_wide(const MadParams &q, int np, bool u16, hipStream_t st);       // stack_mad_wide.hip: 65 .. 128 frames, one pixel per lane
-int launch_mad_pairs(const MadParams &q, int np, hipStream_t st);                // stack_mad_pairs.hip: uint16 frames, 3 .. 64, two pixels per lane
+int launch_mad_pairs(const MadParams &q, int np, hipStream_t st);                // stack_mad_pairs.hip: uint16 frames, two pixels per lane (3 .. 64 itself,
+int launch_mad_pairs_wide(const MadParams &q, int np, hipStream_t st);           // 65 .. 128 in stack_mad_pairs_wide.hip)
 
 }  // namespace apgpu_stack

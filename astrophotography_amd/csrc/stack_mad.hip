@@ -255,12 +255,12 @@ int launch_mad_fast(const StackParams &prm, bool u16, hipStream_t st)
     q.ws = prm.redo;
     q.cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5);
     q.cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
-    if (prm.N > 64) return launch_mad_wide(q, prm.N, u16, st);
     // uint16 frames, two pixels per lane on the packed sorting network (stack_mad_pairs.hip): pixel pairs must be whole words
     if (u16 && (prm.P % 2) == 0 && (prm.stride % 2) == 0 && (reinterpret_cast<uintptr_t>(prm.frames) & 3) == 0 &&
         (!prm.mean64 || (reinterpret_cast<uintptr_t>(prm.mean64) & 15) == 0) && (!prm.std64 || (reinterpret_cast<uintptr_t>(prm.std64) & 15) == 0) &&
         (!prm.mean || (reinterpret_cast<uintptr_t>(prm.mean) & 7) == 0) && (!prm.count || (reinterpret_cast<uintptr_t>(prm.count) & 7) == 0))
         return launch_mad_pairs(q, prm.N, st);
+    if (prm.N > 64) return launch_mad_wide(q, prm.N, u16, st);
     return u16 ? launch_mad_t<uint16_t>(q, prm.N, st) : launch_mad_t<float>(q, prm.N, st);
 }
 #endif

@@ -10,7 +10,7 @@
 // 0 .. 31 of a wavefront hold one 64-pixel block, lanes 32 .. 63 the next; an unsure pixel flags ITS block (the rich kernel redoes it
 // in flag mode), the other half of the wavefront stores its results.  Outputs are written as pairs (16-byte stores of the float64
 // planes).  Same decisions and the same sums as the one-pixel kernel, which serves what this one cannot take: odd pixel counts or
-// strides, unaligned planes, float32 frames, more than 64 frames.
+// strides, unaligned planes, float32 frames.
 #include "stack_mad.h"
 
 #include <hip/hip_runtime.h>
@@ -136,7 +136,7 @@ __device__ __forceinline__ void pair_sums(const uint32_t (&w)[NP], int half, con
 }
 
 template <int NP>
-__global__ __launch_bounds__(256, 3) void stack_mad_pairs_kernel(const MadParams q)
+__global__ __launch_bounds__(256, NP > 64 ? 2 : 3) void stack_mad_pairs_kernel(const MadParams q)
 {
     constexpr int H = NP / 2, UP = (NP + 1) / 2;
     const int lane = threadIdx.x;
@@ -210,7 +210,13 @@ int launch_pairs_np(const MadParams &q, hipStream_t st)
     return check_launch("stack kernel (median / mad_std fast path, uint16 pairs)");
 }
 
+// (two translation units, like stack_mad.hip / stack_mad_wide.hip: stack_mad_pairs_wide.hip includes this file with APGPU_MAD_WIDE
+// for 65 .. 128 frames - w[128] and little else: two wavefronts per SIMD)
+#ifdef APGPU_MAD_WIDE
+constexpr int kPairMin = 65, kPairMax = 128;
+#else
 constexpr int kPairMin = 3, kPairMax = 64;
+#endif
 
 template <int... I>
 int launch_pairs_seq(const MadParams &q, int np, hipStream_t st, std::integer_sequence<int, I...>)
@@ -222,9 +228,17 @@ int launch_pairs_seq(const MadParams &q, int np, hipStream_t st, std::integer_se
 
 }  // namespace
 
-int launch_mad_pairs(const MadParams &q, int np, hipStream_t st)
+#ifdef APGPU_MAD_WIDE
+int launch_mad_pairs_wide(const MadParams &q, int np, hipStream_t st)
 {
     return launch_pairs_seq(q, np, st, std::make_integer_sequence<int, kPairMax - kPairMin + 1>{});
 }
+#else
+int launch_mad_pairs(const MadParams &q, int np, hipStream_t st)
+{
+    if (np > kPairMax) return launch_mad_pairs_wide(q, np, st);
+    return launch_pairs_seq(q, np, st, std::make_integer_sequence<int, kPairMax - kPairMin + 1>{});
+}
+#endif
 
 }  // namespace apgpu_stack

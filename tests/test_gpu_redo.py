@@ -227,9 +227,9 @@ def test_ccdproc_configuration_fast_path(ops, apref, N, dtype):
     that leaves a partial last block.  Unsure blocks go to the rich kernel: the results must equal the oracle either way, the
     workspace's flags must be clear afterwards, and the fast kernel must carry most of the blocks."""
     rng = np.random.default_rng(700 + N + (1 if dtype == np.uint16 else 0))
-    # 15949 pixels: 62 full tiles + a partial one (odd: one pixel per lane); uint16 stacks of up to 64 frames also with an even
+    # 15949 pixels: 62 full tiles + a partial one (odd: one pixel per lane); uint16 stacks also with an even
     # pixel count - two pixels per lane on the packed network (stack_mad_pairs.hip), 30 full 512-pixel tiles + a partial one
-    for H, W in ((41, 389),) + (((40, 390),) if dtype == np.uint16 and N <= 64 else ()):
+    for H, W in ((41, 389),) + (((40, 390),) if dtype == np.uint16 else ()):
         _ccdproc_fast_case(ops, apref, N, dtype, H, W)
 
 
