@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(PKG, 'libapgpu.so')
 
-SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'stack_mad_pairs.hip', 'stack_mad_pairs_wide.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
+SOURCES = ['common.hip', 'elementwise.hip', 'fixbadpix.hip', 'sigclip_global.hip', 'resample.hip', 'resample_stack.hip', 'stack.hip', 'stack_big.hip', 'stack_chunks.hip', 'stack_mad.hip', 'stack_mad_wide.hip', 'stack_mad_pairs.hip', 'stack_mad_pairs_wide.hip', 'combine_f64.hip', 'background.hip', 'lacosmic.hip'] + [
     'stack_inst_f32_calib_h.hip',
     'stack_inst_f32_plain_h.hip',
     'stack_inst_u16_calib_h.hip',
@@ -103,6 +103,8 @@ def _compile(src):
     obj = os.path.join(OBJ, src.replace('.hip', '.o'))
     srcp = os.path.join(CSRC, src)
     extra = ['stack_mad.h'] if src.startswith('stack_mad') else []
+    if src.startswith('resample'):
+        extra.append('resample_core.h')
     if src == 'stack_mad_wide.hip':
         extra.append('stack_mad.hip')                        # (the wide units include the narrow ones)
     if src == 'stack_mad_pairs_wide.hip':
@@ -110,7 +112,7 @@ def _compile(src):
     dep_time = max(os.path.getmtime(srcp), _newest(HEADERS + extra))
     if os.path.exists(obj) and os.path.getmtime(obj) >= dep_time:
         return obj, False
-    cmd = [_hipcc()] + HIPCC_FLAGS + (STACK_TU_FLAGS if src.startswith('stack_inst_') else []) + ['-c', srcp, '-o', obj]
+    cmd = [_hipcc()] + HIPCC_FLAGS + (STACK_TU_FLAGS if src.startswith(('stack_inst_', 'resample_stack')) else []) + ['-c', srcp, '-o', obj]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stdout[-4000:]))

@@ -14,7 +14,8 @@ OPS = {'ADD': 0, 'SUB': 1, 'MUL': 2, 'DIV': 3}
 CENTER = {'median': 0, 'mean': 1}
 DEV = {'std': 0, 'mad_std': 1}
 MAX_STACK = 512
-STACK_EXACT_MOMENTS, STACK_MOMENTS_MEAN, STACK_SINGLE_KERNEL = 1, 2, 4          # apgpu_stack_args.flags
+STACK_EXACT_MOMENTS, STACK_MOMENTS_MEAN, STACK_SINGLE_KERNEL, STACK_NONFINITE_UNCLIPPED = 1, 2, 4, 8    # apgpu_stack_args.flags
+CCDPROC_FORM = {'astropy': 0, 'legacy': 1}                                  # APGPU_CCDPROC_*
 STACK_WS_STATS_OFFSET = 16384                           # APGPU_STACK_WS_STATS_OFFSET: int64 calls, pixels, pixels listed, 64-pixel blocks given up
 
 E_INVAL, E_UNSUPPORTED, E_LAUNCH, E_WORKSPACE = -1, -2, -3, -4
@@ -61,8 +62,11 @@ SIGNATURES = {
                                              C.c_int64, C.c_void_p]),
     'apgpu_moments_finalize_f64p': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_int64, C.c_void_p]),
+    'apgpu_resample_stack_ws_bytes': (C.c_size_t, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]),
+    'apgpu_resample_stack_sigclip': (C.c_int, [C.POINTER(StackArgs), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                               C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_combine_ccdproc_f64_ws_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
-    'apgpu_combine_ccdproc_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_void_p,
+    'apgpu_combine_ccdproc_f64': (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'apgpu_sigclip_global_ws_bytes': (C.c_size_t, [C.c_int64]),
     'apgpu_sigclip_global_f32': (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_int, C.c_void_p,

@@ -26,6 +26,13 @@ _FITS_EXT = ('.fit', '.fits', '.fts')
 
 
 class ApMasterCal:
+    # Which published Combiner.sigma_clipping make_master follows: 'astropy' (ccdproc >= 2.2 delegates to
+    # astropy.stats.sigma_clip - what requirements.txt:18 `ccdproc>=2.1.0` resolves to today) or 'legacy' (ccdproc <= 2.1's own
+    # loop).  They differ for columns holding a non-finite value (unclipped in the astropy form) and, on float64 frames, within an
+    # ulp of a bound (golden group G12 holds both, run for real).  A class attribute: the constructor keeps the
+    # reference's signature (scripts/ap_combine_darks.py:112-116).
+    ccdproc_form = 'astropy'
+
     def __init__(self, rootdir, exclude_pattern, telescop, temptol, loglevel):
         self._logger = _common.make_logger('ApMasterCal', loglevel)
         self._loglevel = loglevel
@@ -152,12 +159,14 @@ class ApMasterCal:
         slab, hdrs = fitsio.read_slab_device([str(f) for f in files])
         if slab.dtype == torch.float64:
             # float64 frames (BITPIX -64): ccdproc combines in float64 anyway; here the float64 combine kernel
-            res = ops.combine_f64(slab, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std')
+            res = ops.combine_f64(slab, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
+                                  form=self.ccdproc_form)
         else:
             res = None
         if res is None:
             res = ops.stack_sigclip(slab, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std',
-                                    outputs=('mean_f64', 'count', 'std_f64'))
+                                    outputs=('mean_f64', 'count', 'std_f64'),
+                                    nonfinite_unclipped=(self.ccdproc_form == 'astropy'))
         # ccdproc's CCDData product (ap_combine_darks.py:411-439): float64 primary, MASK = pixels with every
         # input rejected, UNCERT = std of the surviving values / sqrt(their number) - all in float64
         master = res['mean_f64'].cpu().numpy()

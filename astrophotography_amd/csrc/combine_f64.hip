@@ -5,7 +5,9 @@
 // This kernel is the float64 statement of oracle/apref.c's apref_combine_ccdproc(), operation for operation, so that the
 // result is bit-identical to it (and, through golden group G12, to numpy.ma + astropy):
 //   base = median of the finite values, dev = 1.482602218505602 * median(|x - base|)       (np.ma.median, astropy mad_std)
-//   keep = finite and not (x - base < -low * dev or x - base > high * dev)                   (strict, one pass)
+//   keep = finite and not (x - base < -low * dev or x - base > high * dev)                   (strict, one pass; form LEGACY)
+//   keep = finite and not (x < base - dev * low or x > base + dev * high), and a column holding a non-finite value is not
+//          clipped at all                                             (form ASTROPY: astropy.stats.sigma_clip, ccdproc >= 2.2)
 //   mean = (sum of the kept values in FRAME order) / m,  std = sqrt(sum((x - mean)^2) / m)   (float64)
 // It is a correctness path, not a fast one (float64 frames are the exception): one pixel per lane, the two sorted columns
 // (values, absolute deviations) live in a caller-provided workspace double[2][N][P] (coalesced: slot-major) and are built
@@ -33,7 +35,7 @@ __device__ __forceinline__ double median_sorted(const double *col, int64_t P, in
 }
 
 __global__ __launch_bounds__(256) void combine_ccdproc_f64_kernel(const double *__restrict__ frames, int N, int64_t P, int64_t stride,
-                                                                 double low, double high, double *__restrict__ mean_out,
+                                                                 double low, double high, int form, double *__restrict__ mean_out,
                                                                  int32_t *__restrict__ count_out, double *__restrict__ std_out,
                                                                  double *__restrict__ ws)
 {
@@ -58,14 +60,21 @@ __global__ __launch_bounds__(256) void combine_ccdproc_f64_kernel(const double *
     const double base = median_sorted(A, P, n);
     for (int i = 0; i < n; i++) insert_sorted(B, P, i, fabs(A[(int64_t)i * P] - base));
     const double sd = median_sorted(B, P, n) * 1.482602218505602;
-    const double lo = -low * sd, hi = high * sd;
+    const bool astropy = form == APGPU_CCDPROC_ASTROPY;
+    const double lo = -low * sd, hi = high * sd;                        // LEGACY: thresholds of the differences
+    const double lob = base - sd * low, hib = base + sd * high;         // ASTROPY: bounds of the values (sigma_clipping.py:295-296)
+    const bool unclipped = astropy && n < N;
+    auto rejected = [&](double v) {
+        if (astropy) return !unclipped && (v < lob || v > hib);
+        const double d = v - base;
+        return d < lo || d > hi;
+    };
     double sum = 0.0;
     int m = 0;
     for (int f = 0; f < N; f++) {
         const double v = frames[(int64_t)f * stride + p];
         if (!(fabs(v) < __builtin_inf())) continue;
-        const double d = v - base;
-        if (d < lo || d > hi) continue;
+        if (rejected(v)) continue;
         sum += v;
         m++;
     }
@@ -77,8 +86,7 @@ __global__ __launch_bounds__(256) void combine_ccdproc_f64_kernel(const double *
         for (int f = 0; f < N; f++) {
             const double v = frames[(int64_t)f * stride + p];
             if (!(fabs(v) < __builtin_inf())) continue;
-            const double d = v - base;
-            if (d < lo || d > hi) continue;
+            if (rejected(v)) continue;
             const double e = v - mean;
             q += e * e;
         }
@@ -95,11 +103,12 @@ extern "C" size_t apgpu_combine_ccdproc_f64_ws_bytes(int32_t n_frames, int64_t n
 }
 
 extern "C" int apgpu_combine_ccdproc_f64(const double *frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, double low,
-                                         double high, double *mean, int32_t *count, double *std, void *workspace,
+                                         double high, int32_t form, double *mean, int32_t *count, double *std, void *workspace,
                                          size_t workspace_bytes, void *stream)
 {
     if (!frames || n_frames < 1 || n_pixels < 1) return fail(APGPU_EINVAL, "combine_ccdproc_f64: bad arguments");
     if (!(low >= 0.0) || !(high >= 0.0)) return fail(APGPU_EINVAL, "combine_ccdproc_f64: thresholds must be >= 0");
+    if (form != APGPU_CCDPROC_ASTROPY && form != APGPU_CCDPROC_LEGACY) return fail(APGPU_EINVAL, "combine_ccdproc_f64: bad form %d", form);
     if (!mean && !count && !std) return fail(APGPU_EINVAL, "combine_ccdproc_f64: no output requested");
     if (frame_stride == 0) frame_stride = n_pixels;
     if (frame_stride < n_pixels) return fail(APGPU_EINVAL, "combine_ccdproc_f64: frame_stride < n_pixels");
@@ -108,6 +117,6 @@ extern "C" int apgpu_combine_ccdproc_f64(const double *frames, int32_t n_frames,
     const int64_t grid = (n_pixels + 255) / 256;
     if (grid > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "combine_ccdproc_f64: too many pixels");
     hipLaunchKernelGGL(combine_ccdproc_f64_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), frames, (int)n_frames, n_pixels,
-                       frame_stride, low, high, mean, count, std, static_cast<double *>(workspace));
+                       frame_stride, low, high, (int)form, mean, count, std, static_cast<double *>(workspace));
     return check_launch("combine_ccdproc_f64");
 }

@@ -94,8 +94,10 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
         if (args->moments_f64 < 0 || args->moments_f64 > 4) return fail(APGPU_EINVAL, "stack: bad moments_f64 %d", args->moments_f64);
         if (args->moments && args->moments_f64 && (reinterpret_cast<uintptr_t>(args->moments) & 7))
             return fail(APGPU_EINVAL, "stack: float64 moments must be 8-byte aligned");
-        if (args->flags & ~(APGPU_STACK_EXACT_MOMENTS | APGPU_STACK_MOMENTS_MEAN | APGPU_STACK_SINGLE_KERNEL))
+        if (args->flags & ~(APGPU_STACK_EXACT_MOMENTS | APGPU_STACK_MOMENTS_MEAN | APGPU_STACK_SINGLE_KERNEL | APGPU_STACK_NONFINITE_UNCLIPPED))
             return fail(APGPU_EINVAL, "stack: unknown flags 0x%x", args->flags);
+        if ((args->flags & APGPU_STACK_NONFINITE_UNCLIPPED) && args->dev != APGPU_DEV_MAD_STD)
+            return fail(APGPU_EINVAL, "stack: APGPU_STACK_NONFINITE_UNCLIPPED belongs to the median / mad_std configuration (dev = APGPU_DEV_MAD_STD)");
         if (args->workspace) {
             if (reinterpret_cast<uintptr_t>(args->workspace) & 15) return fail(APGPU_EINVAL, "stack: the workspace must be 16-byte aligned");
             if (args->workspace_bytes < apgpu_stack_ws_bytes(args->n_pixels, nullptr))
@@ -132,6 +134,7 @@ int stack_dispatch(const apgpu_stack_args *args, bool median_only, void *stream,
     prm.std64 = median_only ? nullptr : args->std_f64;
     prm.redo = median_only ? nullptr : static_cast<int32_t *>(args->workspace);
     prm.single_kernel = (args->flags & APGPU_STACK_SINGLE_KERNEL) ? 1 : 0;
+    prm.unclipped_nonfinite = (!median_only && (args->flags & APGPU_STACK_NONFINITE_UNCLIPPED)) ? 1 : 0;
     prm.fast32 = (median_only || (args->flags & APGPU_STACK_EXACT_MOMENTS)) ? 0 : ((args->flags & APGPU_STACK_MOMENTS_MEAN) ? 2 : 1);
 #ifdef APGPU_DEVELOPMENT                                     // measurement knobs, never in a release build
     if (getenv("APGPU_DEBUG_STRIDE0")) prm.stride = 0;      // all frames alias frame 0: compute-only timing

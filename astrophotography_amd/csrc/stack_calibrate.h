@@ -30,6 +30,7 @@ struct StackParams {
     int32_t *redo;          // the workspace of the two-kernel scheme (stack_kernels.h, "workspace layout"): segment counters,
                             // tile flags and per-segment lists of the PIXELS the fast kernel could not finish.  NULL in a
                             // plain launch of the complete kernels (stack_sigclip_kernel: non-NULL = redo pass)
+    int unclipped_nonfinite; // rich kernels only: a column holding a non-finite value is not clipped (APGPU_STACK_NONFINITE_UNCLIPPED)
 };
 
 // The slot counts the dispatcher uses (launch_np) and, for each, the largest N that still selects the previous one: a

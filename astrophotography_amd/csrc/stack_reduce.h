@@ -386,36 +386,44 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     // core sums: four chains, fixed association.  S adds the deviations in mirror pairs (i, NP-1-i) of the sorted column:
     // a pair nearly cancels, so the partial sums - and with them the float32 rounding errors, which scale with the
     // magnitude of what is being added - stay at the column's asymmetry instead of its spread (same number of additions).
-    // (Round 4, measured and not kept: the same chains as 2-wide vectors -> v_pk_add_f32 / v_pk_fma_f32, 136 instead of 202
-    // instructions - but the sorted values leave the network in single registers that inline-asm outputs cannot place into
-    // aligned pairs, so the compiler adds ~50 v_mov and 5 VGPRs: 170, one over the budget of three wavefronts per SIMD.)
-#ifdef APGPU_VARIANT_PACKED_MOMENTS
-    static_assert(T % 2 == 0, "pairs");
-    const v2f cf2 = {cf, cf};
-    v2f Sp[2] = {{0.f, 0.f}, {0.f, 0.f}}, Qp[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-    for (int i = T; i < NP / 2; i += 2) {
-        const v2f lo = {v[i], v[i + 1]}, hi = {v[NP - 1 - i], v[NP - 2 - i]};       // hi: the mirror images, in mirror order
-        const v2f d1 = lo - cf2, d2 = hi - cf2;
-        const int c = (i >> 1) & 1;
-        Sp[c] += d1 + d2;
-        Qp[c] = __builtin_elementwise_fma(d1, d1, Qp[c]);
-        Qp[c ^ 1] = __builtin_elementwise_fma(d2, d2, Qp[c ^ 1]);
-    }
-    const float Sc = (Sp[0].x + Sp[0].y) + (Sp[1].x + Sp[1].y);
-    const float Qc = (Qp[0].x + Qp[0].y) + (Qp[1].x + Qp[1].y);
-#else
-    float Sa[4] = {0.f, 0.f, 0.f, 0.f}, Qa[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = T; i < NP / 2; i++) {
-        const float d1 = v[i] - cf, d2 = v[NP - 1 - i] - cf;
-        Sa[i & 3] += d1 + d2;
-        Qa[i & 3] = __builtin_fmaf(d1, d1, Qa[i & 3]);
-        Qa[(i + 2) & 3] = __builtin_fmaf(d2, d2, Qa[(i + 2) & 3]);
-    }
-    const float Sc = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
-    const float Qc = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+    // PACKED (round 6): the same chains as 2-wide vectors -> v_pk_add_f32 / v_pk_fma_f32, -83 instructions per wavefront at 64
+    // slots.  Round 4 rejected it on the complete kernel (the sorted values leave the network in single registers, the compiler
+    // added ~50 v_mov and 5 VGPRs: 170, one over that kernel's budget of three wavefronts per SIMD).  On the FAST kernel (MODE 1 / 2:
+    // 110 VGPRs, budget 128) the compiler places the pairs without a single move and the register count does not change: 0.892 ->
+    // 0.880 ms on the benchmark, five interleaved runs each on one box (profiles/r06/ab_packed.txt) - although packed float32
+    // instructions are of the 4-cycle class and the scalar forms they replace of the 2-cycle class (tools/issue_cost.hip): what
+    // is saved are issue slots.  Same four chains per sum, same number of terms per chain: the error budget above is unchanged.
+#ifndef APGPU_PACKED_MOMENTS_MAX_NP
+#define APGPU_PACKED_MOMENTS_MAX_NP 64
 #endif
+    constexpr bool kPacked = MODE != 0 && NP <= APGPU_PACKED_MOMENTS_MAX_NP && T % 2 == 0 && (NP / 2 - T) % 2 == 0;
+    float Sc, Qc;
+    if constexpr (kPacked) {
+        const v2f cf2 = {cf, cf};
+        v2f Sp[2] = {{0.f, 0.f}, {0.f, 0.f}}, Qp[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+        for (int i = T; i < NP / 2; i += 2) {
+            const v2f lo = {v[i], v[i + 1]}, hi = {v[NP - 1 - i], v[NP - 2 - i]};       // hi: the mirror images, in mirror order
+            const v2f d1 = lo - cf2, d2 = hi - cf2;
+            const int c = (i >> 1) & 1;
+            Sp[c] += d1 + d2;
+            Qp[c] = __builtin_elementwise_fma(d1, d1, Qp[c]);
+            Qp[c ^ 1] = __builtin_elementwise_fma(d2, d2, Qp[c ^ 1]);
+        }
+        Sc = (Sp[0].x + Sp[0].y) + (Sp[1].x + Sp[1].y);
+        Qc = (Qp[0].x + Qp[0].y) + (Qp[1].x + Qp[1].y);
+    } else {
+        float Sa[4] = {0.f, 0.f, 0.f, 0.f}, Qa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = T; i < NP / 2; i++) {
+            const float d1 = v[i] - cf, d2 = v[NP - 1 - i] - cf;
+            Sa[i & 3] += d1 + d2;
+            Qa[i & 3] = __builtin_fmaf(d1, d1, Qa[i & 3]);
+            Qa[(i + 2) & 3] = __builtin_fmaf(d2, d2, Qa[(i + 2) & 3]);
+        }
+        Sc = (Sa[0] + Sa[1]) + (Sa[2] + Sa[3]);
+        Qc = (Qa[0] + Qa[1]) + (Qa[2] + Qa[3]);
+    }
     // tails, summed from the inside out
     float SL[T + 1], QL[T + 1], SH[T + 1], QH[T + 1];
     SL[T] = 0.f; QL[T] = 0.f; SH[0] = 0.f; QH[0] = 0.f;
@@ -872,7 +880,9 @@ __device__ __forceinline__ void reduce_and_store_rich(const StackParams &prm, fl
     st.wscale = (double)n;
     st.Tlo = 0.0;
     st.Thi = 0.0;
-    bool active = n > 0;
+    // APGPU_STACK_NONFINITE_UNCLIPPED (ccdproc >= 2.2 through astropy.stats.sigma_clip with callables): NaN bounds for a column
+    // that holds a non-finite value - nothing is rejected, the outputs are those of its finite values
+    bool active = n > 0 && !(prm.unclipped_nonfinite != 0 && n < prm.N);
     int it = 0;
     double refresh_below = ldexp((double)n * st.Q, -22);     // see the lean kernel: when to sum the moments afresh
 

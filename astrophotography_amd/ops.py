@@ -254,7 +254,7 @@ def stack_redo_stats(reset=False):
 
 def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median',
                   stdfunc='std', calib=None, pixmask=None, outputs=('mean',), exact=False, moments_mean_only=False,
-                  single_kernel=False, workspace=True):
+                  single_kernel=False, workspace=True, nonfinite_unclipped=False):
     """Per-pixel sigma-clipped reduction along N = astropy sigma_clipped_stats(cube, axis=0)
     (sigma_clipping.py:298-383, 924-937), optionally fused with the calibration of each value.
 
@@ -268,6 +268,8 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
     exact: APGPU_STACK_EXACT_MOMENTS (float64 clip only: the mean is the float64 mean of the survivors rounded once);
     moments_mean_only: APGPU_STACK_MOMENTS_MEAN (the float64 moments will only be turned into a mean).
     single_kernel: APGPU_STACK_SINGLE_KERNEL (one complete kernel instead of the fast kernel + redo pass pair);
+    nonfinite_unclipped: APGPU_STACK_NONFINITE_UNCLIPPED (stdfunc='mad_std' only): a column holding a non-finite value is not
+    clipped - ccdproc >= 2.2's Combiner.sigma_clipping through astropy.stats.sigma_clip (golden group G12, arrays c*_b_*);
     workspace: True = this module's cached workspace for the two-kernel scheme (stack_workspace), False = none (the
     library then allocates a stream-ordered temporary per call), or a tensor from stack_workspace().
     """
@@ -305,7 +307,7 @@ def stack_sigclip(frames, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiter
             raise ValueError('unknown output %r' % (k,))
         setattr(a, k, res[k].data_ptr())
     a.flags = ((_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0) |
-               (_lib.STACK_SINGLE_KERNEL if single_kernel else 0))
+               (_lib.STACK_SINGLE_KERNEL if single_kernel else 0) | (_lib.STACK_NONFINITE_UNCLIPPED if nonfinite_unclipped else 0))
     if workspace is True:
         keep.append(_attach_workspace(a, P, dev))
     elif workspace is not False and workspace is not None:
@@ -369,10 +371,11 @@ def stack_sigclip_chunked(frames, chunk=None, want_std=False, packed=False, fina
     return res
 
 
-def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std'):
+def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', form='astropy'):
     """The ccdproc.combine configuration (scripts/ap_combine_darks.py:394-420) on a FLOAT64 slab [N, ...]: one strict
     pass about the median with mad_std, float64 mean / std / count -> dict(mean_f64, std_f64, count).  float64 frames are
-    never narrowed to float32 (apgpu_combine_ccdproc_f64: a correctness path, bit-identical to the oracle)."""
+    never narrowed to float32 (apgpu_combine_ccdproc_f64: a correctness path, bit-identical to the oracle).
+    form: 'astropy' (ccdproc >= 2.2: astropy.stats.sigma_clip) or 'legacy' (ccdproc <= 2.1), see include/apgpu.h."""
     _need_cuda(frames)
     if frames.dtype != torch.float64:
         raise TypeError('combine_f64 takes a float64 slab, got %s' % frames.dtype)
@@ -390,7 +393,7 @@ def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='m
     nb = lib.apgpu_combine_ccdproc_f64_ws_bytes(N, P)
     ws = torch.empty(nb // 8, dtype=torch.float64, device=dev)
     check(lib.apgpu_combine_ccdproc_f64(_ptr(frames), N, P, frames.stride(0) if N > 1 else P, float(sigma_lower), float(sigma_upper),
-                                        _ptr(res['mean_f64']), _ptr(res['count']), _ptr(res['std_f64']), _ptr(ws), nb, _stream()))
+                                        _lib.CCDPROC_FORM[form], _ptr(res['mean_f64']), _ptr(res['count']), _ptr(res['std_f64']), _ptr(ws), nb, _stream()))
     return res
 
 
@@ -761,6 +764,102 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
                                                 int(per_tile), int(bool(conserve_flux)), _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases), _ptr(out),
                                                 _ptr(wt) if wt is not None else None, h, w, _stream()))
     return out, wt
+
+
+_fused_ws = {}
+
+
+def resample_stack_sigclip(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, conserve_flux=False,
+                           sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc='median', outputs=('mean',),
+                           exact=False, moments_mean_only=False):
+    """resample_affine + stack_sigclip in ONE launch (apgpu_resample_stack_sigclip): the co-add of registered frames without
+    the resampled slab - every output pixel's N Lanczos-3 values go straight into the clip (scripts/resample_all.sh:330-342,
+    one SWarp call there).  frames [N <= 16, H, W] float32; affines / fscale / mask / out_shape / n_phases / conserve_flux as
+    resample_affine; the clip's arguments as stack_sigclip (stdfunc 'std'); outputs among 'mean', 'count', 'moments',
+    'moments_f64', 'moments_f64p'.  Same survivors as the two-step form; the mean within the float32 fast path's rounding."""
+    _need_cuda(frames)
+    frames = _f32c(frames, 'frames')
+    if frames.dim() != 3:
+        raise ValueError('frames must be [N,H,W]')
+    N, H, W = frames.shape
+    if N > 16:
+        raise ValueError('resample_stack_sigclip takes up to 16 frames per call (resample_affine + stack_sigclip beyond)')
+    dev = frames.device
+    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
+    aff = torch.as_tensor(affines, dtype=torch.float64)
+    per_tile = aff.dim() == 4
+    if per_tile:
+        ty, tx = (h + 15) // 16, (w + 63) // 64
+        if tuple(aff.shape) != (N, ty, tx, 6):
+            raise ValueError('per-tile affines must be [N, %d, %d, 6] for a %d x %d output' % (ty, tx, h, w))
+    else:
+        aff = aff.reshape(-1, 6)
+        if aff.shape[0] == 1 and N > 1:
+            aff = aff.expand(N, 6)
+        if aff.shape[0] != N:
+            raise ValueError('affines must hold one 2x3 transform per frame')
+    aff = aff.contiguous().to(dev)
+    fs = None
+    if fscale is not None:
+        fs = torch.as_tensor(fscale, dtype=torch.float32).reshape(-1)
+        if fs.numel() == 1 and N > 1:
+            fs = fs.expand(N)
+        if fs.numel() != N:
+            raise ValueError('fscale must hold one value per frame')
+        fs = fs.contiguous().to(dev)
+    mk = None
+    if mask is not None:
+        _need_cuda(mask)
+        if tuple(mask.shape) != (H, W):
+            raise ValueError('mask must be [H,W]')
+        mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
+    lut = lanczos3_table(n_phases, dev)
+    lib = _lib.load()
+    a = StackArgs()
+    a.frames = frames.data_ptr()
+    a.dtype = _raw_dtype(frames)
+    a.n_frames = N
+    a.n_pixels = h * w
+    a.frame_stride = H * W
+    a.center = _lib.CENTER[cenfunc]
+    a.dev = _lib.DEV['std']
+    a.maxiters = -1 if maxiters is None else int(maxiters)
+    a.sigma_lower = float(sigma if sigma_lower is None else sigma_lower)
+    a.sigma_upper = float(sigma if sigma_upper is None else sigma_upper)
+    shp = (h, w)
+    res = {}
+    for k in outputs:
+        if k == 'mean':
+            res[k] = torch.empty(shp, dtype=torch.float32, device=dev)
+        elif k == 'count':
+            res[k] = torch.empty(shp, dtype=torch.int32, device=dev)
+        elif k == 'moments':
+            if a.moments:
+                raise ValueError('ask for one moment layout')
+            res[k] = torch.empty((3,) + shp, dtype=torch.float32, device=dev)
+            a.moments = res[k].data_ptr()
+            continue
+        elif k in ('moments_f64', 'moments_f64p'):
+            if a.moments:
+                raise ValueError('ask for one moment layout')
+            res[k] = alloc_moments_f64(shp, dev, packed=(k == 'moments_f64p'))
+            a.moments = res[k]['buffer'].data_ptr()
+            a.moments_f64 = 3 if k == 'moments_f64p' else 1
+            continue
+        else:
+            raise ValueError('unknown output %r (mean, count, moments, moments_f64, moments_f64p)' % (k,))
+        setattr(a, k, res[k].data_ptr())
+    a.flags = (_lib.STACK_EXACT_MOMENTS if exact else 0) | (_lib.STACK_MOMENTS_MEAN if moments_mean_only else 0)
+    nb = lib.apgpu_resample_stack_ws_bytes(N, H, W, h, w, int(mk is not None))
+    key = (dev.index, int(torch.cuda.current_stream(dev).cuda_stream))
+    ws = _fused_ws.get(key)
+    if ws is None or ws.numel() < nb:
+        ws = torch.empty(nb + 64, dtype=torch.uint8, device=dev)        # (torch allocations are 512-byte aligned)
+        _fused_ws[key] = ws
+    check(lib.apgpu_resample_stack_sigclip(C.byref(a), H, W, _ptr(mk) if mk is not None else None, _ptr(aff), int(per_tile),
+                                           int(bool(conserve_flux)), _ptr(fs) if fs is not None else None, _ptr(lut), int(n_phases),
+                                           h, w, _ptr(ws), ws.numel(), _stream()))
+    return res
 
 
 def oversampled_affines(affines, oversampling, out_shape):

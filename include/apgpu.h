@@ -172,6 +172,13 @@ typedef struct apgpu_stack_args {
 #define APGPU_STACK_EXACT_MOMENTS 1
 #define APGPU_STACK_MOMENTS_MEAN 2
 #define APGPU_STACK_SINGLE_KERNEL 4   /* never the fast kernel + redo pass pair described below: one complete kernel, no workspace used */
+/*   APGPU_STACK_NONFINITE_UNCLIPPED  (dev == APGPU_DEV_MAD_STD only) a column that holds a non-finite value is not clipped: mean /
+ *                               count / std of its finite values.  This is what ccdproc >= 2.2's Combiner.sigma_clipping does
+ *                               for scripts/ap_combine_darks.py:394-420: it delegates to astropy.stats.sigma_clip, whose general
+ *                               path hands the callables np.ma.median / mad_std a plain array in which invalid values are NaN
+ *                               - NaN bounds, nothing rejected (golden group G12, arrays c*_b_*, run for real).  Without the
+ *                               flag non-finite values are masked and the rest is clipped (ccdproc <= 2.1's own loop). */
+#define APGPU_STACK_NONFINITE_UNCLIPPED 8
 
 /* The two-kernel scheme and its workspace.  A clipped stack of up to 128 frames (and the chunked kernel for 129 .. 512) with
  * lean outputs runs as a FAST kernel - the float32 fast path alone, four wavefronts per SIMD - followed by a REDO PASS of the
@@ -193,7 +200,8 @@ typedef struct apgpu_stack_args {
  *   - the workspace also remembers, from one call to the next, whether the guard is needed: a call that sent under an eighth
  *     of its pixels to the redo pass (listed, or in blocks given up) lets the next call on the same workspace skip the fast
  *     kernel's look at the counters (it costs 1.5 % of the benchmark, 6 % of a 16-frame stack); the first call after the data has turned bad therefore runs unguarded - both
- *     kernels in full, about twice the complete kernel's time in the worst case - and sets the guard for the calls after it.
+ *     kernels in full, measured 1.20 - 1.25 x the complete kernel's time when every column fails (profiles/r05/redo_sweep.txt)
+ *     - and sets the guard for the calls after it.
  *     The ccdproc.combine configuration (one pass of median / mad_std) keeps a mode word of its own in the same line: after a call
  *     that gave up more than an eighth of its sampled 64-pixel blocks, the next call tries only every 16th tile on the fast kernel.
  * workspace == NULL: the call allocates and frees a stream-ordered temporary of the same size itself (hipMallocAsync /
@@ -208,15 +216,21 @@ size_t apgpu_stack_ws_bytes(int64_t n_pixels, size_t *zero_bytes);
 int apgpu_stack_sigclip(const apgpu_stack_args *args, void *stream);
 
 /* A6 on FLOAT64 frames (BITPIX -64 inputs of ApMasterCal: ccdproc's Combiner is float64 throughout, so such frames must
- * not pass through the float32 stack kernels): base = median, dev = mad_std, ONE strict pass (x - base < -low dev or
- * > high dev is rejected), float64 mean in frame order, std of the kept values, survivor count.  frames: double [N][P]
- * with frame_stride elements between frames (0 = n_pixels); outputs may be NULL; workspace: double[2][N][P]
- * (apgpu_combine_ccdproc_f64_ws_bytes).  A correctness path (insertion sort per pixel), bit-identical to
- * oracle/apref.c apref_combine_ccdproc and golden group G12. */
+ * not pass through the float32 stack kernels): base = median, dev = mad_std, ONE strict pass, float64 mean in frame order, std
+ * of the kept values, survivor count.  `form` selects which published Combiner.sigma_clipping is followed, operation for
+ * operation (oracle/apref.c apref_combine_ccdproc_form, golden group G12 - both forms run for real):
+ *   APGPU_CCDPROC_ASTROPY (ccdproc >= 2.2, what requirements.txt:18 resolves to today): astropy.stats.sigma_clip - rejected
+ *       where x < base - dev * low or x > base + dev * high; a column holding a non-finite value is not clipped at all;
+ *   APGPU_CCDPROC_LEGACY  (ccdproc <= 2.1): rejected where x - base < -low * dev or x - base > high * dev; non-finite values
+ *       are masked and the rest is clipped.
+ * frames: double [N][P] with frame_stride elements between frames (0 = n_pixels); outputs may be NULL; workspace:
+ * double[2][N][P] (apgpu_combine_ccdproc_f64_ws_bytes).  A correctness path (insertion sort per pixel). */
+#define APGPU_CCDPROC_ASTROPY 0
+#define APGPU_CCDPROC_LEGACY 1
 size_t apgpu_combine_ccdproc_f64_ws_bytes(int32_t n_frames, int64_t n_pixels);
 int apgpu_combine_ccdproc_f64(const double *frames, int32_t n_frames, int64_t n_pixels, int64_t frame_stride, double low,
-                              double high, double *mean, int32_t *count, double *std, void *workspace, size_t workspace_bytes,
-                              void *stream);
+                              double high, int32_t form, double *mean, int32_t *count, double *std, void *workspace,
+                              size_t workspace_bytes, void *stream);
 
 /* Plain median along N (np.nanmedian(axis=0)); config 4.  Optional fused calibration as above. */
 int apgpu_stack_median(const apgpu_stack_args *args, void *stream);
@@ -384,6 +398,22 @@ int apgpu_resample_oversampled_f32(const float *frames, int32_t n_frames, int64_
  *     order), wsum_out = that sum of weights = the -WEIGHTOUT_NAME image (resample_all.sh:342); NaN / 0 where no frame
  *     contributes.  weights [n_frames] float32 on the device, all finite and > 0. */
 int apgpu_block_mean_f32(const float *fine, int64_t h_out, int64_t w_out, int32_t oversampling, float *out, void *stream);
+
+/* F3 + A7 in one launch: the co-add of scripts/resample_all.sh:330-342 (one SWarp call: resample every frame, combine) without
+ * the resampled slab.  Every output pixel's N values are apgpu_resample_affine_f32's values for it (same tile records, same window
+ * arithmetic, bit for bit; oversampling 1) and their reduction is apgpu_stack_sigclip's lean one (mean / count / moments, centre
+ * median or mean, deviation std): NaN ("frame absent": a window off the frame, on a bad pixel or on a non-finite value) is
+ * skipped as there.  `args` is the stack's argument block with: frames = the INPUT frames [n_frames][h_in * w_in] float32
+ * (frame_stride 0 = h_in * w_in), n_frames <= 16 per call, n_pixels = h_out * w_out, no fused calibration, no pixmask, outputs
+ * among mean / count / moments, flags among APGPU_STACK_EXACT_MOMENTS / APGPU_STACK_MOMENTS_MEAN; its workspace fields are not
+ * used.  The other arguments are apgpu_resample_affine_f32's.  workspace: apgpu_resample_stack_ws_bytes(..) bytes, 64-byte
+ * aligned, caller-owned, need not be initialised: tile records, and with a mask the bad-pixel list and one uint32 per output
+ * pixel (which frames' windows hold a bad pixel).  HBM traffic 4 n_frames P + 4 P instead of 12 n_frames P + 4 P. */
+size_t apgpu_resample_stack_ws_bytes(int32_t n_frames, int64_t h_in, int64_t w_in, int64_t h_out, int64_t w_out, int32_t has_mask);
+int apgpu_resample_stack_sigclip(const apgpu_stack_args *args, int64_t h_in, int64_t w_in, const uint8_t *mask,
+                                 const double *affines, int32_t affines_per_tile, int32_t conserve_flux, const float *fscale,
+                                 const float *lut, int32_t n_phases, int64_t h_out, int64_t w_out, void *workspace,
+                                 size_t workspace_bytes, void *stream);
 int apgpu_weighted_mean_f32(const float *slab, int32_t n_frames, int64_t n_pixels, const float *weights, float *mean_out,
                             float *wsum_out, void *stream);
 

@@ -438,8 +438,8 @@ int apref_stack_sigclip(const void *frames, int dtype, long N, long P, const uin
 /*     Non-finite inputs are masked first (ccdproc masks NaN via np.ma.masked_invalid upstream    */
 /*     only if the CCDData carries a mask; here: NaN/Inf are treated as masked).                  */
 /* ------------------------------------------------------------------------------------------- */
-int apref_combine_ccdproc(const void *frames, int dtype, long N, long P, double low, double high,
-                          double *mean_out, int32_t *count_out, double *std_out)
+int apref_combine_ccdproc_form(const void *frames, int dtype, long N, long P, double low, double high, int form,
+                               double *mean_out, int32_t *count_out, double *std_out)
 {
     if (dtype != 0 && dtype != 2) return -2;
 #pragma omp parallel
@@ -469,11 +469,21 @@ int apref_combine_ccdproc(const void *frames, int dtype, long N, long P, double 
             double sd = mad * 1.482602218505602;
             double sum = 0;
             int m = 0;
+            /* form 1 ("astropy", ccdproc >= 2.2): bounds as astropy's _compute_bounds forms them (sigma_clipping.py:288-296:
+             * min = centre - std * sigma_lower, max = centre + std * sigma_upper), rejected where x < min or x > max; and the
+             * general path hands np.ma.median / mad_std a plain array in which non-finite values are NaN, so a column holding
+             * one gets NaN bounds: nothing is clipped (sigma_clipping.py:455-507).  form 0 ("legacy", ccdproc <= 2.1). */
+            const double lob = base - sd * low, hib = base + sd * high;
+            const int unclipped = form == 1 && n < N;
             for (long f = 0; f < N; f++) {
                 double v = col[f];
                 if (!isfinite(v)) continue;
-                double d = v - base;
-                if (d < -low * sd || d > high * sd) continue;
+                if (form == 1) {
+                    if (!unclipped && (v < lob || v > hib)) continue;
+                } else {
+                    double d = v - base;
+                    if (d < -low * sd || d > high * sd) continue;
+                }
                 sum += v; buf[m++] = v;
             }
             double mean = m > 0 ? sum / m : NAN;
@@ -488,6 +498,13 @@ int apref_combine_ccdproc(const void *frames, int dtype, long N, long P, double 
         free(buf);
     }
     return 0;
+}
+
+/* The form ApMasterCal uses by default: "astropy" (what ccdproc>=2.1.0, requirements.txt:18, resolves to today). */
+int apref_combine_ccdproc(const void *frames, int dtype, long N, long P, double low, double high,
+                          double *mean_out, int32_t *count_out, double *std_out)
+{
+    return apref_combine_ccdproc_form(frames, dtype, N, P, low, high, 1, mean_out, count_out, std_out);
 }
 
 /* Plain median along N (np.median / np.nanmedian of the float64-converted cube; config 4). */

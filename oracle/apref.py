@@ -168,8 +168,13 @@ def stack_sigclip(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=
     return {k: v for k, v in outs.items() if v is not None}
 
 
-def combine_ccdproc(cube, low=5.0, high=5.0):
-    """A6 ccdproc.combine settings of ap_combine_darks.py:394-420 (PARITY UNPINNED)."""
+CCDPROC_FORMS = {'legacy': 0, 'astropy': 1}
+
+
+def combine_ccdproc(cube, low=5.0, high=5.0, form='astropy'):
+    """A6 ccdproc.combine settings of ap_combine_darks.py:394-420 (PARITY UNPINNED: ccdproc absent).  form: which published
+    Combiner.sigma_clipping - 'astropy' (ccdproc >= 2.2: astropy.stats.sigma_clip, golden arrays c*_b_* of G12, run for real)
+    or 'legacy' (ccdproc <= 2.1: x - base against -low dev / high dev on the masked cube, golden arrays c*_mean ...)."""
     cube = np.asarray(cube)
     dt = 0 if cube.dtype == np.float32 else 2
     cube = np.ascontiguousarray(cube) if dt == 0 else np.ascontiguousarray(cube, dtype=np.float64)
@@ -179,8 +184,8 @@ def combine_ccdproc(cube, low=5.0, high=5.0):
     mean = np.empty(shp, np.float64)
     cnt = np.empty(shp, np.int32)
     std = np.empty(shp, np.float64)
-    rc = lib().apref_combine_ccdproc(_p(cube), C.c_int(dt), C.c_long(N), C.c_long(P), C.c_double(low),
-                                     C.c_double(high), _p(mean), _p(cnt), _p(std))
+    rc = lib().apref_combine_ccdproc_form(_p(cube), C.c_int(dt), C.c_long(N), C.c_long(P), C.c_double(low),
+                                          C.c_double(high), C.c_int(CCDPROC_FORMS[form]), _p(mean), _p(cnt), _p(std))
     assert rc == 0
     return dict(mean=mean, count=cnt, std=std)
 

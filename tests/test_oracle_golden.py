@@ -196,26 +196,44 @@ def test_g6_madstd_blocks(golden_dir):
 
 # ---- G12: the Combiner steps of ccdproc.combine, run with the third-party calls it makes ------------------
 def test_g12_combine_ccdproc(golden_dir):
-    """apref_combine_ccdproc against np.ma.median + astropy.stats.mad_std + np.ma.average on float64 masked cubes
-    (tests/golden/make_golden_combine.py): means, survivor counts and stds bit for bit, values exactly on a +-5 dev
-    bound kept (strict inequalities, scripts/ap_combine_darks.py:394-420 -> ccdproc Combiner.sigma_clipping)."""
+    """apref_combine_ccdproc_form against BOTH published forms of ccdproc's Combiner.sigma_clipping, each run with the third-party
+    calls it makes (tests/golden/make_golden_combine.py; scripts/ap_combine_darks.py:394-420):
+      'legacy'  (ccdproc <= 2.1) np.ma.median + astropy.stats.mad_std + differences against -low dev / high dev on the masked cube;
+      'astropy' (ccdproc >= 2.2) astropy.stats.sigma_clip(maxiters=1, cenfunc=np.ma.median, stdfunc=mad_std) run for real.
+    Means, survivor counts and stds bit for bit in both; values exactly on a +-5 dev bound kept (strict inequalities); where the
+    forms disagree - columns holding a non-finite value (unclipped in the astropy form) and float64 values within an ulp of a
+    bound with a non-zero base - the oracle follows each."""
     import json
     g = load(golden_dir, 'g12_combine.npz')
     ties = 0
+    disagree = {'nonfinite': 0, 'f64bounds': 0}
     for m in json.loads(str(g['_meta'])):
         k = m['case']
         fr = g[f'c{k}_frames']
         cube = fr.astype(np.float32) if fr.dtype == np.uint16 else fr          # uint16 -> float32 -> float64 is exact
-        r = apref.combine_ccdproc(cube, 5.0, 5.0)
+        r = apref.combine_ccdproc(cube, 5.0, 5.0, form='legacy')
         assert np.array_equal(r['count'], g[f'c{k}_count']), m
         assert_biteq(r['mean'], g[f'c{k}_mean'])
         assert_biteq(r['std'], g[f'c{k}_std'])
+        rb = apref.combine_ccdproc(cube, 5.0, 5.0)                              # the default: 'astropy'
+        assert np.array_equal(rb['count'], g[f'c{k}_b_count']), m
+        assert_biteq(rb['mean'], g[f'c{k}_b_mean'])
+        assert_biteq(rb['std'], g[f'c{k}_b_std'])
+        differ = g[f'c{k}_count'] != g[f'c{k}_b_count']
+        if m['kind'] == 'f64bounds':
+            disagree['f64bounds'] += int(differ.sum())
+        else:
+            # on finite data the two forms keep the same values; they part only where a column holds NaN / inf
+            nonfinite = ~np.isfinite(np.asarray(fr, dtype=np.float64)).all(axis=0)
+            assert not (differ & ~nonfinite).any(), m
+            disagree['nonfinite'] += int(differ.sum())
         if m['kind'] == 'f64ties' and m['N'] >= 8:
             col, base, dev = fr[:, 0, 0], g[f'c{k}_baseline'][0, 0], g[f'c{k}_dev'][0, 0]
             assert col[-2] - base == 5.0 * dev and col[-1] - base == -5.0 * dev      # exactly ON the bounds ...
-            assert g[f'c{k}_count'][0, 0] == m['N']                                 # ... and kept
+            assert g[f'c{k}_count'][0, 0] == m['N'] and g[f'c{k}_b_count'][0, 0] == m['N']   # ... and kept by both forms
             ties += 1
     assert ties == 5
+    assert disagree['nonfinite'] >= 6 and disagree['f64bounds'] >= 20, disagree
 
 
 # ---- G8: ApImageDifference / ApCalcReadNoise -------------------------------------------------------
