@@ -133,7 +133,7 @@ def _exchange(m, exchange, want_std, group):
     dist.all_reduce(m['buffer'] if (want_std and exchange == 'f64') else m['prefix'], op=dist.ReduceOp.SUM, group=group)
 
 
-def _exchange_rs(m, want_std, group, finalize, out_mean, out_std, count_dtype=torch.int32):
+def _exchange_rs(m, want_std, group, finalize, out_mean, out_std, count_dtype=torch.int32, gather=True):
     """The reduce-scatter form of one stripe (rows divisible by the world size): the float64 sum plane [h, W] (and sumsq,
     with a std) and the count plane - int32 as the kernels write it, or narrowed to float16 - are reduce-scattered by rows,
     the rank finalises ITS rows, the float32 result rows are all-gathered into out_mean (out_std).  Returns the rank's
@@ -152,6 +152,12 @@ def _exchange_rs(m, want_std, group, finalize, out_mean, out_std, count_dtype=to
     got = torch.empty((hb, W), dtype=count_dtype, device=cnt.device)
     dist.reduce_scatter_tensor(got, cnt.contiguous(), op=dist.ReduceOp.SUM, group=group)
     own['count'] = got if got.dtype == torch.int32 else got.to(torch.int32)
+    if not gather:
+        # the result stays ROW-DISTRIBUTED: the rank finalises its rows straight into the output image, nothing is gathered
+        # (what a job needs whose next step is row-parallel too - or whose product every rank writes as its own strip)
+        finalize(own, out_mean[rank * hb:(rank + 1) * hb], out_std[rank * hb:(rank + 1) * hb] if want_std else None, 'f64i')
+        own['rows'] = (rank * hb, (rank + 1) * hb)
+        return own
     my_mean = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device)
     my_std = torch.empty((hb, W), dtype=torch.float32, device=out_mean.device) if want_std else None
     finalize(own, my_mean, my_std, 'f64i')
@@ -173,15 +179,15 @@ def exchange_bytes_per_pixel(exchange='f64', want_std=False, count_bytes=4):
     return 24 if want_std else 16
 
 
-def exchange_bytes_on_wire(exchange, world, n_pixels, want_std=False, count_bytes=4):
+def exchange_bytes_on_wire(exchange, world, n_pixels, want_std=False, count_bytes=4, gather=True):
     """Bytes one rank SENDS per step for n_pixels output pixels (ring collectives): all-reduce = 2 (w-1)/w x payload;
-    'rs' = (w-1)/w x (payload + the float32 result planes that are all-gathered)."""
+    'rs' = (w-1)/w x (payload + the float32 result planes that are all-gathered - nothing with gather=False)."""
     if world <= 1:
         return 0
     f = (world - 1) / world
     payload = exchange_bytes_per_pixel(exchange, want_std, count_bytes)
     if exchange == 'rs':
-        return int(f * (payload + (8 if want_std else 4)) * n_pixels)
+        return int(f * (payload + ((8 if want_std else 4) if gather else 0)) * n_pixels)
     return int(2 * f * payload * n_pixels)
 
 
@@ -215,7 +221,7 @@ def _record(m, stream):
 
 def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std',
                  n_stripes=None, group=None, local_moments=None, finalize=None, return_moments=False, force_collective=False,
-                 exchange=None, want_std=False, hier_chunk=None, timings=None, exact=False, count_dtype=torch.int32):
+                 exchange=None, want_std=False, hier_chunk=None, timings=None, exact=False, count_dtype=torch.int32, gather=True):
     """N-sharded clipped mean: frames_local[n_local, H, W] on this rank -> mean[H, W] on every rank
     (want_std: (mean, std)).
 
@@ -225,6 +231,9 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     docstring.  timings: a list that receives one (start, end) pair of CUDA events per stripe around its all-reduce on the
     communication stream (bench.py's exchange_ms).  count_dtype ('rs'): torch.int32, or torch.float16 when the WHOLE job has
     at most 2048 frames (the caller's knowledge: a rank only sees its own).
+    gather=False ('rs' only, every stripe's rows divisible by the world size): no all-gather - the returned image holds THIS
+    rank's rows of every stripe (the rows own_rows(H, n_stripes, world, rank) names) and is undefined elsewhere: 10 bytes per
+    pixel x (world - 1) / world leave a rank per step (float16 count) where the gathered form sends 14 and the all-reduce 28.
     """
     if exchange is None:
         exchange = 'rs'
@@ -244,6 +253,11 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     if n_stripes is None:
         n_stripes = default_stripes(H, W, payload, want_std)
     clip = dict(sigma=sigma, maxiters=maxiters, cenfunc=cenfunc, stdfunc=stdfunc)
+    if not gather:
+        if exchange != 'rs':
+            raise ValueError("gather=False belongs to exchange='rs'")
+        if world > 1 and any((b - a) % world for a, b in stripe_rows(H, n_stripes)):
+            raise ValueError('gather=False needs every stripe\'s rows divisible by the world size (%d rows in %d stripes, world %d)' % (H, n_stripes, world))
     on_gpu = frames_local.is_cuda
     collective = (world > 1) or (force_collective and dist.is_available() and dist.is_initialized())
     stripes = stripe_rows(H, n_stripes if collective else 1)
@@ -273,7 +287,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
                     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     t0.record(comm)
                 if exchange == 'rs' and (r1 - r0) % world == 0:
-                    own = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype)
+                    own = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype, gather)
                     _record(own, comm)
                     if timings is not None:
                         t1.record(comm)
@@ -294,7 +308,7 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
         for (r0, r1) in stripes:
             m = local_moments(frames_local, calib, r0, r1, clip, payload)
             if collective and exchange == 'rs' and (r1 - r0) % world == 0:
-                m = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype)
+                m = _exchange_rs(m, want_std, group, finalize, mean[r0:r1], std[r0:r1] if want_std else None, count_dtype, gather)
             else:
                 if collective:
                     _exchange(m, payload, want_std, group)
@@ -303,6 +317,16 @@ def stack_nshard(frames_local, calib=None, sigma=3.0, maxiters=5, cenfunc='media
     out = (mean, std) if want_std else mean
     if return_moments:
         return out, parts
+    return out
+
+
+def own_rows(H, n_stripes, world_size, rank):
+    """The global row ranges [(a, b), ...] a rank holds after stack_nshard(.., exchange='rs', gather=False): its 1 / world of
+    every stripe."""
+    out = []
+    for r0, r1 in stripe_rows(H, n_stripes):
+        hb = (r1 - r0) // world_size
+        out.append((r0 + rank * hb, r0 + (rank + 1) * hb))
     return out
 
 

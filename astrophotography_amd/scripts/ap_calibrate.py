@@ -3,6 +3,11 @@
 
 Same positional arguments and flags as the reference script (scripts/ap_calibrate.py:40-122);
 ``--fixcosmic`` runs L.A.Cosmic (ApFixCosmicRays, csrc/lacosmic.hip) after the bad-pixel repair, as in the reference.
+
+Not in the reference: ``--batch LIST`` calibrates every "RAW.fits CALIBRATED.fits" pair of the text file LIST in THIS process
+(ApCalibrate.calibrate_files: masters read once, one slab, one launch; ``-`` in place of the two image arguments).  The
+reference's driver starts one interpreter per frame (scripts/calibrate_all.sh:406-411), which here costs ~1.5 s of start-up per
+frame against ~0.1 s of work (profiles/r06/frame_path.txt).
 """
 import argparse
 import logging
@@ -27,6 +32,10 @@ def command_line_opts(argv):
     parser.add_argument('--fixcosmic', default=False, action='store_true', help='If specified, cosmic rays will be removed with the L.A.Cosmic algorithm after bad pixel correction.')
     parser.add_argument('--dark_still_biased', default=False, action='store_true',
                         help='The master dark has NOT had the bias subtracted yet.')
+    parser.add_argument('--batch', metavar='LIST.TXT', default=None,
+                        help='Calibrate every "RAW.fits CALIBRATED.fits" pair listed in this text file in one process '
+                             '(INPUT_IMAGE.FITS and CALIBRATED_IMAGE.FITS are then ignored: pass -). Chunks of --batch_size frames.')
+    parser.add_argument('--batch_size', default=16, type=int, metavar='N', help='Frames per slab in --batch mode. Default: 16')
     parser.add_argument('-l', '--loglevel', default='INFO', help='Logging message level. Default: INFO')
     return parser.parse_args(argv)
 
@@ -36,6 +45,16 @@ def main(args=None):
     import astrophotography_amd as ap
     calibrator = ap.ApCalibrate(p_args.master_bias, p_args.master_dark, p_args.master_flat, p_args.master_badpix,
                                 p_args.loglevel, p_args.dark_still_biased)
+    if p_args.batch is not None:
+        with open(p_args.batch) as fh:
+            pairs = [ln.split() for ln in fh if ln.strip() and not ln.lstrip().startswith('#')]
+        if any(len(pr) != 2 for pr in pairs):
+            raise RuntimeError(f'{p_args.batch}: every line must hold "RAW.fits CALIBRATED.fits"')
+        n = max(1, int(p_args.batch_size))
+        for i in range(0, len(pairs), n):
+            chunk = pairs[i:i + n]
+            calibrator.calibrate_files([c[0] for c in chunk], [c[1] for c in chunk], p_args.deltapix, p_args.fixcosmic)
+        return 0
     calibrator.calibrate(p_args.raw_image, p_args.calibrated_image, p_args.deltapix, p_args.normflat, p_args.fixcosmic)
     return 0
 

@@ -68,6 +68,8 @@ def parse(argv=None):
                          'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
                          'affine Lanczos-3 resample + 5-iteration clipped mean, the per-GPU share 16 x 8192 x 8192 of 128 frames '
                          '(a bare --workload runs BASELINE\'s dimensions; --frames / --height / --width override them)')
+    ap.add_argument('--no-gather', action='store_true', help="N > 1, --exchange rs: leave the mean ROW-DISTRIBUTED (no all-gather of the "
+                    "result rows: 10 instead of 14 bytes per pixel on the wire); every rank keeps its rows of every stripe")
     ap.add_argument('--stripes', type=int, default=0, help='row stripes for collective/compute overlap (N > 1); 0 = by payload '
                                                             '(parallel.default_stripes: 4 for 4096 x 4096)')
     ap.add_argument('--hier-shards', type=int, default=8, help='--scaling strong: the job is this many shards of '
@@ -367,7 +369,7 @@ def main(argv=None):
                                      outputs=('mean',), exact=args.exact_moments)['mean']
         return parallel.stack_nshard(frames, calib, sigma=3.0, maxiters=5, n_stripes=n_stripes,
                                      force_collective=args.force_collective, exchange=args.exchange, hier_chunk=hier_chunk,
-                                     timings=timings, count_dtype=count_dtype)
+                                     timings=timings, count_dtype=count_dtype, gather=not (args.no_gather and args.exchange == 'rs'))
 
     for _ in range(args.warmup):
         out = step()
@@ -437,6 +439,18 @@ def main(argv=None):
 
     extra = {}
     if wl == 'c2' and not rowshard and not single_launch:
+        # (0) what one SCALE run needs to diagnose itself: the stripes' moment kernels alone (no collective: `compute_ms`, max over
+        # ranks), the collectives' time on the communication stream (`exchange_ms` above) and how much of it hid behind the
+        # kernels: overlap = (compute + exchange - step) / exchange, 1 = fully hidden, 0 = fully exposed
+        import functools
+        lm = functools.partial(parallel._default_local_moments, want_std=False, hier_chunk=hier_chunk, exact=False)
+        clipkw = dict(sigma=3.0, maxiters=5, cenfunc='median', stdfunc='std')
+        rows_of = parallel.stripe_rows(H, n_stripes if (world > 1 or args.force_collective) else 1)
+        cms = timed_extra(lambda: [lm(frames, calib, a, b, clipkw, payload) for a, b in rows_of], min(args.steps, 10))
+        extra['compute_ms'] = cms
+        if exchange_ms:
+            extra['exchange_overlap_frac'] = max(0.0, min(1.0, (cms + exchange_ms - ms_per_step) / exchange_ms))
+            extra['exposed_exchange_ms'] = max(0.0, ms_per_step - cms)
         # (1) strong scaling at one rank: the exact kernel on all frames beside the hierarchical reduction
         if strong and world == 1:
             ems = timed_extra(lambda: ops.stack_sigclip(frames, sigma=3.0, maxiters=5, calib=calib, outputs=('mean',)), min(args.steps, 5))
@@ -581,7 +595,9 @@ def main(argv=None):
                                             ' x %d shards' % (N // hier_chunk) if hier_chunk and N > hier_chunk else ''))
             line['exchange'] = args.exchange
             line['exchange_bytes_per_pixel'] = parallel.exchange_bytes_per_pixel(payload, count_bytes=count_bytes)
-            line['exchange_bytes_on_wire'] = parallel.exchange_bytes_on_wire(args.exchange, world, P, count_bytes=count_bytes)
+            line['exchange_bytes_on_wire'] = parallel.exchange_bytes_on_wire(args.exchange, world, P, count_bytes=count_bytes,
+                                                                             gather=not (args.no_gather and args.exchange == 'rs'))
+            line['exchange_gathered'] = not (args.no_gather and args.exchange == 'rs')
             if args.exchange == 'rs':
                 line['exchange_count_dtype'] = 'float16' if count_bytes == 2 else 'int32'
             line['exchange_ms'] = exchange_ms

@@ -203,6 +203,22 @@ def _rs_worker(rank, world, port, n_total, shape, out_dir):
     assert sum(c[3] for c in calls) == n_stripes * (8 + 2 + 4) * h * W
     assert torch.equal(mean_h, mean_rs)
     del calls[:]
+    # gather=False: the result stays row-distributed - two reduce-scatters per stripe and NO all-gather (10 bytes per pixel with
+    # the float16 count); the rank's rows (parallel.own_rows) equal the gathered form's, bit for bit
+    mean_d = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, count_dtype=torch.float16, gather=False, **kw)
+    assert [c[0] for c in calls] == ['reduce_scatter'] * (2 * n_stripes), calls
+    assert sum(c[3] for c in calls) == n_stripes * (8 + 2) * h * W
+    rows = parallel.own_rows(H, n_stripes, world, rank)
+    assert rows == [(k * h + rank * (h // world), k * h + (rank + 1) * (h // world)) for k in range(n_stripes)]
+    for a0, b0 in rows:
+        assert torch.equal(mean_d[a0:b0], mean_rs[a0:b0])
+    assert parallel.exchange_bytes_on_wire('rs', world, H * W, count_bytes=2, gather=False) == int((world - 1) / world * 10 * H * W)
+    try:
+        parallel.stack_nshard(mine, calib, n_stripes=3, gather=False, **kw)          # 6, 5, 5 rows: not divisible
+        assert world == 1
+    except ValueError:
+        pass
+    del calls[:]
     (mean_s, std_s), _ = parallel.stack_nshard(mine, calib, n_stripes=n_stripes, exchange='rs', want_std=True, return_moments=True, **kw)
     assert [c[0] for c in calls] == (['reduce_scatter'] * 3 + ['all_gather'] * 2) * n_stripes, calls
     del calls[:]

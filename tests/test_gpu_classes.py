@@ -249,9 +249,11 @@ def test_stack_mad_std_vs_oracle():
             what = f'N={N} sigma={sigma} maxiters={maxiters} cen={cen}'
             assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
             assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
-        c = apref.combine_ccdproc(cube, 5.0, 5.0)
-        r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count'))
-        assert np.array_equal(r['count'].cpu().numpy(), c['count'])
+        for form, flag in (('legacy', False), ('astropy', True)):
+            c = apref.combine_ccdproc(cube, 5.0, 5.0, form=form)
+            r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count'),
+                                  nonfinite_unclipped=flag)
+            assert np.array_equal(r['count'].cpu().numpy(), c['count']), (N, form)
 
 
 def test_nshard_collective_path_on_one_gpu():
@@ -483,6 +485,21 @@ def test_read_slab_device_and_float64_masters(tmp_path):
     ref = apref.combine_ccdproc(frames, 5.0, 5.0)
     assert_biteq(r['mean_f64'].cpu().numpy(), ref['mean'])
     assert_biteq(r['std_f64'].cpu().numpy(), ref['std'])
+    # both published forms on the float64 kernel, every float64 case of G12 - including the columns on which they disagree
+    # (values within an ulp of base +- 5 dev: group f64bounds) - bit for bit the golden arrays (numpy.ma + astropy run for real)
+    nd = 0
+    for mm in json.loads(str(g['_meta'])):
+        if mm['kind'] not in ('f64ties', 'f64bounds'):
+            continue
+        kk = mm['case']
+        fr = torch.from_numpy(g[f'c{kk}_frames']).cuda()
+        for form, tag in (('legacy', ''), ('astropy', 'b_')):
+            rr = ops.combine_f64(fr, form=form)
+            assert np.array_equal(rr['count'].cpu().numpy(), g[f'c{kk}_{tag}count']), (mm, form)
+            assert_biteq(rr['mean_f64'].cpu().numpy(), g[f'c{kk}_{tag}mean'])
+            assert_biteq(rr['std_f64'].cpu().numpy(), g[f'c{kk}_{tag}std'])
+        nd += int((g[f'c{kk}_count'] != g[f'c{kk}_b_count']).sum())
+    assert nd >= 20
 
     # float64 masters (what ApMasterCal writes) -> ApCalibrate -> ApStack.stack_files(calibrator=...)
     N = 8

@@ -257,24 +257,35 @@ def _ccdproc_fast_case(ops, apref, N, dtype, H, W):
         cube[1, 7, 10:40] = np.nan
         cube[2, 7, 50] = np.inf
         cube[:, 7, 60] = np.nan
-    ref = apref.combine_ccdproc(cube.astype(np.float32) if dtype == np.uint16 else cube)
     d = dev(cube, ops)
-    ops.stack_redo_stats(reset=True)
-    r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count', 'mean_f64', 'std_f64'))
-    st = ops.stack_redo_stats()
-    what = '%d frames %s' % (N, np.dtype(dtype).name)
-    assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
-    np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
-    assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
-    np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=what)
-    nblocks = (H * W + 63) // 64
-    assert st['calls'] == 1 and st['pixels'] == H * W and 0 < st['blocks_given_up'] < (0.5 if N >= 8 else 0.9) * nblocks, (what, st)
-    assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W), what
-    # the same call on the rich kernel alone, and without a workspace: same numbers
-    for kw in (dict(single_kernel=True), dict(workspace=False)):
-        r2 = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean_f64', 'count'), **kw)
-        assert np.array_equal(r2['count'].cpu().numpy(), ref['count']), (what, kw)
-        np.testing.assert_allclose(r2['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+    what0 = '%d frames %s' % (N, np.dtype(dtype).name)
+    # both published forms of Combiner.sigma_clipping (golden group G12): 'legacy' masks non-finite values and clips the rest,
+    # 'astropy' (APGPU_STACK_NONFINITE_UNCLIPPED) leaves a column that holds one unclipped
+    for form, flag in (('legacy', False), ('astropy', True)):
+        what = what0 + ' ' + form
+        ref = apref.combine_ccdproc(cube.astype(np.float32) if dtype == np.uint16 else cube, form=form)
+        ops.stack_redo_stats(reset=True)
+        r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count', 'mean_f64', 'std_f64'),
+                              nonfinite_unclipped=flag)
+        st = ops.stack_redo_stats()
+        assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
+        np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+        assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
+        np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=what)
+        nblocks = (H * W + 63) // 64
+        assert st['calls'] == 1 and st['pixels'] == H * W and 0 < st['blocks_given_up'] < (0.5 if N >= 8 else 0.9) * nblocks, (what, st)
+        assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W), what
+        # the same call on the rich kernel alone, and without a workspace: same numbers
+        for kw in (dict(single_kernel=True), dict(workspace=False)):
+            r2 = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean_f64', 'count'),
+                                   nonfinite_unclipped=flag, **kw)
+            assert np.array_equal(r2['count'].cpu().numpy(), ref['count']), (what, kw)
+            np.testing.assert_allclose(r2['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+    if dtype == np.float32 and N >= 16:
+        # the forms part on the columns of row 7 that hold a NaN / inf (unless nothing is rejected there anyway)
+        a = apref.combine_ccdproc(cube, form='legacy')['count']
+        b = apref.combine_ccdproc(cube, form='astropy')['count']
+        assert (a != b).any() and np.array_equal(a[:7], b[:7]) and np.array_equal(a[8:], b[8:])
 
 
 def test_ccdproc_configuration_guard(ops, apref):
@@ -287,7 +298,7 @@ def test_ccdproc_configuration_guard(ops, apref):
     bad = clean.copy()
     bad[3].reshape(-1)[::61] = np.nan                        # at least one NaN per 64-pixel block
     nblocks = H * W // 64
-    ref = {id(clean): apref.combine_ccdproc(clean), id(bad): apref.combine_ccdproc(bad)}
+    ref = {id(clean): apref.combine_ccdproc(clean, form='legacy'), id(bad): apref.combine_ccdproc(bad, form='legacy')}
     dc, db = dev(clean, ops), dev(bad, ops)
 
     def call(d, cube):
