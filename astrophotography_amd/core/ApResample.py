@@ -35,12 +35,13 @@ class ApResample:
         if not 1 <= self.oversampling <= 16:
             raise ValueError(f'Error, oversampling {oversampling} is not in 1..16')
 
-    def coadd(self, frames, affines, fscale=None, mask=None, out_shape=None, weights=None, fine_affines=None):
-        """frames [N,H,W] float32 device tensor -> dict(image, count[, weight]) device tensors."""
+    def coadd(self, frames, affines, fscale=None, mask=None, out_shape=None, weights=None, fine_affines=None, fused=False):
+        """frames [N,H,W] float32 device tensor -> dict(image, count[, weight]) device tensors.  fused: ops.coadd's one-launch
+        form (CLIPPED / AVERAGE of up to 16 frames, no resampled slab in memory)."""
         from .. import ops
         return ops.coadd(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, combine=self.combine,
                          sigma=self.sigma, maxiters=self.maxiters, n_phases=self.n_phases, conserve_flux=self.conserve_flux,
-                         oversampling=self.oversampling, weights=weights, fine_affines=fine_affines)
+                         oversampling=self.oversampling, weights=weights, fine_affines=fine_affines, fused=fused)
 
     def _output_gain(self, gains, fscale, weights):
         """Effective gain of the co-add in electrons per output unit, written as GAIN when every input carries the

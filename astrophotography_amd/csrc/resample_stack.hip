@@ -85,9 +85,18 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(const int *__restrict__ 
     }
 }
 
+// The tile records are read through the CONSTANT address space: the record pointer is an ordinary kernel argument inside a struct
+// (no __restrict__), the kernel stores to global memory, so the compiler would read a record with VECTOR loads - and wait for them
+// with vmcnt(0), i.e. for every footprint load in flight as well (the counter is in order): the first build of the kernels below
+// ran the frames of a tile strictly one after the other for this reason alone (8.6 ms per 16 x 8192^2 against 5.1 for the two-step
+// form; profiles/r06/bench_fused_v1.txt).  Nothing writes the records during the kernel: scalar loads.
+typedef const TileRec __attribute__((address_space(4))) CTileRec;
+__device__ __forceinline__ CTileRec *crec(const TileRec *p) { return (CTileRec *)(uintptr_t)p; }
+
 // The tile of frame f: record -> context (tile-uniform: scalar loads).
-__device__ __forceinline__ unsigned load_tile(const TileRec *rp, TileCtx &tc)
+__device__ __forceinline__ unsigned load_tile(const TileRec *rpg, TileCtx &tc)
 {
+    CTileRec *rp = crec(rpg);
 #pragma unroll
     for (int k = 0; k < 6; k++) tc.F[k] = rp->F[k];
     tc.bx0 = rp->bx0;
@@ -248,12 +257,434 @@ __global__ __launch_bounds__(256, 3) void resample_clip_kernel(const StackParams
     }
 }
 
+// ---- the same, built for latency (v2) -------------------------------------------------------------------------------------
+// v1 above runs one frame of a tile after the other with three dependent memory round trips per frame (tile record -> footprint
+// loads -> barrier -> weight-table gathers) and three workgroups per CU to overlap them: 7.6 ms per 16 x 8192^2 where the two-step
+// form takes 5.1 (profiles/r06/bench_fused_v1.txt).  Here
+//   * a workgroup has 512 threads - two pixels per lane: 32 instead of 64 registers of columns - and stays under 128 VGPRs:
+//     four wavefronts per SIMD;
+//   * the Lanczos weight table (up to 1025 rows of 24 bytes) is copied into LDS once per workgroup: a pixel's two table rows are
+//     six ds_read_b64 instead of four gathers from memory (in resample_affine_kernel the gathers were what the kernel waited for;
+//     staging the table lost there because its LDS cost occupancy - here the registers bound the occupancy first);
+//   * the footprints of the next TWO frames are on their way while a frame is evaluated (two register sets, two LDS buffers,
+//     ONE barrier per frame): per CU four footprint fills are in flight at any time.
+// Tiles with a frame off the fast path (frame borders, large transforms, masks applied at the fill) take the frame-by-frame
+// loop of v1 with this kernel's geometry.  Tables of more than 1024 phases: v1.
+struct FusedGeom {
+    static constexpr int kThreads = 512;
+    static constexpr int kRowsPerTrip = 6;                                  // 480 of the 512 lanes: six footprint rows of 80 columns
+    static constexpr int kTrips = 5;                                        // 30 rows >= 16 + 10
+    static constexpr int kCopy = kFastPitch * kRowsPerTrip * kTrips;        // 2400 floats per copy
+    static constexpr int kOffB = ((kCopy + 1 + 31) / 64) * 64 + 32;         // copy B: 32 banks after copy A (resample_core.h, FastGeom)
+    static constexpr int kBuf = kOffB + kCopy;                              // 4864 floats = 19 KB per buffer
+    static constexpr int kTableRows = 1025, kTableFloats = kTableRows * 6;  // 24.6 KB
+    static_assert(kOffB % 64 == 32 && kBuf >= kGenericFloats && kTileH + 10 <= kRowsPerTrip * kTrips, "LDS layout");
+};
+
+template <bool HAS_MASK>
+struct FusedFill {
+    float val[FusedGeom::kTrips];
+    char mk[FusedGeom::kTrips];
+};
+
+// EVERY lane issues EVERY trip's load, unconditionally: the compiler's wait-count pass can then count the loads in flight (behind
+// "if (row < fh && tid < 480)" each load sat in its own exec-masked block, their number was unknown, and every wait for one
+// footprint became vmcnt(0) - a wait for the footprints fetched ahead as well).  Rows beyond the footprint's height and the lanes
+// 480 .. 511 (which address the first columns of the next trip's first row) read inside the frame's buffer or get the bounds
+// check's 0; fused_fill_store drops them.
+template <bool HAS_MASK>
+__device__ __forceinline__ void fused_fill_issue(FusedFill<HAS_MASK> &ff, const float *src, const uint8_t *mask, int bx0, int by0, int fh,
+                                                 int h_in, int w_in, int tid)
+{
+    using G = FusedGeom;
+    const v4i irsrc = make_rsrc(src, (unsigned)(h_in * w_in) * 4u);
+    const v4i mrsrc = make_rsrc(mask, (unsigned)(h_in * w_in));
+    const int r = tid / kFastPitch, c = tid - r * kFastPitch;
+    const int e0 = (by0 + r) * w_in + bx0 + c;
+    const int estep = G::kRowsPerTrip * w_in;
+#pragma unroll
+    for (int k = 0; k < G::kTrips; k++) {
+        ff.val[k] = apgpu_buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
+        if constexpr (HAS_MASK) ff.mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
+        else ff.mk[k] = 0;
+    }
+}
+
+template <bool HAS_MASK>
+__device__ __forceinline__ void fused_fill_store(const FusedFill<HAS_MASK> &ff, int fh, float *tile, int tid)
+{
+    using G = FusedGeom;
+#pragma unroll
+    for (int k = 0; k < G::kTrips; k++) {
+        if (G::kRowsPerTrip * k < fh && tid < G::kRowsPerTrip * kFastPitch) {
+            const bool good = (fabsf(ff.val[k]) < __builtin_inff()) && ff.mk[k] == 0;
+            const float xv = good ? ff.val[k] : __builtin_nanf("");
+            tile[tid + G::kRowsPerTrip * kFastPitch * k] = xv;                  // copy A
+            tile[G::kOffB - 1 + tid + G::kRowsPerTrip * kFastPitch * k] = xv;   // copy B: element e - 1
+        }
+    }
+}
+
+// One pixel of a fast tile, weights from the LDS copy of the table: the arithmetic of eval_fast, operation for operation.
+__device__ __forceinline__ float eval_fast_lds(unsigned long long Xr, unsigned long long Yr, int sh, const float *tile, const float *tab)
+{
+    int js, jr, px, py;
+    phases(Xr, Yr, sh, js, jr, px, py);
+    FastPrep p;
+    typedef __attribute__((address_space(3))) const v2f *lds_v2f;
+    lds_v2f wxp = (lds_v2f)(tab + 6 * px), wyp = (lds_v2f)(tab + 6 * py);
+    p.w.wx01 = wxp[0]; p.w.wx23 = wxp[1]; p.w.wx45 = wxp[2];
+    p.w.wy01 = wyp[0]; p.w.wy23 = wyp[1]; p.w.wy45 = wyp[2];
+    const unsigned s = (unsigned)js, r = (unsigned)jr;
+    p.idx = (int)mad_u24(s & 1u, (unsigned)(FusedGeom::kOffB - 1), mad_u24(r, (unsigned)kFastPitch, s));
+    return eval_fast(p, tile);
+}
+
+// Two VERTICALLY ADJACENT pixels of a fast tile at once (rows y and y + 1 of one column).  For a registration-sized transform
+// the lower pixel's window is the same six columns one input row further down - then the two windows share five of their six
+// rows: the seven rows are read ONCE (21 ds_read_b64 instead of 36) and every row feeds both pixels' sums, each in its own order
+// (row j is row j of the upper window and row j - 1 of the lower one: per pixel exactly eval_fast's sequence of operations).  The
+// y weights of the lower pixel are those of the upper one unless its phase moved on (read again behind a wave vote); a wavefront
+// in which some lane's windows do not line up (the column or the copy changed: every 1 / |sin(rotation)| rows) evaluates the two
+// pixels one after the other.  LDS reads per pixel: 15 instead of 24 - with the weight table in LDS the fused kernel's evaluation
+// was bound by LDS bandwidth (profiles/r06/ablate_fused.txt).
+__device__ __forceinline__ void eval_pair_lds(unsigned long long Xr, unsigned long long Yr, unsigned long long F1, unsigned long long F4, int sh,
+                                              const float *tile, const float *tab, float &v0, float &v1)
+{
+    typedef __attribute__((address_space(3))) const v2f *lds_v2f;
+    int js0, jr0, px0, py0, js1, jr1, px1, py1;
+    phases(Xr, Yr, sh, js0, jr0, px0, py0);
+    phases(Xr + F1, Yr + F4, sh, js1, jr1, px1, py1);
+    const unsigned s0 = (unsigned)js0, r0 = (unsigned)jr0, s1 = (unsigned)js1, r1 = (unsigned)jr1;
+    const int idx0 = (int)mad_u24(s0 & 1u, (unsigned)(FusedGeom::kOffB - 1), mad_u24(r0, (unsigned)kFastPitch, s0));
+    const int idx1 = (int)mad_u24(s1 & 1u, (unsigned)(FusedGeom::kOffB - 1), mad_u24(r1, (unsigned)kFastPitch, s1));
+    lds_v2f wa = (lds_v2f)(tab + 6 * px0), wb = (lds_v2f)(tab + 6 * px1), wc = (lds_v2f)(tab + 6 * py0);
+    const v2f ax01 = wa[0], ax23 = wa[1], ax45 = wa[2];
+    const v2f bx01 = wb[0], bx23 = wb[1], bx45 = wb[2];
+    v2f ay01 = wc[0], ay23 = wc[1], ay45 = wc[2];
+    v2f by01 = ay01, by23 = ay23, by45 = ay45;
+    if (__builtin_amdgcn_ballot_w64(py1 != py0) != 0) {
+        lds_v2f wd = (lds_v2f)(tab + 6 * py1);
+        by01 = wd[0]; by23 = wd[1]; by45 = wd[2];
+    }
+    if (__builtin_amdgcn_ballot_w64(idx1 != idx0 + kFastPitch) == 0) {
+        lds_pair_p t = (lds_pair_p)(tile + idx0);
+        const float ay[6] = {ay01.x, ay01.y, ay23.x, ay23.y, ay45.x, ay45.y};
+        const float by[6] = {by01.x, by01.y, by23.x, by23.y, by45.x, by45.y};
+        v2f V0 = {0.f, 0.f}, V1 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const v2f q0 = t[j * (kFastPitch / 2) + 0], q1 = t[j * (kFastPitch / 2) + 1], q2 = t[j * (kFastPitch / 2) + 2];
+            if (j < 6) {
+                v2f acc = ax01 * q0;
+                acc = __builtin_elementwise_fma(ax23, q1, acc);
+                acc = __builtin_elementwise_fma(ax45, q2, acc);
+                const v2f w = {ay[j], ay[j]};
+                V0 = (j == 0) ? w * acc : __builtin_elementwise_fma(w, acc, V0);
+            }
+            if (j > 0) {
+                v2f acc = bx01 * q0;
+                acc = __builtin_elementwise_fma(bx23, q1, acc);
+                acc = __builtin_elementwise_fma(bx45, q2, acc);
+                const v2f w = {by[j - 1], by[j - 1]};
+                V1 = (j == 1) ? w * acc : __builtin_elementwise_fma(w, acc, V1);
+            }
+            if (j == 2 || j == 4) __builtin_amdgcn_sched_barrier(0);
+        }
+        v0 = V0.x + V0.y;
+        v1 = V1.x + V1.y;
+    } else {
+        FastPrep p0, p1;
+        p0.w.wx01 = ax01; p0.w.wx23 = ax23; p0.w.wx45 = ax45; p0.w.wy01 = ay01; p0.w.wy23 = ay23; p0.w.wy45 = ay45; p0.idx = idx0;
+        p1.w.wx01 = bx01; p1.w.wx23 = bx23; p1.w.wx45 = bx45; p1.w.wy01 = by01; p1.w.wy23 = by23; p1.w.wy45 = by45; p1.idx = idx1;
+        v0 = eval_fast(p0, tile);
+        v1 = eval_fast(p1, tile);
+    }
+}
+
+#ifndef APGPU_FUSED_ABLATE
+#define APGPU_FUSED_ABLATE 0                                 // development (tools/variant_lib.sh): 1 no window evaluation, 2 no footprint fills,
+#endif                                                       // 4 no table copy, 8 no clip (timing only: results are garbage)
+template <int NP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void resample_clip_kernel_v2(const StackParams prm, const FusedArgs fa)
+{
+    static_assert(NP % 4 == 0 && NP >= 4 && NP <= 16, "column slots");
+    using G = FusedGeom;
+    constexpr int TH = kTileH;
+    __shared__ __attribute__((aligned(16))) float bufs[2][G::kBuf];
+    __shared__ __attribute__((aligned(16))) float tab[G::kTableFloats];
+    const int per_frame = fa.gx * fa.gy;
+    const int chunk = (per_frame + 7) >> 3;
+    const int rem = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if (rem >= per_frame) return;
+    const int tyi = rem / fa.gx, txi = rem - tyi * fa.gx;
+    const int x0 = txi * kTileW, y0 = tyi * TH;
+    const int tid = threadIdx.x;
+    const int lx = tid % kTileW, ly = 2 * (tid / kTileW);      // the lane's pixels: column x0 + lx, rows y0 + ly and y0 + ly + 1
+    const int x = x0 + lx;
+    const int h_in = fa.h_in, w_in = fa.w_in, h_out = fa.h_out, w_out = fa.w_out;
+    const int sh = 32 - fa.log2_phases;
+    const int N = fa.n_frames;
+    const bool list_overflow = fa.mask != nullptr && fa.mask_ctl[0] > fa.mask_cap;
+    const TileRec *const rec0 = fa.recs + rem;
+    // the tile's N records -> LDS with ONE coalesced load (16 lanes per 64-byte record): read frame by frame with scalar loads, each
+    // first touch of a record was a memory round trip in front of a barrier - 2.1 ms of the first v2's 7.5 (ablate_fused.txt)
+    __shared__ __attribute__((aligned(16))) unsigned rl[16 * 16];
+    __shared__ int nlist;
+    if (tid < N * 16) rl[tid] = reinterpret_cast<const unsigned *>(rec0 + (int64_t)(tid >> 4) * per_frame)[tid & 15];
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    auto rdw = [&](int f, int k) { return (unsigned)__builtin_amdgcn_readfirstlane((int)rl[f * 16 + k]); };     // dword k of frame f's record
+    auto rec_ctx = [&](int f, TileCtx &tc) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) tc.F[k] = (long long)(((unsigned long long)rdw(f, 2 * k + 1) << 32) | rdw(f, 2 * k));
+        tc.bx0 = (int)rdw(f, 12);
+        tc.by0 = (int)rdw(f, 13);
+        const unsigned dims = rdw(f, 14);
+        tc.fw = (int)(dims & 0xfffu);
+        tc.fh = (int)((dims >> 12) & 0xfffu);
+        const unsigned flags = dims >> 24;
+        tc.staged = (flags & kStaged) != 0;
+        tc.sane_top = (flags & kSaneTop) != 0;
+        tc.sane_bot = (flags & kSaneBot) != 0;
+        tc.fs = __uint_as_float(rdw(f, 15));
+        return flags;
+    };
+    // every frame's tile on the fast path, no mask at the fill?  (lane f of every wavefront looks at frame f)
+    bool all_fast;
+    {
+        const int f = tid & 63;
+        bool bad = false;
+        if (f < N) {
+            const unsigned flags = rl[f * 16 + 14] >> 24;
+            bad = (flags & kFast) == 0 || (fa.mask != nullptr && ((flags & kInlineMask) != 0 || list_overflow));
+        }
+        all_fast = __builtin_amdgcn_ballot_w64(bad) == 0;
+    }
+    v16f col[2];
+    col[0] = v16f(__builtin_inff());
+    col[1] = v16f(__builtin_inff());
+    const float *const frames = static_cast<const float *>(prm.frames);
+    const int64_t fstride = prm.stride;
+
+    if (all_fast) {
+        // Two register sets (fA, fB) and two LDS buffers; every step issues the loads of the frame two ahead UNCONDITIONALLY (the
+        // last steps fetch the last frame again: a cache hit) and stores the set fetched one step ago - straight-line code with the
+        // same number of loads in flight at the loop's entry and at its back edge, so that the compiler's wait counts are exact
+        // (vmcnt(5) in front of a store: the five loads just issued stay in flight).  With the fetch behind "if (g + 2 < N)" the
+        // join of the two paths made every wait a vmcnt(0).
+        FusedFill<false> fA, fB;
+        auto issue = [&](FusedFill<false> &ff, int g) {
+            const int gc = g < N ? g : N - 1;
+            fused_fill_issue<false>(ff, frames + (int64_t)gc * fstride, nullptr, (int)rdw(gc, 12), (int)rdw(gc, 13), 0, h_in, w_in, tid);
+        };
+        auto store = [&](const FusedFill<false> &ff, int g, float *buf) {
+            const int gc = g < N ? g : N - 1;
+            fused_fill_store<false>(ff, (int)((rdw(gc, 14) >> 12) & 0xfffu), buf, tid);
+        };
+        issue(fA, 0);
+        if (!(APGPU_FUSED_ABLATE & 4)) {
+            // the weight table -> LDS ((2^log2_phases + 1) rows of 6 floats; 8-byte aligned)
+            const int nfl2 = (((1 << fa.log2_phases) + 1) * 6) / 2;
+            const v2f *src = reinterpret_cast<const v2f *>(fa.lut);
+            v2f *dst = reinterpret_cast<v2f *>(tab);
+            for (int i = tid; i < nfl2; i += G::kThreads) dst[i] = src[i];
+        }
+        store(fA, 0, bufs[0]);
+        __syncthreads();
+        issue(fB, 1);
+#pragma unroll 1
+        for (int f = 0; f < N; f += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                      // h = 0: frame g in bufs[0], set B in flight, set A re-issued; h = 1: the mirror image
+                const int g = f + h;
+                FusedFill<false> &fetch = h == 0 ? fA : fB;    // receives frame g + 2
+                FusedFill<false> &ready = h == 0 ? fB : fA;    // holds frame g + 1 (issued one step ago)
+                if (!(APGPU_FUSED_ABLATE & 2)) issue(fetch, g + 2);
+                TileCtx tc;
+                rec_ctx(g, tc);
+                float r0v = __builtin_nanf(""), r1v = __builtin_nanf("");
+                if (x < w_out && !(APGPU_FUSED_ABLATE & 1)) {
+                    const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
+                    const unsigned long long us = (unsigned long long)(long long)x0, vs = (unsigned long long)(long long)y0;
+                    const unsigned long long Xs = F0 * us + F1 * vs + F2 - ((unsigned long long)(unsigned)(tc.bx0 + 2) << 32);
+                    const unsigned long long Ys = F3 * us + F4 * vs + F5 - ((unsigned long long)(unsigned)(tc.by0 + 2) << 32);
+                    const unsigned long long X = Xs + F0 * (unsigned long long)(unsigned)lx + F1 * (unsigned long long)(unsigned)ly;
+                    const unsigned long long Y = Ys + F3 * (unsigned long long)(unsigned)lx + F4 * (unsigned long long)(unsigned)ly;
+                    float v0, v1;
+                    eval_pair_lds(X, Y, F1, F4, sh, bufs[h], tab, v0, v1);
+                    r0v = (v0 == v0) ? v0 * tc.fs : __builtin_nanf("");
+                    r1v = (v1 == v1) ? v1 * tc.fs : __builtin_nanf("");
+                }
+                col[0][g] = r0v;
+                col[1][g] = r1v;
+                if (!(APGPU_FUSED_ABLATE & 2)) store(ready, g + 1, bufs[h ^ 1]);
+                __syncthreads();
+                if (g + 1 >= N) break;
+            }
+        }
+    } else {
+        // frame by frame (v1's loop): any path per frame, the mask at the fill where the tile asks for it
+        float *const tile = bufs[0];
+        const v4i lrsrc = make_rsrc(fa.lut, (unsigned)((1 << fa.log2_phases) + 1) * 24u);
+#pragma unroll 1
+        for (int f = 0; f < N; f++) {
+            TileCtx tc;
+            const unsigned flags = rec_ctx(f, tc);
+            const bool fast = (flags & kFast) != 0, interior = (flags & kInterior) != 0;
+            FrameView fv;
+            fv.src = frames + (int64_t)f * fstride;
+            fv.mask = nullptr;
+            fv.h_in = h_in;
+            fv.w_in = w_in;
+            const bool inline_mask = fa.mask != nullptr && ((flags & kInlineMask) != 0 || list_overflow);
+            if (inline_mask) fv.mask = fa.mask;
+            if (f > 0) __syncthreads();
+            if (fast) {
+                if (inline_mask) {
+                    FusedFill<true> ff;
+                    fused_fill_issue<true>(ff, fv.src, fa.mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+                    fused_fill_store<true>(ff, tc.fh, tile, tid);
+                } else {
+                    FusedFill<false> ff;
+                    fused_fill_issue<false>(ff, fv.src, fa.mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+                    fused_fill_store<false>(ff, tc.fh, tile, tid);
+                }
+            } else if (tc.staged) {
+                if (inline_mask) general_fill<true>(tc, fv, tile, tid);
+                else general_fill<false>(tc, fv, tile, tid);
+            }
+            __syncthreads();
+            float r[2] = {__builtin_nanf(""), __builtin_nanf("")};
+            if (x < w_out) {
+                const unsigned long long F0 = tc.F[0], F1 = tc.F[1], F2 = tc.F[2], F3 = tc.F[3], F4 = tc.F[4], F5 = tc.F[5];
+                if (fast) {
+                    const unsigned long long us = (unsigned long long)(long long)x0, vs = (unsigned long long)(long long)y0;
+                    const unsigned long long Xs = F0 * us + F1 * vs + F2 - ((unsigned long long)(unsigned)(tc.bx0 + 2) << 32);
+                    const unsigned long long Ys = F3 * us + F4 * vs + F5 - ((unsigned long long)(unsigned)(tc.by0 + 2) << 32);
+                    unsigned long long X = Xs + F0 * (unsigned long long)(unsigned)lx + F1 * (unsigned long long)(unsigned)ly;
+                    unsigned long long Y = Ys + F3 * (unsigned long long)(unsigned)lx + F4 * (unsigned long long)(unsigned)ly;
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const FastPrep cur = prep_fast<G::kOffB>(X, Y, sh, lrsrc);
+                        X += F1;
+                        Y += F4;
+                        const float v = eval_fast(cur, tile);
+                        r[k] = (v == v) ? v * tc.fs : __builtin_nanf("");
+                    }
+                } else {
+                    const unsigned long long u0 = (unsigned long long)(long long)x, v0 = (unsigned long long)(long long)(y0 + ly);
+                    unsigned long long X = F0 * u0 + F1 * v0 + F2;
+                    unsigned long long Y = F3 * u0 + F4 * v0 + F5;
+#pragma unroll 1
+                    for (int k = 0; k < 2; k++) {
+                        if (y0 + ly + k < h_out) {
+                            const float sv = interior ? sample_general<true>(tc, fv, tile, fa.lut, X, Y, sh, tc.sane_top)
+                                                      : sample_general<false>(tc, fv, tile, fa.lut, X, Y, sh, tc.sane_top);
+                            r[0] = k == 0 ? sv : r[0];
+                            r[1] = k == 1 ? sv : r[1];
+                        }
+                        X += F1;
+                        Y += F4;
+                    }
+                }
+            }
+            col[0][f] = r[0];
+            col[1][f] = r[1];
+        }
+    }
+
+    // The reduction: the lane's two columns on the float32 fast path, one after the other.  A pixel the fast path cannot finish
+    // (an unsure comparison, too many sentinels) needs the exact float64 clip - and here nearly EVERY wavefront holds one (C5: 6 % of
+    // the pixels - the footprints of bad pixels, the frames' borders - i.e. 98 % of the 64-pixel wavefronts): running the exact clip
+    // wavefront by wavefront, as the complete stack kernels do, cost 2.4 ms of the first v2's 7.5.  So such pixels are LISTED - pixel
+    // index + the 16 values, in the LDS the footprints no longer need - and the workgroup reduces its list afterwards, one pixel per
+    // lane, densely: about one wavefront's worth per workgroup.  (A list that overflows: the pixel is reduced on the spot.)
+    if (APGPU_FUSED_ABLATE & 8) {
+        if (x < w_out && y0 + ly + 1 < h_out && prm.mean) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int f = 0; f < NP; f++) { a0 += col[0][f]; a1 += col[1][f]; }
+            prm.mean[(int64_t)(y0 + ly) * w_out + x] = a0;
+            prm.mean[(int64_t)(y0 + ly + 1) * w_out + x] = a1;
+        }
+        return;
+    }
+    constexpr int kEntry = 18;                                 // pixel index (2 dwords) + 16 values
+    constexpr int kListCap = (2 * G::kBuf) / kEntry;
+    unsigned *const list = reinterpret_cast<unsigned *>(&bufs[0][0]);
+    __syncthreads();                                           // the last frame's windows have been read: the footprint buffers are free
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {
+        const int y = y0 + ly + k;
+        const bool inside = x < w_out && y < h_out;
+        const int64_t p = inside ? (int64_t)y * w_out + x : 0;
+        const v16f cur = k == 0 ? col[0] : col[1];
+        const uint32_t hit = (fa.bits && inside) ? fa.bits[p] : 0u;
+        float c[NP];
+        int n = 0;
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            const float xv = cur[f];
+            const bool ok = (fabsf(xv) < __builtin_inff()) && ((hit >> f) & 1u) == 0u;
+            c[f] = ok ? xv : __builtin_inff();
+            n += ok ? 1 : 0;
+        }
+        bool good = false;
+        if constexpr (NP >= 16) {
+            constexpr int T = 6;
+            if (fast32_wanted(prm)) {
+                good = inside;
+                sort_column<NP, T>(c);
+                int nonfin = 0;
+#pragma unroll
+                for (int j = 1; j <= T; j++) nonfin += (c[NP - j] == __builtin_inff()) ? 1 : 0;
+                good = good && nonfin < T;
+                if (wave_any(good)) finish_fast_column<NP, T, false>(c, good, p, 0, nonfin);
+            }
+        }
+        if (inside && !good) {
+            const int slot = atomicAdd(&nlist, 1);
+            if (slot < kListCap) {
+                unsigned *e = list + slot * kEntry;
+                e[0] = (unsigned)p;
+                e[1] = (unsigned)((unsigned long long)p >> 32);
+#pragma unroll
+                for (int f = 0; f < NP; f++) e[2 + f] = __float_as_uint(c[f]);
+            } else {
+                sort_column<NP>(c);                            // (complete: after the pruned network, or unsorted)
+                const StackParams q = read_params(late_params());
+                reduce_and_store<NP, NP>(q, c, n, p, false, false);
+            }
+        }
+    }
+    __syncthreads();
+    const int nl = nlist < kListCap ? nlist : kListCap;
+#pragma unroll 1
+    for (int i = tid; i < nl; i += G::kThreads) {
+        const unsigned *e = list + i * kEntry;
+        const int64_t p = (int64_t)(((unsigned long long)e[1] << 32) | e[0]);
+        float c[NP];
+        int n = 0;
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            c[f] = __uint_as_float(e[2 + f]);
+            n += (c[f] < __builtin_inff()) ? 1 : 0;            // the sentinels are +inf; every other value is finite
+        }
+        sort_column<NP>(c);
+        const StackParams q = read_params(late_params());
+        reduce_and_store<NP, NP>(q, c, n, p, false, false);
+    }
+}
+
 template <int NP>
 void launch_fused(const StackParams &prm, const FusedArgs &fa, hipStream_t st)
 {
     const int per_frame = fa.gx * fa.gy;
     const unsigned grid = (unsigned)(((per_frame + 7) / 8) * 8);
-    hipLaunchKernelGGL((resample_clip_kernel<NP>), dim3(grid), dim3(256), 0, st, prm, fa);
+    static const bool v1_only = getenv("APGPU_FUSED_V1") != nullptr;           // development: the first form, for A/B timing
+    if (fa.log2_phases <= 10 && !v1_only) hipLaunchKernelGGL((resample_clip_kernel_v2<NP>), dim3(grid), dim3(FusedGeom::kThreads), 0, st, prm, fa);
+    else hipLaunchKernelGGL((resample_clip_kernel<NP>), dim3(grid), dim3(256), 0, st, prm, fa);
 }
 
 struct FusedWs {

@@ -996,18 +996,26 @@ def background_weights(frames, fscale=None, sigma=3.0, maxiters=5):
 
 
 def coadd(frames, affines, fscale=None, mask=None, out_shape=None, combine='MEDIAN', sigma=3.0, maxiters=5, n_phases=1024,
-          conserve_flux=False, oversampling=1, weights=None, fine_affines=None):
+          conserve_flux=False, oversampling=1, weights=None, fine_affines=None, fused=False):
     """Resample + combine: SWarp's COMBINE_TYPE MEDIAN / AVERAGE / WEIGHTED / SUM (resample_all.sh:60-73 add modes) plus
     CLIPPED (sigma-clipped mean, median-centred); oversampling = SWarp's OVERSAMPLING.  WEIGHTED takes one weight per frame
     (default: background_weights).  Returns dict(image, count[, weight]) - count = frames contributing, weight = the sum
-    of their weights (WEIGHTED only)."""
+    of their weights (WEIGHTED only).
+    fused=True (CLIPPED / AVERAGE, up to 16 frames, oversampling 1): one launch, no [N, h, w] slab of resampled frames in
+    memory (resample_stack_sigclip: same survivors; 6.2 against 5.1 ms for C5's share on one MI355X, but 4 N h w bytes less HBM -
+    DESIGN 4.4d)."""
+    combine = combine.upper()
+    if fused and int(oversampling) == 1 and combine in ('CLIPPED', 'AVERAGE') and frames.dim() == 3 and frames.shape[0] <= 16:
+        kw = dict(sigma=sigma, maxiters=maxiters) if combine == 'CLIPPED' else dict(sigma=1e30, maxiters=1, cenfunc='mean')
+        r = resample_stack_sigclip(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases,
+                                   conserve_flux=conserve_flux, outputs=('mean', 'count'), **kw)
+        return dict(image=r['mean'], count=r['count'])
     if int(oversampling) > 1:
         res = resample_oversampled(frames, affines, oversampling, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases,
                                    conserve_flux=conserve_flux, fine_affines=fine_affines)
     else:
         res, _ = resample_affine(frames, affines, fscale=fscale, mask=mask, out_shape=out_shape, n_phases=n_phases, weight=False,
                                  conserve_flux=conserve_flux)
-    combine = combine.upper()
     if combine == 'MEDIAN':
         med, cnt = stack_median(res, want_count=True)
         return dict(image=med, count=cnt)

@@ -68,6 +68,8 @@ def parse(argv=None):
                          'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
                          'affine Lanczos-3 resample + 5-iteration clipped mean, the per-GPU share 16 x 8192 x 8192 of 128 frames '
                          '(a bare --workload runs BASELINE\'s dimensions; --frames / --height / --width override them)')
+    ap.add_argument('--fused', action='store_true', help='workload c5, one GPU: the one-launch resample + clip (resample_stack_sigclip) '
+                    'instead of the two-step default')
     ap.add_argument('--no-gather', action='store_true', help="N > 1, --exchange rs: leave the mean ROW-DISTRIBUTED (no all-gather of the "
                     "result rows: 10 instead of 14 bytes per pixel on the wire); every rank keeps its rows of every stripe")
     ap.add_argument('--stripes', type=int, default=0, help='row stripes for collective/compute overlap (N > 1); 0 = by payload '
@@ -359,6 +361,8 @@ def main(argv=None):
         if wl == 'c4':
             return ops.stack_median(frames, calib=calib)
         if wl == 'c5':
+            if args.fused and world == 1:
+                return ops.resample_stack_sigclip(frames, affines, mask=badmask, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
             ops.resample_affine(frames, affines, mask=badmask, out=resampled, weight=False)
             if world == 1:
                 return ops.stack_sigclip(resampled, sigma=3.0, maxiters=5, outputs=('mean',))['mean']
@@ -506,6 +510,9 @@ def main(argv=None):
     if wl == 'c5':
         algo_bytes = (8 * N * P + P) + (4 * N * P + out_bytes * P)     # resample read+write (+mask), stack read + outputs
         kernel_name = 'resample_affine_kernel + ' + ops.stack_kernel_name(N, 'f32', calibrated=False) + ' (step = both launches)'
+        if args.fused and world == 1:
+            algo_bytes = 4 * N * P + P + 4 * P + out_bytes * P           # frames + mask read, the hit-bit plane written and read, mean written
+            kernel_name = 'resample_clip_kernel_v2<%d> (one launch + tile records + bad-pixel bits)' % (4 * ((N + 3) // 4))
         metric = 'Mpixels/sec mask+affine-resample+sigma-clip-stack'
         workload = '%s: %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (
             'C5 (per-GPU share of 128x8192x8192 on 8 GPUs)' if (N, H, W) == (16, 8192, 8192) else 'C5-like (not BASELINE\'s 16x8192x8192 share)', N, H, W)

@@ -152,3 +152,22 @@ def test_fused_errors_are_loud(ops):
         ops.resample_stack_sigclip(fr, np.tile([1, 0, 0, 0, 1, 0], (17, 1)))
     with pytest.raises(ValueError):
         ops.resample_stack_sigclip(fr[:4], np.tile([1, 0, 0, 0, 1, 0], (4, 1)), outputs=('median',))
+
+
+def test_coadd_fused_option_equals_two_step(ops):
+    """ops.coadd(..., fused=True) / ApResample.coadd(fused=True): CLIPPED and AVERAGE through the one-launch kernel - the same
+    survivors and (AVERAGE: nothing is clipped, float64 sums on both sides) the same image as the two-step form."""
+    import torch
+    import astrophotography_amd as ap
+    rng = np.random.default_rng(616)
+    N = 9
+    frames = torch.from_numpy(_frames(rng, N, (130, 150))).cuda()
+    A = _affines(rng, N)
+    mask = torch.from_numpy((rng.random((130, 150)) < 2e-3).astype(np.uint8)).cuda()
+    for combine in ('CLIPPED', 'AVERAGE'):
+        a = ops.coadd(frames, A, mask=mask, combine=combine, fused=True)
+        b = ops.coadd(frames, A, mask=mask, combine=combine)
+        assert torch.equal(a['count'], b['count']), combine
+        assert_ulp(a['image'].cpu().numpy(), b['image'].cpu().numpy(), 1, combine)
+    r = ap.ApResample('CRITICAL', combine='CLIPPED', conserve_flux=False).coadd(frames, A, mask=mask, fused=True)
+    assert torch.equal(r['count'], ops.coadd(frames, A, mask=mask, combine='CLIPPED')['count'])
