@@ -544,9 +544,6 @@ __global__ __launch_bounds__(256, NP <= 64 ? APGPU_FAST_MIN_BLOCKS : ((FULL || P
     const int64_t base = (int64_t)blockIdx.x * 256;
     const int lane = threadIdx.x;
     const int64_t p = base + lane;
-#ifdef APGPU_VARIANT_NO_IEEE                                 // round 6 experiment: MODE.IEEE = 0 (no quieting of signalling NaNs in v_min / v_max)
-    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 9, 1), 0");
-#endif
     __shared__ FrameScalars<NP> fs;                         // (never touched: the ratios come by scalar loads; no LDS is allocated)
     const int N = FULL ? NP : (PADS > 0 ? NP - PADS : prm.N);
     const int plo = FULL ? 0 : (NP - N) >> 1, phi = FULL ? 0 : NP - N - plo;

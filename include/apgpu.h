@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define APGPU_VERSION 120           /* 0.1.2: apgpu_stack_args.workspace, apgpu_stack_ws_bytes */
+#define APGPU_VERSION 130           /* 0.1.3: apgpu_resample_stack_sigclip, APGPU_STACK_NONFINITE_UNCLIPPED, apgpu_combine_ccdproc_f64(form) */
 
 /* error codes */
 #define APGPU_OK            0

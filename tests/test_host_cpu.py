@@ -24,7 +24,7 @@ def test_capi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, 'binding missing for ' + name
     assert set(_lib.SIGNATURES) == declared
-    assert lib.apgpu_version() == 120
+    assert lib.apgpu_version() == 130
     assert lib.apgpu_last_error() is not None
     # argument validation happens before any device work
     assert lib.apgpu_calibrate(None, 0, None, None, None, None, None, 0, None, 1, 1, None) == _lib.E_INVAL

@@ -330,18 +330,19 @@ def a6_case(seed):
         k = int(rng.integers(1, N))
         cube[:k, :, 1] += 50 * sig
     lo, hi = float(rng.choice([1.0, 3.0, 5.0])), float(rng.choice([2.0, 5.0]))
+    form = str(rng.choice(['legacy', 'astropy']))            # which published Combiner.sigma_clipping (golden group G12 holds both)
     if u16:
         cube = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
-        ref = apref.combine_ccdproc(cube.astype(np.float32), lo, hi)
+        ref = apref.combine_ccdproc(cube.astype(np.float32), lo, hi, form=form)
     else:
         cube = cube.astype(np.float32)
         bad = rng.random(cube.shape) < float(rng.choice([0.0, 0.0, 0.002, 0.05]))
         cube[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), bad.sum())
         with np.errstate(all='ignore'):
-            ref = apref.combine_ccdproc(cube, lo, hi)
-    what = f'a6 seed={seed} N={N} {H}x{W} u16={u16} lo={lo} hi={hi}'
+            ref = apref.combine_ccdproc(cube, lo, hi, form=form)
+    what = f'a6 seed={seed} N={N} {H}x{W} u16={u16} lo={lo} hi={hi} form={form}'
     r = ops.stack_sigclip(dev(cube), sigma_lower=lo, sigma_upper=hi, maxiters=1, cenfunc='median', stdfunc='mad_std',
-                          outputs=('mean', 'count', 'mean_f64', 'std_f64'))
+                          outputs=('mean', 'count', 'mean_f64', 'std_f64'), nonfinite_unclipped=(form == 'astropy'))
     assert np.array_equal(r['count'].cpu().numpy(), ref['count']), 'count ' + what
     # (the oracle sums in frame order: its own rounding is up to n eps max|x|, which is all there is to a mean near zero)
     fin = np.abs(cube[np.isfinite(cube)].astype(np.float64))
@@ -350,11 +351,77 @@ def a6_case(seed):
     np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12 * scale, equal_nan=True, err_msg=what)
 
 
+def fused_case(seed):
+    """apgpu_resample_stack_sigclip (resample + clip in one launch) against the oracle's composition stack_sigclip(resample_affine):
+    1 .. 16 frames, registration-sized and large transforms (fast, staged and gather tiles; frame borders), masks (by hit bits and
+    at the fill), non-finite inputs, flux scales, output shapes, per-tile transforms, every clip option, exact flag."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 17))
+    big = rng.integers(0, 3) == 0
+    H, W = int(rng.integers(6, 300 if big else 120)), int(rng.integers(6, 500 if big else 200))
+    frames = (rng.normal(float(rng.choice([0.0, 300.0, 20000.0])), float(rng.choice([1.0, 30.0])), (N, H, W))).astype(np.float32)
+    hits = rng.random(frames.shape) < float(rng.choice([0.0, 0.01, 0.05]))
+    frames[hits] += rng.uniform(100, 5000, hits.sum()).astype(np.float32)
+    if rng.integers(0, 2):
+        bad = rng.random(frames.shape) < 1e-3
+        frames[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), bad.sum())
+    wild = rng.integers(0, 4) == 0
+    A = []
+    for _ in range(N):
+        th = np.deg2rad(rng.uniform(-180, 180) if wild and rng.integers(0, 2) else rng.uniform(-1, 1))
+        sc = float(rng.choice([1.0, rng.uniform(0.5, 2.0)])) if wild else 1.0 + rng.uniform(-1e-3, 1e-3)
+        c, sn = sc * np.cos(th), sc * np.sin(th)
+        A.append([c, -sn, rng.uniform(-8, 8), sn, c, rng.uniform(-8, 8)])
+    A = np.array(A)
+    out_shape = None if rng.integers(0, 2) else (int(rng.integers(1, 150)), int(rng.integers(1, 260)))
+    h, w = (H, W) if out_shape is None else out_shape
+    if rng.integers(0, 4) == 0:                              # one transform per 16 x 64 output tile
+        ty, tx = (h + 15) // 16, (w + 63) // 64
+        A = np.repeat(np.repeat(A[:, None, None, :], ty, 1), tx, 2).copy()
+        A[..., 2] += rng.uniform(-0.2, 0.2, A.shape[:-1])
+        A[..., 5] += rng.uniform(-0.2, 0.2, A.shape[:-1])
+    mask = (rng.random((H, W)) < float(rng.choice([1e-3, 0.02, 0.2]))).astype(np.uint8) if rng.integers(0, 2) else None
+    fs = rng.uniform(0.1, 3.0, N).astype(np.float32) if rng.integers(0, 2) else None
+    nph = int(rng.choice([64, 1024, 4096]))                  # 4096: the weight table does not fit LDS - the first kernel form
+    cf = bool(rng.integers(0, 2))
+    sigma = float(rng.choice([1.5, 2.0, 3.0, 5.0]))         # (not 1.0: two survivors a, b sit ON centre -+ 1.0 std - exact ties, DESIGN 2)
+    maxiters = [1, 2, 5, None][rng.integers(0, 4)]
+    cen = str(rng.choice(['median', 'mean']))
+    exact = bool(rng.integers(0, 3) == 0)
+    what = f'fused seed={seed} {N}x{H}x{W} -> {out_shape} phases={nph} sigma={sigma} maxiters={maxiters} cen={cen} exact={exact} per_tile={A.ndim == 4}'
+    with np.errstate(all='ignore'):
+        res_ref, _ = apref.resample_affine(frames, A, fscale=fs, mask=mask, out_shape=out_shape, n_phases=nph, conserve_flux=cf)
+        ref = apref.stack_sigclip(res_ref, sigma=sigma, maxiters=maxiters, cenfunc=cen)
+    r = ops.resample_stack_sigclip(torch.from_numpy(frames).cuda(), A, fscale=fs, mask=None if mask is None else torch.from_numpy(mask).cuda(),
+                                   out_shape=out_shape, n_phases=nph, conserve_flux=cf, sigma=sigma, maxiters=maxiters, cenfunc=cen,
+                                   outputs=('mean', 'count'), exact=exact)
+    # exact ties (a value that equals a bound in exact arithmetic): pixels on which the oracle itself changes its answer under a
+    # 1e-10 relative change of sigma are left out, as in tests/test_gpu_fuzz.py wide_case
+    with np.errstate(all='ignore'):
+        lo_run = apref.stack_sigclip(res_ref, sigma=sigma * (1 - 1e-10), maxiters=maxiters, cenfunc=cen, want=('count', 'mean'))
+        hi_run = apref.stack_sigclip(res_ref, sigma=sigma * (1 + 1e-10), maxiters=maxiters, cenfunc=cen, want=('count', 'mean'))
+    same = lambda a, b: (a == b) | (np.isnan(a) & np.isnan(b))
+    tie = ~((lo_run['count'] == ref['count']) & (hi_run['count'] == ref['count']) & same(lo_run['mean'], ref['mean']) & same(hi_run['mean'], ref['mean']))
+    assert tie.mean() < 0.5, 'too many tie pixels ' + what
+    cnt = r['count'].cpu().numpy()
+    assert np.array_equal(np.where(tie, 0, cnt), np.where(tie, 0, ref['count'])), 'count ' + what
+    got, want = r['mean'].cpu().numpy(), ref['mean'].astype(np.float32)
+    got[tie], want[tie] = 0.0, 0.0
+    # a mean near zero of values of scale s carries the float32 sum's absolute error (~1e-7 s): an ulp distance says nothing there
+    fin = np.abs(res_ref[np.isfinite(res_ref)])
+    scale = float(np.percentile(fin, 99)) if fin.size else 1.0
+    small = np.abs(want) < 1e-2 * scale
+    assert np.array_equal(np.isnan(got), np.isnan(want)), 'NaN positions ' + what
+    assert np.allclose(got[small], want[small], rtol=0, atol=2e-7 * scale, equal_nan=True), 'mean near zero ' + what
+    got[small], want[small] = 0.0, 0.0
+    assert_ulp(got, want, 1, 'mean ' + what)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--minutes', type=float, default=5.0)
     ap.add_argument('--seed0', type=int, default=100000)
-    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith,fits,chunked,a6')
+    ap.add_argument('--only', default='', help='comma-separated families: big,stack,image,global,calibrate,frame,resample,arith,fits,chunked,a6,fused')
     a = ap.parse_args()
     t_end = time.time() + 60.0 * a.minutes
     fails, runs = [], {}
@@ -363,7 +430,7 @@ def main():
     while time.time() < t_end:
         for name, fn in (('big', big_case), ('stack', lambda s: tf.test_random_stack_configs(ops, apref, s)),
                          ('image', lambda s: tf.test_random_image_kernels(ops, apref, s)), ('global', global_case),
-                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case), ('fits', fits_case), ('chunked', chunked_case), ('a6', a6_case)):
+                         ('calibrate', calibrate_case), ('frame', frame_case), ('resample', resample_case), ('arith', arith_case), ('fits', fits_case), ('chunked', chunked_case), ('a6', a6_case), ('fused', fused_case)):
             if only and name not in only:
                 continue
             try:
