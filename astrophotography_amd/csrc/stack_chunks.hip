@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     S = (Stot + f.Slo) + f.Shi;
     Q = (Qtot + f.Qlo) + f.Qhi;
     const int cnt = N - f.ta - f.tb;
-    f.unsure = f.unsure || !(64.f * Q <= (float)cnt * (c0 * c0));          // mean-accuracy guard, see clip_fast32
+    f.unsure = f.unsure || !(16.f * Q <= (float)cnt * (c0 * c0));          // mean-accuracy guard, see clip_fast32
     {
         // the lanes that are not sure are redone by the exact kernel (stack_big_kernel over the redo list, one listed PIXEL per
         // lane - round 4; rounds 2-3 listed whole wavefronts: 2.3 % of them at 256 frames for a handful of lanes each); they
