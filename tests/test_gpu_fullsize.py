@@ -107,6 +107,19 @@ def test_c5_share_full_size_resample_clip(ops, apref):
     ref = apref.stack_sigclip(res[:, band].cpu().numpy(), sigma=3.0, maxiters=5)
     assert np.array_equal(st['count'][band].cpu().numpy(), ref['count'])
     assert_ulp(st['mean'][band].cpu().numpy(), ref['mean'].astype(np.float32), 1, 'C5 clipped co-add band')
+    # (5) the same co-add in ONE launch (apgpu_resample_stack_sigclip, round 6): all 67 M pixels - the survivors of the two-step
+    #     form, the mean within an ulp of it, NaN exactly where it is NaN
+    del res, wt
+    fu = ops.resample_stack_sigclip(frames, A, mask=mask, sigma=3.0, maxiters=5, outputs=('mean', 'count'))
+    torch.cuda.synchronize()
+    assert torch.equal(fu['count'], st['count'])
+    a, b = fu['mean'], st['mean']
+    assert torch.equal(torch.isnan(a), torch.isnan(b))
+    ia, ib = a.view(torch.int32).to(torch.int64), b.view(torch.int32).to(torch.int64)
+    d = (ia - ib).abs()
+    d[torch.isnan(a)] = 0
+    assert int(d.max()) <= 1, 'fused C5 co-add differs from the two-step form by more than 1 ulp'
+    assert_ulp(fu['mean'][band].cpu().numpy(), ref['mean'].astype(np.float32), 1, 'C5 fused co-add band')
 
 
 def test_c1_mean_combine_and_master_dark_subtract(ops, apref, tmp_path):
