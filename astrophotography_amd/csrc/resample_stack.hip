@@ -1,5 +1,8 @@
 // resample_stack.hip - F3 + A7 in ONE launch (round 6): the registered frames of a co-add are resampled onto the common grid
-// and sigma-clipped along N without the resampled slab ever existing in memory.
+// and sigma-clipped along N without the resampled slab ever existing in memory.  Two kernels: resample_clip_kernel_v2 (the one
+// that runs: 512 threads, tile records and weight table in LDS, footprints fetched two frames ahead) and resample_clip_kernel (the
+// first form, kept for weight tables of more than 1024 phases, which do not fit LDS).  Measured: correct and SLOWER than the two
+// launches it replaces (6.2 against 5.1 ms for C5's share; DESIGN 4.4d has the ablations) - an opt-in that saves the slab's memory.
 //
 // The reference's flow is one SWarp call per stack (scripts/resample_all.sh:330-342: RESAMPLING_TYPE LANCZOS3, COMBINE_TYPE ...),
 // this build's was two: apgpu_resample_affine_f32 writes [N][H][W] float32, apgpu_stack_sigclip reads it back - for C5's
@@ -323,21 +326,6 @@ __device__ __forceinline__ void fused_fill_store(const FusedFill<HAS_MASK> &ff, 
             tile[G::kOffB - 1 + tid + G::kRowsPerTrip * kFastPitch * k] = xv;   // copy B: element e - 1
         }
     }
-}
-
-// One pixel of a fast tile, weights from the LDS copy of the table: the arithmetic of eval_fast, operation for operation.
-__device__ __forceinline__ float eval_fast_lds(unsigned long long Xr, unsigned long long Yr, int sh, const float *tile, const float *tab)
-{
-    int js, jr, px, py;
-    phases(Xr, Yr, sh, js, jr, px, py);
-    FastPrep p;
-    typedef __attribute__((address_space(3))) const v2f *lds_v2f;
-    lds_v2f wxp = (lds_v2f)(tab + 6 * px), wyp = (lds_v2f)(tab + 6 * py);
-    p.w.wx01 = wxp[0]; p.w.wx23 = wxp[1]; p.w.wx45 = wxp[2];
-    p.w.wy01 = wyp[0]; p.w.wy23 = wyp[1]; p.w.wy45 = wyp[2];
-    const unsigned s = (unsigned)js, r = (unsigned)jr;
-    p.idx = (int)mad_u24(s & 1u, (unsigned)(FusedGeom::kOffB - 1), mad_u24(r, (unsigned)kFastPitch, s));
-    return eval_fast(p, tile);
 }
 
 // Two VERTICALLY ADJACENT pixels of a fast tile at once (rows y and y + 1 of one column).  For a registration-sized transform
