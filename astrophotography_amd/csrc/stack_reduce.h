@@ -394,7 +394,7 @@ __device__ __forceinline__ bool clip_fast32(const float (&v)[NP], float sl2f, fl
     // instructions are of the 4-cycle class and the scalar forms they replace of the 2-cycle class (tools/issue_cost.hip): what
     // is saved are issue slots.  Same four chains per sum, same number of terms per chain: the error budget above is unchanged.
 #ifndef APGPU_PACKED_MOMENTS_MAX_NP
-#define APGPU_PACKED_MOMENTS_MAX_NP 64
+#define APGPU_PACKED_MOMENTS_MAX_NP 120   /* (128 slots: at its register budget already - 168 VGPRs, 5 spilled) */
 #endif
     constexpr bool kPacked = MODE != 0 && NP <= APGPU_PACKED_MOMENTS_MAX_NP && T % 2 == 0 && (NP / 2 - T) % 2 == 0;
     float Sc, Qc;
