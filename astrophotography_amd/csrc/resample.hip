@@ -39,6 +39,9 @@ namespace {
 // ones that drew the frame's edge columns, which take the general path, finished long after the rest).  The dispatcher's 0.6 ms
 // for 524,288 workgroups is not on the critical path - it runs ahead of the workgroups - and its dynamic assignment balances
 // the slow edge tiles, which a static walk cannot; the loop also cost 20 - 40 spilled SGPRs.  profiles/r05_c5/ab_resample.txt.)
+#ifndef APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL
+#define APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL 1
+#endif
 template <bool HAS_MASK, bool OVERSAMPLED, int TH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
@@ -94,20 +97,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
     bool inline_mask = false;
     if constexpr (HAS_MASK) inline_mask = (flags & kInlineMask) != 0 || mask_ctl[0] > mask_cap;
     if (inline_mask) fv.mask = mask;
-    if (fast) {
-        if (inline_mask) {
-            FastFill<true, G::kTrips> ff;
-            fast_fill_issue<true, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
-            fast_fill_store<true, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
-        } else {
-            FastFill<false, G::kTrips> ff;
-            fast_fill_issue<false, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
-            fast_fill_store<false, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
-        }
-    } else if (tc.staged) {
-        if (inline_mask) general_fill<true>(tc, fv, tile, tid);
-        else general_fill<false>(tc, fv, tile, tid);
-    }
     // lane -> output column x0 + lx and the rows y0 + ly, + 4, + 8, + 12 (rolling fast path: the rows y0 + R ly .. + R - 1)
     const int lx = tid % kTileW, ly = tid / kTileW;
     const int sh = 32 - log2_phases;
@@ -123,11 +112,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
 #if APGPU_RESAMPLE_KEEP_WY
         steady = (unsigned long long)dist * (TH / 4 - 1) < (1ull << sh);
 #endif
-        if (fast) {                                            // the first pixels' table rows are on their way during the fill
-            const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
-            if (steady) rolling_begin<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
-            else rolling_begin<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc, sh, x0, y0, lx, ly);
+    }
+    // The first pixels' table rows are fetched BESIDE the footprint (round 6): issued between the footprint's loads and its LDS
+    // stores.  Until then they were issued after the stores - i.e. after a vmcnt(0) - and a workgroup paid the two memory round
+    // trips one after the other in front of its barrier (the ISA said so; the source order had promised the overlap since round 5).
+    auto begin_weights = [&]() {
+        if constexpr (kRolling) {
+            const v4i lrsrc0 = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
+            if (steady) rolling_begin<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc0, sh, x0, y0, lx, ly);
+            else rolling_begin<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc0, sh, x0, y0, lx, ly);
         }
+    };
+    if (fast) {
+        if (inline_mask) {
+            FastFill<true, G::kTrips> ff;
+            fast_fill_issue<true, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+#if APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL
+            begin_weights();
+#endif
+            fast_fill_store<true, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
+        } else {
+            FastFill<false, G::kTrips> ff;
+            fast_fill_issue<false, G::kTrips>(ff, fv.src, mask, tc.bx0, tc.by0, tc.fh, h_in, w_in, tid);
+#if APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL
+            begin_weights();
+#endif
+            fast_fill_store<false, G::kTrips, G::kOffB>(ff, tc.fh, tile, tid);
+        }
+#if !APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL
+        begin_weights();
+#endif
+    } else if (tc.staged) {
+        if (inline_mask) general_fill<true>(tc, fv, tile, tid);
+        else general_fill<false>(tc, fv, tile, tid);
     }
     __syncthreads();
 

@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256) void resample_tiles_kernel(const double *__res
 // The footprint of a FAST tile on its way from global memory to LDS: 3 rows of 80 columns per trip (240 of the 256 lanes),
 // every load of the tile in flight before the first LDS store.  Columns beyond the footprint's width are read too (inside
 // the frame's buffer, or returned as 0 by the bounds check) and never used.
+#ifndef APGPU_RESAMPLE_FILL_UNCONDITIONAL
+#define APGPU_RESAMPLE_FILL_UNCONDITIONAL 1
+#endif
 template <bool HAS_MASK, int TRIPS>
 struct FastFill {
     float val[TRIPS];
@@ -838,6 +841,19 @@ __device__ __forceinline__ void fast_fill_issue(FastFill<HAS_MASK, TRIPS> &ff, c
     const int r = tid / kFastPitch, c = tid - r * kFastPitch;
     const int e0 = (by0 + r) * w_in + bx0 + c;
     const int estep = 3 * w_in;
+#if APGPU_RESAMPLE_FILL_UNCONDITIONAL
+    // Round 6: EVERY lane issues EVERY trip's load (rows beyond the footprint's height and the lanes 240 .. 255 read inside the
+    // frame's buffer or get the bounds check's 0; fast_fill_store drops them).  Behind "if (row < fh && tid < 240)" each load sat in
+    // its own exec-masked block, the compiler's wait-count pass could not count them, and the wait in front of the LDS stores was
+    // vmcnt(0) - a wait for whatever else was in flight as well, i.e. the first pixels' weight rows could not be fetched beside the
+    // footprint (resample_affine_kernel issues them between these loads and the stores since this round).
+#pragma unroll
+    for (int k = 0; k < TRIPS; k++) {
+        ff.val[k] = apgpu_buffer_load_f32(irsrc, (e0 + k * estep) * 4, 0, 0);
+        if constexpr (HAS_MASK) ff.mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
+        else ff.mk[k] = 0;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < TRIPS; k++) {
         ff.val[k] = 0.f;
@@ -847,6 +863,7 @@ __device__ __forceinline__ void fast_fill_issue(FastFill<HAS_MASK, TRIPS> &ff, c
             if constexpr (HAS_MASK) ff.mk[k] = apgpu_buffer_load_i8(mrsrc, e0 + k * estep, 0, 0);
         }
     }
+#endif
 }
 
 template <bool HAS_MASK, int TRIPS, int OFFB>
