@@ -707,17 +707,9 @@ def lanczos3_table(n_phases=1024, device='cuda'):
     return _LUT_CACHE[key]
 
 
-def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, out=None, weight=True,
-                    conserve_flux=False):
-    """Affine Lanczos-3 resample of [N,H,W] (or [H,W]) float32 frames onto a common grid.
-
-    affines: [N,6] float64 (tensor / array / nested list): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps an
-    OUTPUT pixel (x = column, y = row) to INPUT coordinates; or [N, tiles_y, tiles_x, 6] with one transform per
-    16 x 64 output tile (wcs.tile_affines: a piecewise-affine TAN -> TAN registration).  fscale: per-frame flux scale (SWarp's FSCALE,
-    1/EXPTIME in resample_all.sh:298) or None.  conserve_flux: also scale by the local pixel-area ratio |det A| (SWarp's
-    FSCALASTRO_TYPE VARIABLE, resample_all.sh:129).  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
-    Returns (resampled [N,h,w] float32 with NaN where undefined, weight uint8 [N,h,w] or None).  The co-add is
-    stack_median / stack_sigclip on the result (both skip NaN)."""
+def _resample_args(frames, affines, fscale, mask, out_shape, n_phases):
+    """Shared argument preparation of the resample entry points: frames [N,H,W] float32 contiguous, transforms as a float64 device
+    tensor ([N,6] or per-tile [N,ty,tx,6]), flux scales, mask as uint8, the weight table -> (frames, N, H, W, h, w, aff, per_tile, fs, mk, lut)."""
     _need_cuda(frames)
     frames = _f32c(frames, 'frames')
     if frames.dim() == 2:
@@ -754,7 +746,22 @@ def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_p
         if tuple(mask.shape) != (H, W):
             raise ValueError('mask must be [H,W]')
         mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
-    lut = lanczos3_table(n_phases, dev)
+    return frames, N, H, W, h, w, aff, per_tile, fs, mk, lanczos3_table(n_phases, dev)
+
+
+def resample_affine(frames, affines, fscale=None, mask=None, out_shape=None, n_phases=1024, out=None, weight=True,
+                    conserve_flux=False):
+    """Affine Lanczos-3 resample of [N,H,W] (or [H,W]) float32 frames onto a common grid.
+
+    affines: [N,6] float64 (tensor / array / nested list): xin = A0*x + A1*y + A2, yin = A3*x + A4*y + A5 maps an
+    OUTPUT pixel (x = column, y = row) to INPUT coordinates; or [N, tiles_y, tiles_x, 6] with one transform per
+    16 x 64 output tile (wcs.tile_affines: a piecewise-affine TAN -> TAN registration).  fscale: per-frame flux scale (SWarp's FSCALE,
+    1/EXPTIME in resample_all.sh:298) or None.  conserve_flux: also scale by the local pixel-area ratio |det A| (SWarp's
+    FSCALASTRO_TYPE VARIABLE, resample_all.sh:129).  mask: [H,W] uint8, non-zero = bad pixel, shared by all frames.
+    Returns (resampled [N,h,w] float32 with NaN where undefined, weight uint8 [N,h,w] or None).  The co-add is
+    stack_median / stack_sigclip on the result (both skip NaN)."""
+    frames, N, H, W, h, w, aff, per_tile, fs, mk, lut = _resample_args(frames, affines, fscale, mask, out_shape, n_phases)
+    dev = frames.device
     if out is None:
         out = torch.empty((N, h, w), dtype=torch.float32, device=dev)
     elif tuple(out.shape) != (N, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
@@ -777,43 +784,10 @@ def resample_stack_sigclip(frames, affines, fscale=None, mask=None, out_shape=No
     one SWarp call there).  frames [N <= 16, H, W] float32; affines / fscale / mask / out_shape / n_phases / conserve_flux as
     resample_affine; the clip's arguments as stack_sigclip (stdfunc 'std'); outputs among 'mean', 'count', 'moments',
     'moments_f64', 'moments_f64p'.  Same survivors as the two-step form; the mean within the float32 fast path's rounding."""
-    _need_cuda(frames)
-    frames = _f32c(frames, 'frames')
-    if frames.dim() != 3:
-        raise ValueError('frames must be [N,H,W]')
-    N, H, W = frames.shape
+    frames, N, H, W, h, w, aff, per_tile, fs, mk, lut = _resample_args(frames, affines, fscale, mask, out_shape, n_phases)
     if N > 16:
         raise ValueError('resample_stack_sigclip takes up to 16 frames per call (resample_affine + stack_sigclip beyond)')
     dev = frames.device
-    h, w = (H, W) if out_shape is None else (int(out_shape[0]), int(out_shape[1]))
-    aff = torch.as_tensor(affines, dtype=torch.float64)
-    per_tile = aff.dim() == 4
-    if per_tile:
-        ty, tx = (h + 15) // 16, (w + 63) // 64
-        if tuple(aff.shape) != (N, ty, tx, 6):
-            raise ValueError('per-tile affines must be [N, %d, %d, 6] for a %d x %d output' % (ty, tx, h, w))
-    else:
-        aff = aff.reshape(-1, 6)
-        if aff.shape[0] == 1 and N > 1:
-            aff = aff.expand(N, 6)
-        if aff.shape[0] != N:
-            raise ValueError('affines must hold one 2x3 transform per frame')
-    aff = aff.contiguous().to(dev)
-    fs = None
-    if fscale is not None:
-        fs = torch.as_tensor(fscale, dtype=torch.float32).reshape(-1)
-        if fs.numel() == 1 and N > 1:
-            fs = fs.expand(N)
-        if fs.numel() != N:
-            raise ValueError('fscale must hold one value per frame')
-        fs = fs.contiguous().to(dev)
-    mk = None
-    if mask is not None:
-        _need_cuda(mask)
-        if tuple(mask.shape) != (H, W):
-            raise ValueError('mask must be [H,W]')
-        mk = mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).to(torch.uint8)
-    lut = lanczos3_table(n_phases, dev)
     lib = _lib.load()
     a = StackArgs()
     a.frames = frames.data_ptr()
