@@ -48,8 +48,10 @@ def make_masters(H, W, config_id=2, device='cuda'):
     return dict(bias=bias.contiguous(), dark=dark.contiguous(), flat=flat.contiguous(), scene=sky.expand(H, W).contiguous())
 
 
-def make_frames(N, masters, nflat, config_id=2, dtype=torch.float32, first_frame=0, out=None):
-    """raw[N,H,W] (float32 or uint16 holding integer ADU) for the masters returned by make_masters."""
+def make_frames(N, masters, nflat, config_id=2, dtype=torch.float32, first_frame=0, out=None, scenes=None):
+    """raw[N,H,W] (float32 or uint16 holding integer ADU) for the masters returned by make_masters.
+    scenes: None (every frame images masters['scene'] at the same place) or a callable f -> [H,W] scene of frame f (a dithered
+    sequence: the sky as frame f saw it, e.g. the scene warped by the inverse of the frame's registration transform)."""
     bias, dark, scene = masters['bias'], masters['dark'], masters['scene']
     H, W = bias.shape
     device = bias.device
@@ -59,6 +61,9 @@ def make_frames(N, masters, nflat, config_id=2, dtype=torch.float32, first_frame
     sig_noise = signal.clamp_min(0).sqrt() + 12
     for f in range(N):
         g = _gen(device, 1000 * config_id + first_frame + f)
+        if scenes is not None:
+            signal = bias + EXP_RATIO * dark + nflat * scenes(f)
+            sig_noise = signal.clamp_min(0).sqrt() + 12
         fr = signal + torch.randn((H, W), generator=g, device=device) * sig_noise
         cr = torch.rand((H, W), generator=g, device=device) < 0.001
         fr = fr + cr * (torch.rand((H, W), generator=g, device=device) * 4500 + 500)

@@ -68,6 +68,9 @@ def parse(argv=None):
                          'frames, per-channel flat + fused calibrate + median stack, 64 x 6248 x 4176; c5: bad-pixel mask + per-frame '
                          'affine Lanczos-3 resample + 5-iteration clipped mean, the per-GPU share 16 x 8192 x 8192 of 128 frames '
                          '(a bare --workload runs BASELINE\'s dimensions; --frames / --height / --width override them)')
+    ap.add_argument('--c5-dithered', action='store_true', help='workload c5: the synthetic frames are a DITHERED sequence - frame f images the '
+                    'scene warped by the inverse of its registration transform, so that the resample aligns the stars (default: every frame '
+                    'images the scene at the same place and the transforms MISalign it: star pixels then fail the clip wholesale)')
     ap.add_argument('--fused', action='store_true', help='workload c5, one GPU: the one-launch resample + clip (resample_stack_sigclip) '
                     'instead of the two-step default')
     ap.add_argument('--no-gather', action='store_true', help="N > 1, --exchange rs: leave the mean ROW-DISTRIBUTED (no all-gather of the "
@@ -315,9 +318,25 @@ def main(argv=None):
     nflat, _ = ops.flat_normalize(masters['flat'])
     tdtype = torch.float32 if args.dtype == 'f32' else torch.uint16
     frames = None
+    c5_affines = None
+    if wl == 'c5':
+        import numpy as np
+        rng = np.random.default_rng(5000 + rank)
+        th = np.deg2rad(rng.uniform(-0.2, 0.2, N))
+        c5_affines = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, N), np.sin(th), np.cos(th), rng.uniform(-3, 3, N)], 1)
     if wl != 'c4':
         first = (rank * 1000) if rowshard else f0               # distinct synthetic frames per rank
-        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=first)
+        scenes = None
+        if wl == 'c5' and args.c5_dithered:
+            # frame f sees scene(A_f^-1 q): the scene resampled with the inverse transform (this library's own Lanczos-3 warp;
+            # pixels the warp leaves undefined get the sky level)
+            def scenes(f):
+                a = c5_affines[f]
+                M = np.array([[a[0], a[1], a[2]], [a[3], a[4], a[5]], [0.0, 0.0, 1.0]])
+                Mi = np.linalg.inv(M)
+                w, _ = ops.resample_affine(masters['scene'][None], [[Mi[0, 0], Mi[0, 1], Mi[0, 2], Mi[1, 0], Mi[1, 1], Mi[1, 2]]], weight=False)
+                return torch.nan_to_num(w[0], nan=525.0)
+        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=tdtype, first_frame=first, scenes=scenes)
     e = synth.EXP_RATIO
     calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat,
                  exp_ratio=torch.full((N,), e, dtype=torch.float32, device=dev), dark_still_biased=False)
@@ -331,10 +350,7 @@ def main(argv=None):
         frames = synth.make_frames(N, masters, nflat4, config_id=4, dtype=torch.uint16, first_frame=0)
         calib = dict(calib, nflat=nflat4)
     if wl == 'c5':
-        import numpy as np
-        rng = np.random.default_rng(5000 + rank)
-        th = np.deg2rad(rng.uniform(-0.2, 0.2, N))
-        affines = np.stack([np.cos(th), -np.sin(th), rng.uniform(-3, 3, N), np.sin(th), np.cos(th), rng.uniform(-3, 3, N)], 1)
+        affines = c5_affines
         cal = ops.calibrate(frames, masters['bias'], masters['dark'], nflat, e)
         del frames
         frames = cal
@@ -514,7 +530,8 @@ def main(argv=None):
             algo_bytes = 4 * N * P + P + 4 * P + out_bytes * P           # frames + mask read, the hit-bit plane written and read, mean written
             kernel_name = 'resample_clip_kernel_v2<%d> (one launch + tile records + bad-pixel bits)' % (4 * ((N + 3) // 4))
         metric = 'Mpixels/sec mask+affine-resample+sigma-clip-stack'
-        workload = '%s: %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' % (
+        workload = ('%s: %dx%dx%d f32 calibrated frames, bad-pixel mask, per-frame affine Lanczos-3 resample, 3-sigma maxiters-5 clipped mean' + (
+            '; DITHERED synthetic sequence (the transforms align the stars)' if args.c5_dithered else '')) % (
             'C5 (per-GPU share of 128x8192x8192 on 8 GPUs)' if (N, H, W) == (16, 8192, 8192) else 'C5-like (not BASELINE\'s 16x8192x8192 share)', N, H, W)
     achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9
 
