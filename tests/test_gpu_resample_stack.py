@@ -171,3 +171,49 @@ def test_coadd_fused_option_equals_two_step(ops):
         assert_ulp(a['image'].cpu().numpy(), b['image'].cpu().numpy(), 1, combine)
     r = ap.ApResample('CRITICAL', combine='CLIPPED', conserve_flux=False).coadd(frames, A, mask=mask, fused=True)
     assert torch.equal(r['count'], ops.coadd(frames, A, mask=mask, combine='CLIPPED')['count'])
+
+
+def test_dithered_sequence_coadds_to_the_scene(ops):
+    """End to end, physically: a DITHERED sequence (frame f images the scene warped by the inverse of its registration transform,
+    independent noise per frame) resampled with the transforms and clipped gives the scene back - stars included: their columns are
+    consistent again, so the clip keeps (nearly) every frame on them, which it cannot on a static scene that the transforms
+    misalign (bench.py --c5-dithered).  Both forms of the co-add."""
+    import torch
+    rng = np.random.default_rng(617)
+    N, H, W = 12, 320, 384
+    yy, xx = torch.meshgrid(torch.arange(H, device='cuda', dtype=torch.float32), torch.arange(W, device='cuda', dtype=torch.float32), indexing='ij')
+    scene = 500.0 + 0.1 * xx
+    stars = [(60.3, 80.7, 9000.0), (160.5, 200.2, 20000.0), (250.1, 90.9, 4000.0), (100.0, 300.0, 12000.0)]
+    for sy, sx, amp in stars:
+        scene = scene + amp * torch.exp(-((xx - sx) ** 2 + (yy - sy) ** 2) / (2 * 2.0 ** 2))
+    A = _affines(rng, N, max_rot_deg=0.3, max_shift=3.0)
+    frames = torch.empty((N, H, W), dtype=torch.float32, device='cuda')
+    g = torch.Generator(device='cuda').manual_seed(617)
+    for f in range(N):
+        a = A[f]
+        Mi = np.linalg.inv(np.array([[a[0], a[1], a[2]], [a[3], a[4], a[5]], [0.0, 0.0, 1.0]]))
+        w, _ = ops.resample_affine(scene[None], [[Mi[0, 0], Mi[0, 1], Mi[0, 2], Mi[1, 0], Mi[1, 1], Mi[1, 2]]], weight=False)
+        s = torch.nan_to_num(w[0], nan=500.0)
+        frames[f] = s + torch.randn((H, W), generator=g, device='cuda') * torch.sqrt(s.clamp_min(1.0))
+    inner = (slice(24, H - 24), slice(24, W - 24))                 # away from the borders the warps leave undefined
+    for fused in (False, True):
+        r = ops.coadd(frames, A, combine='CLIPPED', sigma=3.0, maxiters=5, fused=fused)
+        img, cnt = r['image'][inner], r['count'][inner]
+        err = (img - scene[inner]).abs()
+        noise = torch.sqrt(scene[inner] / N)
+        # two Lanczos-3 interpolations of a sigma = 2 px star lose a little of its peak: compare within 4 sigma of the noise + 1.5 %
+        assert float((err > 4.0 * noise + 0.015 * scene[inner]).float().mean()) < 2e-3, fused
+        for sy, sx, amp in stars:                                 # on the stars' cores the clip keeps (nearly) every frame
+            c = cnt[int(sy) - 24 - 1:int(sy) - 24 + 2, int(sx) - 24 - 1:int(sx) - 24 + 2]
+            assert int(c.min()) >= N - 2, (fused, sy, sx, c.tolist())
+    # the same scene WITHOUT the dither (every frame images it in place) and the same transforms: the resample moves the stars apart,
+    # a core's column now runs from core to wing - its spread inflates the clip's sigma, nothing is rejected, and the co-add smears
+    # the star (the columns are also what the float32 fast path's guards send to the redo pass: bench.py's redo_fraction 0.086)
+    static = scene[None].expand(N, H, W) + torch.randn((N, H, W), generator=g, device='cuda') * torch.sqrt(scene)[None]
+    simg = ops.coadd(static.contiguous(), A, combine='CLIPPED', sigma=3.0, maxiters=5)['image'][inner]
+    dimg = ops.coadd(frames, A, combine='CLIPPED', sigma=3.0, maxiters=5)['image'][inner]
+    for sy, sx, amp in stars:
+        iy, ix = int(round(sy)) - 24, int(round(sx)) - 24
+        truth = float(scene[inner][iy, ix])
+        assert float(dimg[iy, ix]) > 0.95 * truth, (sy, sx, float(dimg[iy, ix]), truth)
+        assert float(simg[iy, ix]) < 0.90 * truth, (sy, sx, float(simg[iy, ix]), truth)
