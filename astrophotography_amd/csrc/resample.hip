@@ -42,6 +42,9 @@ namespace {
 #ifndef APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL
 #define APGPU_RESAMPLE_WEIGHTS_BESIDE_FILL 1
 #endif
+#ifndef APGPU_RESAMPLE_AHEAD_NONSTEADY
+#define APGPU_RESAMPLE_AHEAD_NONSTEADY 0                     // pixels whose weight rows the non-steady path fetches ahead (0: in the trip that uses them)
+#endif
 template <bool HAS_MASK, bool OVERSAMPLED, int TH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void resample_affine_kernel(const float *__restrict__ frames, const uint8_t *__restrict__ mask,
                                                              const TileRec *__restrict__ recs, int ntiles, int gx, int gy,
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
         if constexpr (kRolling) {
             const v4i lrsrc0 = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
             if (steady) rolling_begin<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc0, sh, x0, y0, lx, ly);
-            else rolling_begin<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc0, sh, x0, y0, lx, ly);
+            else rolling_begin<TH, false, APGPU_RESAMPLE_AHEAD_NONSTEADY, APGPU_RESAMPLE_AHEAD>(ro, tc, lrsrc0, sh, x0, y0, lx, ly);
         }
     };
     if (fast) {
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void r
         const v4i lrsrc = make_rsrc(lut, (unsigned)((1 << log2_phases) + 1) * 24u);
         if constexpr (kRolling) {
             if (steady) pixels_fast_rolling<TH, true, APGPU_RESAMPLE_AHEAD, APGPU_RESAMPLE_AHEAD>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
-            else pixels_fast_rolling<TH, false, 0, APGPU_RESAMPLE_AHEAD>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
+            else pixels_fast_rolling<TH, false, APGPU_RESAMPLE_AHEAD_NONSTEADY, APGPU_RESAMPLE_AHEAD>(ro, tc, tile, lrsrc, sh, lx, ly, orsrc, wrsrc, wout != nullptr, w_out);
         } else {
             const int ooff = (ly * w_out + lx) * 4, ostep = 16 * w_out;
             pixels_fast<OVERSAMPLED, TH, 1>(tc, tile, lrsrc, sh, os, x0, y0, lx, ly, orsrc, wrsrc, wout != nullptr, ooff, ostep);
