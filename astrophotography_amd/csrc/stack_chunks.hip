@@ -368,7 +368,8 @@ __device__ __forceinline__ bool window_step(const StackParams &prm, const FrameS
 // chunks in all (6: 257 .. 384 frames, 8: 385 .. 512), and the tails hold 16 values (a 512-frame column loses twice as many
 // values to the same clip as a 256-frame one).
 template <int KS, bool PAIR, typename RawT, bool CALIB, bool FULLCH>
-__global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo_count, int32_t *redo_list)
+__global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo_count, int32_t *redo_list,
+                                                                                       float *rich_tmp)
 {
     constexpr int K = PAIR ? 2 * KS : KS;
     constexpr int T = PAIR ? kChunkTailPairs : kChunkTail, W = kChunkWin;
@@ -508,6 +509,22 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     Q = (Qtot + f.Qlo) + f.Qhi;
     const int cnt = N - f.ta - f.tb;
     f.unsure = f.unsure || !(16.f * Q <= (float)cnt * (c0 * c0));          // mean-accuracy guard, see clip_fast32
+    // Round 6 - the median and std planes of the FINAL survivors (np.nanmedian / np.nanstd of what the clip kept) for 129 .. 512
+    // frames, which used to send the whole stack to the LDS-resident exact kernel (25 ms for 256 frames, 120 for 512):
+    //   median: the middle pair of the final range [ta, N - tb) from the merged window, under the same two conditions as the
+    //           clip's own medians (inside the 16 merged values, inside the zone the windows vouch for);
+    //   std:    numpy's two-pass definition needs the survivors again - they are the values in [GL[ta], GH[T - 1 - tb]] (the
+    //           column's ta smallest and tb largest values are gone; equal values share their fate, so the cut never runs
+    //           through a tie) - so this kernel leaves that range and the mean in rich_tmp, and stack_std_pass_kernel streams
+    //           the frames once more (float64 sum of (x - mean)^2 over the values inside the range).
+    float med1 = 0.f, med2 = 0.f;
+    if (prm.median) {
+        const int j1 = ((f.ta + N - f.tb - 1) >> 1) - mbase, j2 = ((f.ta + N - f.tb) >> 1) - mbase;
+        f.unsure = f.unsure || j1 < 0 || j2 > 15;
+        med1 = pick_rel<0, 16, 16>(M, j1 & 15);
+        med2 = pick_rel<0, 16, 16>(M, j2 & 15);
+        f.unsure = f.unsure || !(med1 >= Lmax && med2 <= Umin);
+    }
     {
         // the lanes that are not sure are redone by the exact kernel (stack_big_kernel over the redo list, one listed PIXEL per
         // lane - round 4; rounds 2-3 listed whole wavefronts: 2.3 % of them at 256 frames for a handful of lanes each); they
@@ -520,6 +537,7 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
             const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
             if (f.unsure) {
                 redo_list[first + mine] = (int32_t)p;
+                if (rich_tmp) rich_tmp[p] = __builtin_nanf("");          // the exact kernel writes this pixel's std: the second pass skips it
                 return;
             }
         }
@@ -528,9 +546,71 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     const float y = __builtin_amdgcn_rcpf(nf32);
     const float q0 = S * y;
     const float ms32 = __builtin_fmaf(__builtin_fmaf(-nf32, q0, S), y, q0);
-    if (prm.mean) prm.mean[p] = c0 + ms32;
+    const float meanf = c0 + ms32;
+    if (prm.mean) prm.mean[p] = meanf;
     if (prm.count) prm.count[p] = cnt;
     if (prm.moments) store_moments(prm.moments, prm.moments64, prm.P, p, cnt, (double)c0, (double)S, (double)Q);
+    if (prm.median) prm.median[p] = (float)(((double)med1 + (double)med2) / 2.0);
+    if (rich_tmp) {
+        // (the trim chains stop before a tail is used up - ta, tb <= T - 1 - so both picks are real values)
+        rich_tmp[p] = pick_rel<0, T, T>(GL, f.ta & (T - 1));
+        rich_tmp[prm.P + p] = pick_rel<0, T, T>(GH, (T - 1 - f.tb) & (T - 1));
+        rich_tmp[2 * prm.P + p] = meanf;
+    }
+}
+
+// The std plane of the survivors for 129 .. 512 frames, second pass (see the epilogue of stack_chunks_kernel): one pixel per lane,
+// the frames streamed once more with the EXACT calibration (IEEE division, ApCalibrate.py:439-464 operation for operation - the chunk
+// kernel's fast calibration gives these values or lists the pixel), float64 sum of (x - mean)^2 over the values inside the pixel's
+// survivor range, std = sqrt(sum / n) - numpy's two-pass nanstd with the clipped mean this call returns.
+template <typename RawT, bool CALIB>
+__global__ __launch_bounds__(256) void stack_std_pass_kernel(const StackParams prm, const float *__restrict__ rich_tmp)
+{
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= prm.P) return;
+    const float vmin = rich_tmp[p];
+    if (!(vmin == vmin)) return;                             // listed: the exact kernel wrote its std
+    const float vmax = rich_tmp[prm.P + p];
+    const double mean = (double)rich_tmp[2 * prm.P + p];
+    float b = 0.f, D = 0.f, nf = 1.f;
+    bool dodiv = false;
+    if constexpr (CALIB) {
+        b = prm.bias[p];
+        D = prm.still_biased ? prm.dark[p] - b : prm.dark[p];          // ApCalibrate.py:440-445
+        if (prm.nflat) {
+            nf = prm.nflat[p];
+            dodiv = (nf != 0.f);                                        // :462
+        }
+    }
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat *eg = (const cfloat *)(uintptr_t)prm.exp_ratio, *pg = (const cfloat *)(uintptr_t)prm.pedestal;
+    const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
+    const int N = prm.N;
+    double q = 0.0;
+    int n = 0;
+    for (int f0 = 0; f0 < N; f0 += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = (f0 + j < N) ? to_f32(fp[(int64_t)(f0 + j) * prm.stride]) : __builtin_nanf("");
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float v = x[j];
+            if constexpr (CALIB) {
+                const int ff = f0 + j < N ? f0 + j : N - 1;
+                const float e = eg ? eg[ff] : 0.f, ped = pg ? pg[ff] : 0.f;
+                if (ped != 0.f) v = v + ped;                 // :318-326
+                v = v - b;                                   // :439
+                const float ds = e * D;                      // :450
+                v = v - ds;                                  // :451
+                if (dodiv) v = __fdiv_rn(v, nf);             // :463
+            }
+            const bool in = (v >= vmin) && (v <= vmax);      // false for NaN; +-inf lie outside every finite range
+            const double d = in ? (double)v - mean : 0.0;
+            q = fma(d, d, q);
+            n += in ? 1 : 0;
+        }
+    }
+    prm.std[p] = n > 0 ? (float)sqrt(q / (double)n) : __builtin_nanf("");
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------------------------
@@ -546,7 +626,7 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
     // register kernel - a chunk costs what the whole 64-frame kernel costs - so the register kernels keep that range)
     if (median_only || prm.N <= 128 || prm.N > 8 * kChunkSlots) return false;
     if (prm.P >= 0x7fffffffLL) return false;                 // the redo list holds pixel indices as int32
-    if (prm.median || prm.std || prm.mean64 || prm.std64) return false;
+    if (prm.mean64 || prm.std64) return false;               // (the float32 median / std planes: round 6, stack_std_pass_kernel)
     if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (prm.fast32 == 0) return false;
     if (prm.moments && !(prm.moments64 == 0 || prm.moments64 == 3 || prm.moments64 == 4) ) return false;
@@ -598,10 +678,29 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
             return launch_big_exact(q, u16, CALIB, false, st, nullptr);
         }
     }
-    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
-    else hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list);
+    // the std plane needs the survivors' range and mean of every pixel between the two passes: 12 bytes per pixel, a stream-ordered
+    // temporary (like the resample's tile records); if it cannot be had the exact kernel reduces the whole stack
+    float *rich_tmp = nullptr;
+    if (prm.std) {
+        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&rich_tmp), (size_t)prm.P * 3 * sizeof(float), st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (own) (void)hipFreeAsync(own, st);
+            return launch_big_exact(q, u16, CALIB, false, st, nullptr);
+        }
+    }
+    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
+    else hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
     int rc = check_launch("stack kernel (chunked, 129..512 frames)");
     if (rc == APGPU_OK) rc = launch_big_exact(q, u16, CALIB, false, st, nullptr, cnt, list, ws);
+    if (rc == APGPU_OK && rich_tmp) {
+        hipLaunchKernelGGL((stack_std_pass_kernel<RawT, CALIB>), dim3((unsigned)grid), dim3(256), 0, st, q, rich_tmp);
+        rc = check_launch("stack kernel (chunked: std plane, second pass)");
+    }
+    if (rich_tmp) {
+        const hipError_t ef = hipFreeAsync(rich_tmp, st);
+        if (rc == APGPU_OK && ef != hipSuccess) rc = fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
+    }
     if (own) {
         const hipError_t ef = hipFreeAsync(own, st);
         if (rc == APGPU_OK && ef != hipSuccess) return fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));

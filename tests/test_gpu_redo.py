@@ -316,3 +316,50 @@ def test_ccdproc_configuration_guard(ops, apref):
     assert call(db, bad) == nblocks                          # mode 1: sampled tiles tried (and given up), the others handed over
     assert call(dc, clean) >= nblocks - nblocks // 16         # still mode 1 (the decision is the previous call's): mostly handed over
     assert call(dc, clean) < nblocks // 8                     # the sampled tiles were clean: mode 0 again
+
+
+@pytest.mark.parametrize('N,dt', [(130, np.float32), (192, np.uint16), (256, np.float32), (300, np.uint16), (384, np.float32), (500, np.float32), (512, np.uint16)])
+def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
+    """129 .. 512 frames with the median and std planes of the survivors (round 6): the chunked float32 path + its second pass
+    (stack_std_pass_kernel) instead of the LDS-resident exact kernel - against the oracle: counts identical, mean and median
+    within 1 ulp, std within 2 ulp; fused calibration with per-frame exposure ratios and pedestals, a zero and a NaN in the flat,
+    non-finite values, a pixel mask, a partly filled last workgroup."""
+    from tests.util import synth_cube, synth_masters
+    rng = np.random.default_rng(900 + N)
+    shape = (11, 97)
+    bias, dark, flat = synth_masters(rng, shape)
+    flat[0, 0] = 0.0
+    flat[0, 1] = np.nan
+    raw = synth_cube(rng, N, shape, dtype=dt)
+    if dt == np.float32:
+        raw = raw + bias + 0.4 * dark
+        raw[5, 3, 4] = np.inf
+        raw[7, 2, 2] = np.nan
+    nflat, _ = apref.flat_normalize(flat)
+    e = rng.uniform(0.3, 0.5, N)
+    ped = np.where(rng.random(N) < 0.3, -50.0, 0.0)
+    pm = (rng.random(shape) < 0.05).astype(np.uint8)
+    cal = apref.calibrate(raw, bias, dark, nflat, e, ped, True)
+    calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=e, pedestal=ped, dark_still_biased=True)
+    d = dev(raw, ops)
+    name = ops.stack_kernel_name(N, 'f32' if dt == np.float32 else 'u16', calibrated=True, outputs=('mean', 'median', 'std'))
+    assert 'stack_chunks_kernel' in name, name
+    for outs in (('mean', 'median', 'std', 'count'), ('median',), ('std', 'count')):
+        for kw in (dict(sigma=3.0, maxiters=5), dict(sigma=2.0, maxiters=None), dict(sigma_lower=2.5, sigma_upper=4.0, maxiters=2)):
+            ref = apref.stack_sigclip(cal, pixmask=pm, **kw)
+            r = ops.stack_sigclip(d, calib=calib, pixmask=dev(pm, ops), outputs=outs, **kw)
+            what = f'big rich N={N} {dt.__name__} {outs} {kw}'
+            if 'count' in outs:
+                assert np.array_equal(r['count'].cpu().numpy(), ref['count']), what
+            if 'mean' in outs:
+                assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, 'mean ' + what)
+            if 'median' in outs:
+                assert_ulp(r['median'].cpu().numpy(), ref['median'].astype(np.float32), 1, 'median ' + what)
+            if 'std' in outs:
+                assert_ulp(r['std'].cpu().numpy(), ref['std'].astype(np.float32), 2, 'std ' + what)
+    # plain (unfused) frames as well
+    ref = apref.stack_sigclip(raw.astype(np.float32), sigma=3.0, maxiters=5)
+    r = ops.stack_sigclip(d, sigma=3.0, maxiters=5, outputs=('mean', 'median', 'std', 'count'))
+    assert np.array_equal(r['count'].cpu().numpy(), ref['count'])
+    assert_ulp(r['median'].cpu().numpy(), ref['median'].astype(np.float32), 1, 'plain median')
+    assert_ulp(r['std'].cpu().numpy(), ref['std'].astype(np.float32), 2, 'plain std')
