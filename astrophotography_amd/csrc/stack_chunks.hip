@@ -60,6 +60,9 @@ constexpr int kChunkMinFrames = 33;                          // a chunk holds it
 #ifndef APGPU_CHUNKS_HALVES
 #define APGPU_CHUNKS_HALVES 1
 #endif
+#ifndef APGPU_CHUNKS_CLAMPED_LOADS
+#define APGPU_CHUNKS_CLAMPED_LOADS 1
+#endif
 #ifndef APGPU_CHUNKS_MINBLOCKS
 #define APGPU_CHUNKS_MINBLOCKS 2
 #endif
@@ -95,6 +98,33 @@ __device__ __forceinline__ void bitonic_sort(float (&t)[T])
         for (int i = 0; i < T; i++)
             if ((i & d) == 0) cmpx(t[i], t[i + d]);
     }
+}
+
+// The frames of a chunk, F0 .. F0 + CNT - 1 of its slots.  A ragged chunk (FULLCH = false: c < 64 frames) loads EVERY slot, the slots
+// beyond the chunk re-reading its last frame (a cache hit; the callers overwrite those slots with sentinels): straight-line code.
+// load_raw (stack_calibrate.h) skips the padding slots of a ragged stack with one wave-uniform branch per slot, and the compiler
+// then waits for every load inside its branch - s_waitcnt vmcnt(0) 31 times per chunk in the uint16 kernels, one memory latency
+// each (round 6, read off the ISA: 300 uint16 frames took 6.8 ms for the median where 384 took 4.1).
+template <int NP, typename RawT, bool FULLCH, int F0, int CNT, int MINN>
+__device__ __forceinline__ void load_chunk_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[CNT])
+{
+#if APGPU_CHUNKS_CLAMPED_LOADS
+    if constexpr (FULLCH || sizeof(RawT) == 4) {            // (float32 chunks: load_raw's branches carry no waits; measured equal or 2-4 % better)
+        load_raw<NP, RawT, FULLCH, F0, CNT, MINN>(prm, base, lane, raw);
+    } else {
+        const RawT *fb = static_cast<const RawT *>(prm.frames) + base + (int64_t)F0 * prm.stride;
+        int nframes = prm.N;
+        asm volatile("" : "+s"(nframes));
+#pragma unroll
+        for (int f = 0; f < CNT; f++) {
+            raw[f] = fb[lane];
+            if (F0 + f + 1 < MINN || F0 + f + 1 < nframes) fb += prm.stride;      // (a scalar select, no branch)
+            if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
+    load_raw<NP, RawT, FULLCH, F0, CNT, MINN>(prm, base, lane, raw);
+#endif
 }
 
 struct ChunkSums {
@@ -134,16 +164,16 @@ __device__ __forceinline__ bool load_chunk(const StackParams &q, const FrameScal
 #if APGPU_CHUNKS_HALVES
         constexpr int HN = NP / 2;
         RawT half[HN];
-        load_raw<NP, RawT, FULLCH, 0, HN, MINN>(q, base, lane, half);
+        load_chunk_raw<NP, RawT, FULLCH, 0, HN, MINN>(q, base, lane, half);
         good = q.pedestal ? calibrate_fast<NP, RawT, true, 0, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N)
                           : calibrate_fast<NP, RawT, false, 0, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N);
-        load_raw<NP, RawT, FULLCH, HN, HN, MINN>(q, base, lane, half);
+        load_chunk_raw<NP, RawT, FULLCH, HN, HN, MINN>(q, base, lane, half);
         const bool good2 = q.pedestal ? calibrate_fast<NP, RawT, true, HN, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N)
                                       : calibrate_fast<NP, RawT, false, HN, HN, false, MINN>(fs, half, b, D, nf, dodiv, v, N);
         good = good && good2;
 #else
         RawT raw[NP];
-        load_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
+        load_chunk_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
         good = q.pedestal ? calibrate_fast<NP, RawT, true, 0, NP, false, MINN>(fs, raw, b, D, nf, dodiv, v, N)
                           : calibrate_fast<NP, RawT, false, 0, NP, false, MINN>(fs, raw, b, D, nf, dodiv, v, N);
 #endif
@@ -151,7 +181,7 @@ __device__ __forceinline__ bool load_chunk(const StackParams &q, const FrameScal
         good = good && range_ok_sorted<NP, MINN>(v, dodiv, N);
     } else {
         RawT raw[NP];
-        load_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
+        load_chunk_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
         int nframes = N;
         asm volatile("" : "+s"(nframes));
         float acc = 0.f;                                    // NaN iff some value is not finite (x * 0 is NaN for NaN and inf)
@@ -722,6 +752,367 @@ int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, 
     const int KS = (prm.N + (pair ? 2 : 1) * kChunkSlots - 1) / ((pair ? 2 : 1) * kChunkSlots);
     if (pair) return KS == 3 ? launch_chunks_t<3, true>(prm, u16, calib, st, describe) : launch_chunks_t<4, true>(prm, u16, calib, st, describe);
     return KS == 3 ? launch_chunks_t<3, false>(prm, u16, calib, st, describe) : launch_chunks_t<4, false>(prm, u16, calib, st, describe);
+}
+
+
+// ---- round 6: order statistics without the clip - the plain median and the median / mad_std configuration, 129 .. 512 frames ----
+//
+// scripts/ap_combine_darks.py:394-420 (ccdproc.combine with np.ma.median / mad_std, ONE pass at 5 deviations; restated in
+// oracle/apref.c:apref_combine_ccdproc_form) takes whatever the directory holds; beyond 128 frames every such call - and every plain
+// median (np.median along N, apgpu_stack_median) - ran on the LDS-resident exact kernel, one wavefront per SIMD: 33 ms for 256 x
+// 4096^2, 147 ms for 512.  What these need of a column are ORDER STATISTICS, which the windows of the chunked scheme give:
+//   pass 1 (stack_rank_chunks_kernel<.., MODE 0>): the two middle values m1 <= m2 of the column - every chunk sorted in registers,
+//           its 32-value middle window kept, the windows merged, the elements of global rank (N - 1) / 2 and N / 2 read off under the
+//           same zone test as the clipped mean's medians.  MODE 2 writes (m1 + m2) / 2 as the median plane and stops there.
+//   pass 2 (MODE 1): the same machinery on a_i = |(x_i - m1) + (x_i - m2)| = 2 |x_i - base| (float32, relative error <= 2u -
+//           stack_mad.hip's e_i) gives the two middle deviations: E = a_(r1) + a_(r2) = 4 MAD (<= 3u).
+//   pass 3 (stack_mad_sums_kernel): the frames streamed once more; a value is rejected when -e > cl E (low side) or e > cu E
+//           (high side), c = thresh x 1.4826 / 2, decided with stack_mad.hip's margin rho = 2^-20 - a comparison inside the margin
+//           makes the pixel unsure -; float64 sums of (x - m1), (x - m1)^2 over the survivors: mean = m1 + S / n, std =
+//           sqrt((Q - S^2 / n) / n).
+// Unsure pixels - a non-finite value (the astropy form leaves such a column unclipped: the exact kernel knows), a median outside
+// the zone, a comparison inside the margin, a spread outside 2^-40 .. 2^40 - carry NaN through the per-pixel temporary, are listed
+// by the last pass and reduced by stack_big_kernel, like the clipped mean's.  Three reads of the frames instead of one.
+template <typename RawT, bool FULLCH, bool DEV>
+__device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kchunk, int nch, int c, int64_t base, int lane, float m1, float m2,
+                                                  float (&win)[kChunkWin], float &Lmax, float &Umin, bool first)
+{
+    constexpr int NP = kChunkSlots, MINN = FULLCH ? NP : kChunkMinFrames - 1;
+    __builtin_amdgcn_sched_barrier(0);
+    StackParams q = prm;
+    q.frames = static_cast<const RawT *>(prm.frames) + (int64_t)kchunk * prm.stride;          // interleaved chunks, as above
+    q.stride = prm.stride * nch;
+    q.N = c;
+    float v[NP];
+    bool good;
+    {
+        RawT raw[NP];
+        load_chunk_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
+        int nframes = c;
+        asm volatile("" : "+s"(nframes));
+        float acc = 0.f;                                    // NaN iff some value is not finite
+#pragma unroll
+        for (int f = 0; f < NP; f++) {
+            if (f >= MINN && f >= nframes) {
+                v[f] = __builtin_inff();                    // padding slot of a ragged chunk (wave-uniform test): sorts last
+            } else {
+                const float x = to_f32(raw[f]);
+                acc = __builtin_fmaf(x, 0.f, acc);
+                v[f] = DEV ? __builtin_fabsf((x - m1) + (x - m2)) : x;
+            }
+        }
+        good = acc == 0.f;
+        asm volatile("" : "+v"(acc));
+    }
+    sort_column<NP>(v);
+    if constexpr (FULLCH) {
+#pragma unroll
+        for (int j = 0; j < kChunkWin; j++) win[j] = v[(NP - kChunkWin) / 2 + j];
+    } else {
+        uniform_slice<kChunkWin, (NP - kChunkWin) / 2, 0, NP>(v, c / 2 - kChunkWin / 2, win);
+    }
+    Lmax = first ? win[0] : fmaxf(Lmax, win[0]);
+    Umin = first ? win[kChunkWin - 1] : fminf(Umin, win[kChunkWin - 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    return good;
+}
+
+template <typename RawT, bool FULLCH, bool DEV, int SIDX, int KS, bool PAIR>
+__device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cbase, int cextra, int64_t base, int lane, float m1, float m2,
+                                                 float (&win)[kChunkWin], float &Lmax, float &Umin, int &below)
+{
+    constexpr int W = kChunkWin;
+    if constexpr (!PAIR) {
+        const int c = cbase + (SIDX < cextra ? 1 : 0);
+        below += c / 2 - W / 2;
+        return rank_chunk_window<RawT, FULLCH, DEV>(prm, SIDX, KS, c, base, lane, m1, m2, win, Lmax, Umin, SIDX == 0);
+    } else {
+        constexpr int ka = 2 * SIDX, kb = 2 * SIDX + 1;
+        const int ca = cbase + (ka < cextra ? 1 : 0), cb = cbase + (kb < cextra ? 1 : 0);
+        float Y[2 * W];
+        bool ok;
+        {
+            float wa[W];
+            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, ka, 2 * KS, ca, base, lane, m1, m2, wa, Lmax, Umin, SIDX == 0);
+#pragma unroll
+            for (int j = 0; j < W; j++) Y[j] = wa[j];
+        }
+        {
+            float wb[W];
+            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, kb, 2 * KS, cb, base, lane, m1, m2, wb, Lmax, Umin, false) && ok;
+#pragma unroll
+            for (int j = 0; j < W; j++) Y[W + j] = wb[j];
+        }
+        window_net_from<2 * W, W, W / 2, W / 2 + W>(Y);      // the pair's 64 window values: the 32 middle ones (window_step above)
+#pragma unroll
+        for (int j = 0; j < W; j++) win[j] = Y[W / 2 + j];
+        Lmax = fmaxf(Lmax, win[0]);
+        Umin = fminf(Umin, win[W - 1]);
+        below += (ca / 2 - W / 2) + (cb / 2 - W / 2) + W / 2;
+        __builtin_amdgcn_sched_barrier(0);
+        return ok;
+    }
+}
+
+// MODE 0: tmp[p], tmp[P + p] = the column's two middle values (NaN, -: not sure).  MODE 1: tmp[2 P + p] = the sum of the two middle
+// values of |(x - m1) + (x - m2)| (not sure: tmp[p] = NaN).  MODE 2: the median plane (+ count = N); a pixel that is not sure is listed.
+template <int KS, bool PAIR, typename RawT, bool FULLCH, int MODE>
+__global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackParams prm, float *tmp, int32_t *redo_count, int32_t *redo_list)
+{
+    constexpr int K = PAIR ? 2 * KS : KS, W = kChunkWin;
+    constexpr bool DEV = MODE == 1;
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+    const int64_t p = base + lane;
+    const int N = prm.N;
+    const int cbase = N / K, cextra = N % K;
+    if (p >= prm.P) return;
+    extern __shared__ float parked[];                       // [(KS - 2) * W][256]
+    float m1 = 0.f, m2 = 0.f;
+    bool ok = true;
+    if constexpr (DEV) {
+        m1 = tmp[p];
+        m2 = tmp[prm.P + p];
+        ok = m1 == m1;
+    }
+    float R0[W], R1[W];
+    float Lmax = 0.f, Umin = 0.f;
+    int below = 0;
+    if constexpr (KS >= 3) {
+        float win[W];
+        ok = rank_window_step<RawT, FULLCH, DEV, 0, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+#pragma unroll
+        for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
+    }
+    if constexpr (KS == 4) {
+        float win[W];
+        ok = rank_window_step<RawT, FULLCH, DEV, 1, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+#pragma unroll
+        for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
+    }
+    ok = rank_window_step<RawT, FULLCH, DEV, KS - 2, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, R0, Lmax, Umin, below) && ok;
+    ok = rank_window_step<RawT, FULLCH, DEV, KS - 1, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, R1, Lmax, Umin, below) && ok;
+    float X[4 * W];
+    {
+        int slot = lane;
+        asm volatile("" : "+v"(slot) : : "memory");
+#pragma unroll
+        for (int j = 0; j < (KS - 2) * W; j++) X[j] = parked[j * 256 + slot];
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            X[(KS - 2) * W + j] = R0[j];
+            X[(KS - 1) * W + j] = R1[j];
+        }
+#pragma unroll
+        for (int j = KS * W; j < 4 * W; j++) X[j] = __builtin_inff();
+    }
+    constexpr int MLO = 16 * KS - 8;
+    window_net_from<4 * W, W, MLO, MLO + 16>(X);
+    float M[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) M[j] = X[MLO + j];
+    const int mbase = below + MLO;
+    const int i1 = ((N - 1) >> 1) - mbase, i2 = (N >> 1) - mbase;
+    bool unsure = !ok || i1 < 0 || i2 > 15;
+    const float a = pick_rel<0, 16, 16>(M, i1 & 15), b = pick_rel<0, 16, 16>(M, i2 & 15);
+    unsure = unsure || !(a >= Lmax && b <= Umin);           // outside the zone the windows vouch for
+    if constexpr (MODE == 0) {
+        tmp[p] = unsure ? __builtin_nanf("") : a;
+        tmp[prm.P + p] = b;
+    } else if constexpr (MODE == 1) {
+        if (unsure) tmp[p] = __builtin_nanf("");
+        else tmp[2 * prm.P + p] = a + b;
+    } else {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(unsure);
+        if (m != 0) {
+            int first = 0;
+            if (__builtin_amdgcn_readfirstlane(lane) == lane) first = atomicAdd(redo_count, (int)__builtin_popcountll(m));
+            first = __builtin_amdgcn_readfirstlane(first);
+            const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            if (unsure) {
+                redo_list[first + mine] = (int32_t)p;
+                return;
+            }
+        }
+        if (prm.median) prm.median[p] = (float)(((double)a + (double)b) / 2.0);
+        if (prm.count) prm.count[p] = N;
+    }
+}
+
+// Pass 3 of the median / mad_std configuration: which values the bounds keep, and their float64 sums (stack_mad_fast_kernel's
+// arithmetic on a streamed column).
+template <typename RawT>
+__global__ __launch_bounds__(256) void stack_mad_sums_kernel(const StackParams prm, const float *__restrict__ tmp, float cl, float cu,
+                                                             int32_t *redo_count, int32_t *redo_list)
+{
+    const int lane = threadIdx.x;
+    const int64_t p = (int64_t)blockIdx.x * 256 + lane;
+    if (p >= prm.P) return;
+    const float m1 = tmp[p], m2 = tmp[prm.P + p];
+    bool unsure = !(m1 == m1);
+    const float E = unsure ? 0.f : tmp[2 * prm.P + p];      // 4 MAD
+    const float rho = 0x1p-20f;
+    const float tl = cl * E, th = cu * E;
+    const float tl_hi = __builtin_fmaf(tl, rho, tl), tl_lo = __builtin_fmaf(tl, -rho, tl);
+    const float th_hi = __builtin_fmaf(th, rho, th), th_lo = __builtin_fmaf(th, -rho, th);
+    const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
+    const int N = prm.N;
+    const double c = (double)m1;
+    double S = 0.0, Q = 0.0;
+    float dmax = 0.f;
+    int n = 0;
+    for (int f0 = 0; f0 < N; f0 += 8) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = to_f32(fp[(int64_t)(f0 + j < N ? f0 + j : N - 1) * prm.stride]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool valid = f0 + j < N;
+            const float e = (x[j] - m1) + (x[j] - m2);     // 2 (x - base)
+            const bool rej_lo = -e > tl_hi, keep_lo = -e <= tl_lo;
+            const bool rej_hi = e > th_hi, keep_hi = e <= th_lo;
+            unsure = unsure || !(rej_lo || keep_lo) || !(rej_hi || keep_hi);   // (a non-finite x never gets here sure: pass 1 gave the pixel up)
+            const bool in = valid && !rej_lo && !rej_hi;
+            const double d = in ? (double)x[j] - c : 0.0;
+            S += d;
+            Q = fma(d, d, Q);
+            n += in ? 1 : 0;
+            dmax = __builtin_fmaxf(dmax, __builtin_fabsf(e));
+        }
+    }
+    unsure = unsure || !(dmax == 0.f || (dmax > 0x1p-40f && dmax < 0x1p40f));
+    const uint64_t m = __builtin_amdgcn_ballot_w64(unsure);
+    if (m != 0) {
+        int first = 0;
+        if (__builtin_amdgcn_readfirstlane(lane) == lane) first = atomicAdd(redo_count, (int)__builtin_popcountll(m));
+        first = __builtin_amdgcn_readfirstlane(first);
+        const int mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (unsure) {
+            redo_list[first + mine] = (int32_t)p;
+            return;
+        }
+    }
+    const double nn = (double)n;
+    const double mean = c + S / nn;
+    if (prm.mean) prm.mean[p] = (float)mean;
+    if (prm.count) prm.count[p] = n;
+    if (prm.mean64) prm.mean64[p] = mean;
+    if (prm.std64) {
+        const double var = (Q - S * S / nn) / nn;
+        prm.std64[p] = sqrt(var > 0.0 ? var : 0.0);
+    }
+}
+
+// Whether a stack of 129 .. 512 frames is the plain median or the one-pass median / mad_std configuration on raw frames
+// (mad_fast_eligible's conditions without the workspace: the list may be a stream-ordered temporary here).
+bool rank_chunks_eligible(const StackParams &prm, bool calib, bool median_only)
+{
+    if (calib || prm.N <= 128 || prm.N > 8 * kChunkSlots || prm.P >= 0x7fffffffLL) return false;
+    if (prm.pixmask || prm.pedestal) return false;
+    if (getenv("APGPU_RANK_CHUNKS_OFF")) return false;      // development: time the exact kernel on the same call
+    if (median_only) return true;
+    if (prm.dev != APGPU_DEV_MAD_STD || prm.center != APGPU_CENTER_MEDIAN || prm.maxiters != 1) return false;
+    if (prm.median || prm.std || prm.moments || prm.single_kernel || prm.fast32 == 0) return false;
+    if (!(prm.sl2 > 0.0 && prm.su2 > 0.0 && prm.sl2 < 1e12 && prm.su2 < 1e12)) return false;
+    return true;
+}
+
+template <int KS, bool PAIR, typename RawT, int MODE>
+static int launch_rank_pass(const StackParams &q, bool fullch, float *tmp, int32_t *cnt, int32_t *list, hipStream_t st)
+{
+    const int64_t grid = (q.P + 255) / 256;
+    const size_t lds = (size_t)(KS - 2) * kChunkWin * 256 * sizeof(float);
+    const void *kern = fullch ? reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, PAIR, RawT, true, MODE>)
+                              : reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, PAIR, RawT, false, MODE>);
+    if (lds > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return kNoRedoList;                             // no room for the parked windows: the caller takes the exact kernel
+        }
+    }
+    if (fullch) hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, PAIR, RawT, true, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
+    else hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, PAIR, RawT, false, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
+    return check_launch("stack kernel (chunked order statistics, 129..512 frames)");
+}
+
+template <int KS, bool PAIR, typename RawT>
+static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+{
+    const bool fullch = prm.N == (PAIR ? 2 : 1) * KS * kChunkSlots;
+    if (describe) {
+        snprintf(describe, 256, "stack_rank_chunks_kernel<%d, %s, %s, %s, %d>", KS, PAIR ? "true" : "false", sizeof(RawT) == 2 ? "unsigned short" : "float",
+                 fullch ? "true" : "false", median_only ? 2 : 0);
+        return APGPU_OK;
+    }
+    if ((prm.P + 255) / 256 > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
+    int32_t *ws = prm.redo, *cnt = nullptr, *list = nullptr, *own = nullptr;
+    StackParams q = prm;
+    q.redo = nullptr;
+    auto exact = [&]() { return launch_big_exact(q, u16, false, median_only, st, nullptr); };
+    if (ws) {
+        cnt = ws;
+        list = ws + ws_list_off(prm.P);
+    } else {
+        hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&own), (size_t)(prm.P + 1) * sizeof(int32_t), st);
+        if (e == hipSuccess) {
+            e = hipMemsetAsync(own, 0, sizeof(int32_t), st);
+            if (e != hipSuccess) (void)hipFreeAsync(own, st);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return exact();
+        }
+        cnt = own;
+        list = own + 1;
+    }
+    float *tmp = nullptr;
+    if (!median_only) {
+        const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&tmp), (size_t)prm.P * 3 * sizeof(float), st);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (own) (void)hipFreeAsync(own, st);
+            return exact();
+        }
+    }
+    int rc;
+    bool launched = false;                                   // something may have been listed: the exact kernel must follow
+    if (median_only) {
+        rc = launch_rank_pass<KS, PAIR, RawT, 2>(q, fullch, nullptr, cnt, list, st);
+        launched = rc == APGPU_OK;
+    } else {
+        rc = launch_rank_pass<KS, PAIR, RawT, 0>(q, fullch, tmp, cnt, list, st);
+        if (rc == APGPU_OK) rc = launch_rank_pass<KS, PAIR, RawT, 1>(q, fullch, tmp, cnt, list, st);
+        if (rc == APGPU_OK) {
+            const float cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5), cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
+            hipLaunchKernelGGL((stack_mad_sums_kernel<RawT>), dim3((unsigned)((prm.P + 255) / 256)), dim3(256), 0, st, q, tmp, cl, cu, cnt, list);
+            rc = check_launch("stack kernel (chunked median / mad_std: sums)");
+            launched = rc == APGPU_OK;
+        }
+    }
+    if (rc == kNoRedoList) rc = exact();                     // (nothing was launched, nothing listed)
+    else if (launched) rc = launch_big_exact(q, u16, false, median_only, st, nullptr, cnt, list, ws);
+    if (tmp) {
+        const hipError_t ef = hipFreeAsync(tmp, st);
+        if (rc == APGPU_OK && ef != hipSuccess) rc = fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
+    }
+    if (own) {
+        const hipError_t ef = hipFreeAsync(own, st);
+        if (rc == APGPU_OK && ef != hipSuccess) rc = fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
+    }
+    return rc;
+}
+
+int launch_rank_chunks(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+{
+    const bool pair = prm.N > 4 * kChunkSlots;
+    const int KS = (prm.N + (pair ? 2 : 1) * kChunkSlots - 1) / ((pair ? 2 : 1) * kChunkSlots);
+    if (u16) {
+        if (pair) return KS == 3 ? launch_rank_k<3, true, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<4, true, uint16_t>(prm, u16, median_only, st, describe);
+        return KS == 3 ? launch_rank_k<3, false, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<4, false, uint16_t>(prm, u16, median_only, st, describe);
+    }
+    if (pair) return KS == 3 ? launch_rank_k<3, true, float>(prm, u16, median_only, st, describe) : launch_rank_k<4, true, float>(prm, u16, median_only, st, describe);
+    return KS == 3 ? launch_rank_k<3, false, float>(prm, u16, median_only, st, describe) : launch_rank_k<4, false, float>(prm, u16, median_only, st, describe);
 }
 
 }  // namespace apgpu_stack

@@ -398,7 +398,7 @@ def combine_f64(frames, sigma_lower=5.0, sigma_upper=5.0, maxiters=1, cenfunc='m
 
 
 def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',), median_only=False, stdfunc='std',
-                      moments_mean_only=False, exact=False):
+                      moments_mean_only=False, exact=False, maxiters=5):
     """Name of the kernel variant the library dispatches for such a stack call (apgpu_stack_kernel_name): what the
     bench line and the profiles call the dominant kernel.  Needs no device."""
     lib = _lib.load()
@@ -410,7 +410,7 @@ def stack_kernel_name(n_frames, dtype='f32', calibrated=True, outputs=('mean',),
     a.frame_stride = 1 << 20
     if calibrated:
         a.bias = a.dark = a.nflat = a.exp_ratio = 0x1000
-    a.center, a.dev, a.maxiters = 0, _lib.DEV[stdfunc], 5
+    a.center, a.dev, a.maxiters = 0, _lib.DEV[stdfunc], int(maxiters)
     a.sigma_lower = a.sigma_upper = 3.0
     if median_only:
         a.median = 0x1000

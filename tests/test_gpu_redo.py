@@ -363,3 +363,91 @@ def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
     assert np.array_equal(r['count'].cpu().numpy(), ref['count'])
     assert_ulp(r['median'].cpu().numpy(), ref['median'].astype(np.float32), 1, 'plain median')
     assert_ulp(r['std'].cpu().numpy(), ref['std'].astype(np.float32), 2, 'plain std')
+
+
+@pytest.mark.parametrize('N,dtype', [(129, np.float32), (192, np.uint16), (200, np.float32), (256, np.float32), (256, np.uint16), (257, np.float32),
+                                     (300, np.uint16), (384, np.float32), (385, np.uint16), (449, np.float32), (512, np.float32), (512, np.uint16)])
+def test_ccdproc_configuration_129_to_512_frames(ops, apref, N, dtype):
+    """The ccdproc.combine configuration (ap_combine_darks.py:394-420: one pass of median / mad_std at 5 deviations, float64 planes)
+    beyond 128 frames (round 6): three chunked passes - the column's middle values, the middle deviations, the float64 sums of what
+    the bounds keep - with the exact kernel behind them for the pixels they are not sure of.  Both published forms against the oracle:
+    counts identical, float64 mean to 4e-16, std to 1e-12; the same numbers from the exact kernel alone and without a workspace."""
+    H, W = 9, 131
+    rng = np.random.default_rng(1700 + N + (1 if dtype == np.uint16 else 0))
+    cube = rng.normal(1000.0, 12.0, (N, H, W))
+    hits = rng.random(cube.shape) < 0.01
+    cube[hits] += rng.uniform(100, 5000, hits.sum())
+    for k in range(3, 40):                                   # columns with k outliers on one side (the clipped mean's tails hold 8 / 16)
+        sgn = 1.0 if k % 2 else -0.4
+        cube[:k, 2, k] += sgn * 2000.0
+    cube[:, 3, :] = np.rint(rng.normal(500.0, 0.6, (N, W)))  # a few distinct integer values: ties, often MAD = 0
+    cube[:, 4, :] = 777.0                                     # constant columns
+    cube[:, 5, :] = np.rint(rng.normal(300.0, 2.0, (N, W)))
+    for x in range(0, W, 3):                                  # a value next to the upper bound (+- a few ulp)
+        col = np.sort(cube[1:, 6, x].astype(np.float32).astype(np.float64))
+        base = np.median(col)
+        mad = np.median(np.abs(col - base))
+        cube[0, 6, x] = base + 5 * 1.482602218505602 * mad * (1 + rng.integers(-3, 4) * 2.0 ** -23)
+    cube[:, 8, :] += np.linspace(0, 60, N)[:, None]          # a drift of five sigma over the sequence (interleaved chunks)
+    if dtype == np.uint16:
+        cube = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
+    else:
+        cube = cube.astype(np.float32)
+        cube[1, 7, 10:40] = np.nan
+        cube[2, 7, 50] = np.inf
+        cube[:, 7, 60] = np.nan
+    d = dev(cube, ops)
+    name = ops.stack_kernel_name(N, 'f32' if dtype == np.float32 else 'u16', calibrated=False, outputs=('mean_f64', 'std_f64'), stdfunc='mad_std', maxiters=1)
+    assert 'stack_rank_chunks_kernel' in name, name
+    for form, flag in (('legacy', False), ('astropy', True)):
+        what = '%d frames %s %s' % (N, np.dtype(dtype).name, form)
+        ref = apref.combine_ccdproc(cube.astype(np.float32) if dtype == np.uint16 else cube, form=form)
+        for kw in (dict(), dict(workspace=False), dict(exact=True)):
+            ops.stack_redo_stats(reset=True)
+            r = ops.stack_sigclip(d, sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count', 'mean_f64', 'std_f64'),
+                                  nonfinite_unclipped=flag, **kw)
+            assert np.array_equal(r['count'].cpu().numpy(), ref['count']), (what, kw)
+            np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True, err_msg=what)
+            assert_ulp(r['mean'].cpu().numpy(), ref['mean'].astype(np.float32), 1, what)
+            np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-12, atol=1e-12, equal_nan=True, err_msg=what)
+            if not kw:
+                st = ops.stack_redo_stats()
+                # the chunked passes carry most of the image: rows 3 (ties at the bound when MAD = 0 are decided exactly), 6 and 7 hold the unsure ones
+                assert st['calls'] == 1 and st['pixels'] == H * W and st['pixels_listed'] < 0.25 * H * W, (what, st)
+                assert _zero_prefix_is_zero(ops, ops.stack_workspace(H * W, d.device), H * W), what
+    # asymmetric thresholds
+    ref = apref.combine_ccdproc(cube.astype(np.float32) if dtype == np.uint16 else cube, low=3.0, high=4.0, form='astropy')
+    r = ops.stack_sigclip(d, sigma_lower=3.0, sigma_upper=4.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('count', 'mean_f64'), nonfinite_unclipped=True)
+    assert np.array_equal(r['count'].cpu().numpy(), ref['count'])
+    np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize('N,dtype', [(129, np.float32), (200, np.uint16), (256, np.float32), (257, np.uint16), (300, np.float32), (384, np.uint16),
+                                     (450, np.float32), (512, np.float32), (512, np.uint16)])
+def test_plain_median_129_to_512_frames(ops, apref, N, dtype):
+    """np.nanmedian along N (config 4) beyond 128 frames on the chunked windows (round 6): an order statistic, so bit-exact; columns
+    holding NaN / inf, a partly filled last workgroup, a drifting sequence, few distinct values."""
+    H, W = 7, 150
+    rng = np.random.default_rng(2700 + N)
+    cube = rng.normal(1000.0, 12.0, (N, H, W))
+    cube[:, 1, :] = np.rint(rng.normal(500.0, 0.6, (N, W)))
+    cube[:, 2, :] = 42.0
+    cube[:, 3, :] += np.linspace(0, 100, N)[:, None]
+    cube[:, 4, :] = np.sort(cube[:, 4, :], axis=0)           # monotone in acquisition order
+    if dtype == np.uint16:
+        cube = np.clip(np.rint(cube), 0, 65535).astype(np.uint16)
+    else:
+        cube = cube.astype(np.float32)
+        cube[3, 5, 5:60] = np.nan
+        cube[4, 5, 70] = np.inf
+        cube[:, 5, 80] = np.nan
+    d = dev(cube, ops)
+    name = ops.stack_kernel_name(N, 'f32' if dtype == np.float32 else 'u16', calibrated=False, median_only=True)
+    assert 'stack_rank_chunks_kernel' in name, name
+    med, cnt = ops.stack_median(d, want_count=True)
+    with np.errstate(all='ignore'):
+        ref = apref.stack_median(cube.astype(np.float32))
+    got = med.cpu().numpy()
+    same = (got == ref.astype(np.float32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), (N, np.argwhere(~same)[:5])
+    assert np.array_equal(cnt.cpu().numpy(), (~np.isnan(cube.astype(np.float32))).sum(0))

@@ -1,0 +1,44 @@
+"""Development aid: the median / mad_std configuration (A6) and the plain median for 129 .. 512 frames - chunked passes (round 6)
+against the exact kernel.   NS=256,512 python tools/bench_big_a6.py"""
+import os
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from astrophotography_amd import ops, synth
+
+H = W = 4096
+dev = torch.device('cuda', 0)
+masters = synth.make_masters(H, W, config_id=2, device=dev)
+nflat, _ = ops.flat_normalize(masters['flat'])
+
+
+def t(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record(); out = fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
+    return min(ts), out
+
+
+for dt in (torch.float32, torch.uint16):
+    for N in [int(x) for x in os.environ.get('NS', '512,384,300,257,256,192,129').split(',')]:
+        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=dt, first_frame=0)
+        kw = dict(sigma=5.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('mean', 'count', 'mean_f64', 'std_f64'), nonfinite_unclipped=True)
+        ops.stack_redo_stats(reset=True)
+        fast, a = t(lambda: ops.stack_sigclip(frames, **kw))
+        st = ops.stack_redo_stats()
+        exact, b = t(lambda: ops.stack_sigclip(frames, exact=True, **kw), reps=1)
+        same = bool(torch.equal(a['count'], b['count']))
+        dm = ((a['mean_f64'] - b['mean_f64']).abs() / b['mean_f64'].abs()).max().item()
+        ds = ((a['std_f64'] - b['std_f64']).abs() / b['std_f64'].clamp_min(1e-9)).max().item()
+        mfast, m1 = t(lambda: ops.stack_median(frames))
+        os.environ['APGPU_RANK_CHUNKS_OFF'] = '1'
+        mexact, m2 = t(lambda: ops.stack_median(frames), reps=1)
+        del os.environ['APGPU_RANK_CHUNKS_OFF']
+        nb = N * frames.element_size()
+        print('N=%3d %-7s A6 float64 planes: chunked %.3f ms (%.1f %% of 8 TB/s on one read), exact kernel %.3f ms, listed %.3f %% | counts equal %s, rel d mean %.2g, rel d std %.2g || '
+              'median: chunked %.3f ms, exact %.3f ms, equal %s' % (N, str(dt).split('.')[-1], fast, 100 * (nb + 24) * H * W / (fast * 1e-3) / 8e12, exact,
+                                                                  100.0 * st['pixels_listed'] / max(st['pixels'], 1), same, dm, ds, mfast, mexact, bool(torch.equal(m1, m2))))
+        del frames

@@ -312,11 +312,14 @@ def chunked_case(seed):
 
 def a6_case(seed):
     """The ccdproc.combine configuration (one pass of median / mad_std, float64 planes) on its fast kernel + rich kernel pair
-    (stack_mad.hip): 3 .. 128 frames, float32 / uint16, thresholds, noise levels from a few distinct integers (ties, MAD = 0) to
+    (stack_mad.hip; a quarter of the cases 129 .. 512 frames: the chunked passes of stack_chunks.hip): float32 / uint16, thresholds, noise levels from a few distinct integers (ties, MAD = 0) to
     wide, outliers on one or both sides, NaN / inf, constant columns, any image size - against the oracle's restatement."""
     rng = np.random.default_rng(seed)
     N = int(rng.integers(3, 129))
     H, W = int(rng.integers(1, 6)), int(rng.integers(1, 400))
+    if rng.integers(0, 4) == 0:                               # round 6: 129 .. 512 frames on the chunked order-statistics passes
+        N = int(rng.choice([int(rng.integers(129, 513)), int(rng.choice([129, 192, 193, 256, 257, 384, 385, 512]))]))
+        W = int(rng.integers(1, 130))
     u16 = bool(rng.integers(0, 2))
     sig = float(rng.choice([0.3, 1.0, 3.0, 40.0]))
     cube = rng.normal(float(rng.choice([50.0, 1000.0, 30000.0])), sig, (N, H, W))
