@@ -1,5 +1,7 @@
 // stack_chunks.hip - 129 .. 256 frames (round 3) and 257 .. 512 frames (round 5: window_step, pairs of chunks) on the float32
-// fast path: the column never exists as a whole.
+// fast path: the column never exists as a whole.  Round 6: the median / std planes of the clipped mean (epilogue +
+// stack_std_pass_kernel), and - second half of the file - the plain median and the median / mad_std configuration on order
+// statistics alone (stack_rank_chunks_kernel, stack_mad_sums_kernel).
 //
 // Same semantics and outputs as the lean register kernels (stack_kernels.h / stack_reduce.h): the sigma-clipped mean /
 // count / partial moments of astropy.stats.sigma_clipped_stats(cube, axis=0) (sigma_clipping.py:298-383, 924-937) with the

@@ -56,7 +56,9 @@ extern "C" {
 #define APGPU_DEV_STD       0
 #define APGPU_DEV_MAD_STD   1
 
-/* largest N one stack call reduces: up to 128 frames the per-pixel column lives in registers, 129 .. 512 in LDS */
+/* largest N one stack call reduces: up to 128 frames the per-pixel column lives in registers; 129 .. 512 frames are reduced chunk by
+ * chunk (64 frames in registers at a time: clipped mean with its median / std planes, plain median, the median / mad_std configuration
+ * on raw frames) with an LDS-resident exact kernel behind them for the pixels they are not sure of and for every other option */
 #define APGPU_MAX_STACK 512
 
 const char *apgpu_last_error(void);

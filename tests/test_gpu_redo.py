@@ -420,6 +420,12 @@ def test_ccdproc_configuration_129_to_512_frames(ops, apref, N, dtype):
     r = ops.stack_sigclip(d, sigma_lower=3.0, sigma_upper=4.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('count', 'mean_f64'), nonfinite_unclipped=True)
     assert np.array_equal(r['count'].cpu().numpy(), ref['count'])
     np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=4e-16, atol=0, equal_nan=True)
+    # a row stripe of the slab reduced in place (frame_stride > n_pixels, an odd first pixel)
+    rs = ops.stack_sigclip(d[:, 1:8], sigma_lower=3.0, sigma_upper=4.0, maxiters=1, cenfunc='median', stdfunc='mad_std', outputs=('count', 'mean_f64', 'std_f64'),
+                           nonfinite_unclipped=True)
+    assert np.array_equal(rs['count'].cpu().numpy(), ref['count'][1:8])
+    np.testing.assert_allclose(rs['mean_f64'].cpu().numpy(), ref['mean'][1:8], rtol=4e-16, atol=0, equal_nan=True)
+    np.testing.assert_allclose(rs['std_f64'].cpu().numpy(), ref['std'][1:8], rtol=1e-12, atol=1e-12, equal_nan=True)
 
 
 @pytest.mark.parametrize('N,dtype', [(129, np.float32), (200, np.uint16), (256, np.float32), (257, np.uint16), (300, np.float32), (384, np.uint16),
@@ -451,3 +457,4 @@ def test_plain_median_129_to_512_frames(ops, apref, N, dtype):
     same = (got == ref.astype(np.float32)) | (np.isnan(got) & np.isnan(ref))
     assert same.all(), (N, np.argwhere(~same)[:5])
     assert np.array_equal(cnt.cpu().numpy(), (~np.isnan(cube.astype(np.float32))).sum(0))
+    np.testing.assert_array_equal(ops.stack_median(d[:, 1:6]).cpu().numpy(), got[1:6])       # a row stripe reduced in place (NaN == NaN here)
