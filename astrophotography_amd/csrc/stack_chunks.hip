@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void stack_std_pass_kernel(const StackParams p
     const cfloat *eg = (const cfloat *)(uintptr_t)prm.exp_ratio, *pg = (const cfloat *)(uintptr_t)prm.pedestal;
     const RawT *fp = static_cast<const RawT *>(prm.frames) + p;
     const int N = prm.N;
-    double q = 0.0;
+    double q = 0.0, s = 0.0;
     int n = 0;
     for (int f0 = 0; f0 < N; f0 += 8) {
         float x[8];
@@ -638,11 +638,19 @@ __global__ __launch_bounds__(256) void stack_std_pass_kernel(const StackParams p
             }
             const bool in = (v >= vmin) && (v <= vmax);      // false for NaN; +-inf lie outside every finite range
             const double d = in ? (double)v - mean : 0.0;
+            s += d;
             q = fma(d, d, q);
             n += in ? 1 : 0;
         }
     }
-    prm.std[p] = n > 0 ? (float)sqrt(q / (double)n) : __builtin_nanf("");
+    // about the pivot `mean` (the float32 mean this call returns, within an ulp of the true one): mean64 = pivot + S / n,
+    // var = (Q - S^2 / n) / n - the float64 planes of ApStack / the N-shard exchange, and the std plane without the pivot's rounding
+    const double nn = (double)n;
+    const double var = n > 0 ? (q - s * s / nn) / nn : 0.0;
+    const double sd = n > 0 ? sqrt(var > 0.0 ? var : 0.0) : (double)__builtin_nanf("");
+    if (prm.std) prm.std[p] = (float)sd;
+    if (prm.mean64) prm.mean64[p] = n > 0 ? mean + s / nn : (double)__builtin_nanf("");
+    if (prm.std64) prm.std64[p] = sd;
 }
 
 // ---- dispatch -----------------------------------------------------------------------------------------------------
@@ -658,7 +666,7 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
     // register kernel - a chunk costs what the whole 64-frame kernel costs - so the register kernels keep that range)
     if (median_only || prm.N <= 128 || prm.N > 8 * kChunkSlots) return false;
     if (prm.P >= 0x7fffffffLL) return false;                 // the redo list holds pixel indices as int32
-    if (prm.mean64 || prm.std64) return false;               // (the float32 median / std planes: round 6, stack_std_pass_kernel)
+    // (the median / std planes and the float64 mean / std planes: round 6, stack_std_pass_kernel)
     if (prm.center != APGPU_CENTER_MEDIAN || prm.dev != APGPU_DEV_STD) return false;
     if (prm.fast32 == 0) return false;
     if (prm.moments && !(prm.moments64 == 0 || prm.moments64 == 3 || prm.moments64 == 4) ) return false;
@@ -713,7 +721,7 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     // the std plane needs the survivors' range and mean of every pixel between the two passes: 12 bytes per pixel, a stream-ordered
     // temporary (like the resample's tile records); if it cannot be had the exact kernel reduces the whole stack
     float *rich_tmp = nullptr;
-    if (prm.std) {
+    if (prm.std || prm.mean64 || prm.std64) {
         const hipError_t e = hipMallocAsync(reinterpret_cast<void **>(&rich_tmp), (size_t)prm.P * 3 * sizeof(float), st);
         if (e != hipSuccess) {
             (void)hipGetLastError();

@@ -344,7 +344,7 @@ def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
     d = dev(raw, ops)
     name = ops.stack_kernel_name(N, 'f32' if dt == np.float32 else 'u16', calibrated=True, outputs=('mean', 'median', 'std'))
     assert 'stack_chunks_kernel' in name, name
-    for outs in (('mean', 'median', 'std', 'count'), ('median',), ('std', 'count')):
+    for outs in (('mean', 'median', 'std', 'count'), ('median',), ('std', 'count'), ('mean', 'count', 'mean_f64', 'std_f64')):
         for kw in (dict(sigma=3.0, maxiters=5), dict(sigma=2.0, maxiters=None), dict(sigma_lower=2.5, sigma_upper=4.0, maxiters=2)):
             ref = apref.stack_sigclip(cal, pixmask=pm, **kw)
             r = ops.stack_sigclip(d, calib=calib, pixmask=dev(pm, ops), outputs=outs, **kw)
@@ -357,6 +357,9 @@ def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
                 assert_ulp(r['median'].cpu().numpy(), ref['median'].astype(np.float32), 1, 'median ' + what)
             if 'std' in outs:
                 assert_ulp(r['std'].cpu().numpy(), ref['std'].astype(np.float32), 2, 'std ' + what)
+            if 'mean_f64' in outs:                            # the float64 planes (ApStack, the N-shard exchange): from the second pass
+                np.testing.assert_allclose(r['mean_f64'].cpu().numpy(), ref['mean'], rtol=1e-13, equal_nan=True, err_msg=what)
+                np.testing.assert_allclose(r['std_f64'].cpu().numpy(), ref['std'], rtol=1e-11, atol=1e-12, equal_nan=True, err_msg=what)
     # plain (unfused) frames as well
     ref = apref.stack_sigclip(raw.astype(np.float32), sigma=3.0, maxiters=5)
     r = ops.stack_sigclip(d, sigma=3.0, maxiters=5, outputs=('mean', 'median', 'std', 'count'))
