@@ -348,7 +348,7 @@ __device__ __forceinline__ void trim_high_t(const float (&GH)[T], FastT &f, cons
     }
 }
 
-// One WINDOW of the final merge.  129 .. 256 frames (PAIR = false): the window of chunk SIDX.  257 .. 512 frames (PAIR = true,
+// One WINDOW of the final merge.  A single chunk (129 .. 256 frames: every window), or a PAIR of chunks (257 .. 512 frames,
 // round 5): chunks 2 SIDX and 2 SIDX + 1 are reduced one after the other - tails and sums exactly as before - and their two
 // windows are merged (Batcher's 32 + 32 merge pruned to the 32 middle outputs) into ONE window of 32: the 16 lowest and 16
 // highest of the 64 are dropped (they are already part of the sums, which cover everything between the tails).  The pair is a
@@ -358,16 +358,17 @@ __device__ __forceinline__ void trim_high_t(const float (&GH)[T], FastT &f, cons
 // the windows vouch for shrinks accordingly: a value x is at merged index (rank - below) iff everything that was left out is
 // known to lie on its proper side of x - the chunk values below / above the chunk windows (Lmax / Umin as before) AND the
 // dropped 16 + 16, which are <= P[0] / >= P[31]: Lmax = max(.., P[0]), Umin = min(.., P[31]), below += 16 per pair.
-template <typename RawT, bool CALIB, bool FULLCH, int SIDX, int KS, bool PAIR, int T>
+template <typename RawT, bool CALIB, bool FULLCH, int SIDX, int KS, int NPAIR, int T>
 __device__ __forceinline__ bool window_step(const StackParams &prm, const FrameScalars<kChunkSlots> *fs, int cbase, int cextra, int64_t base,
                                             int lane, float (&GL)[T], float (&GH)[T], float (&win)[kChunkWin], float &c0, float &Stot,
                                             float &Qtot, float &Lmax, float &Umin, int &below)
 {
-    constexpr int W = kChunkWin;
-    if constexpr (!PAIR) {
-        const int c = cbase + (SIDX < cextra ? 1 : 0);
+    constexpr int W = kChunkWin, K = KS + NPAIR;            // the first NPAIR windows are pairs of chunks, the others single chunks
+    if constexpr (SIDX >= NPAIR) {
+        constexpr int kc = SIDX + NPAIR;
+        const int c = cbase + (kc < cextra ? 1 : 0);
         below += c / 2 - W / 2;
-        return chunk_step<RawT, CALIB, FULLCH, SIDX == 0, KS, T>(prm, fs[SIDX], SIDX, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin);
+        return chunk_step<RawT, CALIB, FULLCH, kc == 0, K, T>(prm, fs[kc], kc, c, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin);
     } else {
         constexpr int ka = 2 * SIDX, kb = 2 * SIDX + 1;
         const int ca = cbase + (ka < cextra ? 1 : 0), cb = cbase + (kb < cextra ? 1 : 0);
@@ -375,13 +376,13 @@ __device__ __forceinline__ bool window_step(const StackParams &prm, const FrameS
         bool ok;
         {
             float wa[W];
-            ok = chunk_step<RawT, CALIB, FULLCH, SIDX == 0, 2 * KS, T>(prm, fs[ka], ka, ca, base, lane, GL, GH, wa, c0, Stot, Qtot, Lmax, Umin);
+            ok = chunk_step<RawT, CALIB, FULLCH, SIDX == 0, K, T>(prm, fs[ka], ka, ca, base, lane, GL, GH, wa, c0, Stot, Qtot, Lmax, Umin);
 #pragma unroll
             for (int j = 0; j < W; j++) Y[j] = wa[j];
         }
         {
             float wb[W];
-            ok = chunk_step<RawT, CALIB, FULLCH, false, 2 * KS, T>(prm, fs[kb], kb, cb, base, lane, GL, GH, wb, c0, Stot, Qtot, Lmax, Umin) && ok;
+            ok = chunk_step<RawT, CALIB, FULLCH, false, K, T>(prm, fs[kb], kb, cb, base, lane, GL, GH, wb, c0, Stot, Qtot, Lmax, Umin) && ok;
 #pragma unroll
             for (int j = 0; j < W; j++) Y[W + j] = wb[j];
         }
@@ -396,15 +397,17 @@ __device__ __forceinline__ bool window_step(const StackParams &prm, const FrameS
     }
 }
 
-// KS windows reach the final merge (3 or 4; the template also takes 2).  PAIR: every window is made of two chunks, K = 2 KS
+// KS windows reach the final merge (3 or 4; the template also takes 2).  The first NPAIR of them are made of two chunks each, K = KS +
+// NPAIR chunks in all (round 5: NPAIR = KS, 6 or 8 chunks; round 6: also 5 = one pair + three single chunks for 257 .. 320 frames and
+// 7 = three pairs + one for 385 .. 448 - a chunk costs what it costs whether it holds 43 frames or 64, so fewer, fuller chunks),
 // chunks in all (6: 257 .. 384 frames, 8: 385 .. 512), and the tails hold 16 values (a 512-frame column loses twice as many
 // values to the same clip as a 256-frame one).
-template <int KS, bool PAIR, typename RawT, bool CALIB, bool FULLCH>
+template <int KS, int NPAIR, typename RawT, bool CALIB, bool FULLCH>
 __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kernel(const StackParams prm, int32_t *redo_count, int32_t *redo_list,
                                                                                        float *rich_tmp)
 {
-    constexpr int K = PAIR ? 2 * KS : KS;
-    constexpr int T = PAIR ? kChunkTailPairs : kChunkTail, W = kChunkWin;
+    constexpr int K = KS + NPAIR;
+    constexpr int T = NPAIR > 0 ? kChunkTailPairs : kChunkTail, W = kChunkWin;
     __shared__ FrameScalars<kChunkSlots> fs[K];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -435,18 +438,18 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     int below = 0;                                          // values below the windows (wave-uniform)
     if constexpr (KS >= 3) {
         float win[W];
-        ok = window_step<RawT, CALIB, FULLCH, 0, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+        ok = window_step<RawT, CALIB, FULLCH, 0, KS, NPAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
     }
     if constexpr (KS == 4) {
         float win[W];
-        ok = window_step<RawT, CALIB, FULLCH, 1, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+        ok = window_step<RawT, CALIB, FULLCH, 1, KS, NPAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, win, c0, Stot, Qtot, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
     }
-    ok = window_step<RawT, CALIB, FULLCH, KS - 2, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin, below) && ok;
-    ok = window_step<RawT, CALIB, FULLCH, KS - 1, KS, PAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+    ok = window_step<RawT, CALIB, FULLCH, KS - 2, KS, NPAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R0, c0, Stot, Qtot, Lmax, Umin, below) && ok;
+    ok = window_step<RawT, CALIB, FULLCH, KS - 1, KS, NPAIR, T>(prm, fs, cbase, cextra, base, lane, GL, GH, R1, c0, Stot, Qtot, Lmax, Umin, below) && ok;
     float X[4 * W];                                         // the KS windows side by side, +inf beyond them
     {
         int slot = lane;
@@ -674,12 +677,12 @@ bool chunks_eligible(const StackParams &prm, bool median_only)
     return true;
 }
 
-template <int KS, bool PAIR, typename RawT, bool CALIB>
+template <int KS, int NPAIR, typename RawT, bool CALIB>
 static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, char *describe)
 {
-    const bool fullch = prm.N == (PAIR ? 2 : 1) * KS * kChunkSlots;
+    const bool fullch = prm.N == (KS + NPAIR) * kChunkSlots;
     if (describe) {
-        snprintf(describe, 256, "stack_chunks_kernel<%d, %s, %s, %s, %s>", KS, PAIR ? "true" : "false", sizeof(RawT) == 2 ? "unsigned short" : "float",
+        snprintf(describe, 256, "stack_chunks_kernel<%d, %d, %s, %s, %s>", KS, NPAIR, sizeof(RawT) == 2 ? "unsigned short" : "float",
                  CALIB ? "true" : "false", fullch ? "true" : "false");
         return APGPU_OK;
     }
@@ -709,8 +712,8 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     }
     const size_t lds = (size_t)(KS - 2) * kChunkWin * 256 * sizeof(float);
     if (lds > 48 * 1024) {
-        const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>)
-                                  : reinterpret_cast<const void *>(stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>);
+        const void *kern = fullch ? reinterpret_cast<const void *>(stack_chunks_kernel<KS, NPAIR, RawT, CALIB, true>)
+                                  : reinterpret_cast<const void *>(stack_chunks_kernel<KS, NPAIR, RawT, CALIB, false>);
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {                              // no room for the parked windows: the exact kernel does the whole stack
             (void)hipGetLastError();
@@ -729,8 +732,8 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
             return launch_big_exact(q, u16, CALIB, false, st, nullptr);
         }
     }
-    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
-    else hipLaunchKernelGGL((stack_chunks_kernel<KS, PAIR, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
+    if (fullch) hipLaunchKernelGGL((stack_chunks_kernel<KS, NPAIR, RawT, CALIB, true>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
+    else hipLaunchKernelGGL((stack_chunks_kernel<KS, NPAIR, RawT, CALIB, false>), dim3((unsigned)grid), dim3(256), lds, st, q, cnt, list, rich_tmp);
     int rc = check_launch("stack kernel (chunked, 129..512 frames)");
     if (rc == APGPU_OK) rc = launch_big_exact(q, u16, CALIB, false, st, nullptr, cnt, list, ws);
     if (rc == APGPU_OK && rich_tmp) {
@@ -748,20 +751,37 @@ static int launch_chunks_k(const StackParams &prm, bool u16, hipStream_t st, cha
     return rc;
 }
 
-template <int KS, bool PAIR>
+template <int KS, int NPAIR>
 static int launch_chunks_t(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
 {
-    if (u16) return calib ? launch_chunks_k<KS, PAIR, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<KS, PAIR, uint16_t, false>(prm, u16, st, describe);
-    return calib ? launch_chunks_k<KS, PAIR, float, true>(prm, u16, st, describe) : launch_chunks_k<KS, PAIR, float, false>(prm, u16, st, describe);
+    if (u16) return calib ? launch_chunks_k<KS, NPAIR, uint16_t, true>(prm, u16, st, describe) : launch_chunks_k<KS, NPAIR, uint16_t, false>(prm, u16, st, describe);
+    return calib ? launch_chunks_k<KS, NPAIR, float, true>(prm, u16, st, describe) : launch_chunks_k<KS, NPAIR, float, false>(prm, u16, st, describe);
+}
+
+// How a stack of 129 .. 512 frames is cut: K = ceil(N / 64) chunks of N / K (+ 1) frames, KS = 3 or 4 windows of which the first K - KS
+// are pairs.  K = 3, 4: one window per chunk; 5: (4, 1); 6: (3, 3); 7: (4, 3); 8: (4, 4).
+#ifndef APGPU_CHUNKS_ODD_COUNTS
+#define APGPU_CHUNKS_ODD_COUNTS 1                            // 0: round 5's cut (6 chunks up to 384 frames, 8 beyond)
+#endif
+static inline int chunk_count(int N)
+{
+    int K = (N + kChunkSlots - 1) / kChunkSlots;
+#if !APGPU_CHUNKS_ODD_COUNTS
+    if (K == 5 || K == 7) K++;
+#endif
+    return K;
 }
 
 int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe)
 {
-    // 129 .. 256 frames: 3 or 4 chunks, one window each; 257 .. 512: 3 or 4 PAIRS of chunks (6 or 8 chunks of 42 .. 64 frames)
-    const bool pair = prm.N > 4 * kChunkSlots;
-    const int KS = (prm.N + (pair ? 2 : 1) * kChunkSlots - 1) / ((pair ? 2 : 1) * kChunkSlots);
-    if (pair) return KS == 3 ? launch_chunks_t<3, true>(prm, u16, calib, st, describe) : launch_chunks_t<4, true>(prm, u16, calib, st, describe);
-    return KS == 3 ? launch_chunks_t<3, false>(prm, u16, calib, st, describe) : launch_chunks_t<4, false>(prm, u16, calib, st, describe);
+    switch (chunk_count(prm.N)) {
+    case 3: return launch_chunks_t<3, 0>(prm, u16, calib, st, describe);
+    case 4: return launch_chunks_t<4, 0>(prm, u16, calib, st, describe);
+    case 5: return launch_chunks_t<4, 1>(prm, u16, calib, st, describe);
+    case 6: return launch_chunks_t<3, 3>(prm, u16, calib, st, describe);
+    case 7: return launch_chunks_t<4, 3>(prm, u16, calib, st, describe);
+    default: return launch_chunks_t<4, 4>(prm, u16, calib, st, describe);
+    }
 }
 
 
@@ -827,15 +847,16 @@ __device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kc
     return good;
 }
 
-template <typename RawT, bool FULLCH, bool DEV, int SIDX, int KS, bool PAIR>
+template <typename RawT, bool FULLCH, bool DEV, int SIDX, int KS, int NPAIR>
 __device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cbase, int cextra, int64_t base, int lane, float m1, float m2,
                                                  float (&win)[kChunkWin], float &Lmax, float &Umin, int &below)
 {
-    constexpr int W = kChunkWin;
-    if constexpr (!PAIR) {
-        const int c = cbase + (SIDX < cextra ? 1 : 0);
+    constexpr int W = kChunkWin, K = KS + NPAIR;
+    if constexpr (SIDX >= NPAIR) {
+        constexpr int kc = SIDX + NPAIR;
+        const int c = cbase + (kc < cextra ? 1 : 0);
         below += c / 2 - W / 2;
-        return rank_chunk_window<RawT, FULLCH, DEV>(prm, SIDX, KS, c, base, lane, m1, m2, win, Lmax, Umin, SIDX == 0);
+        return rank_chunk_window<RawT, FULLCH, DEV>(prm, kc, K, c, base, lane, m1, m2, win, Lmax, Umin, kc == 0);
     } else {
         constexpr int ka = 2 * SIDX, kb = 2 * SIDX + 1;
         const int ca = cbase + (ka < cextra ? 1 : 0), cb = cbase + (kb < cextra ? 1 : 0);
@@ -843,13 +864,13 @@ __device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cba
         bool ok;
         {
             float wa[W];
-            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, ka, 2 * KS, ca, base, lane, m1, m2, wa, Lmax, Umin, SIDX == 0);
+            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, ka, K, ca, base, lane, m1, m2, wa, Lmax, Umin, SIDX == 0);
 #pragma unroll
             for (int j = 0; j < W; j++) Y[j] = wa[j];
         }
         {
             float wb[W];
-            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, kb, 2 * KS, cb, base, lane, m1, m2, wb, Lmax, Umin, false) && ok;
+            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, kb, K, cb, base, lane, m1, m2, wb, Lmax, Umin, false) && ok;
 #pragma unroll
             for (int j = 0; j < W; j++) Y[W + j] = wb[j];
         }
@@ -866,10 +887,10 @@ __device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cba
 
 // MODE 0: tmp[p], tmp[P + p] = the column's two middle values (NaN, -: not sure).  MODE 1: tmp[2 P + p] = the sum of the two middle
 // values of |(x - m1) + (x - m2)| (not sure: tmp[p] = NaN).  MODE 2: the median plane (+ count = N); a pixel that is not sure is listed.
-template <int KS, bool PAIR, typename RawT, bool FULLCH, int MODE>
+template <int KS, int NPAIR, typename RawT, bool FULLCH, int MODE>
 __global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackParams prm, float *tmp, int32_t *redo_count, int32_t *redo_list)
 {
-    constexpr int K = PAIR ? 2 * KS : KS, W = kChunkWin;
+    constexpr int K = KS + NPAIR, W = kChunkWin;
     constexpr bool DEV = MODE == 1;
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
@@ -890,18 +911,18 @@ __global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackPa
     int below = 0;
     if constexpr (KS >= 3) {
         float win[W];
-        ok = rank_window_step<RawT, FULLCH, DEV, 0, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+        ok = rank_window_step<RawT, FULLCH, DEV, 0, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
     }
     if constexpr (KS == 4) {
         float win[W];
-        ok = rank_window_step<RawT, FULLCH, DEV, 1, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+        ok = rank_window_step<RawT, FULLCH, DEV, 1, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
     }
-    ok = rank_window_step<RawT, FULLCH, DEV, KS - 2, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, R0, Lmax, Umin, below) && ok;
-    ok = rank_window_step<RawT, FULLCH, DEV, KS - 1, KS, PAIR>(prm, cbase, cextra, base, lane, m1, m2, R1, Lmax, Umin, below) && ok;
+    ok = rank_window_step<RawT, FULLCH, DEV, KS - 2, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, R0, Lmax, Umin, below) && ok;
+    ok = rank_window_step<RawT, FULLCH, DEV, KS - 1, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, R1, Lmax, Umin, below) && ok;
     float X[4 * W];
     {
         int slot = lane;
@@ -1027,13 +1048,13 @@ bool rank_chunks_eligible(const StackParams &prm, bool calib, bool median_only)
     return true;
 }
 
-template <int KS, bool PAIR, typename RawT, int MODE>
+template <int KS, int NPAIR, typename RawT, int MODE>
 static int launch_rank_pass(const StackParams &q, bool fullch, float *tmp, int32_t *cnt, int32_t *list, hipStream_t st)
 {
     const int64_t grid = (q.P + 255) / 256;
     const size_t lds = (size_t)(KS - 2) * kChunkWin * 256 * sizeof(float);
-    const void *kern = fullch ? reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, PAIR, RawT, true, MODE>)
-                              : reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, PAIR, RawT, false, MODE>);
+    const void *kern = fullch ? reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, NPAIR, RawT, true, MODE>)
+                              : reinterpret_cast<const void *>(stack_rank_chunks_kernel<KS, NPAIR, RawT, false, MODE>);
     if (lds > 48 * 1024) {
         const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
@@ -1041,17 +1062,17 @@ static int launch_rank_pass(const StackParams &q, bool fullch, float *tmp, int32
             return kNoRedoList;                             // no room for the parked windows: the caller takes the exact kernel
         }
     }
-    if (fullch) hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, PAIR, RawT, true, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
-    else hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, PAIR, RawT, false, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
+    if (fullch) hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, NPAIR, RawT, true, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
+    else hipLaunchKernelGGL((stack_rank_chunks_kernel<KS, NPAIR, RawT, false, MODE>), dim3((unsigned)grid), dim3(256), lds, st, q, tmp, cnt, list);
     return check_launch("stack kernel (chunked order statistics, 129..512 frames)");
 }
 
-template <int KS, bool PAIR, typename RawT>
+template <int KS, int NPAIR, typename RawT>
 static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
 {
-    const bool fullch = prm.N == (PAIR ? 2 : 1) * KS * kChunkSlots;
+    const bool fullch = prm.N == (KS + NPAIR) * kChunkSlots;
     if (describe) {
-        snprintf(describe, 256, "stack_rank_chunks_kernel<%d, %s, %s, %s, %d>", KS, PAIR ? "true" : "false", sizeof(RawT) == 2 ? "unsigned short" : "float",
+        snprintf(describe, 256, "stack_rank_chunks_kernel<%d, %d, %s, %s, %d>", KS, NPAIR, sizeof(RawT) == 2 ? "unsigned short" : "float",
                  fullch ? "true" : "false", median_only ? 2 : 0);
         return APGPU_OK;
     }
@@ -1088,11 +1109,11 @@ static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hip
     int rc;
     bool launched = false;                                   // something may have been listed: the exact kernel must follow
     if (median_only) {
-        rc = launch_rank_pass<KS, PAIR, RawT, 2>(q, fullch, nullptr, cnt, list, st);
+        rc = launch_rank_pass<KS, NPAIR, RawT, 2>(q, fullch, nullptr, cnt, list, st);
         launched = rc == APGPU_OK;
     } else {
-        rc = launch_rank_pass<KS, PAIR, RawT, 0>(q, fullch, tmp, cnt, list, st);
-        if (rc == APGPU_OK) rc = launch_rank_pass<KS, PAIR, RawT, 1>(q, fullch, tmp, cnt, list, st);
+        rc = launch_rank_pass<KS, NPAIR, RawT, 0>(q, fullch, tmp, cnt, list, st);
+        if (rc == APGPU_OK) rc = launch_rank_pass<KS, NPAIR, RawT, 1>(q, fullch, tmp, cnt, list, st);
         if (rc == APGPU_OK) {
             const float cl = (float)(sqrt(prm.sl2) * 1.482602218505602 * 0.5), cu = (float)(sqrt(prm.su2) * 1.482602218505602 * 0.5);
             hipLaunchKernelGGL((stack_mad_sums_kernel<RawT>), dim3((unsigned)((prm.P + 255) / 256)), dim3(256), 0, st, q, tmp, cl, cu, cnt, list);
@@ -1113,16 +1134,22 @@ static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hip
     return rc;
 }
 
+template <int KS, int NPAIR>
+static int launch_rank_t(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+{
+    return u16 ? launch_rank_k<KS, NPAIR, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<KS, NPAIR, float>(prm, u16, median_only, st, describe);
+}
+
 int launch_rank_chunks(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
 {
-    const bool pair = prm.N > 4 * kChunkSlots;
-    const int KS = (prm.N + (pair ? 2 : 1) * kChunkSlots - 1) / ((pair ? 2 : 1) * kChunkSlots);
-    if (u16) {
-        if (pair) return KS == 3 ? launch_rank_k<3, true, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<4, true, uint16_t>(prm, u16, median_only, st, describe);
-        return KS == 3 ? launch_rank_k<3, false, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<4, false, uint16_t>(prm, u16, median_only, st, describe);
+    switch (chunk_count(prm.N)) {
+    case 3: return launch_rank_t<3, 0>(prm, u16, median_only, st, describe);
+    case 4: return launch_rank_t<4, 0>(prm, u16, median_only, st, describe);
+    case 5: return launch_rank_t<4, 1>(prm, u16, median_only, st, describe);
+    case 6: return launch_rank_t<3, 3>(prm, u16, median_only, st, describe);
+    case 7: return launch_rank_t<4, 3>(prm, u16, median_only, st, describe);
+    default: return launch_rank_t<4, 4>(prm, u16, median_only, st, describe);
     }
-    if (pair) return KS == 3 ? launch_rank_k<3, true, float>(prm, u16, median_only, st, describe) : launch_rank_k<4, true, float>(prm, u16, median_only, st, describe);
-    return KS == 3 ? launch_rank_k<3, false, float>(prm, u16, median_only, st, describe) : launch_rank_k<4, false, float>(prm, u16, median_only, st, describe);
 }
 
 }  // namespace apgpu_stack

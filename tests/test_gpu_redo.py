@@ -178,8 +178,8 @@ def test_workspace_contract(ops, apref):
     assert ws[o:o + 8].view(torch.int64)[0].item() == before + 1 and _zero_prefix_is_zero(ops, ws, H * W)
 
 
-@pytest.mark.parametrize('N,dtype', [(257, np.float32), (320, np.uint16), (384, np.float32), (385, np.uint16), (470, np.float32), (512, np.float32),
-                                     (512, np.uint16)])
+@pytest.mark.parametrize('N,dtype', [(257, np.float32), (320, np.uint16), (384, np.float32), (385, np.uint16), (448, np.float32), (470, np.float32), (512, np.float32),
+                                     (512, np.uint16), (300, np.uint16), (420, np.uint16)])
 def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
     """257 .. 512 frames on the chunked kernel (round 5: pairs of chunks, tails of 16): fused calibration, a sky level that drifts
     in acquisition order, 1 % outliers per frame (five per column on average: some columns use the tails up), a dead column,
@@ -202,7 +202,9 @@ def test_chunked_pairs_257_to_512_frames(ops, apref, N, dtype):
         mean_ref, cnt_ref = apref.calibrate_stack(raw, bias, dark, nf, el, sigma=3.0, maxiters=5)
     calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nf, ops), exp_ratio=el)
     name = ops.stack_kernel_name(N, 'u16' if dtype == np.uint16 else 'f32', calibrated=True)
-    assert name.startswith('stack_chunks_kernel<%d, true' % (3 if N <= 384 else 4)), name
+    K = -(-N // 64)                                          # chunks; KS windows, the first K - KS of them pairs (5 = 4 + 1 and 7 = 4 + 3: round 6)
+    KS = 3 if K in (3, 6) else 4
+    assert name.startswith('stack_chunks_kernel<%d, %d,' % (KS, K - KS)), name
     d = dev(raw, ops)
     ops.stack_redo_stats(reset=True)
     r = ops.stack_sigclip(d, sigma=3.0, maxiters=5, calib=calib, outputs=('mean', 'count'))
@@ -318,7 +320,8 @@ def test_ccdproc_configuration_guard(ops, apref):
     assert call(dc, clean) < nblocks // 8                     # the sampled tiles were clean: mode 0 again
 
 
-@pytest.mark.parametrize('N,dt', [(130, np.float32), (192, np.uint16), (256, np.float32), (300, np.uint16), (384, np.float32), (500, np.float32), (512, np.uint16)])
+@pytest.mark.parametrize('N,dt', [(130, np.float32), (192, np.uint16), (256, np.float32), (300, np.uint16), (320, np.float32), (384, np.float32), (400, np.uint16),
+                                  (448, np.float32), (500, np.float32), (512, np.uint16)])
 def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
     """129 .. 512 frames with the median and std planes of the survivors (round 6): the chunked float32 path + its second pass
     (stack_std_pass_kernel) instead of the LDS-resident exact kernel - against the oracle: counts identical, mean and median
@@ -369,7 +372,7 @@ def test_big_stacks_median_and_std_planes_on_the_chunk_path(ops, apref, N, dt):
 
 
 @pytest.mark.parametrize('N,dtype', [(129, np.float32), (192, np.uint16), (200, np.float32), (256, np.float32), (256, np.uint16), (257, np.float32),
-                                     (300, np.uint16), (384, np.float32), (385, np.uint16), (449, np.float32), (512, np.float32), (512, np.uint16)])
+                                     (300, np.uint16), (320, np.float32), (384, np.float32), (385, np.uint16), (448, np.float32), (449, np.float32), (512, np.float32), (512, np.uint16)])
 def test_ccdproc_configuration_129_to_512_frames(ops, apref, N, dtype):
     """The ccdproc.combine configuration (ap_combine_darks.py:394-420: one pass of median / mad_std at 5 deviations, float64 planes)
     beyond 128 frames (round 6): three chunked passes - the column's middle values, the middle deviations, the float64 sums of what
@@ -432,7 +435,7 @@ def test_ccdproc_configuration_129_to_512_frames(ops, apref, N, dtype):
 
 
 @pytest.mark.parametrize('N,dtype', [(129, np.float32), (200, np.uint16), (256, np.float32), (257, np.uint16), (300, np.float32), (384, np.uint16),
-                                     (450, np.float32), (512, np.float32), (512, np.uint16)])
+                                     (320, np.uint16), (440, np.float32), (448, np.uint16), (450, np.float32), (512, np.float32), (512, np.uint16)])
 def test_plain_median_129_to_512_frames(ops, apref, N, dtype):
     """np.nanmedian along N (config 4) beyond 128 frames on the chunked windows (round 6): an order statistic, so bit-exact; columns
     holding NaN / inf, a partly filled last workgroup, a drifting sequence, few distinct values."""
