@@ -166,7 +166,8 @@ class ApCalibrate:
         if isinstance(odata, np.ndarray):
             fitsio.write(str(outdata_file), odata, hdr, overwrite=True)
         else:
-            fitsio.write_device(str(outdata_file), odata, hdr, overwrite=True)     # big-endian encode on the device
+            # big-endian encode on the device; calibrate_files hands a pool of writer threads over (self._write_pool)
+            fitsio.write_device(str(outdata_file), odata, hdr, overwrite=True, pool=getattr(self, '_write_pool', None))
         self._logger.info(f'Wrote bias/dark/flat corrected file to {outdata_file}')
 
     def _base_keywords(self):
@@ -288,6 +289,23 @@ class ApCalibrate:
         t1 = time.perf_counter()
         cal = self.calibrate_slab(slab, ratios, peds)
         t_compute, t_write = 0.0, 0.0
+        # the output files are written by a few threads while the next frame is repaired and encoded (fitsio.WritePool)
+        self._write_pool = fitsio.shared_write_pool() if len(raw_images) > 1 else None
+        try:
+            t_compute, t_write = self._calibrate_files_loop(raw_images, cal_images, cal, hdrs, delta_pix, fixcosmic)
+        finally:
+            pool, self._write_pool = self._write_pool, None
+            if pool is not None:
+                tw = time.perf_counter()
+                pool.wait()                                 # every file in place (or the first error) before this call returns
+                t_write += time.perf_counter() - tw
+        if timings is not None:
+            timings.update(read=t1 - t0, compute=t_compute, write=t_write, total=time.perf_counter() - t0, frames=len(raw_images))
+
+    def _calibrate_files_loop(self, raw_images, cal_images, cal, hdrs, delta_pix, fixcosmic):
+        from .. import ops
+        import torch
+        t_compute, t_write = 0.0, 0.0
         for i, (src, dst) in enumerate(zip(raw_images, cal_images)):
             tc = time.perf_counter()
             odict = self._base_keywords()
@@ -315,5 +333,4 @@ class ApCalibrate:
             self._write_corrected_image(src, dst, img, odict)
             t_compute += tw - tc
             t_write += time.perf_counter() - tw
-        if timings is not None:
-            timings.update(read=t1 - t0, compute=t_compute, write=t_write, total=time.perf_counter() - t0, frames=len(raw_images))
+        return t_compute, t_write

@@ -309,6 +309,20 @@ def _structural(hdr, data):
 
 def read(path, want_data=True):
     """Primary HDU -> (data, Header).  Mirrors fits.open(path, uint=True, do_not_scale_image_data=False)."""
+    if not want_data:
+        # the header blocks and whatever follows the data unit (extensions, kept verbatim) - not the data unit itself: the per-frame
+        # flow reads the raw frame's header again for every output file (ApCalibrate.py:348-404), 34 MB each time in the first form
+        hdr, pos = _read_header_only(path)
+        naxis = int(hdr.get('NAXIS', 0))
+        bitpix = int(hdr['BITPIX'])
+        if bitpix not in _BITPIX_DTYPE:
+            raise OSError('%s: unsupported BITPIX %d' % (path, bitpix))
+        count = int(np.prod([int(hdr['NAXIS%d' % i]) for i in range(1, naxis + 1)])) if naxis > 0 else 0
+        nbytes = count * abs(bitpix) // 8
+        with open(path, 'rb') as f:
+            f.seek(pos + ((nbytes + BLOCK - 1) // BLOCK) * BLOCK)
+            hdr._tail = f.read()
+        return None, hdr
     with open(path, 'rb') as f:
         raw = f.read()
     if raw[:6] != b'SIMPLE':
@@ -699,8 +713,87 @@ def read_slab_device(paths, device='cuda', dtype='auto', timings=None):
     return slab, hdrs
 
 
-def write_device(path, tensor, header=None, overwrite=True):
-    """float32 / float64 device tensor -> BITPIX -32 / -64 primary HDU (big-endian conversion on the device)."""
+_staging_buf = {}
+
+
+def _staging(nbytes):
+    """A pinned host buffer of at least nbytes (one per thread, grown as needed): the D2H copy of a frame runs at the link's
+    rate into pinned memory and at a fraction of it into pageable memory."""
+    import threading
+    import torch
+    key = threading.get_ident()
+    buf = _staging_buf.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+        _staging_buf[key] = buf
+    return buf[:nbytes]
+
+
+class WritePool:
+    """File writes of device frames overlapped with each other and with the caller's next frame (round 6): `workers` threads, each
+    write from its own pinned staging buffer.  write_device(.., pool=p) returns once the frame's bytes are in a staging buffer (the
+    device tensor may be reused); p.wait() returns when every file is in place and re-raises the first error.  Writing a 4096^2
+    float32 frame into the page cache is a 67 MB copy on one core (~20 ms): four of them run side by side."""
+
+    def __init__(self, workers=4):
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        self._ex = ThreadPoolExecutor(max_workers=workers)
+        self._free = queue.Queue()
+        for _ in range(workers):
+            self._free.put([None])                           # one slot per worker; its buffer is allocated on first use
+        self._futures = []
+
+    def staging(self, nbytes):
+        import torch
+        slot = self._free.get()                              # blocks while every buffer is being written out
+        if slot[0] is None or slot[0].numel() < nbytes:
+            slot[0] = torch.empty(int(nbytes), dtype=torch.uint8, pin_memory=True)
+        return slot
+
+    def submit(self, slot, fn):
+        def run():
+            try:
+                fn()
+            finally:
+                self._free.put(slot)
+        self._futures.append(self._ex.submit(run))
+
+    def wait(self):
+        futures, self._futures = self._futures, []
+        err = None
+        for f in futures:
+            try:
+                f.result()
+            except Exception as e:                           # noqa: BLE001 - reported after every write has finished
+                err = err or e
+        if err is not None:
+            raise err
+
+    def close(self):
+        try:
+            self.wait()
+        finally:
+            self._ex.shutdown(wait=True)
+
+
+_shared_pool = []
+
+
+def shared_write_pool(workers=None):
+    """The process's WritePool (created on first use, its pinned buffers kept: pinning 67 MB costs more than writing it).
+    APGPU_WRITE_THREADS sets the number of writer threads (default 4; one pinned frame-sized buffer each)."""
+    if not _shared_pool:
+        import atexit
+        workers = int(workers or os.environ.get('APGPU_WRITE_THREADS', 4))
+        _shared_pool.append(WritePool(max(1, workers)))
+        atexit.register(_shared_pool[0].close)
+    return _shared_pool[0]
+
+
+def write_device(path, tensor, header=None, overwrite=True, pool=None):
+    """float32 / float64 device tensor -> BITPIX -32 / -64 primary HDU (big-endian conversion on the device).
+    pool: a WritePool - the file is written by one of its threads after this call returned (pool.wait() before reading it)."""
     import ctypes as C
     import torch
     from . import _lib
@@ -715,18 +808,32 @@ def write_device(path, tensor, header=None, overwrite=True):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     enc = _lib.load().apgpu_fits_encode_f64 if f64 else _lib.load().apgpu_fits_encode_f32
     _lib.check(enc(C.c_void_p(tensor.data_ptr()), C.c_void_p(payload.data_ptr()), tensor.numel(), stream))
-    data_bytes = payload.cpu().numpy().tobytes()
+    # device -> a pinned staging buffer (kept between calls) -> the file, without an intermediate bytes object: the pageable
+    # .cpu() + .tobytes() of the first form were 25 of the 52 ms a 4096^2 float32 frame took to write (profiles/r06/frame_path_first.txt)
+    nbytes = payload.numel()
+    slot = pool.staging(nbytes) if pool is not None else None
+    host = slot[0][:nbytes] if slot is not None else _staging(nbytes)
+    host.copy_(payload, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
     hdr = _structural(header if header is not None else Header(),
                       _ShapeOnly(tuple(tensor.shape), np.dtype(np.float64 if f64 else np.float32)))
-    pad = (-len(data_bytes)) % BLOCK
+    head = hdr.tostring().encode('ascii')
     tail = getattr(header, '_tail', b'') if header is not None else b''
     tmp = str(path) + '.tmp%d' % os.getpid()
-    with open(tmp, 'wb') as f:
-        f.write(hdr.tostring().encode('ascii'))
-        f.write(data_bytes)
-        f.write(b'\0' * pad)
-        f.write(tail)
-    os.replace(tmp, path)
+
+    def put():
+        data_bytes = memoryview(host.numpy())
+        with open(tmp, 'wb') as f:
+            f.write(head)
+            f.write(data_bytes)
+            f.write(b'\0' * ((-nbytes) % BLOCK))
+            f.write(tail)
+        os.replace(tmp, path)
+
+    if pool is not None:
+        pool.submit(slot, put)
+    else:
+        put()
     return hdr
 
 
