@@ -145,6 +145,9 @@ __device__ __forceinline__ void stage_frame_scalars(const StackParams &prm, Fram
 // only half of the raw values sit in registers next to v[]); F0 > 0 is a real frame for every N that selects this NP.
 // MINN: slots below MINN are real frames for every N this instantiation serves (prev_slots; 0 = no such knowledge).
 // NSTATIC > 0: the frame count is this compile-time value (kernels instantiated per pad count): the tests below fold.
+#ifndef APGPU_PIN_RAGGED_F32
+#define APGPU_PIN_RAGGED_F32 0      // a translation unit may set it: the same pin for float32 frames (fused calibration sinks likewise)
+#endif
 template <int NP, typename RawT, bool FULL, int F0 = 0, int CNT = NP, int MINN = 0, int NSTATIC = 0>
 __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, int lane, RawT (&raw)[CNT])
 {
@@ -162,6 +165,14 @@ __device__ __forceinline__ void load_raw(const StackParams &prm, int64_t base, i
         if (FULL || (SKIP && F0 + f + 1 < MINN) || F0 + f + 1 < nframes) fb += prm.stride;
         // fence: otherwise the scheduler materialises all NP frame addresses (2 SGPRs each) at once
         if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    // uint16 frames, ragged stack: the compiler sinks the caller's uint16 -> float32 conversion into each slot's branch, next to
+    // the load, and then has to wait for that load there - s_waitcnt vmcnt(0) once per conditional slot, one exposed memory latency
+    // each (round 6, read off the ISA of the 129..512-frame kernels, whose 128-slot chunks have 128 such slots: the exact kernel took
+    // 73 ms for 256 uint16 frames where float32 frames took 27).  Pinning the raw values HERE keeps the conversions behind the loads.
+    if constexpr ((sizeof(RawT) == 2 || APGPU_PIN_RAGGED_F32) && !FULL && MINN < NP && NSTATIC == 0) {
+#pragma unroll
+        for (int f = 0; f < CNT; f++) asm volatile("" : "+v"(raw[f]));
     }
 }
 
