@@ -594,6 +594,17 @@ __global__ __launch_bounds__(256, APGPU_CHUNKS_MINBLOCKS) void stack_chunks_kern
     }
 }
 
+// One value of a streamed column (the second / third passes below), frame f of N.  uint16 frames: an unconditional load with the frame
+// index clamped - in a conditional one the compiler sinks the conversion next to the load and waits there (load_raw's note in
+// stack_calibrate.h; measured on these passes: uint16 A6 256 frames 7.5 against 9.2 ms).  float32 frames: the conditional load - the
+// clamped form cost the std pass 11 % (3.9 against 3.5 ms for 256 frames).  The caller ignores the value of a frame f >= N.
+template <typename RawT>
+__device__ __forceinline__ float stream_value(const RawT *fp, int f, int N, int64_t stride)
+{
+    if constexpr (sizeof(RawT) == 2) return to_f32(fp[(int64_t)(f < N ? f : N - 1) * stride]);
+    else return f < N ? to_f32(fp[(int64_t)f * stride]) : 0.f;
+}
+
 // The std plane of the survivors for 129 .. 512 frames, second pass (see the epilogue of stack_chunks_kernel): one pixel per lane,
 // the frames streamed once more with the EXACT calibration (IEEE division, ApCalibrate.py:439-464 operation for operation - the chunk
 // kernel's fast calibration gives these values or lists the pixel), float64 sum of (x - mean)^2 over the values inside the pixel's
@@ -626,10 +637,10 @@ __global__ __launch_bounds__(256) void stack_std_pass_kernel(const StackParams p
     for (int f0 = 0; f0 < N; f0 += 8) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = (f0 + j < N) ? to_f32(fp[(int64_t)(f0 + j) * prm.stride]) : __builtin_nanf("");
+        for (int j = 0; j < 8; j++) x[j] = stream_value<RawT>(fp, f0 + j, N, prm.stride);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            float v = x[j];
+            float v = (f0 + j < N) ? x[j] : __builtin_nanf("");
             if constexpr (CALIB) {
                 const int ff = f0 + j < N ? f0 + j : N - 1;
                 const float e = eg ? eg[ff] : 0.f, ped = pg ? pg[ff] : 0.f;
@@ -995,7 +1006,7 @@ __global__ __launch_bounds__(256) void stack_mad_sums_kernel(const StackParams p
     for (int f0 = 0; f0 < N; f0 += 8) {
         float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = to_f32(fp[(int64_t)(f0 + j < N ? f0 + j : N - 1) * prm.stride]);
+        for (int j = 0; j < 8; j++) x[j] = stream_value<RawT>(fp, f0 + j, N, prm.stride);
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const bool valid = f0 + j < N;
