@@ -521,3 +521,56 @@ def test_mad_window_crossing_equals_scan():
         else:
             mad = b1
         assert mad == np.median(np.abs(x.astype(np.float64) - np.median(x.astype(np.float64)))), (trial, n)
+
+
+def test_fitsio_header_only_read_and_write_pool(tmp_path):
+    """Round 6, the per-frame flow on files: fitsio.read(want_data=False) reads the header blocks and the bytes behind the data unit
+    (extensions, kept verbatim) without the data unit - same Header, same tail as the full read; fitsio.WritePool hands file writes to
+    its threads from per-slot staging buffers, keeps at most `workers` in flight, and wait() re-raises the first error after every
+    write has finished."""
+    import threading
+    import time
+    from astrophotography_amd import fitsio
+    a = (np.arange(37 * 53) % 65536).astype(np.uint16).reshape(37, 53)
+    h = fitsio.Header()
+    h['OBJECT'] = 'm31'
+    h['EXPTIME'] = 3.5
+    p = str(tmp_path / 'a.fits')
+    fitsio.write(p, a, h, extensions=[('BADPIX', np.ones((4, 5), np.uint8), None)])
+    d1, h1 = fitsio.read(p)
+    d0, h0 = fitsio.read(p, want_data=False)
+    assert d0 is None and np.array_equal(d1, a)
+    assert h0.tostring() == h1.tostring() and h0._tail == h1._tail and len(h0._tail) == 2 * 2880
+    q = str(tmp_path / 'b.fits')
+    fitsio.write(q, np.ones((8, 8), np.float32), h)
+    assert fitsio.read(q, want_data=False)[1]._tail == b'' and fitsio.getheader(q)['EXPTIME'] == 3.5
+
+    class HostPool(fitsio.WritePool):                       # the pool's mechanics without pinned memory (no device here)
+        def staging(self, nbytes):
+            slot = self._free.get()
+            slot[0] = bytearray(nbytes)
+            return slot
+
+    pool = HostPool(workers=2)
+    inflight, peak, done = [0], [0], []
+    lock = threading.Lock()
+
+    def job(i):
+        with lock:
+            inflight[0] += 1
+            peak[0] = max(peak[0], inflight[0])
+        time.sleep(0.02)
+        with lock:
+            inflight[0] -= 1
+            done.append(i)
+
+    for i in range(7):
+        pool.submit(pool.staging(16), lambda i=i: job(i))   # staging() blocks while both slots are being written out
+    pool.wait()
+    assert sorted(done) == list(range(7)) and peak[0] <= 2
+    pool.submit(pool.staging(1), lambda: 1 / 0)
+    pool.submit(pool.staging(1), lambda: job(99))
+    with pytest.raises(ZeroDivisionError):
+        pool.wait()
+    assert 99 in done                                       # the write behind the failing one still happened
+    pool.close()
