@@ -4,7 +4,7 @@ import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from astrophotography_amd import ops, synth
 
 H = W = 4096

@@ -1,5 +1,5 @@
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from astrophotography_amd import ops, synth
 dev = torch.device('cuda', 0)
 masters = synth.make_masters(4096, 4096, config_id=3, device=dev)
