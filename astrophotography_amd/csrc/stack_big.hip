@@ -223,14 +223,14 @@ int launch_big_exact(const StackParams &prm, bool u16, bool calib, bool median_o
 bool chunks_eligible(const StackParams &prm, bool median_only);                                        // stack_chunks.hip
 int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, char *describe);
 bool rank_chunks_eligible(const StackParams &prm, bool calib, bool median_only);                       // stack_chunks.hip (round 6)
-int launch_rank_chunks(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe);
+int launch_rank_chunks(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe);
 
 // 129 .. 512 frames: the chunked float32 fast path where it applies (clipped mean; round 6: its median / std planes, the plain
-// median and the median / mad_std configuration on raw frames), else the exact kernel.
+// median - with fused calibration too - and the median / mad_std configuration on raw frames), else the exact kernel.
 int launch_big(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
     if (chunks_eligible(prm, median_only)) return launch_chunks(prm, u16, calib, st, describe);
-    if (rank_chunks_eligible(prm, calib, median_only)) return launch_rank_chunks(prm, u16, median_only, st, describe);
+    if (rank_chunks_eligible(prm, calib, median_only)) return launch_rank_chunks(prm, u16, calib, median_only, st, describe);
     StackParams q = prm;
     q.redo = nullptr;
     return launch_big_exact(q, u16, calib, median_only, st, describe, nullptr, nullptr, nullptr);

@@ -814,9 +814,9 @@ int launch_chunks(const StackParams &prm, bool u16, bool calib, hipStream_t st, 
 // Unsure pixels - a non-finite value (the astropy form leaves such a column unclipped: the exact kernel knows), a median outside
 // the zone, a comparison inside the margin, a spread outside 2^-40 .. 2^40 - carry NaN through the per-pixel temporary, are listed
 // by the last pass and reduced by stack_big_kernel, like the clipped mean's.  Three reads of the frames instead of one.
-template <typename RawT, bool FULLCH, bool DEV>
-__device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kchunk, int nch, int c, int64_t base, int lane, float m1, float m2,
-                                                  float (&win)[kChunkWin], float &Lmax, float &Umin, bool first)
+template <typename RawT, bool FULLCH, bool DEV, bool CALIB>
+__device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, const FrameScalars<kChunkSlots> &fs, int kchunk, int nch, int c, int64_t base,
+                                                  int lane, float m1, float m2, float (&win)[kChunkWin], float &Lmax, float &Umin, bool first)
 {
     constexpr int NP = kChunkSlots, MINN = FULLCH ? NP : kChunkMinFrames - 1;
     __builtin_amdgcn_sched_barrier(0);
@@ -826,7 +826,12 @@ __device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kc
     q.N = c;
     float v[NP];
     bool good;
-    {
+    if constexpr (CALIB) {
+        // the median of CALIBRATED frames (config 4 beyond 128 frames): the chunk kernel's loader - fast calibration, sort, range guards;
+        // false: the fast path does not vouch for this lane's values, the exact kernel takes the pixel
+        static_assert(!DEV, "the median / mad_std passes take raw frames");
+        good = load_chunk<RawT, true, FULLCH>(q, fs, base, lane, v);
+    } else {
         RawT raw[NP];
         load_chunk_raw<NP, RawT, FULLCH, 0, NP, MINN>(q, base, lane, raw);
         int nframes = c;
@@ -844,8 +849,8 @@ __device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kc
         }
         good = acc == 0.f;
         asm volatile("" : "+v"(acc));
+        sort_column<NP>(v);
     }
-    sort_column<NP>(v);
     if constexpr (FULLCH) {
 #pragma unroll
         for (int j = 0; j < kChunkWin; j++) win[j] = v[(NP - kChunkWin) / 2 + j];
@@ -858,16 +863,16 @@ __device__ __forceinline__ bool rank_chunk_window(const StackParams &prm, int kc
     return good;
 }
 
-template <typename RawT, bool FULLCH, bool DEV, int SIDX, int KS, int NPAIR>
-__device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cbase, int cextra, int64_t base, int lane, float m1, float m2,
-                                                 float (&win)[kChunkWin], float &Lmax, float &Umin, int &below)
+template <typename RawT, bool FULLCH, bool DEV, bool CALIB, int SIDX, int KS, int NPAIR>
+__device__ __forceinline__ bool rank_window_step(const StackParams &prm, const FrameScalars<kChunkSlots> *fs, int cbase, int cextra, int64_t base, int lane,
+                                                 float m1, float m2, float (&win)[kChunkWin], float &Lmax, float &Umin, int &below)
 {
     constexpr int W = kChunkWin, K = KS + NPAIR;
     if constexpr (SIDX >= NPAIR) {
         constexpr int kc = SIDX + NPAIR;
         const int c = cbase + (kc < cextra ? 1 : 0);
         below += c / 2 - W / 2;
-        return rank_chunk_window<RawT, FULLCH, DEV>(prm, kc, K, c, base, lane, m1, m2, win, Lmax, Umin, kc == 0);
+        return rank_chunk_window<RawT, FULLCH, DEV, CALIB>(prm, fs[CALIB ? kc : 0], kc, K, c, base, lane, m1, m2, win, Lmax, Umin, kc == 0);
     } else {
         constexpr int ka = 2 * SIDX, kb = 2 * SIDX + 1;
         const int ca = cbase + (ka < cextra ? 1 : 0), cb = cbase + (kb < cextra ? 1 : 0);
@@ -875,13 +880,13 @@ __device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cba
         bool ok;
         {
             float wa[W];
-            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, ka, K, ca, base, lane, m1, m2, wa, Lmax, Umin, SIDX == 0);
+            ok = rank_chunk_window<RawT, FULLCH, DEV, CALIB>(prm, fs[CALIB ? ka : 0], ka, K, ca, base, lane, m1, m2, wa, Lmax, Umin, SIDX == 0);
 #pragma unroll
             for (int j = 0; j < W; j++) Y[j] = wa[j];
         }
         {
             float wb[W];
-            ok = rank_chunk_window<RawT, FULLCH, DEV>(prm, kb, K, cb, base, lane, m1, m2, wb, Lmax, Umin, false) && ok;
+            ok = rank_chunk_window<RawT, FULLCH, DEV, CALIB>(prm, fs[CALIB ? kb : 0], kb, K, cb, base, lane, m1, m2, wb, Lmax, Umin, false) && ok;
 #pragma unroll
             for (int j = 0; j < W; j++) Y[W + j] = wb[j];
         }
@@ -898,20 +903,35 @@ __device__ __forceinline__ bool rank_window_step(const StackParams &prm, int cba
 
 // MODE 0: tmp[p], tmp[P + p] = the column's two middle values (NaN, -: not sure).  MODE 1: tmp[2 P + p] = the sum of the two middle
 // values of |(x - m1) + (x - m2)| (not sure: tmp[p] = NaN).  MODE 2: the median plane (+ count = N); a pixel that is not sure is listed.
+// MODE 3: MODE 2 with fused calibration (ApCalibrate.py:439-464 on the fast path, the chunk kernel's loader).
 template <int KS, int NPAIR, typename RawT, bool FULLCH, int MODE>
 __global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackParams prm, float *tmp, int32_t *redo_count, int32_t *redo_list)
 {
     constexpr int K = KS + NPAIR, W = kChunkWin;
-    constexpr bool DEV = MODE == 1;
+    constexpr bool DEV = MODE == 1, CALIB = MODE == 3;
+    __shared__ FrameScalars<kChunkSlots> fs[CALIB ? K : 1];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * blockDim.x;
     const int64_t p = base + lane;
     const int N = prm.N;
     const int cbase = N / K, cextra = N % K;
+    if constexpr (CALIB) {                                  // the per-frame scalars of every chunk, as stack_chunks_kernel stages them
+        for (int k = 0; k < K; k++) {
+            const int c = cbase + (k < cextra ? 1 : 0);
+            for (int t = threadIdx.x; t < kChunkSlots; t += blockDim.x) {
+                const int ff = k + (t < c ? t : c - 1) * K;
+                fs[k].e[t] = prm.exp_ratio ? prm.exp_ratio[ff] : 0.f;
+                fs[k].ped[t] = prm.pedestal ? prm.pedestal[ff] : 0.f;
+                fs[k].pad[t] = t < c ? -__builtin_inff() : __builtin_inff();
+            }
+        }
+        __syncthreads();
+    }
     if (p >= prm.P) return;
     extern __shared__ float parked[];                       // [(KS - 2) * W][256]
     float m1 = 0.f, m2 = 0.f;
     bool ok = true;
+    if constexpr (MODE >= 2) ok = !(prm.pixmask && prm.pixmask[p]);     // a masked pixel: the exact kernel's answer
     if constexpr (DEV) {
         m1 = tmp[p];
         m2 = tmp[prm.P + p];
@@ -922,18 +942,18 @@ __global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackPa
     int below = 0;
     if constexpr (KS >= 3) {
         float win[W];
-        ok = rank_window_step<RawT, FULLCH, DEV, 0, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+        ok = rank_window_step<RawT, FULLCH, DEV, CALIB, 0, KS, NPAIR>(prm, fs, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[j * 256 + lane] = win[j];
     }
     if constexpr (KS == 4) {
         float win[W];
-        ok = rank_window_step<RawT, FULLCH, DEV, 1, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
+        ok = rank_window_step<RawT, FULLCH, DEV, CALIB, 1, KS, NPAIR>(prm, fs, cbase, cextra, base, lane, m1, m2, win, Lmax, Umin, below) && ok;
 #pragma unroll
         for (int j = 0; j < W; j++) parked[(W + j) * 256 + lane] = win[j];
     }
-    ok = rank_window_step<RawT, FULLCH, DEV, KS - 2, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, R0, Lmax, Umin, below) && ok;
-    ok = rank_window_step<RawT, FULLCH, DEV, KS - 1, KS, NPAIR>(prm, cbase, cextra, base, lane, m1, m2, R1, Lmax, Umin, below) && ok;
+    ok = rank_window_step<RawT, FULLCH, DEV, CALIB, KS - 2, KS, NPAIR>(prm, fs, cbase, cextra, base, lane, m1, m2, R0, Lmax, Umin, below) && ok;
+    ok = rank_window_step<RawT, FULLCH, DEV, CALIB, KS - 1, KS, NPAIR>(prm, fs, cbase, cextra, base, lane, m1, m2, R1, Lmax, Umin, below) && ok;
     float X[4 * W];
     {
         int slot = lane;
@@ -964,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void stack_rank_chunks_kernel(const StackPa
     } else if constexpr (MODE == 1) {
         if (unsure) tmp[p] = __builtin_nanf("");
         else tmp[2 * prm.P + p] = a + b;
-    } else {
+    } else {                                                // MODE 2 / 3: the median plane
         const uint64_t m = __builtin_amdgcn_ballot_w64(unsure);
         if (m != 0) {
             int first = 0;
@@ -1049,10 +1069,10 @@ __global__ __launch_bounds__(256) void stack_mad_sums_kernel(const StackParams p
 // (mad_fast_eligible's conditions without the workspace: the list may be a stream-ordered temporary here).
 bool rank_chunks_eligible(const StackParams &prm, bool calib, bool median_only)
 {
-    if (calib || prm.N <= 128 || prm.N > 8 * kChunkSlots || prm.P >= 0x7fffffffLL) return false;
-    if (prm.pixmask || prm.pedestal) return false;
+    if (prm.N <= 128 || prm.N > 8 * kChunkSlots || prm.P >= 0x7fffffffLL) return false;
     if (getenv("APGPU_RANK_CHUNKS_OFF")) return false;      // development: time the exact kernel on the same call
-    if (median_only) return true;
+    if (median_only) return calib || !prm.pedestal;         // fused calibration and a pixel mask: the median only (MODE 3 / the list)
+    if (calib || prm.pixmask || prm.pedestal) return false;
     if (prm.dev != APGPU_DEV_MAD_STD || prm.center != APGPU_CENTER_MEDIAN || prm.maxiters != 1) return false;
     if (prm.median || prm.std || prm.moments || prm.single_kernel || prm.fast32 == 0) return false;
     if (!(prm.sl2 > 0.0 && prm.su2 > 0.0 && prm.sl2 < 1e12 && prm.su2 < 1e12)) return false;
@@ -1079,19 +1099,19 @@ static int launch_rank_pass(const StackParams &q, bool fullch, float *tmp, int32
 }
 
 template <int KS, int NPAIR, typename RawT>
-static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+static int launch_rank_k(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
     const bool fullch = prm.N == (KS + NPAIR) * kChunkSlots;
     if (describe) {
         snprintf(describe, 256, "stack_rank_chunks_kernel<%d, %d, %s, %s, %d>", KS, NPAIR, sizeof(RawT) == 2 ? "unsigned short" : "float",
-                 fullch ? "true" : "false", median_only ? 2 : 0);
+                 fullch ? "true" : "false", median_only ? (calib ? 3 : 2) : 0);
         return APGPU_OK;
     }
     if ((prm.P + 255) / 256 > 0x7fffffffLL) return fail(APGPU_EUNSUPPORTED, "stack: too many pixels (%lld)", (long long)prm.P);
     int32_t *ws = prm.redo, *cnt = nullptr, *list = nullptr, *own = nullptr;
     StackParams q = prm;
     q.redo = nullptr;
-    auto exact = [&]() { return launch_big_exact(q, u16, false, median_only, st, nullptr); };
+    auto exact = [&]() { return launch_big_exact(q, u16, calib, median_only, st, nullptr); };
     if (ws) {
         cnt = ws;
         list = ws + ws_list_off(prm.P);
@@ -1120,7 +1140,7 @@ static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hip
     int rc;
     bool launched = false;                                   // something may have been listed: the exact kernel must follow
     if (median_only) {
-        rc = launch_rank_pass<KS, NPAIR, RawT, 2>(q, fullch, nullptr, cnt, list, st);
+        rc = calib ? launch_rank_pass<KS, NPAIR, RawT, 3>(q, fullch, nullptr, cnt, list, st) : launch_rank_pass<KS, NPAIR, RawT, 2>(q, fullch, nullptr, cnt, list, st);
         launched = rc == APGPU_OK;
     } else {
         rc = launch_rank_pass<KS, NPAIR, RawT, 0>(q, fullch, tmp, cnt, list, st);
@@ -1133,7 +1153,7 @@ static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hip
         }
     }
     if (rc == kNoRedoList) rc = exact();                     // (nothing was launched, nothing listed)
-    else if (launched) rc = launch_big_exact(q, u16, false, median_only, st, nullptr, cnt, list, ws);
+    else if (launched) rc = launch_big_exact(q, u16, calib, median_only, st, nullptr, cnt, list, ws);
     if (tmp) {
         const hipError_t ef = hipFreeAsync(tmp, st);
         if (rc == APGPU_OK && ef != hipSuccess) rc = fail(APGPU_ELAUNCH, "stack (chunks): free: %s", hipGetErrorString(ef));
@@ -1146,20 +1166,20 @@ static int launch_rank_k(const StackParams &prm, bool u16, bool median_only, hip
 }
 
 template <int KS, int NPAIR>
-static int launch_rank_t(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+static int launch_rank_t(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
-    return u16 ? launch_rank_k<KS, NPAIR, uint16_t>(prm, u16, median_only, st, describe) : launch_rank_k<KS, NPAIR, float>(prm, u16, median_only, st, describe);
+    return u16 ? launch_rank_k<KS, NPAIR, uint16_t>(prm, u16, calib, median_only, st, describe) : launch_rank_k<KS, NPAIR, float>(prm, u16, calib, median_only, st, describe);
 }
 
-int launch_rank_chunks(const StackParams &prm, bool u16, bool median_only, hipStream_t st, char *describe)
+int launch_rank_chunks(const StackParams &prm, bool u16, bool calib, bool median_only, hipStream_t st, char *describe)
 {
     switch (chunk_count(prm.N)) {
-    case 3: return launch_rank_t<3, 0>(prm, u16, median_only, st, describe);
-    case 4: return launch_rank_t<4, 0>(prm, u16, median_only, st, describe);
-    case 5: return launch_rank_t<4, 1>(prm, u16, median_only, st, describe);
-    case 6: return launch_rank_t<3, 3>(prm, u16, median_only, st, describe);
-    case 7: return launch_rank_t<4, 3>(prm, u16, median_only, st, describe);
-    default: return launch_rank_t<4, 4>(prm, u16, median_only, st, describe);
+    case 3: return launch_rank_t<3, 0>(prm, u16, calib, median_only, st, describe);
+    case 4: return launch_rank_t<4, 0>(prm, u16, calib, median_only, st, describe);
+    case 5: return launch_rank_t<4, 1>(prm, u16, calib, median_only, st, describe);
+    case 6: return launch_rank_t<3, 3>(prm, u16, calib, median_only, st, describe);
+    case 7: return launch_rank_t<4, 3>(prm, u16, calib, median_only, st, describe);
+    default: return launch_rank_t<4, 4>(prm, u16, calib, median_only, st, describe);
     }
 }
 

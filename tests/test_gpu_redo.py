@@ -464,3 +464,46 @@ def test_plain_median_129_to_512_frames(ops, apref, N, dtype):
     assert same.all(), (N, np.argwhere(~same)[:5])
     assert np.array_equal(cnt.cpu().numpy(), (~np.isnan(cube.astype(np.float32))).sum(0))
     np.testing.assert_array_equal(ops.stack_median(d[:, 1:6]).cpu().numpy(), got[1:6])       # a row stripe reduced in place (NaN == NaN here)
+
+
+@pytest.mark.parametrize('N,dtype', [(130, np.uint16), (192, np.float32), (256, np.uint16), (257, np.float32), (300, np.uint16), (384, np.float32),
+                                     (400, np.uint16), (448, np.float32), (512, np.uint16), (512, np.float32)])
+def test_calibrated_median_129_to_512_frames(ops, apref, N, dtype):
+    """Config 4's reduction (fused bias / dark / flat + median along N) beyond 128 frames on the chunked windows (round 6, MODE 3): per-frame
+    exposure ratios and pedestals, a zero and a NaN in the flat, non-finite values, a pixel mask - against the oracle's median of the
+    calibrated cube (float32 values, so the median is exact up to the rounding of the middle pair's mean: 1 ulp), counts, a row stripe."""
+    from tests.util import synth_cube
+    rng = np.random.default_rng(3900 + N)
+    shape = (10, 83)
+    bias, dark, flat = synth_masters(rng, shape)
+    flat[0, 0] = 0.0
+    flat[0, 1] = np.nan
+    raw = synth_cube(rng, N, shape, dtype=dtype)
+    if dtype == np.float32:
+        raw = raw + bias + 0.4 * dark
+        raw[5, 3, 4] = np.inf
+        raw[7, 2, 2] = np.nan
+    nflat, _ = apref.flat_normalize(flat)
+    e = rng.uniform(0.3, 0.5, N)
+    ped = np.where(rng.random(N) < 0.3, -50.0, 0.0)
+    pm = (rng.random(shape) < 0.05).astype(np.uint8)
+    cal = apref.calibrate(raw, bias, dark, nflat, e, ped, True)
+    d = dev(raw, ops)
+    name = ops.stack_kernel_name(N, 'f32' if dtype == np.float32 else 'u16', calibrated=True, median_only=True)
+    assert 'stack_rank_chunks_kernel' in name and name.rstrip('>').endswith('3'), name
+    for use_ped, use_pm in ((True, True), (False, False)):
+        calib = dict(bias=dev(bias, ops), dark=dev(dark, ops), nflat=dev(nflat, ops), exp_ratio=e, pedestal=ped if use_ped else None, dark_still_biased=True)
+        c = cal if use_ped else apref.calibrate(raw, bias, dark, nflat, e, None, True)
+        with np.errstate(all='ignore'):
+            mm = apref.stack_median(c).astype(np.float32)
+        nn = (~np.isnan(c)).sum(0).astype(np.int32)
+        if use_pm:
+            mm[pm != 0] = np.nan
+            nn[pm != 0] = 0
+        med, cnt = ops.stack_median(d, calib=calib, pixmask=dev(pm, ops) if use_pm else None, want_count=True)
+        what = 'calibrated median N=%d %s ped=%s mask=%s' % (N, np.dtype(dtype).name, use_ped, use_pm)
+        assert np.array_equal(cnt.cpu().numpy(), nn), what
+        assert_ulp(med.cpu().numpy(), mm, 1, what)
+        rows = ops.stack_median(d[:, 2:9], calib={k: (v[2:9] if k in ('bias', 'dark', 'nflat') else v) for k, v in calib.items()},
+                                pixmask=dev(pm[2:9], ops) if use_pm else None)
+        np.testing.assert_array_equal(rows.cpu().numpy(), med[2:9].cpu().numpy(), err_msg='stripe ' + what)

@@ -42,3 +42,15 @@ for dt in (torch.float32, torch.uint16):
               'median: chunked %.3f ms, exact %.3f ms, equal %s' % (N, str(dt).split('.')[-1], fast, 100 * (nb + 24) * H * W / (fast * 1e-3) / 8e12, exact,
                                                                   100.0 * st['pixels_listed'] / max(st['pixels'], 1), same, dm, ds, mfast, mexact, bool(torch.equal(m1, m2))))
         del frames
+
+# config 4's reduction beyond 128 frames: fused calibration + median (MODE 3) against the exact kernel
+for dt in (torch.float32, torch.uint16):
+    for N in [int(x) for x in os.environ.get('NS', '512,256').split(',')]:
+        frames = synth.make_frames(N, masters, nflat, config_id=2, dtype=dt, first_frame=0)
+        calib = dict(bias=masters['bias'], dark=masters['dark'], nflat=nflat, exp_ratio=torch.full((N,), synth.EXP_RATIO, dtype=torch.float32, device=dev))
+        mfast, m1 = t(lambda: ops.stack_median(frames, calib=calib))
+        os.environ['APGPU_RANK_CHUNKS_OFF'] = '1'
+        mexact, m2 = t(lambda: ops.stack_median(frames, calib=calib), reps=1)
+        del os.environ['APGPU_RANK_CHUNKS_OFF']
+        print('N=%3d %-7s calibrated median: chunked %.3f ms, exact kernel %.3f ms, equal %s' % (N, str(dt).split('.')[-1], mfast, mexact, bool(torch.equal(m1, m2))))
+        del frames
